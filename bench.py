@@ -1,0 +1,260 @@
+#!/usr/bin/env python3
+"""bench.py -- NID Gauss-Newton iterations/sec on MI355X (BASELINE.json metric).
+
+One "step" = one NID cost + Jacobian evaluation of every active cell at one
+SE(3) candidate plus the Huber-weighted reduction to the 6x6 normal equations,
+delivered to host memory.  Workload at N=1 is
+BASELINE.json configs[1]: the 640x480 pair, 16x16 cells, 8-bin B-spline
+histogram (synthetic pair: the ETH-CVG data is not available offline).
+
+N > 1: one process per GPU (torch.distributed, backend nccl = RCCL), the cells
+of the SAME pair are partitioned over the ranks (strong scaling) and the
+per-rank partial [chi2, b(6), H upper (21), n_active] block (32 doubles) is
+all-reduced over xGMI every step.
+
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--config", default="A", choices=["A", "B", "S"])
+    ap.add_argument("--bins", type=int, default=8)
+    ap.add_argument("--block-threads", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    return ap.parse_args()
+
+
+def pose_trajectory(synth, pair, n):
+    """LM-like sequence of candidates around the disturbed start pose."""
+    rng = np.random.default_rng(20211003)
+    out = []
+    for _ in range(n):
+        out.append(synth.perturb_pose7(pair.pose_init, rng.normal(0, 1.5e-3, 3), rng.normal(0, 2e-3, 3)))
+    return out
+
+
+def cpu_baseline(pair, bins, seconds):
+    """The oracle (CPU restatement of the reference's CPU edge) timed on this
+    host, single thread like the reference (OpenMP off, g2o/CMakeLists.txt:58).
+    Rebuilt with -march=native here (g2o/CMakeLists.txt:67); bounded sample."""
+    from oracle import oracle_py
+    lib = None
+    try:
+        out = os.path.join("/tmp", f"libnid_oracle_native_{os.getpid()}.so")
+        oracle_py.build(march="-march=native", out=out)
+        lib = oracle_py.load(out)
+    except Exception:
+        lib = oracle_py.load()
+    synth = importlib.import_module("nid-pose-estimation_amd.synth")
+    o = oracle_py.Oracle(pair.rows, pair.cols, pair.cell, bins, pair.fx, pair.fy, pair.cx, pair.cy, lib=lib)
+    pts = oracle_py.backproject(pair.depth_m, synth.matrix_colmajor16(pair.T_wc0), pair.fx, pair.fy, pair.cx, pair.cy)
+    o.set_reference(pts, pair.im0)
+    o.set_target(pair.im1)
+    o.compute_href(pair.pose_init)
+    poses = pose_trajectory(synth, pair, 64)
+    delta = float(np.sqrt(0.95))
+    n = 0
+    t0 = time.perf_counter()
+    while True:
+        _, _, err, J = o.evaluate(poses[n % len(poses)], True)
+        oracle_py.normal_equations(err, J, delta)
+        n += 1
+        el = time.perf_counter() - t0
+        if el >= seconds or n >= 400:
+            break
+    return {"value": n / el, "unit": "iterations/s", "cores": 1, "kind": "port",
+            "sample": f"{n} cost+Jacobian evaluations + 6x6 reduction of the same {pair.cols}x{pair.rows} pair, "
+                      f"{el:.1f} s on 1 host core (oracle rebuilt -O3 -march=native -ffp-contract=off)"}
+
+
+def main():
+    args = parse()
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_
+        dist = dist_
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (no CPU fallback of the product path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    capi = importlib.import_module("nid-pose-estimation_amd.capi")
+    synth = importlib.import_module("nid-pose-estimation_amd.synth")
+    parallel = importlib.import_module("nid-pose-estimation_amd.parallel")
+    pair = synth.make_pair(args.config)
+    ncell = pair.cell * pair.cell
+    lo, hi = parallel.cell_range(rank, world, ncell)
+    ctx = capi.from_pair(pair, args.bins, device=local_rank, cell_begin=lo, cell_end=hi)
+    if args.block_threads:
+        ctx.set_block_threads(args.block_threads)
+    stream = torch.cuda.current_stream(dev)
+    ctx.set_stream(stream.cuda_stream)
+    cnt, href = ctx.compute_href(pair.pose_init)
+    delta = float(np.sqrt(0.95))
+    K, W = args.steps, args.warmup
+    poses = pose_trajectory(synth, pair, 256)
+    nslots = capi.NID_SLOTS
+
+    # device-side result ring: one 32-double block per slot (all-reduced when world > 1)
+    ring = torch.zeros((nslots, capi.NID_REDUCED_LEN), dtype=torch.float64, device=dev)
+    host_ring = torch.zeros((nslots, capi.NID_REDUCED_LEN), dtype=torch.float64).pin_memory()
+
+    def step(i):
+        s = i % nslots
+        if world == 1:
+            if i >= nslots:
+                ctx.wait(s)                      # results of step i-nslots are in host memory
+            ctx.launch(s, poses[i % len(poses)], delta, True)
+        else:
+            if i >= nslots:
+                ctx.wait(s)
+            ctx.launch(s, poses[i % len(poses)], delta, True, reduced_dev=ring[s].data_ptr())
+            dist.all_reduce(ring[s])             # RCCL sum over xGMI, 256 B
+            host_ring[s].copy_(ring[s], non_blocking=True)
+
+    def drain(n):
+        for i in range(max(0, n - nslots), n):
+            ctx.wait(i % nslots)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for i in range(W):
+        step(i)
+    drain(W)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(K):
+        step(i)
+    drain(K)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # sanity: the last result is finite and every rank agrees after the all-reduce
+    if world == 1:
+        ctx.launch(0, poses[0], delta, True)
+        H, b, chi2, na = ctx.wait(0)
+    else:
+        ctx.launch(0, poses[0], delta, True, reduced_dev=ring[0].data_ptr())
+        dist.all_reduce(ring[0])
+        torch.cuda.synchronize(dev)
+        ctx.wait(0)
+        H, b, chi2, na = capi.unpack_reduced(ring[0].cpu().numpy())
+    assert np.isfinite(chi2) and np.all(np.isfinite(H)) and na > 0
+
+    # dominant-kernel duration, HIP events on the launch stream, same launches
+    ctx.enable_timing(True)
+    ev_ms, rd_ms = [], []
+    for i in range(min(K, 200)):
+        ctx.launch(0, poses[i % len(poses)], delta, True)
+        ctx.wait(0)
+        a, r = ctx.last_kernel_ms(0)
+        ev_ms.append(a)
+        rd_ms.append(r)
+    ctx.enable_timing(False)
+    # back-to-back kernel stream between two events (what rocprofv3 --stats averages)
+    e0 = torch.cuda.Event(enable_timing=True)
+    e1 = torch.cuda.Event(enable_timing=True)
+    nb2b = min(K, 1000)
+    torch.cuda.synchronize(dev)
+    e0.record(stream)
+    for i in range(nb2b):
+        s = i % nslots
+        if i >= nslots:
+            ctx.wait(s)
+        ctx.launch(s, poses[i % len(poses)], delta, True)
+    e1.record(stream)
+    drain(nb2b)
+    torch.cuda.synchronize(dev)
+    b2b_ms = e0.elapsed_time(e1) / nb2b
+
+    if rank == 0:
+        eval_ms = float(np.median(ev_ms))
+        contract = ctx.contract_bytes()  # this rank's cells
+        achieved = contract / (eval_ms * 1e-3) / 1e9
+        out = {
+            "metric": "NID GN iterations/sec (640x480 dense pair)" if args.config == "A" else
+                      f"NID GN iterations/sec ({pair.cols}x{pair.rows} dense pair)",
+            "value": K / elapsed,
+            "unit": "iterations/s",
+            "n_gpus": world,
+            "steps": K,
+            "warmup": W,
+            "ms_per_step": elapsed / K * 1e3,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": f"{pair.cols}x{pair.rows} synthetic RGB-D pair, {pair.cell}x{pair.cell} cells of "
+                            f"{pair.rows // pair.cell}x{pair.cols // pair.cell} px, {args.bins}-bin cubic B-spline "
+                            f"histograms, cost+Jacobian+Huber 6x6 reduction per step, "
+                            f"{int((cnt[lo:hi] >= 300).sum())} active cells on rank 0",
+                "cells": ncell, "bins": args.bins,
+                "parallelism": f"cells/{world}" + ("" if world == 1 else " + RCCL all-reduce(32 f64)"),
+                "pipelining": f"{nslots} launches in flight, results land in pinned host memory",
+            },
+            "roofline": {
+                "bound": "hbm",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": None,
+                "kernel": "nid::k_eval<JAC>",
+                "kernel_ms": eval_ms,
+                "reduce_kernel_ms": float(np.median(rd_ms)),
+                "step_device_ms_back_to_back": b2b_ms,
+                "algorithmic_bytes_per_launch": contract,
+                "note": "achieved = contract bytes (68 B/px + 64 B/cell, SURVEY 8d) / median HIP-event duration "
+                        "of the evaluation kernel; the tile is L2/MALL-resident after the first launch",
+            },
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(pair, args.bins, args.cpu_seconds)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

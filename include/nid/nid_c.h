@@ -1,0 +1,170 @@
+/*
+ * nid_c.h -- C-ABI of the MI355X-native NID cost/Jacobian path (libnid_hip.so).
+ *
+ * Drop-in boundary for the three operator entry points of arpg/NID-Pose-Estimation
+ * (paths relative to the reference checkout):
+ *
+ *   Calculate3Dpoint   CudaPoints3d.cuh:6      -> nid_set_reference_depth / nid_get_points3d
+ *   CudaComputeHref    CudaComputeHref.cuh:5   -> nid_set_reference_* + nid_set_target_u8 + nid_compute_href
+ *   g2o::CudaComputeH  g2o/g2o/core/computeH.cuh:8 -> nid_evaluate / nid_evaluate_matrix
+ *   per-edge quadratic form + Huber, g2o/g2o/core/base_unary_edge.hpp:43-72,
+ *   robust_kernel_impl.cpp:65-91              -> nid_normal_equations (fused on device)
+ *
+ * The legacy C++ signatures themselves are provided, unchanged, by
+ * include/nid/legacy_ops.h on top of this ABI.
+ *
+ * Conventions (same as the reference operators):
+ *  - every pointer is a caller-owned HOST buffer unless its name ends in _dev;
+ *  - images are row-major; a pose matrix is COLUMN-major 4x4 (Eigen .data());
+ *  - pose7 = {qx,qy,qz,qw,tx,ty,tz} of g2o::SE3Quat (world -> camera 1);
+ *  - cell id = col_cell + cell_num * row_cell (computeH.cu:220);
+ *  - per-cell outputs of inactive cells (N_c < 300 or NaN Href) are NaN
+ *    (computeH.cu:271-275, 313-322);
+ *  - all arithmetic is IEEE f64; histogram bins are accumulated in 64-bit
+ *    fixed point (order-independent, bitwise reproducible), see DESIGN.md.
+ *
+ * Errors: every call returns NID_OK (0) or a negative nid_status; nothing
+ * throws across the boundary.  A context is bound to one HIP device and is
+ * not thread-safe; use one context per host thread (the reference is single
+ * threaded: computeH.cu:378,449).
+ */
+#ifndef NID_C_H
+#define NID_C_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NID_ABI_VERSION 1
+
+typedef enum {
+  NID_OK = 0,
+  NID_ERR_INVALID_ARG = -1,
+  NID_ERR_NO_DEVICE = -2,    /* no HIP device / HIP runtime error at init */
+  NID_ERR_HIP = -3,          /* HIP runtime error (see nid_last_error) */
+  NID_ERR_UNSUPPORTED = -4,  /* shape outside what the kernels are built for */
+  NID_ERR_STATE = -5,        /* call order: reference/target/href not set */
+  NID_ERR_NOMEM = -6
+} nid_status;
+
+/* in-bound test of the Jacobian pass: SURVEY.md section 0.2 */
+#define NID_JACBOUND_CPU  0 /* u+3 <= cols-1  types_six_dof_expmap.cpp:433 (parity target) */
+#define NID_JACBOUND_CUDA 1 /* u+3 <= cols    computeH.cu:164 */
+/* world->camera transform of a point */
+#define NID_XFORM_QUAT   0  /* quaternion rotate + t, SE3Quat::map se3quat.h:217-220 */
+#define NID_XFORM_MATRIX 1  /* 4x4 matrix rows, computeH.cu:152-154 */
+
+typedef struct nid_ctx nid_ctx;
+
+typedef struct {
+  int32_t rows, cols;     /* image size */
+  int32_t cell_num;       /* cells per side (16 -> 256 cells) */
+  int32_t bin_num;        /* B-spline bins, 4..16 (reference default 10) */
+  int32_t bs_degree;      /* must be 3 */
+  int32_t device;         /* HIP device ordinal */
+  int32_t cell_begin;     /* this context owns cells [cell_begin, cell_end) ... */
+  int32_t cell_end;       /* ... 0,0 = all cells (multi-GPU: one shard per rank) */
+  double fx, fy, cx, cy;  /* camera_intrincis[0..3] (NID_pose_estimation.cpp:232-233) */
+} nid_config;
+
+/* ---- life cycle -------------------------------------------------------- */
+int nid_abi_version(void);
+const char *nid_status_string(int status);
+const char *nid_last_error(const nid_ctx *ctx); /* text of the last HIP error */
+int nid_device_count(void);                     /* 0 when no GPU; never initialises a context */
+
+int nid_create(const nid_config *cfg, nid_ctx **out);
+int nid_destroy(nid_ctx *ctx);
+int nid_set_options(nid_ctx *ctx, int jac_bound_mode, int xform_mode);
+/* run every kernel of this context on a caller-owned hipStream_t (e.g. the
+ * current torch stream) instead of the context's own stream; NULL restores it */
+int nid_set_stream(nid_ctx *ctx, void *hip_stream);
+/* tuning knob: threads per workgroup of the evaluation kernel (0 = default) */
+int nid_set_block_threads(nid_ctx *ctx, int threads);
+
+/* ---- once per frame pair ------------------------------------------------ */
+/* Calculate3Dpoint: depth in metres (f64, rows*cols), T_wc0 column-major.
+ * Back-projects on the device into the cell-tiled layout. */
+int nid_set_reference_depth(nid_ctx *ctx, const double *depth_m, const uint8_t *im0,
+                            const double *T_wc0_colmajor16);
+/* same, from an existing AoS point cloud (NaN xyz = invalid), as handed to
+ * CudaComputeHref / CudaComputeH */
+int nid_set_reference_points(nid_ctx *ctx, const double *points3d, const uint8_t *im0);
+/* copy the back-projected points back in Calculate3Dpoint's output layout */
+int nid_get_points3d(nid_ctx *ctx, double *points3d);
+int nid_set_target_u8(nid_ctx *ctx, const uint8_t *im1);
+/* legacy f64 image carrying u8 values ((double)im.data[i], NID_pose_estimation.cpp:245-251);
+ * NID_ERR_UNSUPPORTED if a value is not an integer in [0,255] */
+int nid_set_target_f64(nid_ctx *ctx, const double *im1);
+int nid_set_reference_image_f64(const double *im0, int64_t n, uint8_t *out_u8);
+
+/* CudaComputeHref at the initial pose.  bs_counter[cells], Href[cells] (NaN =
+ * inactive); bs_value (4 per pixel) and bs_index (1 per pixel) may be NULL;
+ * when given they are filled in image order with the CPU-edge convention
+ * (weights 0 for pixels out of frame at the initial pose, bs_index = -1 for
+ * invalid depth). */
+int nid_compute_href(nid_ctx *ctx, const double *pose7, int32_t *bs_counter, double *Href,
+                     double *bs_value, int32_t *bs_index);
+int nid_compute_href_matrix(nid_ctx *ctx, const double *pose_colmajor16, int32_t *bs_counter,
+                            double *Href, double *bs_value, int32_t *bs_index);
+/* install externally computed reference weights (the legacy CudaComputeH gets
+ * bs_counter / bs_ref / bs_index_ref / Href from its caller every call) */
+int nid_set_href_state(nid_ctx *ctx, const int32_t *bs_counter, const double *Href,
+                       const double *bs_value, const int32_t *bs_index);
+
+/* ---- per Gauss-Newton / LM iteration ------------------------------------ */
+/* g2o::CudaComputeH twin: Htarget[cells], Hjoint[cells], err[cells] =
+ * (2*Hj - Href - Ht)/Hj, der[6*cells] (only when want_jac).  Output pointers
+ * may be NULL.  Only the context's own cell range is written.  Blocking. */
+int nid_evaluate(nid_ctx *ctx, const double *pose7, int want_jac, double *Htarget,
+                 double *Hjoint, double *err, double *der);
+int nid_evaluate_matrix(nid_ctx *ctx, const double *pose_colmajor16, int want_jac,
+                        double *Htarget, double *Hjoint, double *err, double *der);
+
+/* Fused: evaluate + Huber-weighted reduction over the context's cells on the
+ * device.  H36 row-major full 6x6, b6 (g2o sign: b = -sum rho1 J^T e),
+ * chi2 = sum rho0, n_active.  Blocking. */
+int nid_normal_equations(nid_ctx *ctx, const double *pose7, int want_jac, double huber_delta,
+                         double *H36, double *b6, double *chi2, int32_t *n_active);
+
+/* Non-blocking forms for pipelining and multi-GPU.  `slot` in [0, NID_SLOTS):
+ * results of a launch stay in the slot until nid_wait() collects them. */
+#define NID_SLOTS 8
+#define NID_REDUCED_LEN 32 /* [0]=chi2 [1..6]=b [7..27]=H upper triangle row-major [28]=n_active */
+int nid_launch(nid_ctx *ctx, int slot, const double *pose7, int want_jac, double huber_delta);
+int nid_wait(nid_ctx *ctx, int slot, double *H36, double *b6, double *chi2, int32_t *n_active);
+/* device address of slot's reduced block (NID_REDUCED_LEN doubles) and of its
+ * per-cell block (cells_local x NID_CELL_OUT doubles: Hc,Hj,err,J[6], pad) so
+ * that a caller can run a collective on them (RCCL all-reduce / all-gather) */
+#define NID_CELL_OUT 10
+int nid_slot_buffers(nid_ctx *ctx, int slot, void **reduced_dev, void **cellout_dev);
+/* launch variant that writes the reduced block into a caller-owned DEVICE
+ * buffer (e.g. a torch tensor that torch.distributed all-reduces) */
+int nid_launch_to(nid_ctx *ctx, int slot, const double *pose7, int want_jac, double huber_delta,
+                  void *reduced_dev);
+int nid_unpack_reduced(const double *reduced, double *H36, double *b6, double *chi2,
+                       int32_t *n_active);
+
+/* ---- introspection / tests ---------------------------------------------- */
+/* per-pixel intermediates of the most recent nid_evaluate* in image order
+ * (NaN / -1 where a pixel was not visited); any pointer may be NULL */
+int nid_debug_enable_pixel_dump(nid_ctx *ctx, int enable);
+int nid_debug_get_pixel_dump(nid_ctx *ctx, double *u, double *v, double *ic, int32_t *jc,
+                             double *wc4);
+/* host evaluation of the closed-form B-spline used by the kernels */
+void nid_bspline4_host(double u, int bin_num, double *B4, double *D4);
+/* host twin of the kernels' division-by-small-constant helper */
+double nid_div_small_host(double x, double d);
+/* timing of the last launch on its stream, ms (hipEvent) */
+int nid_last_kernel_ms(nid_ctx *ctx, int slot, float *eval_ms, float *reduce_ms);
+int nid_enable_timing(nid_ctx *ctx, int enable);
+/* algorithmic (contract) bytes of one evaluation over this context's cells:
+ * 68 B per pixel + 64 B per cell */
+int64_t nid_contract_bytes(const nid_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,294 @@
+"""ctypes binding of the C-ABI (include/nid/nid_c.h) exported by libnid_hip.so.
+
+This is plumbing for tests and bench.py; the product is the shared library.
+Loading fails loudly when the HIP library has not been built -- there is no
+CPU fallback of any kind.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libnid_hip.so")
+
+NID_OK = 0
+NID_SLOTS = 8
+NID_REDUCED_LEN = 32
+NID_CELL_OUT = 10
+JACBOUND_CPU, JACBOUND_CUDA = 0, 1
+XFORM_QUAT, XFORM_MATRIX = 0, 1
+
+c_dp = C.POINTER(C.c_double)
+c_ip = C.POINTER(C.c_int32)
+c_u8p = C.POINTER(C.c_uint8)
+c_fp = C.POINTER(C.c_float)
+
+
+class NidConfig(C.Structure):
+    _fields_ = [("rows", C.c_int32), ("cols", C.c_int32), ("cell_num", C.c_int32),
+                ("bin_num", C.c_int32), ("bs_degree", C.c_int32), ("device", C.c_int32),
+                ("cell_begin", C.c_int32), ("cell_end", C.c_int32),
+                ("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double), ("cy", C.c_double)]
+
+
+# every symbol include/nid/nid_c.h declares (tests/test_abi.py checks the export table)
+SYMBOLS = [
+    "nid_abi_version", "nid_status_string", "nid_last_error", "nid_device_count", "nid_create",
+    "nid_destroy", "nid_set_options", "nid_set_stream", "nid_set_block_threads",
+    "nid_set_reference_depth", "nid_set_reference_points", "nid_get_points3d", "nid_set_target_u8",
+    "nid_set_target_f64", "nid_set_reference_image_f64", "nid_compute_href",
+    "nid_compute_href_matrix", "nid_set_href_state", "nid_evaluate", "nid_evaluate_matrix",
+    "nid_normal_equations", "nid_launch", "nid_wait", "nid_slot_buffers", "nid_launch_to",
+    "nid_unpack_reduced", "nid_debug_enable_pixel_dump", "nid_debug_get_pixel_dump",
+    "nid_bspline4_host", "nid_div_small_host", "nid_last_kernel_ms", "nid_enable_timing",
+    "nid_contract_bytes",
+]
+
+_lib = None
+
+
+class NidError(RuntimeError):
+    pass
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise NidError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'`"
+                       " (there is no CPU fallback)")
+    lib = C.CDLL(LIB_PATH)
+    vp = C.c_void_p
+    lib.nid_abi_version.restype = C.c_int
+    lib.nid_status_string.restype = C.c_char_p
+    lib.nid_status_string.argtypes = [C.c_int]
+    lib.nid_last_error.restype = C.c_char_p
+    lib.nid_last_error.argtypes = [vp]
+    lib.nid_device_count.restype = C.c_int
+    lib.nid_create.argtypes = [C.POINTER(NidConfig), C.POINTER(vp)]
+    lib.nid_destroy.argtypes = [vp]
+    lib.nid_set_options.argtypes = [vp, C.c_int, C.c_int]
+    lib.nid_set_stream.argtypes = [vp, vp]
+    lib.nid_set_block_threads.argtypes = [vp, C.c_int]
+    lib.nid_set_reference_depth.argtypes = [vp, c_dp, c_u8p, c_dp]
+    lib.nid_set_reference_points.argtypes = [vp, c_dp, c_u8p]
+    lib.nid_get_points3d.argtypes = [vp, c_dp]
+    lib.nid_set_target_u8.argtypes = [vp, c_u8p]
+    lib.nid_set_target_f64.argtypes = [vp, c_dp]
+    lib.nid_set_reference_image_f64.argtypes = [c_dp, C.c_int64, c_u8p]
+    lib.nid_compute_href.argtypes = [vp, c_dp, c_ip, c_dp, c_dp, c_ip]
+    lib.nid_compute_href_matrix.argtypes = [vp, c_dp, c_ip, c_dp, c_dp, c_ip]
+    lib.nid_set_href_state.argtypes = [vp, c_ip, c_dp, c_dp, c_ip]
+    lib.nid_evaluate.argtypes = [vp, c_dp, C.c_int, c_dp, c_dp, c_dp, c_dp]
+    lib.nid_evaluate_matrix.argtypes = [vp, c_dp, C.c_int, c_dp, c_dp, c_dp, c_dp]
+    lib.nid_normal_equations.argtypes = [vp, c_dp, C.c_int, C.c_double, c_dp, c_dp, c_dp, c_ip]
+    lib.nid_launch.argtypes = [vp, C.c_int, c_dp, C.c_int, C.c_double]
+    lib.nid_launch_to.argtypes = [vp, C.c_int, c_dp, C.c_int, C.c_double, vp]
+    lib.nid_wait.argtypes = [vp, C.c_int, c_dp, c_dp, c_dp, c_ip]
+    lib.nid_slot_buffers.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(vp)]
+    lib.nid_unpack_reduced.argtypes = [c_dp, c_dp, c_dp, c_dp, c_ip]
+    lib.nid_debug_enable_pixel_dump.argtypes = [vp, C.c_int]
+    lib.nid_debug_get_pixel_dump.argtypes = [vp, c_dp, c_dp, c_dp, c_ip, c_dp]
+    lib.nid_bspline4_host.restype = None
+    lib.nid_bspline4_host.argtypes = [C.c_double, C.c_int, c_dp, c_dp]
+    lib.nid_div_small_host.restype = C.c_double
+    lib.nid_div_small_host.argtypes = [C.c_double, C.c_double]
+    lib.nid_last_kernel_ms.argtypes = [vp, C.c_int, c_fp, c_fp]
+    lib.nid_enable_timing.argtypes = [vp, C.c_int]
+    lib.nid_contract_bytes.restype = C.c_int64
+    lib.nid_contract_bytes.argtypes = [vp]
+    _lib = lib
+    return lib
+
+
+def _d(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _dp(a):
+    return a.ctypes.data_as(c_dp) if a is not None else None
+
+
+def _ip(a):
+    return a.ctypes.data_as(c_ip) if a is not None else None
+
+
+def _u8(a):
+    return np.ascontiguousarray(a, dtype=np.uint8)
+
+
+class Context:
+    """One frame pair on one MI355X (or one cell shard of it)."""
+
+    def __init__(self, rows, cols, cell_num, bin_num, fx, fy, cx, cy, device=0, cell_begin=0,
+                 cell_end=0, jac_bound=JACBOUND_CPU, xform=XFORM_QUAT):
+        self.lib = load()
+        cfg = NidConfig(rows, cols, cell_num, bin_num, 3, device, cell_begin, cell_end, fx, fy, cx, cy)
+        h = C.c_void_p()
+        rc = self.lib.nid_create(C.byref(cfg), C.byref(h))
+        if rc != NID_OK:
+            raise NidError(f"nid_create: {self.lib.nid_status_string(rc).decode()} ({rc})")
+        self.h = h
+        self.rows, self.cols, self.cell_num, self.bin_num = rows, cols, cell_num, bin_num
+        self.ncell = cell_num * cell_num
+        self.cell_begin = cell_begin
+        self.cell_end = cell_end if cell_end else self.ncell
+        self._check(self.lib.nid_set_options(self.h, jac_bound, xform), "nid_set_options")
+
+    def _check(self, rc, what):
+        if rc != NID_OK:
+            msg = self.lib.nid_last_error(self.h).decode() if self.h else ""
+            raise NidError(f"{what}: {self.lib.nid_status_string(rc).decode()} ({rc}) {msg}")
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.nid_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- setup --------------------------------------------------------------
+    def set_reference_depth(self, depth_m, im0, T_wc0_colmajor16):
+        d, im, T = _d(depth_m).reshape(-1), _u8(im0).reshape(-1), _d(T_wc0_colmajor16)
+        assert d.size == self.rows * self.cols and im.size == d.size and T.size == 16
+        self._check(self.lib.nid_set_reference_depth(self.h, _dp(d), im.ctypes.data_as(c_u8p), _dp(T)),
+                    "nid_set_reference_depth")
+
+    def set_reference_points(self, points3d, im0):
+        p, im = _d(points3d).reshape(-1), _u8(im0).reshape(-1)
+        assert p.size == 3 * self.rows * self.cols and im.size == self.rows * self.cols
+        self._check(self.lib.nid_set_reference_points(self.h, _dp(p), im.ctypes.data_as(c_u8p)),
+                    "nid_set_reference_points")
+
+    def get_points3d(self):
+        out = np.empty(3 * self.rows * self.cols)
+        self._check(self.lib.nid_get_points3d(self.h, _dp(out)), "nid_get_points3d")
+        return out
+
+    def set_target(self, im1):
+        im = _u8(im1).reshape(-1)
+        assert im.size == self.rows * self.cols
+        self._check(self.lib.nid_set_target_u8(self.h, im.ctypes.data_as(c_u8p)), "nid_set_target_u8")
+
+    def compute_href(self, pose7, dump=False):
+        cnt = np.zeros(self.ncell, dtype=np.int32)
+        href = np.full(self.ncell, np.nan)
+        N = self.rows * self.cols
+        bsv = np.zeros((N, 4)) if dump else None
+        bsi = np.zeros(N, dtype=np.int32) if dump else None
+        self._check(self.lib.nid_compute_href(self.h, _dp(_d(pose7)), _ip(cnt), _dp(href), _dp(bsv), _ip(bsi)),
+                    "nid_compute_href")
+        return (cnt, href, bsv, bsi) if dump else (cnt, href)
+
+    # ---- per iteration --------------------------------------------------------
+    def evaluate(self, pose7, want_jac=True):
+        Hc = np.full(self.ncell, np.nan)
+        Hj = np.full(self.ncell, np.nan)
+        err = np.full(self.ncell, np.nan)
+        J = np.full((self.ncell, 6), np.nan) if want_jac else None
+        self._check(self.lib.nid_evaluate(self.h, _dp(_d(pose7)), 1 if want_jac else 0, _dp(Hc), _dp(Hj),
+                                          _dp(err), _dp(J)), "nid_evaluate")
+        return Hc, Hj, err, J
+
+    def evaluate_matrix(self, pose16, want_jac=True):
+        Hc = np.full(self.ncell, np.nan)
+        Hj = np.full(self.ncell, np.nan)
+        err = np.full(self.ncell, np.nan)
+        J = np.full((self.ncell, 6), np.nan) if want_jac else None
+        self._check(self.lib.nid_evaluate_matrix(self.h, _dp(_d(pose16)), 1 if want_jac else 0, _dp(Hc),
+                                                 _dp(Hj), _dp(err), _dp(J)), "nid_evaluate_matrix")
+        return Hc, Hj, err, J
+
+    def normal_equations(self, pose7, delta, want_jac=True):
+        H = np.zeros(36)
+        b = np.zeros(6)
+        chi2 = C.c_double(0)
+        na = C.c_int32(0)
+        self._check(self.lib.nid_normal_equations(self.h, _dp(_d(pose7)), 1 if want_jac else 0, float(delta),
+                                                  _dp(H), _dp(b), C.byref(chi2), C.byref(na)),
+                    "nid_normal_equations")
+        return H.reshape(6, 6), b, chi2.value, na.value
+
+    def launch(self, slot, pose7, delta, want_jac=True, reduced_dev=None):
+        p = _d(pose7)
+        if reduced_dev is None:
+            rc = self.lib.nid_launch(self.h, slot, _dp(p), 1 if want_jac else 0, float(delta))
+        else:
+            rc = self.lib.nid_launch_to(self.h, slot, _dp(p), 1 if want_jac else 0, float(delta),
+                                        C.c_void_p(reduced_dev))
+        self._check(rc, "nid_launch")
+
+    def wait(self, slot):
+        H = np.zeros(36)
+        b = np.zeros(6)
+        chi2 = C.c_double(0)
+        na = C.c_int32(0)
+        self._check(self.lib.nid_wait(self.h, slot, _dp(H), _dp(b), C.byref(chi2), C.byref(na)), "nid_wait")
+        return H.reshape(6, 6), b, chi2.value, na.value
+
+    def set_stream(self, stream_handle):
+        self._check(self.lib.nid_set_stream(self.h, C.c_void_p(stream_handle)), "nid_set_stream")
+
+    def set_block_threads(self, n):
+        self._check(self.lib.nid_set_block_threads(self.h, int(n)), "nid_set_block_threads")
+
+    def enable_timing(self, on=True):
+        self._check(self.lib.nid_enable_timing(self.h, 1 if on else 0), "nid_enable_timing")
+
+    def last_kernel_ms(self, slot):
+        a, b = C.c_float(0), C.c_float(0)
+        self._check(self.lib.nid_last_kernel_ms(self.h, slot, C.byref(a), C.byref(b)), "nid_last_kernel_ms")
+        return a.value, b.value
+
+    def contract_bytes(self):
+        return int(self.lib.nid_contract_bytes(self.h))
+
+    # ---- debug ----------------------------------------------------------------
+    def enable_pixel_dump(self, on=True):
+        self._check(self.lib.nid_debug_enable_pixel_dump(self.h, 1 if on else 0), "nid_debug_enable_pixel_dump")
+
+    def pixel_dump(self):
+        N = self.rows * self.cols
+        u = np.zeros(N); v = np.zeros(N); ic = np.zeros(N)
+        jc = np.zeros(N, dtype=np.int32); wc = np.zeros((N, 4))
+        self._check(self.lib.nid_debug_get_pixel_dump(self.h, _dp(u), _dp(v), _dp(ic), _ip(jc), _dp(wc)),
+                    "nid_debug_get_pixel_dump")
+        return dict(u=u, v=v, ic=ic, jc=jc, wc=wc)
+
+
+def unpack_reduced(r):
+    lib = load()
+    r = _d(r)
+    H = np.zeros(36)
+    b = np.zeros(6)
+    chi2 = C.c_double(0)
+    na = C.c_int32(0)
+    lib.nid_unpack_reduced(_dp(r), _dp(H), _dp(b), C.byref(chi2), C.byref(na))
+    return H.reshape(6, 6), b, chi2.value, na.value
+
+
+def bspline4_host(u, bin_num):
+    B = np.zeros(4)
+    D = np.zeros(4)
+    load().nid_bspline4_host(float(u), int(bin_num), _dp(B), _dp(D))
+    return B, D
+
+
+def from_pair(pair, bin_num, device=0, cell_begin=0, cell_end=0, jac_bound=JACBOUND_CPU, xform=XFORM_QUAT):
+    """Context set up like the reference's main() (NID_pose_estimation.cpp:253-257):
+    back-projection (on the device) + target image; the caller runs compute_href."""
+    import importlib
+    synth = importlib.import_module("nid-pose-estimation_amd.synth")
+    ctx = Context(pair.rows, pair.cols, pair.cell, bin_num, pair.fx, pair.fy, pair.cx, pair.cy, device=device,
+                  cell_begin=cell_begin, cell_end=cell_end, jac_bound=jac_bound, xform=xform)
+    ctx.set_reference_depth(pair.depth_m, pair.im0, synth.matrix_colmajor16(pair.T_wc0))
+    ctx.set_target(pair.im1)
+    return ctx

@@ -1,0 +1,690 @@
+// nid_capi.hip -- context management and the C-ABI of include/nid/nid_c.h.
+//
+// Host side of the operator boundary that replaces the reference's three
+// CUDA host wrappers (Calculate3Dpoint CudaPoints3d.cu:35-73, CudaComputeHref
+// CudaComputeHref.cu:139-222, g2o::CudaComputeH computeH.cu:373-502).  Unlike
+// those, nothing is allocated, zeroed or re-uploaded per call: every buffer is
+// persistent in the context, the pose travels as a kernel argument, and a call
+// is [evaluation kernel -> reduction kernel -> small D2H].
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "nid/nid_c.h"
+#include "nid_kernels.hip.h"
+
+using namespace nid;
+
+namespace {
+
+struct Slot {
+  double *cellout_dev = nullptr;
+  double *reduced_dev = nullptr;
+  double *cellout_host = nullptr;  // pinned
+  double *reduced_host = nullptr;  // pinned
+  hipEvent_t done = nullptr, e0 = nullptr, e1 = nullptr, e2 = nullptr;
+  bool pending = false;
+  bool timed = false;
+  bool external_target = false;
+};
+
+}  // namespace
+
+struct nid_ctx {
+  nid_config cfg{};
+  Geometry g{};
+  int jac_bound = NID_JACBOUND_CPU;
+  int xform = NID_XFORM_QUAT;
+  int block_threads = 0;
+  hipStream_t own_stream = nullptr, stream = nullptr;
+  Tiles t{};
+  uint8_t *im1_dev = nullptr, *im0_dev = nullptr;
+  double *depth_dev = nullptr, *points_dev = nullptr, *Twc_dev = nullptr;
+  int *Nc_dev = nullptr;
+  double *Href_dev = nullptr;
+  double *dbg_u = nullptr, *dbg_v = nullptr, *dbg_ic = nullptr, *dbg_wc = nullptr;
+  int *dbg_jc = nullptr;
+  bool dbg_enabled = false;
+  bool timing = false;
+  bool have_ref = false, have_target = false, have_href = false, ref_from_depth = false;
+  double hist_scale = 0, hist_inv_scale = 0;
+  Slot slots[NID_SLOTS];
+  std::string last_error;
+};
+
+namespace {
+
+#define NID_HIP(ctx, expr)                                                            \
+  do {                                                                                \
+    hipError_t _e = (expr);                                                           \
+    if (_e != hipSuccess) {                                                           \
+      (ctx)->last_error = std::string(#expr) + ": " + hipGetErrorString(_e);          \
+      return NID_ERR_HIP;                                                             \
+    }                                                                                 \
+  } while (0)
+
+template <typename T>
+int dev_alloc(nid_ctx *ctx, T **p, size_t n) {
+  NID_HIP(ctx, hipMalloc(reinterpret_cast<void **>(p), n * sizeof(T)));
+  return NID_OK;
+}
+
+void pose_from_pose7(const double *p, int mode, Pose *out) {
+  // to_homogeneous_matrix (se3quat.h:270-278) = Eigen toRotationMatrix
+  for (int i = 0; i < 7; i++) out->q[i] = p[i];
+  const double x = p[0], y = p[1], z = p[2], w = p[3];
+  const double tx = 2 * x, ty = 2 * y, tz = 2 * z;
+  const double twx = tx * w, twy = ty * w, twz = tz * w;
+  const double txx = tx * x, txy = ty * x, txz = tz * x;
+  const double tyy = ty * y, tyz = tz * y, tzz = tz * z;
+  double *M = out->M;
+  M[0] = 1 - (tyy + tzz); M[1] = txy - twz;       M[2] = txz + twy;        M[3] = p[4];
+  M[4] = txy + twz;       M[5] = 1 - (txx + tzz); M[6] = tyz - twx;        M[7] = p[5];
+  M[8] = txz - twy;       M[9] = tyz + twx;       M[10] = 1 - (txx + tyy); M[11] = p[6];
+  out->mode = mode;
+}
+
+void pose_from_matrix16(const double *m, Pose *out) {
+  for (int i = 0; i < 7; i++) out->q[i] = 0.0;
+  out->q[3] = 1.0;
+  for (int r = 0; r < 3; r++)
+    for (int c = 0; c < 4; c++) out->M[4 * r + c] = m[c * 4 + r];
+  out->mode = NID_XFORM_MATRIX;
+}
+
+size_t eval_lds_bytes(const Geometry &g, int nt) {
+  const int nbins = g.nb * g.nb + g.nb;
+  return (size_t)nbins * kHistCopies * 8 + (size_t)((nbins + 1) & ~1) * 8 + (size_t)12 * (nt / 64) * 8;
+}
+
+// (threads, pixels per thread) pairs the evaluation kernel is instantiated for
+#define NID_EVAL_CASES(X) \
+  X(256, 1) X(256, 2) X(256, 3) X(256, 4) X(256, 5) X(256, 6) X(256, 8) \
+  X(512, 3) X(640, 2) X(1024, 2) X(1024, 4) X(1024, 8)
+
+bool pick_eval_shape(const nid_ctx *ctx, int *nt, int *ppt) {
+  const int ps = ctx->g.pstride;
+  auto instantiated = [](int t, int p) {
+#define X(T, P) if (t == T && p == P) return true;
+    NID_EVAL_CASES(X)
+#undef X
+    return false;
+  };
+  int want = ctx->block_threads;
+  if (want == 0) {
+    const char *env = getenv("NID_BLOCK_THREADS");
+    if (env) want = atoi(env);
+  }
+  if (want > 0) {
+    int p = (ps + want - 1) / want;
+    if (want == 256 && p == 7) p = 8;
+    if (instantiated(want, p)) { *nt = want; *ppt = p; return true; }
+    return false;
+  }
+  if (ps <= 2048) {
+    int p = (ps + 255) / 256;
+    if (p == 7) p = 8;
+    *nt = 256; *ppt = p;
+    return instantiated(256, p);
+  }
+  if (ps <= 8192) {
+    int p = (ps + 1023) / 1024;
+    p = p <= 2 ? 2 : (p <= 4 ? 4 : 8);
+    *nt = 1024; *ppt = p;
+    return true;
+  }
+  return false;
+}
+
+template <int NT, int PPT>
+void launch_eval_t(const EvalParams &P, bool jac, size_t lds, hipStream_t s) {
+  if (jac)
+    hipLaunchKernelGGL((k_eval<NT, PPT, true>), dim3(P.g.nloc), dim3(NT), lds, s, P);
+  else
+    hipLaunchKernelGGL((k_eval<NT, PPT, false>), dim3(P.g.nloc), dim3(NT), lds, s, P);
+}
+
+int launch_eval(nid_ctx *ctx, const EvalParams &P, bool jac) {
+  int nt = 0, ppt = 0;
+  if (!pick_eval_shape(ctx, &nt, &ppt)) return NID_ERR_UNSUPPORTED;
+  const size_t lds = eval_lds_bytes(P.g, nt);
+  if (lds > 160 * 1024) return NID_ERR_UNSUPPORTED;
+#define X(T, PP) \
+  if (nt == T && ppt == PP) { launch_eval_t<T, PP>(P, jac, lds, ctx->stream); NID_HIP(ctx, hipGetLastError()); return NID_OK; }
+  NID_EVAL_CASES(X)
+#undef X
+  return NID_ERR_UNSUPPORTED;
+}
+
+void fill_eval_params(nid_ctx *ctx, const Pose &pose, double *cellout, EvalParams *P) {
+  P->g = ctx->g;
+  P->pose = pose;
+  P->t = ctx->t;
+  P->im1 = ctx->im1_dev;
+  P->Nc = ctx->Nc_dev;
+  P->Href = ctx->Href_dev;
+  P->cellout = cellout;
+  P->jac_cols = (ctx->jac_bound == NID_JACBOUND_CPU) ? ctx->g.cols - 1 : ctx->g.cols;
+  P->hist_scale = ctx->hist_scale;
+  P->hist_inv_scale = ctx->hist_inv_scale;
+  if (ctx->dbg_enabled) {
+    P->dbg_u = ctx->dbg_u; P->dbg_v = ctx->dbg_v; P->dbg_ic = ctx->dbg_ic;
+    P->dbg_wc = ctx->dbg_wc; P->dbg_jc = ctx->dbg_jc;
+  } else {
+    P->dbg_u = P->dbg_v = P->dbg_ic = P->dbg_wc = nullptr;
+    P->dbg_jc = nullptr;
+  }
+}
+
+int check_ready(nid_ctx *ctx) {
+  if (!ctx) return NID_ERR_INVALID_ARG;
+  if (!ctx->have_ref || !ctx->have_target || !ctx->have_href) {
+    ctx->last_error = "reference / target / href state not set";
+    return NID_ERR_STATE;
+  }
+  return NID_OK;
+}
+
+int launch_slot(nid_ctx *ctx, int slot, const Pose &pose, int want_jac, double delta,
+                void *reduced_target) {
+  int rc = check_ready(ctx);
+  if (rc) return rc;
+  if (slot < 0 || slot >= NID_SLOTS) return NID_ERR_INVALID_ARG;
+  Slot &S = ctx->slots[slot];
+  EvalParams P;
+  fill_eval_params(ctx, pose, S.cellout_dev, &P);
+  if (ctx->dbg_enabled) {
+    const size_t N = (size_t)ctx->g.rows * ctx->g.cols;
+    NID_HIP(ctx, hipMemsetAsync(ctx->dbg_u, 0xFF, N * 8, ctx->stream));
+    NID_HIP(ctx, hipMemsetAsync(ctx->dbg_v, 0xFF, N * 8, ctx->stream));
+    NID_HIP(ctx, hipMemsetAsync(ctx->dbg_ic, 0xFF, N * 8, ctx->stream));
+    NID_HIP(ctx, hipMemsetAsync(ctx->dbg_wc, 0xFF, N * 32, ctx->stream));
+    NID_HIP(ctx, hipMemsetAsync(ctx->dbg_jc, 0xFF, N * 4, ctx->stream));
+  }
+  S.timed = ctx->timing;
+  if (S.timed) NID_HIP(ctx, hipEventRecord(S.e0, ctx->stream));
+  rc = launch_eval(ctx, P, want_jac != 0);
+  if (rc) return rc;
+  if (S.timed) NID_HIP(ctx, hipEventRecord(S.e1, ctx->stream));
+  double *target = reduced_target ? static_cast<double *>(reduced_target) : S.reduced_dev;
+  const float dsqr = (float)(delta * delta);  // RobustKernelHuber::setDelta, float dsqr
+  hipLaunchKernelGGL(k_reduce, dim3(1), dim3(256), 0, ctx->stream, S.cellout_dev, ctx->g.nloc,
+                     want_jac ? 1 : 0, delta, dsqr, target);
+  NID_HIP(ctx, hipGetLastError());
+  if (S.timed) NID_HIP(ctx, hipEventRecord(S.e2, ctx->stream));
+  S.external_target = reduced_target != nullptr;
+  if (!S.external_target)
+    NID_HIP(ctx, hipMemcpyAsync(S.reduced_host, S.reduced_dev, kReducedLen * sizeof(double),
+                                hipMemcpyDeviceToHost, ctx->stream));
+  NID_HIP(ctx, hipEventRecord(S.done, ctx->stream));
+  S.pending = true;
+  return NID_OK;
+}
+
+int evaluate_common(nid_ctx *ctx, const Pose &pose, int want_jac, double *Ht, double *Hj,
+                    double *err, double *der) {
+  int rc = check_ready(ctx);
+  if (rc) return rc;
+  Slot &S = ctx->slots[0];
+  EvalParams P;
+  fill_eval_params(ctx, pose, S.cellout_dev, &P);
+  if (ctx->dbg_enabled) {
+    const size_t N = (size_t)ctx->g.rows * ctx->g.cols;
+    NID_HIP(ctx, hipMemsetAsync(ctx->dbg_u, 0xFF, N * 8, ctx->stream));
+    NID_HIP(ctx, hipMemsetAsync(ctx->dbg_v, 0xFF, N * 8, ctx->stream));
+    NID_HIP(ctx, hipMemsetAsync(ctx->dbg_ic, 0xFF, N * 8, ctx->stream));
+    NID_HIP(ctx, hipMemsetAsync(ctx->dbg_wc, 0xFF, N * 32, ctx->stream));
+    NID_HIP(ctx, hipMemsetAsync(ctx->dbg_jc, 0xFF, N * 4, ctx->stream));
+  }
+  rc = launch_eval(ctx, P, want_jac != 0);
+  if (rc) return rc;
+  const size_t bytes = (size_t)ctx->g.nloc * kCellOut * sizeof(double);
+  NID_HIP(ctx, hipMemcpyAsync(S.cellout_host, S.cellout_dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  NID_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  for (int cl = 0; cl < ctx->g.nloc; cl++) {
+    const double *o = S.cellout_host + (size_t)cl * kCellOut;
+    const int c = ctx->g.cell_begin + cl;
+    if (Ht) Ht[c] = o[0];
+    if (Hj) Hj[c] = o[1];
+    if (err) err[c] = o[2];
+    if (der && want_jac) for (int n = 0; n < 6; n++) der[6 * c + n] = o[3 + n];
+  }
+  return NID_OK;
+}
+
+int href_common(nid_ctx *ctx, const Pose &pose, int32_t *bs_counter, double *Href, double *bs_value,
+                int32_t *bs_index) {
+  if (!ctx) return NID_ERR_INVALID_ARG;
+  if (!ctx->have_ref) { ctx->last_error = "reference not set"; return NID_ERR_STATE; }
+  hipLaunchKernelGGL((k_href<256>), dim3(ctx->g.nloc), dim3(256), 0, ctx->stream, ctx->g, pose, ctx->t,
+                     ctx->Nc_dev, ctx->Href_dev, ctx->hist_scale, ctx->hist_inv_scale);
+  NID_HIP(ctx, hipGetLastError());
+  const int nloc = ctx->g.nloc;
+  std::vector<int> nc(nloc);
+  std::vector<double> hr(nloc);
+  NID_HIP(ctx, hipMemcpyAsync(nc.data(), ctx->Nc_dev, nloc * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  NID_HIP(ctx, hipMemcpyAsync(hr.data(), ctx->Href_dev, nloc * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  NID_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  for (int cl = 0; cl < nloc; cl++) {
+    if (bs_counter) bs_counter[ctx->g.cell_begin + cl] = nc[cl];
+    if (Href) Href[ctx->g.cell_begin + cl] = hr[cl];
+  }
+  if (bs_value || bs_index) {
+    const Geometry &g = ctx->g;
+    const size_t plane = (size_t)g.nloc * g.pstride;
+    std::vector<double> W(bs_value ? 4 * plane : 0);
+    std::vector<int8_t> JR(plane);
+    if (bs_value) NID_HIP(ctx, hipMemcpy(W.data(), ctx->t.W, 4 * plane * sizeof(double), hipMemcpyDeviceToHost));
+    NID_HIP(ctx, hipMemcpy(JR.data(), ctx->t.JR, plane, hipMemcpyDeviceToHost));
+    for (int cl = 0; cl < g.nloc; cl++) {
+      const int c = g.cell_begin + cl, ci = c / g.cell_num, cj = c % g.cell_num;
+      for (int s = 0; s < g.ps; s++) {
+        const size_t id = (size_t)(ci * g.rb + s / g.cb) * g.cols + cj * g.cb + s % g.cb;
+        const size_t gi = (size_t)cl * g.pstride + s;
+        if (bs_value) for (int k = 0; k < 4; k++) bs_value[4 * id + k] = W[k * plane + gi];
+        if (bs_index) bs_index[id] = JR[gi];
+      }
+    }
+  }
+  ctx->have_href = true;
+  return NID_OK;
+}
+
+int upload_tiles(nid_ctx *ctx, const double *depth_m, const double *points3d, const uint8_t *im0,
+                 const double *Twc) {
+  const Geometry &g = ctx->g;
+  const size_t N = (size_t)g.rows * g.cols;
+  NID_HIP(ctx, hipMemcpyAsync(ctx->im0_dev, im0, N, hipMemcpyHostToDevice, ctx->stream));
+  const double *depth_dev = nullptr, *points_dev = nullptr;
+  if (depth_m) {
+    NID_HIP(ctx, hipMemcpyAsync(ctx->depth_dev, depth_m, N * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    NID_HIP(ctx, hipMemcpyAsync(ctx->Twc_dev, Twc, 16 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    depth_dev = ctx->depth_dev;
+  } else {
+    if (!ctx->points_dev) { int rc = dev_alloc(ctx, &ctx->points_dev, 3 * N); if (rc) return rc; }
+    NID_HIP(ctx, hipMemcpyAsync(ctx->points_dev, points3d, 3 * N * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    points_dev = ctx->points_dev;
+  }
+  const long total = (long)g.nloc * g.pstride;
+  hipLaunchKernelGGL(k_tile, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, g, depth_dev,
+                     points_dev, ctx->im0_dev, ctx->Twc_dev, ctx->t, (double *)nullptr);
+  NID_HIP(ctx, hipGetLastError());
+  NID_HIP(ctx, hipStreamSynchronize(ctx->stream));  // host source buffers may be released by the caller
+  ctx->have_ref = true;
+  ctx->have_href = false;
+  ctx->ref_from_depth = depth_m != nullptr;
+  return NID_OK;
+}
+
+}  // namespace
+
+// ===========================================================================
+extern "C" {
+
+int nid_abi_version(void) { return NID_ABI_VERSION; }
+
+const char *nid_status_string(int s) {
+  switch (s) {
+    case NID_OK: return "ok";
+    case NID_ERR_INVALID_ARG: return "invalid argument";
+    case NID_ERR_NO_DEVICE: return "no HIP device";
+    case NID_ERR_HIP: return "HIP runtime error";
+    case NID_ERR_UNSUPPORTED: return "unsupported shape";
+    case NID_ERR_STATE: return "call order: reference/target/href state missing";
+    case NID_ERR_NOMEM: return "out of memory";
+    default: return "unknown status";
+  }
+}
+
+const char *nid_last_error(const nid_ctx *ctx) { return ctx ? ctx->last_error.c_str() : ""; }
+
+int nid_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int nid_create(const nid_config *cfg, nid_ctx **out) {
+  if (!cfg || !out) return NID_ERR_INVALID_ARG;
+  *out = nullptr;
+  if (cfg->bs_degree != 3 || cfg->bin_num < 4 || cfg->bin_num > kMaxBins || cfg->cell_num < 1 ||
+      cfg->rows < cfg->cell_num || cfg->cols < cfg->cell_num)
+    return NID_ERR_INVALID_ARG;
+  const int ncell = cfg->cell_num * cfg->cell_num;
+  int cb_ = cfg->cell_begin, ce_ = cfg->cell_end;
+  if (cb_ == 0 && ce_ == 0) ce_ = ncell;
+  if (cb_ < 0 || ce_ > ncell || cb_ >= ce_) return NID_ERR_INVALID_ARG;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return NID_ERR_NO_DEVICE;
+  if (cfg->device < 0 || cfg->device >= ndev) return NID_ERR_INVALID_ARG;
+  nid_ctx *ctx = new (std::nothrow) nid_ctx();
+  if (!ctx) return NID_ERR_NOMEM;
+  ctx->cfg = *cfg;
+  Geometry &g = ctx->g;
+  g.rows = cfg->rows; g.cols = cfg->cols; g.cell_num = cfg->cell_num;
+  g.rb = cfg->rows / cfg->cell_num; g.cb = cfg->cols / cfg->cell_num;
+  g.ps = g.rb * g.cb; g.pstride = (g.ps + 63) & ~63;
+  g.cell_begin = cb_; g.nloc = ce_ - cb_;
+  g.nb = cfg->bin_num; g.S = cfg->bin_num - 3;
+  g.fx = cfg->fx; g.fy = cfg->fy; g.cx = cfg->cx; g.cy = cfg->cy;
+  if (g.ps > 8192) { delete ctx; return NID_ERR_UNSUPPORTED; }
+  int bits = 0;
+  while ((1 << bits) < g.ps + 1) bits++;
+  ctx->hist_scale = std::ldexp(1.0, 62 - bits);
+  ctx->hist_inv_scale = std::ldexp(1.0, -(62 - bits));
+  auto fail = [&](int rc) { nid_destroy(ctx); return rc; };
+  if (hipSetDevice(cfg->device) != hipSuccess) return fail(NID_ERR_NO_DEVICE);
+  if (hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess) return fail(NID_ERR_HIP);
+  ctx->stream = ctx->own_stream;
+  const size_t N = (size_t)g.rows * g.cols;
+  const size_t plane = (size_t)g.nloc * g.pstride;
+  int rc;
+  if ((rc = dev_alloc(ctx, &ctx->t.X, plane))) return fail(rc);
+  if ((rc = dev_alloc(ctx, &ctx->t.Y, plane))) return fail(rc);
+  if ((rc = dev_alloc(ctx, &ctx->t.Z, plane))) return fail(rc);
+  if ((rc = dev_alloc(ctx, &ctx->t.W, 4 * plane))) return fail(rc);
+  if ((rc = dev_alloc(ctx, &ctx->t.JR, plane))) return fail(rc);
+  if ((rc = dev_alloc(ctx, &ctx->t.I0, plane))) return fail(rc);
+  if ((rc = dev_alloc(ctx, &ctx->im1_dev, N + 64))) return fail(rc);
+  if ((rc = dev_alloc(ctx, &ctx->im0_dev, N))) return fail(rc);
+  if ((rc = dev_alloc(ctx, &ctx->depth_dev, N))) return fail(rc);
+  if ((rc = dev_alloc(ctx, &ctx->Twc_dev, 16))) return fail(rc);
+  if ((rc = dev_alloc(ctx, &ctx->Nc_dev, g.nloc))) return fail(rc);
+  if ((rc = dev_alloc(ctx, &ctx->Href_dev, g.nloc))) return fail(rc);
+  for (int s = 0; s < NID_SLOTS; s++) {
+    Slot &S = ctx->slots[s];
+    if ((rc = dev_alloc(ctx, &S.cellout_dev, (size_t)g.nloc * kCellOut))) return fail(rc);
+    if ((rc = dev_alloc(ctx, &S.reduced_dev, kReducedLen))) return fail(rc);
+    if (hipHostMalloc(reinterpret_cast<void **>(&S.cellout_host), (size_t)g.nloc * kCellOut * sizeof(double),
+                      hipHostMallocDefault) != hipSuccess) return fail(NID_ERR_NOMEM);
+    if (hipHostMalloc(reinterpret_cast<void **>(&S.reduced_host), kReducedLen * sizeof(double),
+                      hipHostMallocDefault) != hipSuccess) return fail(NID_ERR_NOMEM);
+    if (hipEventCreateWithFlags(&S.done, hipEventDisableTiming) != hipSuccess) return fail(NID_ERR_HIP);
+    if (hipEventCreate(&S.e0) != hipSuccess || hipEventCreate(&S.e1) != hipSuccess ||
+        hipEventCreate(&S.e2) != hipSuccess) return fail(NID_ERR_HIP);
+  }
+  *out = ctx;
+  return NID_OK;
+}
+
+int nid_destroy(nid_ctx *ctx) {
+  if (!ctx) return NID_OK;
+  (void)hipSetDevice(ctx->cfg.device);
+  if (ctx->own_stream) (void)hipStreamSynchronize(ctx->own_stream);
+  (void)hipFree(ctx->t.X); (void)hipFree(ctx->t.Y); (void)hipFree(ctx->t.Z); (void)hipFree(ctx->t.W);
+  (void)hipFree(ctx->t.JR); (void)hipFree(ctx->t.I0);
+  (void)hipFree(ctx->im1_dev); (void)hipFree(ctx->im0_dev); (void)hipFree(ctx->depth_dev);
+  (void)hipFree(ctx->points_dev); (void)hipFree(ctx->Twc_dev);
+  (void)hipFree(ctx->Nc_dev); (void)hipFree(ctx->Href_dev);
+  (void)hipFree(ctx->dbg_u); (void)hipFree(ctx->dbg_v); (void)hipFree(ctx->dbg_ic);
+  (void)hipFree(ctx->dbg_wc); (void)hipFree(ctx->dbg_jc);
+  for (int s = 0; s < NID_SLOTS; s++) {
+    Slot &S = ctx->slots[s];
+    (void)hipFree(S.cellout_dev); (void)hipFree(S.reduced_dev);
+    if (S.cellout_host) (void)hipHostFree(S.cellout_host);
+    if (S.reduced_host) (void)hipHostFree(S.reduced_host);
+    if (S.done) (void)hipEventDestroy(S.done);
+    if (S.e0) (void)hipEventDestroy(S.e0);
+    if (S.e1) (void)hipEventDestroy(S.e1);
+    if (S.e2) (void)hipEventDestroy(S.e2);
+  }
+  if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+  delete ctx;
+  return NID_OK;
+}
+
+int nid_set_options(nid_ctx *ctx, int jac_bound_mode, int xform_mode) {
+  if (!ctx || jac_bound_mode < 0 || jac_bound_mode > 1 || xform_mode < 0 || xform_mode > 1)
+    return NID_ERR_INVALID_ARG;
+  ctx->jac_bound = jac_bound_mode;
+  ctx->xform = xform_mode;
+  return NID_OK;
+}
+
+int nid_set_stream(nid_ctx *ctx, void *hip_stream) {
+  if (!ctx) return NID_ERR_INVALID_ARG;
+  ctx->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : ctx->own_stream;
+  return NID_OK;
+}
+
+int nid_set_block_threads(nid_ctx *ctx, int threads) {
+  if (!ctx || threads < 0) return NID_ERR_INVALID_ARG;
+  const int old = ctx->block_threads;
+  ctx->block_threads = threads;
+  int nt, ppt;
+  if (!pick_eval_shape(ctx, &nt, &ppt)) { ctx->block_threads = old; return NID_ERR_UNSUPPORTED; }
+  return NID_OK;
+}
+
+int nid_set_reference_depth(nid_ctx *ctx, const double *depth_m, const uint8_t *im0, const double *Twc) {
+  if (!ctx || !depth_m || !im0 || !Twc) return NID_ERR_INVALID_ARG;
+  NID_HIP(ctx, hipSetDevice(ctx->cfg.device));
+  return upload_tiles(ctx, depth_m, nullptr, im0, Twc);
+}
+
+int nid_set_reference_points(nid_ctx *ctx, const double *points3d, const uint8_t *im0) {
+  if (!ctx || !points3d || !im0) return NID_ERR_INVALID_ARG;
+  NID_HIP(ctx, hipSetDevice(ctx->cfg.device));
+  return upload_tiles(ctx, nullptr, points3d, im0, nullptr);
+}
+
+int nid_get_points3d(nid_ctx *ctx, double *points3d) {
+  if (!ctx || !points3d) return NID_ERR_INVALID_ARG;
+  if (!ctx->have_ref) return NID_ERR_STATE;
+  NID_HIP(ctx, hipSetDevice(ctx->cfg.device));
+  const size_t N = (size_t)ctx->g.rows * ctx->g.cols;
+  if (!ctx->points_dev) { int rc = dev_alloc(ctx, &ctx->points_dev, 3 * N); if (rc) return rc; }
+  if (ctx->ref_from_depth) {
+    hipLaunchKernelGGL(k_backproject_plain, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, ctx->stream,
+                       ctx->g, ctx->depth_dev, ctx->Twc_dev, ctx->points_dev);
+    NID_HIP(ctx, hipGetLastError());
+  }
+  NID_HIP(ctx, hipMemcpyAsync(points3d, ctx->points_dev, 3 * N * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  NID_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return NID_OK;
+}
+
+int nid_set_target_u8(nid_ctx *ctx, const uint8_t *im1) {
+  if (!ctx || !im1) return NID_ERR_INVALID_ARG;
+  NID_HIP(ctx, hipSetDevice(ctx->cfg.device));
+  const size_t N = (size_t)ctx->g.rows * ctx->g.cols;
+  NID_HIP(ctx, hipMemcpyAsync(ctx->im1_dev, im1, N, hipMemcpyHostToDevice, ctx->stream));
+  NID_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->have_target = true;
+  return NID_OK;
+}
+
+int nid_set_reference_image_f64(const double *im, int64_t n, uint8_t *out) {
+  if (!im || !out || n < 0) return NID_ERR_INVALID_ARG;
+  for (int64_t i = 0; i < n; i++) {
+    const double v = im[i];
+    if (!(v >= 0.0 && v <= 255.0) || v != std::floor(v)) return NID_ERR_UNSUPPORTED;
+    out[i] = (uint8_t)v;
+  }
+  return NID_OK;
+}
+
+int nid_set_target_f64(nid_ctx *ctx, const double *im1) {
+  if (!ctx || !im1) return NID_ERR_INVALID_ARG;
+  const size_t N = (size_t)ctx->g.rows * ctx->g.cols;
+  std::vector<uint8_t> tmp(N);
+  int rc = nid_set_reference_image_f64(im1, (int64_t)N, tmp.data());
+  if (rc) { ctx->last_error = "f64 image is not u8-valued"; return rc; }
+  return nid_set_target_u8(ctx, tmp.data());
+}
+
+int nid_compute_href(nid_ctx *ctx, const double *pose7, int32_t *bs_counter, double *Href,
+                     double *bs_value, int32_t *bs_index) {
+  if (!ctx || !pose7) return NID_ERR_INVALID_ARG;
+  NID_HIP(ctx, hipSetDevice(ctx->cfg.device));
+  Pose p; pose_from_pose7(pose7, ctx->xform, &p);
+  return href_common(ctx, p, bs_counter, Href, bs_value, bs_index);
+}
+
+int nid_compute_href_matrix(nid_ctx *ctx, const double *pose16, int32_t *bs_counter, double *Href,
+                            double *bs_value, int32_t *bs_index) {
+  if (!ctx || !pose16) return NID_ERR_INVALID_ARG;
+  NID_HIP(ctx, hipSetDevice(ctx->cfg.device));
+  Pose p; pose_from_matrix16(pose16, &p);
+  return href_common(ctx, p, bs_counter, Href, bs_value, bs_index);
+}
+
+int nid_set_href_state(nid_ctx *ctx, const int32_t *bs_counter, const double *Href,
+                       const double *bs_value, const int32_t *bs_index) {
+  (void)bs_index;  // the reference bin index is recomputed from im0 for every pixel (Appendix A.2)
+  if (!ctx || !bs_counter || !Href || !bs_value) return NID_ERR_INVALID_ARG;
+  if (!ctx->have_ref) return NID_ERR_STATE;
+  NID_HIP(ctx, hipSetDevice(ctx->cfg.device));
+  const Geometry &g = ctx->g;
+  const size_t plane = (size_t)g.nloc * g.pstride;
+  std::vector<double> W(4 * plane, 0.0);
+  for (int cl = 0; cl < g.nloc; cl++) {
+    const int c = g.cell_begin + cl, ci = c / g.cell_num, cj = c % g.cell_num;
+    for (int s = 0; s < g.ps; s++) {
+      const size_t id = (size_t)(ci * g.rb + s / g.cb) * g.cols + cj * g.cb + s % g.cb;
+      const size_t gi = (size_t)cl * g.pstride + s;
+      for (int k = 0; k < 4; k++) {
+        const double w = bs_value[4 * id + k];
+        W[k * plane + gi] = std::isnan(w) ? 0.0 : w;  // CUDA-path NaN marker -> CPU-edge zero (D2)
+      }
+    }
+  }
+  NID_HIP(ctx, hipMemcpy(ctx->t.W, W.data(), 4 * plane * sizeof(double), hipMemcpyHostToDevice));
+  NID_HIP(ctx, hipMemcpy(ctx->Nc_dev, bs_counter + g.cell_begin, g.nloc * sizeof(int), hipMemcpyHostToDevice));
+  NID_HIP(ctx, hipMemcpy(ctx->Href_dev, Href + g.cell_begin, g.nloc * sizeof(double), hipMemcpyHostToDevice));
+  ctx->have_href = true;
+  return NID_OK;
+}
+
+int nid_evaluate(nid_ctx *ctx, const double *pose7, int want_jac, double *Ht, double *Hj, double *err,
+                 double *der) {
+  if (!ctx || !pose7) return NID_ERR_INVALID_ARG;
+  NID_HIP(ctx, hipSetDevice(ctx->cfg.device));
+  Pose p; pose_from_pose7(pose7, ctx->xform, &p);
+  return evaluate_common(ctx, p, want_jac, Ht, Hj, err, der);
+}
+
+int nid_evaluate_matrix(nid_ctx *ctx, const double *pose16, int want_jac, double *Ht, double *Hj,
+                        double *err, double *der) {
+  if (!ctx || !pose16) return NID_ERR_INVALID_ARG;
+  NID_HIP(ctx, hipSetDevice(ctx->cfg.device));
+  Pose p; pose_from_matrix16(pose16, &p);
+  return evaluate_common(ctx, p, want_jac, Ht, Hj, err, der);
+}
+
+int nid_unpack_reduced(const double *r, double *H36, double *b6, double *chi2, int32_t *n_active) {
+  if (!r) return NID_ERR_INVALID_ARG;
+  if (chi2) *chi2 = r[0];
+  if (b6) for (int n = 0; n < 6; n++) b6[n] = r[1 + n];
+  if (H36) {
+    int idx = 7;
+    for (int a = 0; a < 6; a++)
+      for (int b = a; b < 6; b++) { H36[a * 6 + b] = r[idx]; H36[b * 6 + a] = r[idx]; idx++; }
+  }
+  if (n_active) *n_active = (int32_t)r[28];
+  return NID_OK;
+}
+
+int nid_launch(nid_ctx *ctx, int slot, const double *pose7, int want_jac, double delta) {
+  if (!ctx || !pose7) return NID_ERR_INVALID_ARG;
+  Pose p; pose_from_pose7(pose7, ctx->xform, &p);
+  return launch_slot(ctx, slot, p, want_jac, delta, nullptr);
+}
+
+int nid_launch_to(nid_ctx *ctx, int slot, const double *pose7, int want_jac, double delta, void *reduced_dev) {
+  if (!ctx || !pose7 || !reduced_dev) return NID_ERR_INVALID_ARG;
+  Pose p; pose_from_pose7(pose7, ctx->xform, &p);
+  return launch_slot(ctx, slot, p, want_jac, delta, reduced_dev);
+}
+
+int nid_wait(nid_ctx *ctx, int slot, double *H36, double *b6, double *chi2, int32_t *n_active) {
+  if (!ctx || slot < 0 || slot >= NID_SLOTS) return NID_ERR_INVALID_ARG;
+  Slot &S = ctx->slots[slot];
+  if (!S.pending) return NID_ERR_STATE;
+  NID_HIP(ctx, hipEventSynchronize(S.done));
+  S.pending = false;
+  if (S.external_target) return NID_OK;
+  return nid_unpack_reduced(S.reduced_host, H36, b6, chi2, n_active);
+}
+
+int nid_normal_equations(nid_ctx *ctx, const double *pose7, int want_jac, double delta, double *H36,
+                         double *b6, double *chi2, int32_t *n_active) {
+  if (!ctx || !pose7) return NID_ERR_INVALID_ARG;
+  NID_HIP(ctx, hipSetDevice(ctx->cfg.device));
+  int rc = nid_launch(ctx, 0, pose7, want_jac, delta);
+  if (rc) return rc;
+  return nid_wait(ctx, 0, H36, b6, chi2, n_active);
+}
+
+int nid_slot_buffers(nid_ctx *ctx, int slot, void **reduced_dev, void **cellout_dev) {
+  if (!ctx || slot < 0 || slot >= NID_SLOTS) return NID_ERR_INVALID_ARG;
+  if (reduced_dev) *reduced_dev = ctx->slots[slot].reduced_dev;
+  if (cellout_dev) *cellout_dev = ctx->slots[slot].cellout_dev;
+  return NID_OK;
+}
+
+int nid_debug_enable_pixel_dump(nid_ctx *ctx, int enable) {
+  if (!ctx) return NID_ERR_INVALID_ARG;
+  NID_HIP(ctx, hipSetDevice(ctx->cfg.device));
+  if (enable && !ctx->dbg_u) {
+    const size_t N = (size_t)ctx->g.rows * ctx->g.cols;
+    int rc;
+    if ((rc = dev_alloc(ctx, &ctx->dbg_u, N))) return rc;
+    if ((rc = dev_alloc(ctx, &ctx->dbg_v, N))) return rc;
+    if ((rc = dev_alloc(ctx, &ctx->dbg_ic, N))) return rc;
+    if ((rc = dev_alloc(ctx, &ctx->dbg_wc, 4 * N))) return rc;
+    if ((rc = dev_alloc(ctx, &ctx->dbg_jc, N))) return rc;
+  }
+  ctx->dbg_enabled = enable != 0;
+  return NID_OK;
+}
+
+int nid_debug_get_pixel_dump(nid_ctx *ctx, double *u, double *v, double *ic, int32_t *jc, double *wc4) {
+  if (!ctx || !ctx->dbg_u) return NID_ERR_STATE;
+  NID_HIP(ctx, hipSetDevice(ctx->cfg.device));
+  const size_t N = (size_t)ctx->g.rows * ctx->g.cols;
+  NID_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (u) NID_HIP(ctx, hipMemcpy(u, ctx->dbg_u, N * 8, hipMemcpyDeviceToHost));
+  if (v) NID_HIP(ctx, hipMemcpy(v, ctx->dbg_v, N * 8, hipMemcpyDeviceToHost));
+  if (ic) NID_HIP(ctx, hipMemcpy(ic, ctx->dbg_ic, N * 8, hipMemcpyDeviceToHost));
+  if (jc) NID_HIP(ctx, hipMemcpy(jc, ctx->dbg_jc, N * 4, hipMemcpyDeviceToHost));
+  if (wc4) NID_HIP(ctx, hipMemcpy(wc4, ctx->dbg_wc, N * 32, hipMemcpyDeviceToHost));
+  return NID_OK;
+}
+
+void nid_bspline4_host(double u, int bin_num, double *B4, double *D4) {
+  double B[4], D[4];
+  nid::bspline4<true>(u, (int)std::floor(u), bin_num - 3, B, D);
+  for (int k = 0; k < 4; k++) { if (B4) B4[k] = B[k]; if (D4) D4[k] = D[k]; }
+}
+
+double nid_div_small_host(double x, double d) { return nid::div_small(x, d); }
+
+int nid_enable_timing(nid_ctx *ctx, int enable) {
+  if (!ctx) return NID_ERR_INVALID_ARG;
+  ctx->timing = enable != 0;
+  return NID_OK;
+}
+
+int nid_last_kernel_ms(nid_ctx *ctx, int slot, float *eval_ms, float *reduce_ms) {
+  if (!ctx || slot < 0 || slot >= NID_SLOTS) return NID_ERR_INVALID_ARG;
+  Slot &S = ctx->slots[slot];
+  if (!S.timed) return NID_ERR_STATE;
+  NID_HIP(ctx, hipEventSynchronize(S.e2));
+  if (eval_ms) NID_HIP(ctx, hipEventElapsedTime(eval_ms, S.e0, S.e1));
+  if (reduce_ms) NID_HIP(ctx, hipEventElapsedTime(reduce_ms, S.e1, S.e2));
+  return NID_OK;
+}
+
+int64_t nid_contract_bytes(const nid_ctx *ctx) {
+  if (!ctx) return 0;
+  return (int64_t)68 * ctx->g.nloc * ctx->g.ps + (int64_t)64 * ctx->g.nloc;
+}
+
+}  // extern "C"

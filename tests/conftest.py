@@ -1,0 +1,45 @@
+import importlib
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def synth():
+    return importlib.import_module("nid-pose-estimation_amd.synth")
+
+
+@pytest.fixture(scope="session")
+def capi():
+    return importlib.import_module("nid-pose-estimation_amd.capi")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    from oracle import oracle_py
+    oracle_py.load()
+    return oracle_py
+
+
+@pytest.fixture(scope="session")
+def pair_S(synth):
+    return synth.make_pair("S")
+
+
+@pytest.fixture(scope="session")
+def pair_S_edge(synth):
+    return synth.make_pair("S", edge_cases=True)
+
+
+@pytest.fixture(scope="session")
+def pair_A(synth):
+    return synth.make_pair("A")

@@ -1,0 +1,82 @@
+"""The C-ABI library loads without a GPU and exports every symbol that
+include/nid/nid_c.h declares; argument validation works without a device."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    txt = open(os.path.join(ROOT, "include", "nid", "nid_c.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(nid_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_header_symbols_are_exported(capi):
+    lib = capi.load()
+    declared = _declared_symbols()
+    assert len(declared) >= 30
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in nid_c.h but not exported"
+    assert sorted(capi.SYMBOLS) == declared
+    nm = subprocess.run(["nm", "-D", "--defined-only", capi.LIB_PATH], capture_output=True, text=True).stdout
+    exported = set(re.findall(r" T (nid_[a-z0-9_]+)", nm))
+    assert set(declared) <= exported
+
+
+def test_abi_version_and_strings(capi):
+    lib = capi.load()
+    assert lib.nid_abi_version() == 1
+    assert lib.nid_status_string(0) == b"ok"
+    assert b"invalid" in lib.nid_status_string(-1)
+
+
+def test_create_rejects_bad_config_without_touching_a_gpu(capi):
+    lib = capi.load()
+    h = C.c_void_p()
+    bad = capi.NidConfig(480, 640, 16, 10, 2, 0, 0, 0, 1.0, 1.0, 0.0, 0.0)      # degree != 3
+    assert lib.nid_create(C.byref(bad), C.byref(h)) == -1
+    bad = capi.NidConfig(480, 640, 16, 40, 3, 0, 0, 0, 1.0, 1.0, 0.0, 0.0)      # too many bins
+    assert lib.nid_create(C.byref(bad), C.byref(h)) == -1
+    bad = capi.NidConfig(480, 640, 16, 10, 3, 0, 200, 100, 1.0, 1.0, 0.0, 0.0)  # empty shard
+    assert lib.nid_create(C.byref(bad), C.byref(h)) == -1
+    assert lib.nid_create(None, C.byref(h)) == -1
+
+
+def test_no_device_fails_loudly(capi):
+    lib = capi.load()
+    if lib.nid_device_count() > 0:
+        pytest.skip("a GPU is visible")
+    h = C.c_void_p()
+    ok = capi.NidConfig(480, 640, 16, 10, 3, 0, 0, 0, 481.2, -480.0, 319.5, 239.5)
+    assert lib.nid_create(C.byref(ok), C.byref(h)) == -2   # NID_ERR_NO_DEVICE, no CPU fallback
+    with pytest.raises(capi.NidError):
+        capi.Context(480, 640, 16, 10, 481.2, -480.0, 319.5, 239.5)
+
+
+def test_unpack_reduced_layout(capi):
+    r = np.zeros(32)
+    r[0] = 3.5
+    r[1:7] = np.arange(1, 7)
+    r[7:28] = np.arange(21) + 10
+    r[28] = 17
+    H, b, chi2, na = capi.unpack_reduced(r)
+    assert chi2 == 3.5 and na == 17
+    assert np.array_equal(b, np.arange(1, 7))
+    assert np.array_equal(H, H.T)
+    assert H[0, 0] == 10 and H[0, 5] == 15 and H[1, 1] == 16 and H[5, 5] == 30
+
+
+def test_f64_image_conversion(capi):
+    lib = capi.load()
+    src = np.array([0.0, 1.0, 254.0, 255.0])
+    out = np.zeros(4, dtype=np.uint8)
+    assert lib.nid_set_reference_image_f64(src.ctypes.data_as(capi.c_dp), 4, out.ctypes.data_as(capi.c_u8p)) == 0
+    assert list(out) == [0, 1, 254, 255]
+    src = np.array([0.5])
+    assert lib.nid_set_reference_image_f64(src.ctypes.data_as(capi.c_dp), 1, out.ctypes.data_as(capi.c_u8p)) == -4

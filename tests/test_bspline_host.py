@@ -1,0 +1,49 @@
+"""The kernels' closed-form B-spline (csrc/nid_bspline.h, compiled for the host
+through the nid_bspline4_host hook of the C-ABI) must be BIT-identical to the
+reference recursion as restated by the oracle (types_six_dof_expmap.cpp:738-800).
+No GPU needed: this runs the host instantiation of the same header."""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+
+
+def _bits(x):
+    return np.asarray(x, dtype=np.float64).view(np.uint64)
+
+
+@pytest.mark.parametrize("nb", [4, 5, 6, 8, 10, 12, 14, 16])
+def test_closed_form_equals_recursion_bitwise(capi, oracle, nb):
+    S = nb - 3
+    rng = np.random.default_rng(nb)
+    us = np.concatenate([
+        rng.uniform(0, S, 20000),
+        np.arange(0, S, 1.0),                                   # knots incl. the u == 0 quirk
+        np.nextafter(np.arange(0, S, 1.0), np.inf),              # just right of a knot
+        np.nextafter(np.arange(1, S + 1, 1.0), -np.inf),         # just left of a knot
+        np.array([254.999 * S / 255.0, 1e-300, 5e-324]),         # clamp value, tiny, denormal
+        (rng.integers(0, 255 * 4, 4000) / 4.0) * S / 255.0,      # bilinear-like rational intensities
+    ])
+    us = us[(us >= 0) & (us < S)]
+    lib = oracle.load()
+    for u in us:
+        j = int(math.floor(u))
+        B, D = capi.bspline4_host(u, nb)
+        Bo = [lib.nid_oracle_bspline(nb, j + k, 4, float(u)) for k in range(4)]
+        Do = [lib.nid_oracle_bspline_der(nb, j + k, 4, float(u)) for k in range(4)]
+        # -0.0 vs +0.0 cannot reach any sum; compare values, and bits for non-zeros
+        for a, b in zip(list(B) + list(D), Bo + Do):
+            if a == 0.0 and b == 0.0:
+                continue
+            assert _bits(a) == _bits(b), (nb, u, B, Bo, D, Do)
+
+
+def test_div_small_is_correctly_rounded(capi):
+    lib = capi.load()
+    rng = np.random.default_rng(7)
+    xs = np.concatenate([rng.uniform(-8, 8, 200000), rng.uniform(0, 1e-3, 50000),
+                         np.ldexp(rng.uniform(1, 2, 50000), rng.integers(-60, 10, 50000))])
+    for d in (1.0, 2.0, 3.0):
+        got = np.array([lib.nid_div_small_host(float(x), d) for x in xs[:60000]])
+        assert np.array_equal(_bits(got), _bits(xs[:60000] / d)), d

@@ -1,0 +1,289 @@
+"""Parity of the HIP path (through the C-ABI) against the CPU oracle on the same
+seeded inputs.  Tolerances: per-cell Href/Hc/Hj/err
+1e-11 absolute; per-cell Jacobian 1e-9 relative to the cell array's largest
+component (summation order differs); in-bound counts, bin indices and every
+per-pixel intermediate (u, v, bilinear intensity, B-spline weights) bit-exact."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ATOL_H = 1e-11
+RTOL_J = 1e-9
+DELTA = float(np.sqrt(0.95))
+
+
+def _bits(a):
+    return np.ascontiguousarray(a, dtype=np.float64).view(np.uint64)
+
+
+def _poses(synth, pair):
+    far = synth.perturb_pose7(pair.pose_init, [0.0, 0.03, 0.0], [0.25, -0.15, 0.0])  # partially out of frame
+    near = synth.perturb_pose7(pair.pose_init, [0.002, -0.001, 0.003], [0.004, 0.002, -0.003])
+    return {"init": pair.pose_init, "true": pair.pose_true, "near": near, "far": far}
+
+
+def _compare_cells(got, ref, cnt):
+    Hc, Hj, err, J = got
+    Hc_o, Hj_o, err_o, J_o = ref
+    act = cnt >= 300
+    assert np.array_equal(np.isnan(err), ~act)
+    assert np.array_equal(np.isnan(err_o), ~act)
+    np.testing.assert_allclose(Hc[act], Hc_o[act], rtol=0, atol=ATOL_H)
+    np.testing.assert_allclose(Hj[act], Hj_o[act], rtol=0, atol=ATOL_H)
+    np.testing.assert_allclose(err[act], err_o[act], rtol=0, atol=ATOL_H)
+    if J is not None:
+        scale = np.abs(J_o[act]).max()
+        np.testing.assert_allclose(J[act], J_o[act], rtol=0, atol=RTOL_J * scale)
+        assert np.all(np.isnan(J[~act]))
+
+
+@pytest.mark.parametrize("nb", [6, 8, 10, 14])
+@pytest.mark.parametrize("which", ["plain", "edge"])
+def test_small_pair_all_stages(capi, oracle, synth, pair_S, pair_S_edge, nb, which):
+    pair = pair_S if which == "plain" else pair_S_edge
+    ctx = capi.from_pair(pair, nb)
+    o = oracle.from_pair(pair, nb)
+    # a2: back-projection is bit-exact (same operation order, no contraction)
+    pts = ctx.get_points3d()
+    m = ~np.isnan(o.points3d)
+    assert np.array_equal(np.isnan(pts), np.isnan(o.points3d))
+    assert np.array_equal(_bits(pts[m]), _bits(o.points3d[m]))
+    # a3/a4: reference stage
+    cnt, href, bsv, bsi = ctx.compute_href(pair.pose_init, dump=True)
+    cnt_o, href_o = o.compute_href(pair.pose_init)
+    assert np.array_equal(cnt, cnt_o)
+    act = cnt_o >= 300
+    assert np.array_equal(np.isnan(href), ~act)
+    np.testing.assert_allclose(href[act], href_o[act], rtol=0, atol=ATOL_H)
+    if which == "edge":
+        assert (~act).any(), "edge-case pair must contain an inactive cell"
+    for name, pose in _poses(synth, pair).items():
+        got = ctx.evaluate(pose, True)
+        ref = o.evaluate(pose, True)
+        _compare_cells(got, ref, cnt_o)
+        got_c = ctx.evaluate(pose, False)
+        assert np.array_equal(_bits(got_c[0][act]), _bits(got[0][act])), "cost-only and cost+Jacobian kernels disagree"
+        assert np.array_equal(_bits(got_c[2][act]), _bits(got[2][act]))
+    # reference weights / bin indices of the tile are the oracle's, bit for bit
+    d = o.dump_pixels()
+    valid = m.reshape(-1, 3)[:, 0]
+    G, rb, cb = pair.cell, pair.rows // pair.cell, pair.cols // pair.cell
+    rr, cc = np.divmod(np.arange(pair.rows * pair.cols), pair.cols)
+    incell = (rr < G * rb) & (cc < G * cb)
+    sel = valid & incell
+    assert np.array_equal(bsi[sel], d["jr"][sel])
+    assert np.all(bsi[incell & ~valid] == -1)
+    assert np.array_equal(_bits(bsv[sel]), _bits(d["wr"][sel]))
+
+
+@pytest.mark.parametrize("nb", [8, 10])
+def test_per_pixel_intermediates_bit_exact(capi, oracle, synth, pair_S_edge, nb):
+    pair = pair_S_edge
+    ctx = capi.from_pair(pair, nb)
+    o = oracle.from_pair(pair, nb)
+    cnt, _ = ctx.compute_href(pair.pose_init)
+    o.compute_href(pair.pose_init)
+    ctx.enable_pixel_dump(True)
+    for name, pose in _poses(synth, pair).items():
+        ctx.evaluate(pose, True)
+        o.evaluate(pose, True)
+        g = ctx.pixel_dump()
+        d = o.dump_pixels()
+        G, rb, cb = pair.cell, pair.rows // pair.cell, pair.cols // pair.cell
+        rr, cc = np.divmod(np.arange(pair.rows * pair.cols), pair.cols)
+        cell = (rr // rb) * G + cc // cb
+        visited = ~np.isnan(d["u"]) & (cnt[cell] >= 300)
+        assert visited.sum() > 1000
+        assert np.array_equal(_bits(g["u"][visited]), _bits(d["u"][visited])), name
+        assert np.array_equal(_bits(g["v"][visited]), _bits(d["v"][visited])), name
+        assert np.array_equal(g["jc"][visited], d["jc"][visited]), name
+        inb = visited & (d["jc"] >= 0)
+        assert inb.sum() > 1000
+        assert np.array_equal(_bits(g["ic"][inb]), _bits(d["ic"][inb])), name
+        assert np.array_equal(_bits(g["wc"][inb]), _bits(d["wc"][inb])), name
+    ctx.enable_pixel_dump(False)
+
+
+@pytest.mark.parametrize("jac_bound,xform", [("cpu", "quat"), ("cuda", "quat"), ("cpu", "matrix"), ("cuda", "matrix")])
+def test_semantic_switches(capi, oracle, synth, pair_S, jac_bound, xform):
+    """CPU-edge (cols-1, quaternion) vs CUDA-kernel (cols, matrix) semantics, SURVEY 0.2 / D1 / D3."""
+    pair, nb = pair_S, 10
+    ctx = capi.from_pair(pair, nb, jac_bound=capi.JACBOUND_CPU if jac_bound == "cpu" else capi.JACBOUND_CUDA,
+                         xform=capi.XFORM_QUAT if xform == "quat" else capi.XFORM_MATRIX)
+    o = oracle.from_pair(pair, nb, jac_bound=jac_bound, xform=xform)
+    cnt, _ = ctx.compute_href(pair.pose_init)
+    cnt_o, _ = o.compute_href(pair.pose_init)
+    assert np.array_equal(cnt, cnt_o)
+    for pose in _poses(synth, pair).values():
+        _compare_cells(ctx.evaluate(pose, True), o.evaluate(pose, True), cnt_o)
+    if xform == "matrix":
+        M = oracle.se3_to_matrix16(pair.pose_init)
+        a = ctx.evaluate_matrix(M, True)
+        b = ctx.evaluate(pair.pose_init, True)
+        act = cnt_o >= 300
+        assert np.array_equal(_bits(a[2][act]), _bits(b[2][act]))
+        assert np.array_equal(_bits(a[3][act]), _bits(b[3][act]))
+
+
+def test_cuda_bound_differs_only_on_the_right_border(capi, synth, pair_A):
+    """the two Jacobian bounds disagree only in cells that own a pixel with cols-4 < u <= cols-3."""
+    pair, nb = pair_A, 10
+    a = capi.from_pair(pair, nb, jac_bound=capi.JACBOUND_CPU)
+    b = capi.from_pair(pair, nb, jac_bound=capi.JACBOUND_CUDA)
+    cnt, _ = a.compute_href(pair.pose_init)
+    b.compute_href(pair.pose_init)
+    Ja = a.evaluate(pair.pose_init, True)[3]
+    Jb = b.evaluate(pair.pose_init, True)[3]
+    act = cnt >= 300
+    same = np.all(_bits(Ja) == _bits(Jb), axis=1) | ~act
+    G = pair.cell
+    diff_cells = np.where(~same)[0]
+    assert len(diff_cells) > 0
+    assert np.all(diff_cells % G >= G - 2), diff_cells
+
+
+@pytest.mark.parametrize("nb", [8, 10])
+def test_config_A_cells_and_normal_equations(capi, oracle, synth, pair_A, nb):
+    pair = pair_A
+    ctx = capi.from_pair(pair, nb)
+    o = oracle.from_pair(pair, nb)
+    cnt, href = ctx.compute_href(pair.pose_init)
+    cnt_o, href_o = o.compute_href(pair.pose_init)
+    assert np.array_equal(cnt, cnt_o)
+    act = cnt_o >= 300
+    np.testing.assert_allclose(href[act], href_o[act], rtol=0, atol=ATOL_H)
+    for name, pose in _poses(synth, pair).items():
+        got = ctx.evaluate(pose, True)
+        ref = o.evaluate(pose, True)
+        _compare_cells(got, ref, cnt_o)
+        H, b, chi2, na = ctx.normal_equations(pose, DELTA)
+        H_o, b_o, chi2_o, na_o = oracle.normal_equations(ref[2], ref[3], DELTA)
+        assert na == na_o == int(act.sum())
+        np.testing.assert_allclose(chi2, chi2_o, rtol=1e-13)
+        np.testing.assert_allclose(H, H_o, rtol=0, atol=1e-9 * np.abs(H_o).max())
+        np.testing.assert_allclose(b, b_o, rtol=0, atol=1e-9 * np.abs(b_o).max())
+        # cost-only reduction: chi2 only
+        _, _, chi2_c, na_c = ctx.normal_equations(pose, DELTA, want_jac=False)
+        assert na_c == na_o
+        np.testing.assert_allclose(chi2_c, chi2_o, rtol=1e-13)
+
+
+def test_reference_from_points_equals_reference_from_depth(capi, oracle, pair_S_edge):
+    pair, nb = pair_S_edge, 10
+    a = capi.from_pair(pair, nb)
+    o = oracle.from_pair(pair, nb)
+    b = capi.Context(pair.rows, pair.cols, pair.cell, nb, pair.fx, pair.fy, pair.cx, pair.cy)
+    b.set_reference_points(o.points3d, pair.im0)
+    b.set_target(pair.im1)
+    ca, ha = a.compute_href(pair.pose_init)
+    cb, hb = b.compute_href(pair.pose_init)
+    assert np.array_equal(ca, cb)
+    act = ca >= 300
+    assert np.array_equal(_bits(ha[act]), _bits(hb[act]))
+    ra = a.evaluate(pair.pose_init, True)
+    rb = b.evaluate(pair.pose_init, True)
+    for x, y in zip(ra, rb):
+        assert np.array_equal(_bits(x[act]), _bits(y[act]))
+
+
+def test_bitwise_reproducible_and_block_shape_independent(capi, synth, pair_A):
+    """Histograms are accumulated in 64-bit fixed point, so entropies are identical
+    bit for bit from run to run and for every workgroup shape; the Jacobian's
+    12-value tree depends on the shape only through its summation order."""
+    pair, nb = pair_A, 10
+    ctx = capi.from_pair(pair, nb)
+    cnt, _ = ctx.compute_href(pair.pose_init)
+    act = cnt >= 300
+    base = ctx.evaluate(pair.pose_init, True)
+    again = ctx.evaluate(pair.pose_init, True)
+    for x, y in zip(base, again):
+        assert np.array_equal(_bits(x[act]), _bits(y[act]))
+    for nt in (512, 640, 1024):
+        ctx.set_block_threads(nt)
+        other = ctx.evaluate(pair.pose_init, True)
+        for k in range(3):
+            assert np.array_equal(_bits(base[k][act]), _bits(other[k][act])), (nt, k)
+        scale = np.abs(base[3][act]).max()
+        np.testing.assert_allclose(other[3][act], base[3][act], rtol=0, atol=1e-12 * scale)
+    ctx.set_block_threads(0)
+
+
+def test_cell_shards_equal_the_whole(capi, synth, pair_A):
+    """Multi-GPU partition: contexts owning cell ranges reproduce the
+    unsharded per-cell outputs bit for bit; partial 6x6 blocks add up."""
+    pair, nb = pair_A, 8
+    whole = capi.from_pair(pair, nb)
+    cnt, href = whole.compute_href(pair.pose_init)
+    act = cnt >= 300
+    full = whole.evaluate(pair.pose_init, True)
+    H, b, chi2, na = whole.normal_equations(pair.pose_init, DELTA)
+    ncell = pair.cell * pair.cell
+    parts = 4
+    Hs, bs, cs, ns = np.zeros((6, 6)), np.zeros(6), 0.0, 0
+    for r in range(parts):
+        lo, hi = r * ncell // parts, (r + 1) * ncell // parts
+        sh = capi.from_pair(pair, nb, cell_begin=lo, cell_end=hi)
+        c2, h2 = sh.compute_href(pair.pose_init)
+        assert np.array_equal(c2[lo:hi], cnt[lo:hi])
+        got = sh.evaluate(pair.pose_init, True)
+        m = act[lo:hi]
+        for x, y in zip(got, full):
+            assert np.array_equal(_bits(x[lo:hi][m]), _bits(y[lo:hi][m]))
+        Hp, bp, cp, np_ = sh.normal_equations(pair.pose_init, DELTA)
+        Hs += Hp; bs += bp; cs += cp; ns += np_
+    assert ns == na
+    np.testing.assert_allclose(cs, chi2, rtol=1e-13)
+    np.testing.assert_allclose(Hs, H, rtol=0, atol=1e-12 * np.abs(H).max())
+    np.testing.assert_allclose(bs, b, rtol=0, atol=1e-12 * np.abs(b).max())
+
+
+def test_pipelined_slots(capi, synth, pair_A):
+    pair, nb = pair_A, 10
+    ctx = capi.from_pair(pair, nb)
+    ctx.compute_href(pair.pose_init)
+    poses = [synth.perturb_pose7(pair.pose_init, [1e-3 * k, 0, 0], [0, 1e-3 * k, 0]) for k in range(capi.NID_SLOTS)]
+    for k, p in enumerate(poses):
+        ctx.launch(k, p, DELTA)
+    got = [ctx.wait(k) for k in range(len(poses))]
+    for k, p in enumerate(poses):
+        H, b, chi2, na = ctx.normal_equations(p, DELTA)
+        assert np.array_equal(_bits(H), _bits(got[k][0]))
+        assert np.array_equal(_bits(b), _bits(got[k][1]))
+        assert chi2 == got[k][2] and na == got[k][3]
+
+
+def test_config_B_full_size(capi, oracle, synth):
+    """1280x960 / 32x32 cells (BASELINE config 3): full oracle comparison plus the
+    size-independent properties (determinism, shard == whole)."""
+    pair, nb = synth.make_pair("B"), 8
+    ctx = capi.from_pair(pair, nb)
+    o = oracle.from_pair(pair, nb)
+    cnt, href = ctx.compute_href(pair.pose_init)
+    cnt_o, href_o = o.compute_href(pair.pose_init)
+    assert np.array_equal(cnt, cnt_o)
+    act = cnt_o >= 300
+    assert act.sum() > 900
+    np.testing.assert_allclose(href[act], href_o[act], rtol=0, atol=ATOL_H)
+    got = ctx.evaluate(pair.pose_init, True)
+    _compare_cells(got, o.evaluate(pair.pose_init, True), cnt_o)
+    again = ctx.evaluate(pair.pose_init, True)
+    for x, y in zip(got, again):
+        assert np.array_equal(_bits(x[act]), _bits(y[act]))
+    sh = capi.from_pair(pair, nb, cell_begin=512, cell_end=640)
+    sh.compute_href(pair.pose_init)
+    part = sh.evaluate(pair.pose_init, True)
+    m = act[512:640]
+    for x, y in zip(part, got):
+        assert np.array_equal(_bits(x[512:640][m]), _bits(y[512:640][m]))
+
+
+def test_error_paths(capi, pair_S):
+    pair = pair_S
+    ctx = capi.Context(pair.rows, pair.cols, pair.cell, 10, pair.fx, pair.fy, pair.cx, pair.cy)
+    with pytest.raises(capi.NidError):
+        ctx.evaluate(pair.pose_init, True)          # nothing uploaded yet
+    with pytest.raises(capi.NidError):
+        ctx.compute_href(pair.pose_init)
+    with pytest.raises(capi.NidError):
+        ctx.set_block_threads(384)                  # shape the kernel is not built for
