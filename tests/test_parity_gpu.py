@@ -33,8 +33,11 @@ def _compare_cells(got, ref, cnt):
     np.testing.assert_allclose(Hj[act], Hj_o[act], rtol=0, atol=ATOL_H)
     np.testing.assert_allclose(err[act], err_o[act], rtol=0, atol=ATOL_H)
     if J is not None:
-        scale = np.abs(J_o[act]).max()
-        np.testing.assert_allclose(J[act], J_o[act], rtol=0, atol=RTOL_J * scale)
+        # an active cell whose pixels all left the frame has Hj == 0: err = -inf, J = NaN on both sides
+        fin = np.isfinite(J_o[act])
+        assert np.array_equal(np.isfinite(J[act]), fin)
+        scale = np.abs(J_o[act][fin]).max()
+        np.testing.assert_allclose(J[act][fin], J_o[act][fin], rtol=0, atol=RTOL_J * scale)
         assert np.all(np.isnan(J[~act]))
 
 
