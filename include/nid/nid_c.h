@@ -153,6 +153,10 @@ int nid_unpack_reduced(const double *reduced, double *H36, double *b6, double *c
 int nid_debug_enable_pixel_dump(nid_ctx *ctx, int enable);
 int nid_debug_get_pixel_dump(nid_ctx *ctx, double *u, double *v, double *ic, int32_t *jc,
                              double *wc4);
+/* diagnostic: s_memtime stamps of wave 0 of every workgroup at the phase
+ * boundaries of the evaluation kernel, [cells_local][8] */
+int nid_debug_enable_stamps(nid_ctx *ctx, int enable);
+int nid_debug_get_stamps(nid_ctx *ctx, int64_t *stamps);
 /* host evaluation of the closed-form B-spline used by the kernels */
 void nid_bspline4_host(double u, int bin_num, double *B4, double *D4);
 /* host twin of the kernels' division-by-small-constant helper */

@@ -43,7 +43,7 @@ SYMBOLS = [
     "nid_compute_href_matrix", "nid_set_href_state", "nid_evaluate", "nid_evaluate_matrix",
     "nid_normal_equations", "nid_launch", "nid_wait", "nid_slot_buffers", "nid_launch_to",
     "nid_unpack_reduced", "nid_debug_enable_pixel_dump", "nid_debug_get_pixel_dump",
-    "nid_bspline4_host", "nid_div_small_host", "nid_last_kernel_ms", "nid_enable_timing",
+    "nid_debug_enable_stamps", "nid_debug_get_stamps", "nid_bspline4_host", "nid_div_small_host", "nid_last_kernel_ms", "nid_enable_timing",
     "nid_contract_bytes",
 ]
 
@@ -93,6 +93,8 @@ def load():
     lib.nid_unpack_reduced.argtypes = [c_dp, c_dp, c_dp, c_dp, c_ip]
     lib.nid_debug_enable_pixel_dump.argtypes = [vp, C.c_int]
     lib.nid_debug_get_pixel_dump.argtypes = [vp, c_dp, c_dp, c_dp, c_ip, c_dp]
+    lib.nid_debug_enable_stamps.argtypes = [vp, C.c_int]
+    lib.nid_debug_get_stamps.argtypes = [vp, C.POINTER(C.c_int64)]
     lib.nid_bspline4_host.restype = None
     lib.nid_bspline4_host.argtypes = [C.c_double, C.c_int, c_dp, c_dp]
     lib.nid_div_small_host.restype = C.c_double
@@ -254,6 +256,15 @@ class Context:
     # ---- debug ----------------------------------------------------------------
     def enable_pixel_dump(self, on=True):
         self._check(self.lib.nid_debug_enable_pixel_dump(self.h, 1 if on else 0), "nid_debug_enable_pixel_dump")
+
+    def enable_stamps(self, on=True):
+        self._check(self.lib.nid_debug_enable_stamps(self.h, 1 if on else 0), "nid_debug_enable_stamps")
+
+    def stamps(self):
+        n = self.cell_end - self.cell_begin
+        out = np.zeros((n, 8), dtype=np.int64)
+        self._check(self.lib.nid_debug_get_stamps(self.h, out.ctypes.data_as(C.POINTER(C.c_int64))), "nid_debug_get_stamps")
+        return out
 
     def pixel_dump(self):
         N = self.rows * self.cols

@@ -8,6 +8,7 @@
 // is [evaluation kernel -> reduction kernel -> small D2H].
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -25,9 +26,14 @@ namespace {
 
 struct Slot {
   double *cellout_dev = nullptr;
-  double *reduced_dev = nullptr;
+  double *reduced_dev = nullptr;   // device scratch target (evaluate path / slot_buffers)
+  double *quad_dev = nullptr;      // per-cell quadratic forms
+  unsigned *ticket_dev = nullptr;  // [0] top, [1+g] groups
+  double *gpart_dev = nullptr;     // group sums
   double *cellout_host = nullptr;  // pinned
-  double *reduced_host = nullptr;  // pinned
+  double *reduced_host = nullptr;  // pinned, mapped: [32 doubles][u64 sequence word]
+  double *reduced_host_devptr = nullptr;
+  unsigned long long seq = 0;      // sequence number of the last launch into this slot
   hipEvent_t done = nullptr, e0 = nullptr, e1 = nullptr, e2 = nullptr;
   bool pending = false;
   bool timed = false;
@@ -50,10 +56,12 @@ struct nid_ctx {
   double *Href_dev = nullptr;
   double *dbg_u = nullptr, *dbg_v = nullptr, *dbg_ic = nullptr, *dbg_wc = nullptr;
   int *dbg_jc = nullptr;
+  long long *dbg_stamps = nullptr;
   bool dbg_enabled = false;
   bool timing = false;
   bool have_ref = false, have_target = false, have_href = false, ref_from_depth = false;
   double hist_scale = 0, hist_inv_scale = 0;
+  int group_size = 1, ngroups = 1;
   Slot slots[NID_SLOTS];
   std::string last_error;
 };
@@ -100,7 +108,9 @@ void pose_from_matrix16(const double *m, Pose *out) {
 
 size_t eval_lds_bytes(const Geometry &g, int nt) {
   const int nbins = g.nb * g.nb + g.nb;
-  return (size_t)nbins * kHistCopies * 8 + (size_t)((nbins + 1) & ~1) * 8 + (size_t)12 * (nt / 64) * 8;
+  const size_t red = (size_t)std::max(12 * (nt / 64), nt + 2);
+  return (size_t)nbins * kHistCopies * 8 + (size_t)((nbins + 1) & ~1) * 8 +
+         (size_t)kMaxBins * kRcpRow * 8 + red * 8;
 }
 
 // (threads, pixels per thread) pairs the evaluation kernel is instantiated for
@@ -162,7 +172,18 @@ int launch_eval(nid_ctx *ctx, const EvalParams &P, bool jac) {
   return NID_ERR_UNSUPPORTED;
 }
 
-void fill_eval_params(nid_ctx *ctx, const Pose &pose, double *cellout, EvalParams *P) {
+void fill_eval_params(nid_ctx *ctx, const Pose &pose, Slot &S, double delta, double *out_reduced,
+                      unsigned long long *host_seq, EvalParams *P) {
+  double *cellout = S.cellout_dev;
+  P->huber_delta = delta;
+  P->huber_dsqr = (float)(delta * delta);  // RobustKernelHuber::setDelta, float dsqr (robust_kernel_impl.h:84)
+  P->quad = S.quad_dev;
+  P->ticket = S.ticket_dev;
+  P->gpart = S.gpart_dev;
+  P->group_size = ctx->group_size;
+  P->out_reduced = out_reduced;
+  P->host_seq = host_seq;
+  P->launch_seq = S.seq;
   P->g = ctx->g;
   P->pose = pose;
   P->t = ctx->t;
@@ -180,6 +201,7 @@ void fill_eval_params(nid_ctx *ctx, const Pose &pose, double *cellout, EvalParam
     P->dbg_u = P->dbg_v = P->dbg_ic = P->dbg_wc = nullptr;
     P->dbg_jc = nullptr;
   }
+  P->dbg_stamps = ctx->dbg_stamps;
 }
 
 int check_ready(nid_ctx *ctx) {
@@ -197,8 +219,13 @@ int launch_slot(nid_ctx *ctx, int slot, const Pose &pose, int want_jac, double d
   if (rc) return rc;
   if (slot < 0 || slot >= NID_SLOTS) return NID_ERR_INVALID_ARG;
   Slot &S = ctx->slots[slot];
+  S.seq++;
+  S.external_target = reduced_target != nullptr;
+  double *target = S.external_target ? static_cast<double *>(reduced_target) : S.reduced_host_devptr;
+  unsigned long long *host_seq =
+      S.external_target ? nullptr : reinterpret_cast<unsigned long long *>(S.reduced_host_devptr + kReducedLen);
   EvalParams P;
-  fill_eval_params(ctx, pose, S.cellout_dev, &P);
+  fill_eval_params(ctx, pose, S, delta, target, host_seq, &P);
   if (ctx->dbg_enabled) {
     const size_t N = (size_t)ctx->g.rows * ctx->g.cols;
     NID_HIP(ctx, hipMemsetAsync(ctx->dbg_u, 0xFF, N * 8, ctx->stream));
@@ -212,17 +239,7 @@ int launch_slot(nid_ctx *ctx, int slot, const Pose &pose, int want_jac, double d
   rc = launch_eval(ctx, P, want_jac != 0);
   if (rc) return rc;
   if (S.timed) NID_HIP(ctx, hipEventRecord(S.e1, ctx->stream));
-  double *target = reduced_target ? static_cast<double *>(reduced_target) : S.reduced_dev;
-  const float dsqr = (float)(delta * delta);  // RobustKernelHuber::setDelta, float dsqr
-  hipLaunchKernelGGL(k_reduce, dim3(1), dim3(256), 0, ctx->stream, S.cellout_dev, ctx->g.nloc,
-                     want_jac ? 1 : 0, delta, dsqr, target);
-  NID_HIP(ctx, hipGetLastError());
-  if (S.timed) NID_HIP(ctx, hipEventRecord(S.e2, ctx->stream));
-  S.external_target = reduced_target != nullptr;
-  if (!S.external_target)
-    NID_HIP(ctx, hipMemcpyAsync(S.reduced_host, S.reduced_dev, kReducedLen * sizeof(double),
-                                hipMemcpyDeviceToHost, ctx->stream));
-  NID_HIP(ctx, hipEventRecord(S.done, ctx->stream));
+  if (S.external_target) NID_HIP(ctx, hipEventRecord(S.done, ctx->stream));
   S.pending = true;
   return NID_OK;
 }
@@ -233,7 +250,7 @@ int evaluate_common(nid_ctx *ctx, const Pose &pose, int want_jac, double *Ht, do
   if (rc) return rc;
   Slot &S = ctx->slots[0];
   EvalParams P;
-  fill_eval_params(ctx, pose, S.cellout_dev, &P);
+  fill_eval_params(ctx, pose, S, std::sqrt(0.95), S.reduced_dev, nullptr, &P);
   if (ctx->dbg_enabled) {
     const size_t N = (size_t)ctx->g.rows * ctx->g.cols;
     NID_HIP(ctx, hipMemsetAsync(ctx->dbg_u, 0xFF, N * 8, ctx->stream));
@@ -384,6 +401,9 @@ int nid_create(const nid_config *cfg, nid_ctx **out) {
   ctx->stream = ctx->own_stream;
   const size_t N = (size_t)g.rows * g.cols;
   const size_t plane = (size_t)g.nloc * g.pstride;
+  // two-level reduction geometry: ~sqrt(nloc) cells per group
+  ctx->group_size = std::max(1, (int)std::ceil(std::sqrt((double)g.nloc)));
+  ctx->ngroups = (g.nloc + ctx->group_size - 1) / ctx->group_size;
   int rc;
   if ((rc = dev_alloc(ctx, &ctx->t.X, plane))) return fail(rc);
   if ((rc = dev_alloc(ctx, &ctx->t.Y, plane))) return fail(rc);
@@ -401,10 +421,17 @@ int nid_create(const nid_config *cfg, nid_ctx **out) {
     Slot &S = ctx->slots[s];
     if ((rc = dev_alloc(ctx, &S.cellout_dev, (size_t)g.nloc * kCellOut))) return fail(rc);
     if ((rc = dev_alloc(ctx, &S.reduced_dev, kReducedLen))) return fail(rc);
+    if ((rc = dev_alloc(ctx, &S.quad_dev, (size_t)g.nloc * kQuad))) return fail(rc);
+    if ((rc = dev_alloc(ctx, &S.ticket_dev, (size_t)ctx->ngroups + 4))) return fail(rc);
+    if (hipMemset(S.ticket_dev, 0, ((size_t)ctx->ngroups + 4) * sizeof(unsigned)) != hipSuccess) return fail(NID_ERR_HIP);
+    if ((rc = dev_alloc(ctx, &S.gpart_dev, (size_t)ctx->ngroups * kQuad))) return fail(rc);
     if (hipHostMalloc(reinterpret_cast<void **>(&S.cellout_host), (size_t)g.nloc * kCellOut * sizeof(double),
                       hipHostMallocDefault) != hipSuccess) return fail(NID_ERR_NOMEM);
-    if (hipHostMalloc(reinterpret_cast<void **>(&S.reduced_host), kReducedLen * sizeof(double),
-                      hipHostMallocDefault) != hipSuccess) return fail(NID_ERR_NOMEM);
+    if (hipHostMalloc(reinterpret_cast<void **>(&S.reduced_host), (kReducedLen + 2) * sizeof(double),
+                      hipHostMallocMapped) != hipSuccess) return fail(NID_ERR_NOMEM);
+    std::memset(S.reduced_host, 0, (kReducedLen + 2) * sizeof(double));
+    if (hipHostGetDevicePointer(reinterpret_cast<void **>(&S.reduced_host_devptr), S.reduced_host, 0) != hipSuccess)
+      return fail(NID_ERR_HIP);
     if (hipEventCreateWithFlags(&S.done, hipEventDisableTiming) != hipSuccess) return fail(NID_ERR_HIP);
     if (hipEventCreate(&S.e0) != hipSuccess || hipEventCreate(&S.e1) != hipSuccess ||
         hipEventCreate(&S.e2) != hipSuccess) return fail(NID_ERR_HIP);
@@ -423,10 +450,11 @@ int nid_destroy(nid_ctx *ctx) {
   (void)hipFree(ctx->points_dev); (void)hipFree(ctx->Twc_dev);
   (void)hipFree(ctx->Nc_dev); (void)hipFree(ctx->Href_dev);
   (void)hipFree(ctx->dbg_u); (void)hipFree(ctx->dbg_v); (void)hipFree(ctx->dbg_ic);
-  (void)hipFree(ctx->dbg_wc); (void)hipFree(ctx->dbg_jc);
+  (void)hipFree(ctx->dbg_wc); (void)hipFree(ctx->dbg_jc); (void)hipFree(ctx->dbg_stamps);
   for (int s = 0; s < NID_SLOTS; s++) {
     Slot &S = ctx->slots[s];
     (void)hipFree(S.cellout_dev); (void)hipFree(S.reduced_dev);
+    (void)hipFree(S.quad_dev); (void)hipFree(S.ticket_dev); (void)hipFree(S.gpart_dev);
     if (S.cellout_host) (void)hipHostFree(S.cellout_host);
     if (S.reduced_host) (void)hipHostFree(S.reduced_host);
     if (S.done) (void)hipEventDestroy(S.done);
@@ -607,9 +635,24 @@ int nid_wait(nid_ctx *ctx, int slot, double *H36, double *b6, double *chi2, int3
   if (!ctx || slot < 0 || slot >= NID_SLOTS) return NID_ERR_INVALID_ARG;
   Slot &S = ctx->slots[slot];
   if (!S.pending) return NID_ERR_STATE;
-  NID_HIP(ctx, hipEventSynchronize(S.done));
   S.pending = false;
-  if (S.external_target) return NID_OK;
+  if (S.external_target) {
+    NID_HIP(ctx, hipEventSynchronize(S.done));
+    return NID_OK;
+  }
+  // the last workgroup stores the 32 results, then the sequence word (system-scope release)
+  volatile unsigned long long *seqw = reinterpret_cast<volatile unsigned long long *>(S.reduced_host + kReducedLen);
+  unsigned long spins = 0;
+  while (__atomic_load_n(seqw, __ATOMIC_ACQUIRE) != S.seq) {
+    if (++spins > 20000000ul) {  // fall back to the runtime so that a device error surfaces
+      NID_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      if (__atomic_load_n(seqw, __ATOMIC_ACQUIRE) != S.seq) {
+        ctx->last_error = "result sequence word never arrived";
+        return NID_ERR_HIP;
+      }
+      break;
+    }
+  }
   return nid_unpack_reduced(S.reduced_host, H36, b6, chi2, n_active);
 }
 
@@ -658,6 +701,29 @@ int nid_debug_get_pixel_dump(nid_ctx *ctx, double *u, double *v, double *ic, int
   return NID_OK;
 }
 
+int nid_debug_enable_stamps(nid_ctx *ctx, int enable) {
+  if (!ctx) return NID_ERR_INVALID_ARG;
+  NID_HIP(ctx, hipSetDevice(ctx->cfg.device));
+  if (enable && !ctx->dbg_stamps) {
+    int rc = dev_alloc(ctx, &ctx->dbg_stamps, (size_t)ctx->g.nloc * 8);
+    if (rc) return rc;
+    NID_HIP(ctx, hipMemset(ctx->dbg_stamps, 0, (size_t)ctx->g.nloc * 8 * sizeof(long long)));
+  } else if (!enable && ctx->dbg_stamps) {
+    NID_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    (void)hipFree(ctx->dbg_stamps);
+    ctx->dbg_stamps = nullptr;
+  }
+  return NID_OK;
+}
+
+int nid_debug_get_stamps(nid_ctx *ctx, int64_t *stamps) {
+  if (!ctx || !stamps || !ctx->dbg_stamps) return NID_ERR_STATE;
+  NID_HIP(ctx, hipSetDevice(ctx->cfg.device));
+  NID_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  NID_HIP(ctx, hipMemcpy(stamps, ctx->dbg_stamps, (size_t)ctx->g.nloc * 8 * sizeof(long long), hipMemcpyDeviceToHost));
+  return NID_OK;
+}
+
 void nid_bspline4_host(double u, int bin_num, double *B4, double *D4) {
   double B[4], D[4];
   nid::bspline4<true>(u, (int)std::floor(u), bin_num - 3, B, D);
@@ -676,9 +742,9 @@ int nid_last_kernel_ms(nid_ctx *ctx, int slot, float *eval_ms, float *reduce_ms)
   if (!ctx || slot < 0 || slot >= NID_SLOTS) return NID_ERR_INVALID_ARG;
   Slot &S = ctx->slots[slot];
   if (!S.timed) return NID_ERR_STATE;
-  NID_HIP(ctx, hipEventSynchronize(S.e2));
+  NID_HIP(ctx, hipEventSynchronize(S.e1));
   if (eval_ms) NID_HIP(ctx, hipEventElapsedTime(eval_ms, S.e0, S.e1));
-  if (reduce_ms) NID_HIP(ctx, hipEventElapsedTime(reduce_ms, S.e1, S.e2));
+  if (reduce_ms) *reduce_ms = 0.0f;  // the reduction is fused into the evaluation kernel
   return NID_OK;
 }
 

@@ -15,7 +15,8 @@
 //  * phase 2 (Jacobian): per pixel two scalars s = sum Wj*wr*dw, t = sum Wc*dw
 //    replace the reference's 6*bin^2 derivative tensor (same algebra, only the
 //    summation order differs), then a 12-value wavefront + LDS reduction;
-//  * a second 1-workgroup kernel applies Huber and reduces to the 6x6 system.
+//  * each cell's Huber-weighted quadratic form is written write-through and the
+//    workgroup that arrives last sums them (fixed order) into the 6x6 system.
 //
 // Reference semantics restated here (never copied): CalculateProKernel /
 // CalculateHKernel / CalculateDerKernel g2o/g2o/core/computeH.cu:93-368 and the
@@ -67,10 +68,35 @@ struct EvalParams {
   double *cellout;      // [nloc*kCellOut]
   int jac_cols;         // cols or cols-1
   double hist_scale, hist_inv_scale;
+  // fused Huber + 6x6 reduction
+  double huber_delta;
+  float huber_dsqr;
+  double *quad;                    // [nloc*32] per-cell quadratic-form blocks (sc1 traffic)
+  double *gpart;                   // [ngroups*32] group sums (second reduction level)
+  unsigned *ticket;                // [0] top arrival counter, [1+g] group counters; zero between launches
+  int group_size;                  // cells per first-level group
+  double *out_reduced;             // 32 doubles: device memory or pinned host memory
+  unsigned long long *host_seq;    // pinned host word that receives launch_seq (or null)
+  unsigned long long launch_seq;
   // optional per-pixel dump (image order), null when disabled
   double *dbg_u, *dbg_v, *dbg_ic, *dbg_wc;
   int *dbg_jc;
+  // optional phase stamps (s_memtime) of wave 0 of every workgroup: [nloc][8]; diagnostic runs only
+  long long *dbg_stamps;
 };
+
+// Stamp k: ordered AFTER the values passed as dependencies and BEFORE any later
+// volatile asm (launder) / memory operation.  One asm statement per the guide.
+__device__ __forceinline__ void nid_stamp(long long *buf, int k, double d0 = 0.0, double d1 = 0.0,
+                                          double d2 = 0.0, double d3 = 0.0) {
+  unsigned long long t;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) : "v"(d0), "v"(d1), "v"(d2), "v"(d3) : "memory");
+  if (threadIdx.x == 0) buf[(size_t)blockIdx.x * 8 + k] = (long long)t;
+}
+#define NID_STAMP(k, ...)                                    \
+  do {                                                       \
+    if (P.dbg_stamps) nid_stamp(P.dbg_stamps, (k), ##__VA_ARGS__); \
+  } while (0)
 
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ void xform_point(const Pose &P, double x, double y, double z,
@@ -110,6 +136,57 @@ __device__ __forceinline__ double bilinear_u8(const uint8_t *__restrict__ im, in
   return dxdy * i11 + (dy - dxdy) * i10 + (dx - dxdy) * i01 + (1 - dx - dy + dxdy) * i00;
 }
 
+// 4x4 target-image window around a warped pixel, one 32-bit word per row
+// (byte k of a row word = column wx + k).  Every tap of the five bilinear
+// samples a pixel needs -- (u,v), (u+-1,v), (u,v+-1) -- lies inside it, so the
+// image is read once per pixel (4 unaligned dword loads) and the Jacobian phase
+// touches no global memory.  wx = max((int)u - 1, 0), wy = max((int)v - 1, 0).
+struct Win {
+  unsigned r0, r1, r2, r3;
+  int wx, wy;
+};
+
+__device__ __forceinline__ unsigned load_u32_unaligned(const uint8_t *p) {
+  unsigned v;
+  __builtin_memcpy(&v, p, 4);
+  return v;
+}
+
+__device__ __forceinline__ unsigned win_row(const Win &w, int k) {
+  const unsigned a = (k & 1) ? w.r1 : w.r0;
+  const unsigned b = (k & 1) ? w.r3 : w.r2;
+  return (k & 2) ? b : a;
+}
+
+__device__ __forceinline__ double win_tap(unsigned row, int k) {
+  return (double)((row >> ((k & 3) * 8)) & 0xffu);
+}
+
+// bilinear_u8 on the window: same arithmetic, taps from registers.  A tap index
+// that leaves the window can only belong to a tap whose weight is exactly 0
+// (x or y rounded up to an integer) -- any finite byte is then correct.
+__device__ __forceinline__ double bilinear_w(const Win &w, double x, double y) {
+  const int ix = (int)x;
+  const int iy = (int)y;
+  const double dx = x - ix;
+  const double dy = y - iy;
+  const double dxdy = dx * dy;
+  int kx = ix - w.wx, ky = iy - w.wy;
+  kx = min(max(kx, 0), 3);
+  ky = min(max(ky, 0), 3);
+  const unsigned ra = win_row(w, ky), rb = win_row(w, min(ky + 1, 3));
+  const double i00 = win_tap(ra, kx), i01 = win_tap(ra, kx + 1);
+  const double i10 = win_tap(rb, kx), i11 = win_tap(rb, kx + 1);
+  return dxdy * i11 + (dy - dxdy) * i10 + (dx - dxdy) * i01 + (1 - dx - dy + dxdy) * i00;
+}
+
+// Opaque re-definition of a register value: code that depends on the result
+// cannot be hoisted above this point (keeps phase-2 arithmetic out of phase 1,
+// where it would only lengthen live ranges).
+__device__ __forceinline__ void launder(double &v) { asm volatile("" : "+v"(v)); }
+__device__ __forceinline__ void launder(unsigned &v) { asm volatile("" : "+v"(v)); }
+__device__ __forceinline__ void launder(int &v) { asm volatile("" : "+v"(v)); }
+
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
@@ -137,11 +214,11 @@ __device__ __forceinline__ void block_sum(double (&v)[NV], double *red, int tid)
   }
 }
 
-__device__ __forceinline__ void hist_add(unsigned long long *hist, int bin, int copy, double w,
-                                         double scale) {
-  // 64-bit fixed point: exact, order-independent accumulation (ds_add_u64)
-  const long long q = __double2ll_rn(w * scale);
-  atomicAdd(&hist[bin * kHistCopies + copy], (unsigned long long)q);
+// 64-bit fixed point by the 2^52 magic number: for 0 <= w*scale < 2^52 the low
+// 52 bits of RN(w*scale + 2^52) ARE round-to-nearest-even(w*scale).
+__device__ __forceinline__ unsigned long long fx_encode(double w, double scale) {
+  const double t = fma(w, scale, 0x1p52);
+  return (unsigned long long)__double_as_longlong(t) - 0x4330000000000000ull;
 }
 
 // ---------------------------------------------------------------------------
@@ -251,7 +328,7 @@ __global__ __launch_bounds__(NT) void k_href(Geometry g, Pose pose, Tiles t, int
         double d[4];
         bspline4<false>(bin_pos_ref, jr, g.S, w, d);
 #pragma unroll
-        for (int k = 0; k < 4; k++) hist_add(hist, jr + k, copy, w[k], hist_scale);
+        for (int k = 0; k < 4; k++) atomicAdd(&hist[(jr + k) * kHistCopies + copy], fx_encode(w[k], hist_scale));
       }
     }
 #pragma unroll
@@ -278,7 +355,114 @@ __global__ __launch_bounds__(NT) void k_href(Geometry g, Pose pose, Tiles t, int
 }
 
 // ---------------------------------------------------------------------------
-// The hot kernel: cost (+ Jacobian) of one cell per workgroup.
+// The hot kernel: cost (+ Jacobian) of one cell per workgroup, the cell's
+// Huber-weighted quadratic form, and -- in the workgroup that finishes last --
+// the sum over all cells (the 6x6 normal equations), written straight to the
+// caller's result buffer (device memory or pinned host memory).
+//
+// Inter-workgroup hand-off (cdna_hip_programming.md Guideline 16, table row 1):
+// the per-cell 32-double block is stored write-through (sc1, relaxed agent-scope
+// atomics) by wave 0 only, wave 0 drains vmcnt, one lane takes a ticket with an
+// agent-scope atomic add; the workgroup whose add returns nblocks-1 reads every
+// block back with sc1 loads (no fence needed on that row) and reduces in a fixed
+// order.  No dispatch-order or placement assumption; the ticket is reset by the
+// last arriver and zeroed once at context creation.
+__device__ __forceinline__ void store_sc1(double *p, double v) {
+  __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), (unsigned long long)__double_as_longlong(v),
+                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double load_sc1(const double *p) {
+  return __longlong_as_double((long long)__hip_atomic_load(
+      reinterpret_cast<const unsigned long long *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+
+constexpr int kQuad = 32;  // per-cell block: rho0 | b[6] | H upper[21] | 1.0 | 0 0 0
+
+// which (a,b) of the upper triangle a quad slot 7..27 holds
+__device__ __forceinline__ void quad_ab(int slot, int &a, int &b) {
+  int k = slot - 7, aa = 0, len = 6;
+  while (k >= len) { k -= len; aa++; len--; }
+  a = aa; b = aa + k;
+}
+
+// Sum `count` 32-double blocks (stride kQuad) starting at `src` in a fixed order:
+// thread (v = tid & 31, sub = tid >> 5) adds blocks sub, sub+SUB, ... with all of
+// its (sc1) loads in flight, then the SUB partial sums are combined in order.
+// Result: lanes tid < 32 hold element tid.
+template <int NT>
+__device__ __forceinline__ double sum_blocks(const double *src, int count, double *part, int tid) {
+  constexpr int SUB = NT / 32;
+  const int v = tid & 31, sub = tid >> 5;
+  double x[8];
+  double s = 0.0;
+  for (int c0 = sub; c0 < count; c0 += 8 * SUB) {
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      const int c = c0 + k * SUB;
+      x[k] = (c < count) ? load_sc1(src + (size_t)c * kQuad + v) : 0.0;
+    }
+#pragma unroll
+    for (int k = 0; k < 8; k++) s += x[k];
+  }
+  part[sub * 32 + v] = s;
+  __syncthreads();
+  double r = 0.0;
+  if (tid < 32) {
+    r = part[tid];
+    for (int k = 1; k < SUB; k++) r += part[k * 32 + tid];
+  }
+  return r;
+}
+
+// Two-level in-launch reduction of the per-cell blocks (cells -> groups of
+// P.group_size cells -> total), each level a ticket + last-arriver sum, so the
+// serial read of any one workgroup is <= max(group_size, ngroups) * 256 B.
+template <int NT>
+__device__ __forceinline__ void finish_and_reduce(const EvalParams &P, int cl, int tid,
+                                                  double *lds_scratch /* >= NT + 2 doubles */) {
+  unsigned *flag = reinterpret_cast<unsigned *>(lds_scratch);
+  double *part = lds_scratch + 2;
+  const int gs = P.group_size;
+  const int gq = cl / gs;
+  const int ngroups = (P.g.nloc + gs - 1) / gs;
+  const int gcount = min(gs, P.g.nloc - gq * gs);
+  // level 0: this cell's block has been stored (sc1) by wave 0 -- drain, take a group ticket
+  if (tid < 64) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (tid == 0) {
+      const unsigned old = __hip_atomic_fetch_add(P.ticket + 1 + gq, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      flag[0] = (old == (unsigned)(gcount - 1)) ? 1u : 0u;
+    }
+  }
+  __syncthreads();
+  if (flag[0] == 0u) return;  // uniform
+  __syncthreads();            // flag consumed before the scratch is reused
+  double r = sum_blocks<NT>(P.quad + (size_t)gq * gs * kQuad, gcount, part, tid);
+  // level 1: publish the group sum, take the top ticket
+  if (tid < 64) {
+    if (tid < 32) store_sc1(P.gpart + (size_t)gq * kQuad + tid, r);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (tid == 0) {
+      __hip_atomic_store(P.ticket + 1 + gq, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned old = __hip_atomic_fetch_add(P.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      flag[0] = (old == (unsigned)(ngroups - 1)) ? 1u : 0u;
+    }
+  }
+  __syncthreads();
+  if (flag[0] == 0u) return;
+  __syncthreads();
+  r = sum_blocks<NT>(P.gpart, ngroups, part, tid);
+  if (tid < 32) P.out_reduced[tid] = r;
+  if (tid == 0) __hip_atomic_store(P.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (P.host_seq && tid < 64) {  // results live in pinned host memory: publish at system scope
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (tid == 0) {
+      __threadfence_system();
+      __hip_atomic_store(P.host_seq, P.launch_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+}
+
 template <int NT, int PPT, bool JAC>
 __global__ __launch_bounds__(NT) void k_eval(EvalParams P) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -286,104 +470,136 @@ __global__ __launch_bounds__(NT) void k_eval(EvalParams P) {
   const int nb = g.nb;
   const int nbins = nb * nb + nb;  // [0,nb): target histogram, then joint row-major [ref][target]
   constexpr int NW = NT / 64;
-  // LDS carve (all 16-B aligned): hist | tab | red
+  // LDS carve (all 16-B aligned): hist | tab | rtab | red
   unsigned long long *hist = reinterpret_cast<unsigned long long *>(smem);
   double *tab = reinterpret_cast<double *>(smem + (size_t)nbins * kHistCopies * 8);
-  double *red = tab + ((nbins + 1) & ~1);
+  double *rtab = tab + ((nbins + 1) & ~1);
+  double *red = rtab + kMaxBins * kRcpRow;   // max(12*NW, (NT/32)*32 + 2) doubles
 
   const int cl = blockIdx.x, tid = threadIdx.x;
   const int n_c = P.Nc[cl];
   const double href = P.Href[cl];
   double *out = P.cellout + (size_t)cl * kCellOut;
+  double *quad = P.quad + (size_t)cl * kQuad;
   if (n_c < 300 || isnan(href)) {  // level-1 edge: never evaluated (computeH.cu:271-275)
     if (tid < kCellOut) out[tid] = (tid == kCellOut - 1) ? (double)n_c : NAN;
+    if (tid < kQuad) store_sc1(quad + tid, 0.0);
+    finish_and_reduce<NT>(P, cl, tid, red);
     return;
   }
 
+  NID_STAMP(0);
   for (int i = tid; i < nbins * kHistCopies; i += NT) hist[i] = 0ull;
+  if (tid < g.S * 6) {  // RN(1/d) for the six knot differences of every span
+    const int jj = tid / 6, e = tid % 6;
+    rtab[jj * kRcpRow + e] = 1.0 / span_denominator(jj, e, g.S);
+  }
 
   const int copy = tid & (kHistCopies - 1);
   const size_t base = (size_t)cl * g.pstride;
   const size_t plane = (size_t)g.nloc * g.pstride;
 
-  // per-pixel state carried from phase 1 to phase 2
-  double s_x[PPT], s_y[PPT], s_iz[PPT], s_u[PPT], s_v[PPT];
-  double s_wr[PPT][4], s_dw[PPT][4];
-  int s_jr[PPT], s_jc[PPT];
-  unsigned s_flags = 0;  // bit i: pixel i contributes to the Jacobian
-
-  // ---- loads first (all independent), then compute -------------------------
-  double lx[PPT], ly[PPT], lz[PPT];
+  // ---- stage 0: coalesced tile loads (all independent) -----------------------
+  double lx[PPT], ly[PPT], lz[PPT], s_wr[PPT][4];
+  int s_jr[PPT];
 #pragma unroll
   for (int i = 0; i < PPT; i++) {
     const int s = i * NT + tid;
-    s_jr[i] = -1;
-    if (s < g.pstride) {
-      const size_t gi = base + s;
-      s_jr[i] = P.t.JR[gi];
-      lx[i] = P.t.X[gi]; ly[i] = P.t.Y[gi]; lz[i] = P.t.Z[gi];
+    const bool in_tile = s < g.pstride;
+    const size_t gi = base + (in_tile ? s : 0);
+    const int jr = P.t.JR[gi];
+    s_jr[i] = in_tile ? jr : -1;
+    lx[i] = P.t.X[gi]; ly[i] = P.t.Y[gi]; lz[i] = P.t.Z[gi];
 #pragma unroll
-      for (int k = 0; k < 4; k++) s_wr[i][k] = P.t.W[k * plane + gi];
-    }
+    for (int k = 0; k < 4; k++) s_wr[i][k] = P.t.W[k * plane + gi];
   }
-  __syncthreads();  // histogram zeroed
 
-  // ---- phase 1: warp, sample, target weights, histograms -------------------
+  // ---- stage 1: warp + in-frame tests (branch-free) ---------------------------
+  double s_x[PPT], s_y[PPT], s_z[PPT], s_u[PPT], s_v[PPT];
+  bool s_in[PPT];
 #pragma unroll
   for (int i = 0; i < PPT; i++) {
-    s_jc[i] = -1;
-    if (s_jr[i] < 0) continue;
     double qx, qy, qz;
     xform_point(P.pose, lx[i], ly[i], lz[i], qx, qy, qz);
     // types_six_dof_expmap.cpp:562-563: fx * x / z + cx
     const double u = g.fx * qx / qz + g.cx;
     const double v = g.fy * qy / qz + g.cy;
-    const bool inb = (u >= 0 && u + 3 <= g.cols && v >= 0 && v + 3 <= g.rows);
-    double ic = NAN, wc[4] = {NAN, NAN, NAN, NAN};
-    int jc = -1;
-    if (inb) {
-      ic = bilinear_u8(P.im1, g.cols, u, v);
-      if (ic >= 255) ic = 254.999;
-      if (ic < 0) ic = 0.0;
-      const double pc = ic * ((double)nb - 3.0) / 255.0;
-      jc = (int)floor(pc);
-      double dw[4];
-      bspline4<JAC>(pc, jc, g.S, wc, dw);
+    s_in[i] = (s_jr[i] >= 0) && (u >= 0 && u + 3 <= g.cols && v >= 0 && v + 3 <= g.rows);
+    s_x[i] = qx; s_y[i] = qy; s_z[i] = qz; s_u[i] = u; s_v[i] = v;
+  }
+
+  // ---- stage 2: bilinear sample of the target (taps of out-of-frame pixels are
+  //      redirected to pixel (0,0), their result is discarded) -------------------
+  Win s_w[PPT];
 #pragma unroll
-      for (int k = 0; k < 4; k++) hist_add(hist, jc + k, copy, wc[k], P.hist_scale);
-      const int jr = s_jr[i];
+  for (int i = 0; i < PPT; i++) {
+    const double us = s_in[i] ? s_u[i] : 0.0, vs = s_in[i] ? s_v[i] : 0.0;
+    s_w[i].wx = max((int)us - 1, 0);
+    s_w[i].wy = max((int)vs - 1, 0);
+    const uint8_t *p = P.im1 + (size_t)s_w[i].wy * g.cols + s_w[i].wx;
+    s_w[i].r0 = load_u32_unaligned(p);
+    s_w[i].r1 = load_u32_unaligned(p + g.cols);
+    s_w[i].r2 = load_u32_unaligned(p + 2 * g.cols);
+    s_w[i].r3 = load_u32_unaligned(p + 3 * g.cols);
+  }
+  double s_ic[PPT];
+#pragma unroll
+  for (int i = 0; i < PPT; i++) {
+    const double us = s_in[i] ? s_u[i] : 0.0, vs = s_in[i] ? s_v[i] : 0.0;
+    double ic = bilinear_w(s_w[i], us, vs);
+    if (ic >= 255) ic = 254.999;
+    if (ic < 0) ic = 0.0;
+    s_ic[i] = ic;
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  NID_STAMP(1, s_ic[0], s_ic[PPT - 1]);
+  __syncthreads();  // histogram zeroed, rtab ready
+#pragma unroll
+  for (int i = 0; i < PPT; i++) launder(s_ic[i]);
+
+  // ---- stage 3: target B-spline weights, histogram accumulation --------------
+  double s_dw[PPT][4];
+  int s_jc[PPT];
+#pragma unroll
+  for (int i = 0; i < PPT; i++) {
+    const double pc = s_ic[i] * ((double)nb - 3.0) / 255.0;
+    const int jc = (int)floor(pc);
+    double wc[4], dw[4];
+    bspline4_tab<JAC>(pc, jc, g.S, rtab, wc, dw);
+    s_jc[i] = jc;
+    if (JAC) {
+#pragma unroll
+      for (int k = 0; k < 4; k++) s_dw[i][k] = dw[k];
+    }
+    if (s_in[i]) {
+      unsigned long long *hc = hist + (size_t)jc * kHistCopies + copy;
+#pragma unroll
+      for (int k = 0; k < 4; k++) atomicAdd(hc + k * kHistCopies, fx_encode(wc[k], P.hist_scale));
+      unsigned long long *hj = hist + (size_t)(nb + s_jr[i] * nb + jc) * kHistCopies + copy;
 #pragma unroll
       for (int m = 0; m < 4; m++)
 #pragma unroll
         for (int k = 0; k < 4; k++)
-          hist_add(hist, nb + (jr + m) * nb + jc + k, copy, s_wr[i][m] * wc[k], P.hist_scale);
-      if (JAC) {
-        // linearizeOplus recomputes u as fx*(x/z)+cx (types_six_dof_expmap.cpp:407-422, Q6)
-        const double iz = 1.0 / qz;
-        const double uj = g.fx * (qx / qz) + g.cx;
-        const double vj = g.fy * (qy / qz) + g.cy;
-        const bool jin = (uj >= 0 && uj + 3 <= P.jac_cols && vj >= 0 && vj + 3 <= g.rows);
-        if (jin) s_flags |= (1u << i);
-        s_x[i] = qx; s_y[i] = qy; s_iz[i] = iz; s_u[i] = uj; s_v[i] = vj;
-#pragma unroll
-        for (int k = 0; k < 4; k++) s_dw[i][k] = dw[k];
-      }
+          atomicAdd(hj + (size_t)(m * nb + k) * kHistCopies, fx_encode(s_wr[i][m] * wc[k], P.hist_scale));
     }
-    s_jc[i] = jc;
-    if (P.dbg_u) {
+    if (P.dbg_u && s_jr[i] >= 0) {
       const int s = i * NT + tid;
       const int c = g.cell_begin + cl;
       const int r = (c / g.cell_num) * g.rb + s / g.cb;
       const int col = (c % g.cell_num) * g.cb + s % g.cb;
       const size_t id = (size_t)r * g.cols + col;
-      P.dbg_u[id] = u; P.dbg_v[id] = v; P.dbg_ic[id] = ic; P.dbg_jc[id] = jc;
+      P.dbg_u[id] = s_u[i]; P.dbg_v[id] = s_v[i];
+      P.dbg_ic[id] = s_in[i] ? s_ic[i] : NAN;
+      P.dbg_jc[id] = s_in[i] ? jc : -1;
 #pragma unroll
-      for (int k = 0; k < 4; k++) P.dbg_wc[4 * id + k] = wc[k];
+      for (int k = 0; k < 4; k++) P.dbg_wc[4 * id + k] = s_in[i] ? wc[k] : NAN;
     }
+    __builtin_amdgcn_sched_barrier(0);  // one pixel at a time: bounds the live register set
   }
+  NID_STAMP(2);
   __syncthreads();
 
-  // ---- fold the copies, probabilities, entropies, weight tables ------------
+  // ---- fold the copies, probabilities, entropies, weight tables ---------------
   double ent[2] = {0.0, 0.0};  // sum p*log2(p): target, joint
   for (int b = tid; b < nbins; b += NT) {
     unsigned long long acc = 0;
@@ -400,30 +616,53 @@ __global__ __launch_bounds__(NT) void k_eval(EvalParams P) {
     tab[b] = w;
   }
   block_sum<NT, 2>(ent, red, tid);  // contains the barrier that publishes tab[]
+  NID_STAMP(3, ent[0], ent[1]);
   const double Hc = 0.0 - ent[0];
   const double Hj = 0.0 - ent[1];
+  const double err = (2 * Hj - href - Hc) / Hj;  // types_six_dof_expmap.h:227
+  // Huber (robust_kernel_impl.cpp:77-91, float dsqr)
+  const double e2 = err * err;
+  double rho0 = e2, rho1 = 1.0;
+  if (!(e2 <= P.huber_dsqr)) {
+    const double sqrte = sqrt(e2);
+    rho0 = 2 * sqrte * P.huber_delta - P.huber_dsqr;
+    rho1 = P.huber_delta / sqrte;
+  }
 
   if (!JAC) {
     if (tid == 0) {
-      out[0] = Hc; out[1] = Hj;
-      out[2] = (2 * Hj - href - Hc) / Hj;  // types_six_dof_expmap.h:227
+      out[0] = Hc; out[1] = Hj; out[2] = err;
       out[kCellOut - 1] = (double)n_c;
     }
+    if (tid < kQuad) store_sc1(quad + tid, tid == 0 ? rho0 : (tid == 28 ? 1.0 : 0.0));
+    __syncthreads();  // `red` is reused by the reduction
+    finish_and_reduce<NT>(P, cl, tid, red);
     return;
   }
 
-  // ---- phase 2: Jacobian ----------------------------------------------------
-  const double kappa = (double)g.S / 255.0;  // d_mi_i, types_six_dof_expmap.cpp:393
+  // ---- phase 2: Jacobian --------------------------------------------------------
+  // linearizeOplus recomputes u as fx*(x/z)+cx (types_six_dof_expmap.cpp:407-422, Q6)
+  const double kappa = (double)g.S / 255.0;  // d_mi_i, :393
   double acc[12];
 #pragma unroll
   for (int n = 0; n < 12; n++) acc[n] = 0.0;
 #pragma unroll
   for (int i = 0; i < PPT; i++) {
-    if (!(s_flags & (1u << i))) continue;
-    const double u = s_u[i], v = s_v[i];
-    const double gx = (bilinear_u8(P.im1, g.cols, u + 1, v) - bilinear_u8(P.im1, g.cols, u - 1, v)) / 2;
-    const double gy = (bilinear_u8(P.im1, g.cols, u, v + 1) - bilinear_u8(P.im1, g.cols, u, v - 1)) / 2;
-    const double x = s_x[i], y = s_y[i], invz = s_iz[i];
+    launder(s_x[i]); launder(s_y[i]); launder(s_z[i]);
+    launder(s_w[i].r0); launder(s_w[i].r1); launder(s_w[i].r2); launder(s_w[i].r3);
+    launder(s_w[i].wx); launder(s_w[i].wy);
+  }
+#pragma unroll
+  for (int i = 0; i < PPT; i++) {
+    const double zz = s_in[i] ? s_z[i] : 1.0;  // discarded pixels: finite stand-ins, zero weight below
+    const double x = s_in[i] ? s_x[i] : 0.0, y = s_in[i] ? s_y[i] : 0.0;
+    const double invz = 1.0 / zz;
+    const double uj = g.fx * (x / zz) + g.cx;
+    const double vj = g.fy * (y / zz) + g.cy;
+    const bool jin = s_in[i] && (uj >= 0 && uj + 3 <= P.jac_cols && vj >= 0 && vj + 3 <= g.rows);
+    const double u = jin ? uj : 1.0, v = jin ? vj : 1.0;  // safe taps for discarded pixels
+    const double gx = (bilinear_w(s_w[i], u + 1, v) - bilinear_w(s_w[i], u - 1, v)) / 2;
+    const double gy = (bilinear_w(s_w[i], u, v + 1) - bilinear_w(s_w[i], u, v - 1)) / 2;
     const double invz_2 = invz * invz;
     // types_six_dof_expmap.cpp:438-450
     double Ju[6], Jv[6];
@@ -439,88 +678,75 @@ __global__ __launch_bounds__(NT) void k_eval(EvalParams P) {
     Jv[3] = 0;
     Jv[4] = invz * g.fy;
     Jv[5] = -y * invz_2 * g.fy;
-    const int jr = s_jr[i], jc = s_jc[i];
-    // s = sum_{k,m} Wj[jr+k][jc+m] * (wr[k]*dw[m]*kappa) ; t = sum_m Wc[jc+m] * (dw[m]*kappa)
-    double s = 0.0, tt = 0.0;
+    // s = kappa * sum_k wr[k] * (sum_m Wj[jr+k][jc+m] dw[m]);  t = kappa * sum_m Wc[jc+m] dw[m]
+    // -- the reference's 6*bin^2 tensor contracted per pixel (same algebra, smooth: FMAs allowed)
+    const int jr = jin ? s_jr[i] : 0, jc = jin ? s_jc[i] : 0;
+    const double *tj = tab + nb + jr * nb + jc;
+    double tt = 0.0, ss = 0.0;
 #pragma unroll
-    for (int m = 0; m < 4; m++) tt += tab[jc + m] * (s_dw[i][m] * kappa);
+    for (int m = 0; m < 4; m++) tt = fma(tab[jc + m], s_dw[i][m], tt);
 #pragma unroll
-    for (int k = 0; k < 4; k++)
+    for (int k = 0; k < 4; k++) {
+      double inner = 0.0;
 #pragma unroll
-      for (int m = 0; m < 4; m++)
-        s += tab[nb + (jr + k) * nb + jc + m] * (s_wr[i][k] * s_dw[i][m] * kappa);
+      for (int m = 0; m < 4; m++) inner = fma(tj[k * nb + m], s_dw[i][m], inner);
+      ss = fma(s_wr[i][k], inner, ss);
+    }
+    ss = jin ? ss * kappa : 0.0;
+    tt = jin ? tt * kappa : 0.0;
 #pragma unroll
     for (int n = 0; n < 6; n++) {
-      const double dI = gx * Ju[n] + gy * Jv[n];  // d_i_pose, :460
-      acc[n] += s * dI;
-      acc[6 + n] += tt * dI;
+      const double dI = fma(gx, Ju[n], gy * Jv[n]);  // d_i_pose, :460
+      acc[n] = fma(ss, dI, acc[n]);
+      acc[6 + n] = fma(tt, dI, acc[6 + n]);
     }
+    __builtin_amdgcn_sched_barrier(0);  // one pixel at a time: bounds the live register set
   }
+  NID_STAMP(4, acc[0], acc[5], acc[6], acc[11]);
   __syncthreads();  // `red` is reused
   block_sum<NT, 12>(acc, red, tid);
-  if (tid < 6) {
+  NID_STAMP(5, acc[0], acc[5], acc[6], acc[11]);
+  if (tid < 64) {
     // CalculateDerKernel tail (computeH.cu:358-366) == types_six_dof_expmap.cpp:521-528
-    const double d_hj = acc[tid] / (double)n_c;
-    const double d_hl = acc[6 + tid] / (double)n_c;
     const double inv_square_hj = 1.0 / (Hj * Hj);
-    out[3 + tid] = (d_hj * (Hc + href) - d_hl * Hj) * inv_square_hj;
-  }
-  if (tid == 0) {
-    out[0] = Hc; out[1] = Hj;
-    out[2] = (2 * Hj - href - Hc) / Hj;
-    out[kCellOut - 1] = (double)n_c;
-  }
-}
-
-// ---------------------------------------------------------------------------
-// Huber + per-cell quadratic form + reduction to the 6x6 normal equations:
-// BaseUnaryEdge::constructQuadraticForm (base_unary_edge.hpp:43-72),
-// RobustKernelHuber::robustify (robust_kernel_impl.cpp:77-91, float dsqr :84 of .h)
-// reduced[0]=chi2, [1..6]=b, [7..27]=H upper triangle, [28]=n_active.
-__global__ __launch_bounds__(256) void k_reduce(const double *__restrict__ cellout, int nloc,
-                                                int have_jac, double delta, float dsqr,
-                                                double *__restrict__ reduced) {
-  __shared__ double red[29 * 4];
-  const int tid = threadIdx.x;
-  double v[29];
+    double J[6];
 #pragma unroll
-  for (int k = 0; k < 29; k++) v[k] = 0.0;
-  for (int c = tid; c < nloc; c += 256) {
-    const double *o = cellout + (size_t)c * kCellOut;
-    const double e = o[2];
-    if (isnan(e)) continue;
-    const double e2 = e * e;
-    double rho0, rho1;
-    if (e2 <= dsqr) { rho0 = e2; rho1 = 1.0; }
-    else {
-      const double sqrte = sqrt(e2);
-      rho0 = 2 * sqrte * delta - dsqr;
-      rho1 = delta / sqrte;
+    for (int n = 0; n < 6; n++) {
+      const double d_hj = acc[n] / (double)n_c;
+      const double d_hl = acc[6 + n] / (double)n_c;
+      J[n] = (d_hj * (Hc + href) - d_hl * Hj) * inv_square_hj;
     }
-    v[0] += rho0;
-    v[28] += 1.0;
-    if (have_jac) {
-      double J[6];
+    if (tid == 0) {
+      out[0] = Hc; out[1] = Hj; out[2] = err;
 #pragma unroll
-      for (int n = 0; n < 6; n++) J[n] = o[3 + n];
+      for (int n = 0; n < 6; n++) out[3 + n] = J[n];
+      out[kCellOut - 1] = (double)n_c;
+    }
+    if (tid < kQuad) {
+      // constructQuadraticForm (base_unary_edge.hpp:56-63): b -= (rho1*J)*e ; H += (J*rho1)*J^T
+      double val = 0.0;
+      if (tid == 0) val = rho0;
+      else if (tid == 28) val = 1.0;
+      else if (tid < 7) {
+        double Jn = 0.0;
 #pragma unroll
-      for (int n = 0; n < 6; n++) v[1 + n] -= (rho1 * J[n]) * e;
-      int idx = 7;
+        for (int n = 0; n < 6; n++) if (n == tid - 1) Jn = J[n];
+        val = 0.0 - (rho1 * Jn) * err;
+      } else if (tid < 28) {
+        int a, b;
+        quad_ab(tid, a, b);
+        double Ja = 0.0, Jb = 0.0;
 #pragma unroll
-      for (int a = 0; a < 6; a++)
-#pragma unroll
-        for (int b = a; b < 6; b++) v[idx++] += (J[a] * rho1) * J[b];
+        for (int n = 0; n < 6; n++) { if (n == a) Ja = J[n]; if (n == b) Jb = J[n]; }
+        val = (Ja * rho1) * Jb;
+      }
+      store_sc1(quad + tid, val);
     }
   }
-  block_sum<256, 29>(v, red, tid);
-  if (tid < 29) {
-    double r = 0.0;
-#pragma unroll
-    for (int k = 0; k < 29; k++) if (k == tid) r = v[k];
-    reduced[tid] = r;
-  } else if (tid < kReducedLen) {
-    reduced[tid] = 0.0;
-  }
+  __syncthreads();  // `red` is reused by the reduction
+  NID_STAMP(6);
+  finish_and_reduce<NT>(P, cl, tid, red);
+  NID_STAMP(7);
 }
 
 }  // namespace nid

@@ -1,0 +1,30 @@
+"""Diagnostic: per-phase cycle shares of the evaluation kernel (s_memtime stamps).
+Usage: python tools_stamps.py [A|B] [bins] [block_threads]"""
+import importlib, sys
+import numpy as np
+sys.path.insert(0, '.')
+capi = importlib.import_module("nid-pose-estimation_amd.capi")
+synth = importlib.import_module("nid-pose-estimation_amd.synth")
+cfg = sys.argv[1] if len(sys.argv) > 1 else "A"
+bins = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+nt = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+pair = synth.make_pair(cfg)
+ctx = capi.from_pair(pair, bins)
+if nt: ctx.set_block_threads(nt)
+cnt, _ = ctx.compute_href(pair.pose_init)
+delta = float(np.sqrt(0.95))
+for _ in range(5):
+    ctx.normal_equations(pair.pose_init, delta)
+ctx.enable_stamps(True)
+ctx.normal_equations(pair.pose_init, delta)
+st = ctx.stamps()
+act = cnt >= 300
+s = st[act]
+names = ["zero+loads+warp+sample", "bspline+atomics", "fold+entropy", "phase2(jac)", "blocksum12", "cellquad", "reduce tail"]
+d = np.diff(s, axis=1)
+print("cfg", cfg, "bins", bins, "nt", nt, "active", act.sum())
+for k, n in enumerate(names):
+    print(f"{n:26s} median {np.median(d[:,k]):9.0f} cyc   max {d[:,k].max():9.0f}")
+print("total per block median", np.median(s[:,7]-s[:,0]), "max", (s[:,7]-s[:,0]).max())
+print("kernel span (first start -> last end)", st[:,7].max() - st[act][:,0].min())
+print("start spread", s[:,0].max()-s[:,0].min())
