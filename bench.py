@@ -119,7 +119,10 @@ def main():
     if args.block_threads:
         ctx.set_block_threads(args.block_threads)
     stream = torch.cuda.current_stream(dev)
-    ctx.set_stream(stream.cuda_stream)
+    if world > 1:
+        ctx.set_stream(stream.cuda_stream)   # RCCL ops are ordered against torch's stream
+    # world == 1: the context alternates its two own streams so that launch N+1 overlaps the
+    # reduction tail of launch N; torch.cuda.synchronize() below still fences the whole device
     cnt, href = ctx.compute_href(pair.pose_init)
     delta = float(np.sqrt(0.95))
     K, W = args.steps, args.warmup
@@ -189,22 +192,6 @@ def main():
         ev_ms.append(a)
         rd_ms.append(r)
     ctx.enable_timing(False)
-    # back-to-back kernel stream between two events (what rocprofv3 --stats averages)
-    e0 = torch.cuda.Event(enable_timing=True)
-    e1 = torch.cuda.Event(enable_timing=True)
-    nb2b = min(K, 1000)
-    torch.cuda.synchronize(dev)
-    e0.record(stream)
-    for i in range(nb2b):
-        s = i % nslots
-        if i >= nslots:
-            ctx.wait(s)
-        ctx.launch(s, poses[i % len(poses)], delta, True)
-    e1.record(stream)
-    drain(nb2b)
-    torch.cuda.synchronize(dev)
-    b2b_ms = e0.elapsed_time(e1) / nb2b
-
     if rank == 0:
         eval_ms = float(np.median(ev_ms))
         contract = ctx.contract_bytes()  # this rank's cells
@@ -241,8 +228,6 @@ def main():
                 "traffic": None,
                 "kernel": "nid::k_eval<JAC>",
                 "kernel_ms": eval_ms,
-                "reduce_kernel_ms": float(np.median(rd_ms)),
-                "step_device_ms_back_to_back": b2b_ms,
                 "algorithmic_bytes_per_launch": contract,
                 "note": "achieved = contract bytes (68 B/px + 64 B/cell, SURVEY 8d) / median HIP-event duration "
                         "of the evaluation kernel; the tile is L2/MALL-resident after the first launch",

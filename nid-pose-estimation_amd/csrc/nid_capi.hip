@@ -48,7 +48,11 @@ struct nid_ctx {
   int jac_bound = NID_JACBOUND_CPU;
   int xform = NID_XFORM_QUAT;
   int block_threads = 0;
-  hipStream_t own_stream = nullptr, stream = nullptr;
+  // own_stream: setup + blocking calls; aux_stream: odd slots of the pipelined path, so that
+  // launch N+1 overlaps the reduction tail and the launch gap of launch N (separate
+  // per-slot buffers make that safe).  An external stream (nid_set_stream) disables it.
+  hipStream_t own_stream = nullptr, aux_stream = nullptr, stream = nullptr;
+  bool external_stream = false;
   Tiles t{};
   uint8_t *im1_dev = nullptr, *im0_dev = nullptr;
   double *depth_dev = nullptr, *points_dev = nullptr, *Twc_dev = nullptr;
@@ -108,7 +112,7 @@ void pose_from_matrix16(const double *m, Pose *out) {
 
 size_t eval_lds_bytes(const Geometry &g, int nt) {
   const int nbins = g.nb * g.nb + g.nb;
-  const size_t red = (size_t)std::max(12 * (nt / 64), nt + 2);
+  const size_t red = (size_t)std::max(6 * (nt / 64), nt + 2);
   return (size_t)nbins * kHistCopies * 8 + (size_t)((nbins + 1) & ~1) * 8 +
          (size_t)kMaxBins * kRcpRow * 8 + red * 8;
 }
@@ -160,13 +164,13 @@ void launch_eval_t(const EvalParams &P, bool jac, size_t lds, hipStream_t s) {
     hipLaunchKernelGGL((k_eval<NT, PPT, false>), dim3(P.g.nloc), dim3(NT), lds, s, P);
 }
 
-int launch_eval(nid_ctx *ctx, const EvalParams &P, bool jac) {
+int launch_eval(nid_ctx *ctx, const EvalParams &P, bool jac, hipStream_t stream) {
   int nt = 0, ppt = 0;
   if (!pick_eval_shape(ctx, &nt, &ppt)) return NID_ERR_UNSUPPORTED;
   const size_t lds = eval_lds_bytes(P.g, nt);
   if (lds > 160 * 1024) return NID_ERR_UNSUPPORTED;
 #define X(T, PP) \
-  if (nt == T && ppt == PP) { launch_eval_t<T, PP>(P, jac, lds, ctx->stream); NID_HIP(ctx, hipGetLastError()); return NID_OK; }
+  if (nt == T && ppt == PP) { launch_eval_t<T, PP>(P, jac, lds, stream); NID_HIP(ctx, hipGetLastError()); return NID_OK; }
   NID_EVAL_CASES(X)
 #undef X
   return NID_ERR_UNSUPPORTED;
@@ -234,12 +238,16 @@ int launch_slot(nid_ctx *ctx, int slot, const Pose &pose, int want_jac, double d
     NID_HIP(ctx, hipMemsetAsync(ctx->dbg_wc, 0xFF, N * 32, ctx->stream));
     NID_HIP(ctx, hipMemsetAsync(ctx->dbg_jc, 0xFF, N * 4, ctx->stream));
   }
+  // Measured on MI355X (round 1): alternating two streams per launch is 2.2x SLOWER (52 vs 24 us
+  // per step) than one in-order stream, so the aux stream is opt-in (NID_TWO_STREAMS=1).
+  static const bool two_streams = getenv("NID_TWO_STREAMS") != nullptr;
+  hipStream_t st = (two_streams && !ctx->external_stream && !ctx->dbg_enabled && (slot & 1)) ? ctx->aux_stream : ctx->stream;
   S.timed = ctx->timing;
-  if (S.timed) NID_HIP(ctx, hipEventRecord(S.e0, ctx->stream));
-  rc = launch_eval(ctx, P, want_jac != 0);
+  if (S.timed) NID_HIP(ctx, hipEventRecord(S.e0, st));
+  rc = launch_eval(ctx, P, want_jac != 0, st);
   if (rc) return rc;
-  if (S.timed) NID_HIP(ctx, hipEventRecord(S.e1, ctx->stream));
-  if (S.external_target) NID_HIP(ctx, hipEventRecord(S.done, ctx->stream));
+  if (S.timed) NID_HIP(ctx, hipEventRecord(S.e1, st));
+  if (S.external_target) NID_HIP(ctx, hipEventRecord(S.done, st));
   S.pending = true;
   return NID_OK;
 }
@@ -259,7 +267,7 @@ int evaluate_common(nid_ctx *ctx, const Pose &pose, int want_jac, double *Ht, do
     NID_HIP(ctx, hipMemsetAsync(ctx->dbg_wc, 0xFF, N * 32, ctx->stream));
     NID_HIP(ctx, hipMemsetAsync(ctx->dbg_jc, 0xFF, N * 4, ctx->stream));
   }
-  rc = launch_eval(ctx, P, want_jac != 0);
+  rc = launch_eval(ctx, P, want_jac != 0, ctx->stream);
   if (rc) return rc;
   const size_t bytes = (size_t)ctx->g.nloc * kCellOut * sizeof(double);
   NID_HIP(ctx, hipMemcpyAsync(S.cellout_host, S.cellout_dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
@@ -398,6 +406,7 @@ int nid_create(const nid_config *cfg, nid_ctx **out) {
   auto fail = [&](int rc) { nid_destroy(ctx); return rc; };
   if (hipSetDevice(cfg->device) != hipSuccess) return fail(NID_ERR_NO_DEVICE);
   if (hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess) return fail(NID_ERR_HIP);
+  if (hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking) != hipSuccess) return fail(NID_ERR_HIP);
   ctx->stream = ctx->own_stream;
   const size_t N = (size_t)g.rows * g.cols;
   const size_t plane = (size_t)g.nloc * g.pstride;
@@ -462,6 +471,7 @@ int nid_destroy(nid_ctx *ctx) {
     if (S.e1) (void)hipEventDestroy(S.e1);
     if (S.e2) (void)hipEventDestroy(S.e2);
   }
+  if (ctx->aux_stream) { (void)hipStreamSynchronize(ctx->aux_stream); (void)hipStreamDestroy(ctx->aux_stream); }
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
   delete ctx;
   return NID_OK;
@@ -478,6 +488,7 @@ int nid_set_options(nid_ctx *ctx, int jac_bound_mode, int xform_mode) {
 int nid_set_stream(nid_ctx *ctx, void *hip_stream) {
   if (!ctx) return NID_ERR_INVALID_ARG;
   ctx->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : ctx->own_stream;
+  ctx->external_stream = hip_stream != nullptr;
   return NID_OK;
 }
 
@@ -646,6 +657,7 @@ int nid_wait(nid_ctx *ctx, int slot, double *H36, double *b6, double *chi2, int3
   while (__atomic_load_n(seqw, __ATOMIC_ACQUIRE) != S.seq) {
     if (++spins > 20000000ul) {  // fall back to the runtime so that a device error surfaces
       NID_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      NID_HIP(ctx, hipStreamSynchronize(ctx->aux_stream));
       if (__atomic_load_n(seqw, __ATOMIC_ACQUIRE) != S.seq) {
         ctx->last_error = "result sequence word never arrived";
         return NID_ERR_HIP;

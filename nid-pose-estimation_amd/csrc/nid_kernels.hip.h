@@ -162,6 +162,34 @@ __device__ __forceinline__ double win_tap(unsigned row, int k) {
   return (double)((row >> ((k & 3) * 8)) & 0xffu);
 }
 
+// the two window rows a sample at ordinate y interpolates between, and its dy
+struct RowPair {
+  unsigned ra, rb;
+  double dy;
+};
+__device__ __forceinline__ RowPair win_rows(const Win &w, double y) {
+  const int iy = (int)y;
+  RowPair r;
+  r.dy = y - iy;
+  int ky = iy - w.wy;
+  ky = min(max(ky, 0), 3);
+  r.ra = win_row(w, ky);
+  r.rb = win_row(w, min(ky + 1, 3));
+  return r;
+}
+// types_six_dof_expmap.h:310-328 on register taps (same operation order)
+__device__ __forceinline__ double bilinear_rows(const RowPair &r, int wx, double x) {
+  const int ix = (int)x;
+  const double dx = x - ix;
+  const double dy = r.dy;
+  const double dxdy = dx * dy;
+  int kx = ix - wx;
+  kx = min(max(kx, 0), 3);
+  const double i00 = win_tap(r.ra, kx), i01 = win_tap(r.ra, kx + 1);
+  const double i10 = win_tap(r.rb, kx), i11 = win_tap(r.rb, kx + 1);
+  return dxdy * i11 + (dy - dxdy) * i10 + (dx - dxdy) * i01 + (1 - dx - dy + dxdy) * i00;
+}
+
 // bilinear_u8 on the window: same arithmetic, taps from registers.  A tap index
 // that leaves the window can only belong to a tap whose weight is exactly 0
 // (x or y rounded up to an integer) -- any finite byte is then correct.
@@ -187,9 +215,22 @@ __device__ __forceinline__ void launder(double &v) { asm volatile("" : "+v"(v));
 __device__ __forceinline__ void launder(unsigned &v) { asm volatile("" : "+v"(v)); }
 __device__ __forceinline__ void launder(int &v) { asm volatile("" : "+v"(v)); }
 
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+// Wave64 sum by DPP (VALU cross-lane moves, no LDS traffic): quad swaps, row
+// (half-)mirror, then row_bcast15 / row_bcast31.  The total ends in lane 63.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_mov_f64(double x) {
+  int lo = __double2loint(x), hi = __double2hiint(x);
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xf, false);
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_sum_to_lane63(double v) {
+  v += dpp_mov_f64<0xB1, 0xf>(v);   // quad_perm [1,0,3,2]
+  v += dpp_mov_f64<0x4E, 0xf>(v);   // quad_perm [2,3,0,1]
+  v += dpp_mov_f64<0x141, 0xf>(v);  // row_half_mirror
+  v += dpp_mov_f64<0x140, 0xf>(v);  // row_mirror
+  v += dpp_mov_f64<0x142, 0xa>(v);  // row_bcast15 -> rows 1,3
+  v += dpp_mov_f64<0x143, 0xc>(v);  // row_bcast31 -> rows 2,3
   return v;
 }
 
@@ -199,9 +240,9 @@ template <int NT, int NV>
 __device__ __forceinline__ void block_sum(double (&v)[NV], double *red, int tid) {
   constexpr int NW = NT / 64;
 #pragma unroll
-  for (int k = 0; k < NV; k++) v[k] = wave_sum(v[k]);
+  for (int k = 0; k < NV; k++) v[k] = wave_sum_to_lane63(v[k]);
   const int wave = tid >> 6, lane = tid & 63;
-  if (lane == 0) {
+  if (lane == 63) {
 #pragma unroll
     for (int k = 0; k < NV; k++) red[wave * NV + k] = v[k];
   }
@@ -514,9 +555,10 @@ __global__ __launch_bounds__(NT) void k_eval(EvalParams P) {
     for (int k = 0; k < 4; k++) s_wr[i][k] = P.t.W[k * plane + gi];
   }
 
-  // ---- stage 1: warp + in-frame tests (branch-free) ---------------------------
+  // ---- stage 1: warp, in-frame test, issue the 4x4 window loads ------------------
   double s_x[PPT], s_y[PPT], s_z[PPT], s_u[PPT], s_v[PPT];
   bool s_in[PPT];
+  Win s_w[PPT];
 #pragma unroll
   for (int i = 0; i < PPT; i++) {
     double qx, qy, qz;
@@ -526,52 +568,39 @@ __global__ __launch_bounds__(NT) void k_eval(EvalParams P) {
     const double v = g.fy * qy / qz + g.cy;
     s_in[i] = (s_jr[i] >= 0) && (u >= 0 && u + 3 <= g.cols && v >= 0 && v + 3 <= g.rows);
     s_x[i] = qx; s_y[i] = qy; s_z[i] = qz; s_u[i] = u; s_v[i] = v;
-  }
-
-  // ---- stage 2: bilinear sample of the target (taps of out-of-frame pixels are
-  //      redirected to pixel (0,0), their result is discarded) -------------------
-  Win s_w[PPT];
-#pragma unroll
-  for (int i = 0; i < PPT; i++) {
-    const double us = s_in[i] ? s_u[i] : 0.0, vs = s_in[i] ? s_v[i] : 0.0;
-    s_w[i].wx = max((int)us - 1, 0);
-    s_w[i].wy = max((int)vs - 1, 0);
+    // out-of-frame pixels load the window at (0,0); it is never used
+    s_w[i].wx = s_in[i] ? max((int)u - 1, 0) : 0;
+    s_w[i].wy = s_in[i] ? max((int)v - 1, 0) : 0;
     const uint8_t *p = P.im1 + (size_t)s_w[i].wy * g.cols + s_w[i].wx;
     s_w[i].r0 = load_u32_unaligned(p);
     s_w[i].r1 = load_u32_unaligned(p + g.cols);
     s_w[i].r2 = load_u32_unaligned(p + 2 * g.cols);
     s_w[i].r3 = load_u32_unaligned(p + 3 * g.cols);
   }
-  double s_ic[PPT];
-#pragma unroll
-  for (int i = 0; i < PPT; i++) {
-    const double us = s_in[i] ? s_u[i] : 0.0, vs = s_in[i] ? s_v[i] : 0.0;
-    double ic = bilinear_w(s_w[i], us, vs);
-    if (ic >= 255) ic = 254.999;
-    if (ic < 0) ic = 0.0;
-    s_ic[i] = ic;
-    __builtin_amdgcn_sched_barrier(0);
-  }
-  NID_STAMP(1, s_ic[0], s_ic[PPT - 1]);
+  NID_STAMP(1, s_u[0], s_v[PPT - 1]);
   __syncthreads();  // histogram zeroed, rtab ready
-#pragma unroll
-  for (int i = 0; i < PPT; i++) launder(s_ic[i]);
 
-  // ---- stage 3: target B-spline weights, histogram accumulation --------------
+  // ---- stage 2: sample, target B-spline weights, histogram accumulation ---------
   double s_dw[PPT][4];
   int s_jc[PPT];
 #pragma unroll
   for (int i = 0; i < PPT; i++) {
-    const double pc = s_ic[i] * ((double)nb - 3.0) / 255.0;
-    const int jc = (int)floor(pc);
-    double wc[4], dw[4];
-    bspline4_tab<JAC>(pc, jc, g.S, rtab, wc, dw);
-    s_jc[i] = jc;
-    if (JAC) {
-#pragma unroll
-      for (int k = 0; k < 4; k++) s_dw[i][k] = dw[k];
-    }
+    s_jc[i] = 0;
+    double ic = NAN, wc[4] = {NAN, NAN, NAN, NAN};
     if (s_in[i]) {
+      const RowPair rp = win_rows(s_w[i], s_v[i]);
+      ic = bilinear_rows(rp, s_w[i].wx, s_u[i]);
+      if (ic >= 255) ic = 254.999;
+      if (ic < 0) ic = 0.0;
+      const double pc = ic * ((double)nb - 3.0) / 255.0;
+      const int jc = (int)floor(pc);
+      double dw[4];
+      bspline4_tab<JAC>(pc, jc, g.S, rtab, wc, dw);
+      s_jc[i] = jc;
+      if (JAC) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) s_dw[i][k] = dw[k];
+      }
       unsigned long long *hc = hist + (size_t)jc * kHistCopies + copy;
 #pragma unroll
       for (int k = 0; k < 4; k++) atomicAdd(hc + k * kHistCopies, fx_encode(wc[k], P.hist_scale));
@@ -589,10 +618,10 @@ __global__ __launch_bounds__(NT) void k_eval(EvalParams P) {
       const int col = (c % g.cell_num) * g.cb + s % g.cb;
       const size_t id = (size_t)r * g.cols + col;
       P.dbg_u[id] = s_u[i]; P.dbg_v[id] = s_v[i];
-      P.dbg_ic[id] = s_in[i] ? s_ic[i] : NAN;
-      P.dbg_jc[id] = s_in[i] ? jc : -1;
+      P.dbg_ic[id] = ic;
+      P.dbg_jc[id] = s_in[i] ? s_jc[i] : -1;
 #pragma unroll
-      for (int k = 0; k < 4; k++) P.dbg_wc[4 * id + k] = s_in[i] ? wc[k] : NAN;
+      for (int k = 0; k < 4; k++) P.dbg_wc[4 * id + k] = wc[k];
     }
     __builtin_amdgcn_sched_barrier(0);  // one pixel at a time: bounds the live register set
   }
@@ -602,9 +631,13 @@ __global__ __launch_bounds__(NT) void k_eval(EvalParams P) {
   // ---- fold the copies, probabilities, entropies, weight tables ---------------
   double ent[2] = {0.0, 0.0};  // sum p*log2(p): target, joint
   for (int b = tid; b < nbins; b += NT) {
+    const uint4 *hv = reinterpret_cast<const uint4 *>(hist + (size_t)b * kHistCopies);
     unsigned long long acc = 0;
-#pragma unroll 8
-    for (int c = 0; c < kHistCopies; c++) acc += hist[b * kHistCopies + ((c + b) & (kHistCopies - 1))];
+#pragma unroll
+    for (int c = 0; c < kHistCopies / 2; c++) {  // 16-byte reads, start rotated per bin (bank spread)
+      const uint4 q = hv[(c + b) & (kHistCopies / 2 - 1)];
+      acc += ((unsigned long long)q.y << 32 | q.x) + ((unsigned long long)q.w << 32 | q.z);
+    }
     // CalculateHKernel: pro /= bs_counter (computeH.cu:277-291), N_c of the initial pose (Q1)
     const double p = ((double)(long long)acc * P.hist_inv_scale) / (double)n_c;
     double w = 0.0;
@@ -636,16 +669,22 @@ __global__ __launch_bounds__(NT) void k_eval(EvalParams P) {
     }
     if (tid < kQuad) store_sc1(quad + tid, tid == 0 ? rho0 : (tid == 28 ? 1.0 : 0.0));
     __syncthreads();  // `red` is reused by the reduction
+    NID_STAMP(6);
     finish_and_reduce<NT>(P, cl, tid, red);
+    NID_STAMP(7);
     return;
   }
 
   // ---- phase 2: Jacobian --------------------------------------------------------
-  // linearizeOplus recomputes u as fx*(x/z)+cx (types_six_dof_expmap.cpp:407-422, Q6)
-  const double kappa = (double)g.S / 255.0;  // d_mi_i, :393
-  double acc[12];
+  // J[n] = (dHj[n]*(Hc+Href) - dHc[n]*Hj)/Hj^2 with dHj = sum s*dI/N_c, dHc = sum t*dI/N_c
+  // (types_six_dof_expmap.cpp:486-528) is linear in the per-pixel contributions, so one
+  // coefficient c = s*(Hc+Href) - t*Hj per pixel and six sums G[n] = sum c*dI[n] suffice;
+  // s = sum_k wr[k] * (sum_m Wj[jr+k][jc+m] dw[m]), t = sum_m Wc[jc+m] dw[m] contract the
+  // reference's 6*bin^2 tensor per pixel.  Smooth algebra: FMAs allowed.
+  const double cA = Hc + href, cB = Hj;
+  double acc[6];
 #pragma unroll
-  for (int n = 0; n < 12; n++) acc[n] = 0.0;
+  for (int n = 0; n < 6; n++) acc[n] = 0.0;
 #pragma unroll
   for (int i = 0; i < PPT; i++) {
     launder(s_x[i]); launder(s_y[i]); launder(s_z[i]);
@@ -654,68 +693,60 @@ __global__ __launch_bounds__(NT) void k_eval(EvalParams P) {
   }
 #pragma unroll
   for (int i = 0; i < PPT; i++) {
-    const double zz = s_in[i] ? s_z[i] : 1.0;  // discarded pixels: finite stand-ins, zero weight below
-    const double x = s_in[i] ? s_x[i] : 0.0, y = s_in[i] ? s_y[i] : 0.0;
-    const double invz = 1.0 / zz;
-    const double uj = g.fx * (x / zz) + g.cx;
-    const double vj = g.fy * (y / zz) + g.cy;
-    const bool jin = s_in[i] && (uj >= 0 && uj + 3 <= P.jac_cols && vj >= 0 && vj + 3 <= g.rows);
-    const double u = jin ? uj : 1.0, v = jin ? vj : 1.0;  // safe taps for discarded pixels
-    const double gx = (bilinear_w(s_w[i], u + 1, v) - bilinear_w(s_w[i], u - 1, v)) / 2;
-    const double gy = (bilinear_w(s_w[i], u, v + 1) - bilinear_w(s_w[i], u, v - 1)) / 2;
-    const double invz_2 = invz * invz;
-    // types_six_dof_expmap.cpp:438-450
-    double Ju[6], Jv[6];
-    Ju[0] = -x * y * invz_2 * g.fx;
-    Ju[1] = (1 + (x * x * invz_2)) * g.fx;
-    Ju[2] = -y * invz * g.fx;
-    Ju[3] = invz * g.fx;
-    Ju[4] = 0;
-    Ju[5] = -x * invz_2 * g.fx;
-    Jv[0] = -(1 + y * y * invz_2) * g.fy;
-    Jv[1] = x * y * invz_2 * g.fy;
-    Jv[2] = x * invz * g.fy;
-    Jv[3] = 0;
-    Jv[4] = invz * g.fy;
-    Jv[5] = -y * invz_2 * g.fy;
-    // s = kappa * sum_k wr[k] * (sum_m Wj[jr+k][jc+m] dw[m]);  t = kappa * sum_m Wc[jc+m] dw[m]
-    // -- the reference's 6*bin^2 tensor contracted per pixel (same algebra, smooth: FMAs allowed)
-    const int jr = jin ? s_jr[i] : 0, jc = jin ? s_jc[i] : 0;
-    const double *tj = tab + nb + jr * nb + jc;
-    double tt = 0.0, ss = 0.0;
+    if (s_in[i]) {
+      // linearizeOplus recomputes u as fx*(x/z)+cx (types_six_dof_expmap.cpp:407-422, Q6)
+      const double x = s_x[i], y = s_y[i], zz = s_z[i];
+      const double invz = 1.0 / zz;
+      const double u = g.fx * (x / zz) + g.cx;
+      const double v = g.fy * (y / zz) + g.cy;
+      if (u >= 0 && u + 3 <= P.jac_cols && v >= 0 && v + 3 <= g.rows) {
+        const int wx = s_w[i].wx;
+        const RowPair r0 = win_rows(s_w[i], v);
+        const double gx = (bilinear_rows(r0, wx, u + 1) - bilinear_rows(r0, wx, u - 1)) / 2;
+        const RowPair rp = win_rows(s_w[i], v + 1), rm = win_rows(s_w[i], v - 1);
+        const double gy = (bilinear_rows(rp, wx, u) - bilinear_rows(rm, wx, u)) / 2;
+        const int jr = s_jr[i], jc = s_jc[i];
+        const double *tj = tab + nb + jr * nb + jc;
+        double tt = 0.0, ss = 0.0;
 #pragma unroll
-    for (int m = 0; m < 4; m++) tt = fma(tab[jc + m], s_dw[i][m], tt);
+        for (int m = 0; m < 4; m++) tt = fma(tab[jc + m], s_dw[i][m], tt);
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-      double inner = 0.0;
+        for (int k = 0; k < 4; k++) {
+          double inner = 0.0;
 #pragma unroll
-      for (int m = 0; m < 4; m++) inner = fma(tj[k * nb + m], s_dw[i][m], inner);
-      ss = fma(s_wr[i][k], inner, ss);
-    }
-    ss = jin ? ss * kappa : 0.0;
-    tt = jin ? tt * kappa : 0.0;
-#pragma unroll
-    for (int n = 0; n < 6; n++) {
-      const double dI = fma(gx, Ju[n], gy * Jv[n]);  // d_i_pose, :460
-      acc[n] = fma(ss, dI, acc[n]);
-      acc[6 + n] = fma(tt, dI, acc[6 + n]);
+          for (int m = 0; m < 4; m++) inner = fma(tj[k * nb + m], s_dw[i][m], inner);
+          ss = fma(s_wr[i][k], inner, ss);
+        }
+        const double c = fma(ss, cA, -(tt * cB));
+        const double cgx = c * gx, cgy = c * gy;
+        const double invz_2 = invz * invz;
+        // rows of d(u,v)/d(xi), types_six_dof_expmap.cpp:438-450 (omega first, then upsilon)
+        const double ju0 = -x * y * invz_2 * g.fx, ju1 = (1 + (x * x * invz_2)) * g.fx;
+        const double ju2 = -y * invz * g.fx, ju3 = invz * g.fx, ju5 = -x * invz_2 * g.fx;
+        const double jv0 = -(1 + y * y * invz_2) * g.fy, jv1 = x * y * invz_2 * g.fy;
+        const double jv2 = x * invz * g.fy, jv4 = invz * g.fy, jv5 = -y * invz_2 * g.fy;
+        acc[0] = fma(cgx, ju0, fma(cgy, jv0, acc[0]));
+        acc[1] = fma(cgx, ju1, fma(cgy, jv1, acc[1]));
+        acc[2] = fma(cgx, ju2, fma(cgy, jv2, acc[2]));
+        acc[3] = fma(cgx, ju3, acc[3]);
+        acc[4] = fma(cgy, jv4, acc[4]);
+        acc[5] = fma(cgx, ju5, fma(cgy, jv5, acc[5]));
+      }
     }
     __builtin_amdgcn_sched_barrier(0);  // one pixel at a time: bounds the live register set
   }
-  NID_STAMP(4, acc[0], acc[5], acc[6], acc[11]);
+  NID_STAMP(4, acc[0], acc[2], acc[3], acc[5]);
   __syncthreads();  // `red` is reused
-  block_sum<NT, 12>(acc, red, tid);
-  NID_STAMP(5, acc[0], acc[5], acc[6], acc[11]);
+  block_sum<NT, 6>(acc, red, tid);
+  NID_STAMP(5, acc[0], acc[2], acc[3], acc[5]);
   if (tid < 64) {
-    // CalculateDerKernel tail (computeH.cu:358-366) == types_six_dof_expmap.cpp:521-528
-    const double inv_square_hj = 1.0 / (Hj * Hj);
+    // CalculateDerKernel tail (computeH.cu:358-366) == types_six_dof_expmap.cpp:486-528:
+    // kappa = d_mi_i (:393), 1/N_c (:488,494), 1/Hj^2 (:521)
+    const double kappa = (double)g.S / 255.0;
+    const double scale = (kappa / (double)n_c) * (1.0 / (Hj * Hj));
     double J[6];
 #pragma unroll
-    for (int n = 0; n < 6; n++) {
-      const double d_hj = acc[n] / (double)n_c;
-      const double d_hl = acc[6 + n] / (double)n_c;
-      J[n] = (d_hj * (Hc + href) - d_hl * Hj) * inv_square_hj;
-    }
+    for (int n = 0; n < 6; n++) J[n] = acc[n] * scale;
     if (tid == 0) {
       out[0] = Hc; out[1] = Hj; out[2] = err;
 #pragma unroll
