@@ -1,0 +1,60 @@
+// legacy_ops.h -- the reference's three operator entry points, same names, same
+// argument lists, same C++ linkage, implemented on the HIP library:
+//
+//   void Calculate3Dpoint(...)     replaces CudaPoints3d.cuh:6    (CudaPoints3d.cu:35-73)
+//   void CudaComputeHref(...)      replaces CudaComputeHref.cuh:5 (CudaComputeHref.cu:139-222)
+//   void g2o::CudaComputeH(...)    replaces g2o/g2o/core/computeH.cuh:8 (computeH.cu:373-502)
+//
+// A maintainer of the reference swaps the three .cu files for legacy_ops.cpp and
+// links libnid_hip.so; NID_pose_estimation.cpp and the g2o hooks
+// (optimization_algorithm_levenberg.cpp:98,173; sparse_optimizer.cpp:423) call
+// them unchanged.
+//
+// Conventions kept: column-major 4x4 poses; camera_intrincis =
+// {fx, fy, cx, cy, depth_factor}; images row-major f64 holding u8 values;
+// points3d AoS xyz with NaN = invalid; Htarget/Hjoint are in/out (the callee
+// subtracts onto caller-zeroed storage, computeH.cu:285,298); der is untouched
+// when calculate_der == false; pro_target / pro_joint are accepted and ignored.
+// Errors are printed to stderr and execution continues, like the reference
+// (computeH.cu:454-473) -- the signatures return void.
+//
+// Differences, all deliberate: no per-call allocation / memset / re-upload (the
+// frame-pair state is cached per (rows, cols, cell_num, bin_num) and re-uploaded
+// only when a caller buffer's address changes, or always with
+// NID_LEGACY_ALWAYS_UPLOAD=1); out-of-frame reference weights are NaN in the
+// arrays handed back (as CudaComputeHref.cu:126-130 writes them) but are treated
+// as 0 inside, the CPU edge's convention; the Jacobian in-frame
+// test defaults to the CPU edge's `cols-1` (the parity target),
+// nid_legacy_set_jacobian_bound(1) selects the CUDA kernel's `cols`.
+#ifndef NID_LEGACY_OPS_H
+#define NID_LEGACY_OPS_H
+
+void Calculate3Dpoint(double *depth, double *pose_c2w, double *points_3d, double *camera_intrincis,
+                      int rows, int cols);
+
+void CudaComputeHref(double *im0, double *points3d, double *pose, double *camera_intrincis, int bin_num,
+                     int bs_degree, int cell_num, int rows, int cols, double *bs_value, int *bs_index,
+                     int *bs_counter, double *Href);
+
+namespace g2o {
+void CudaComputeH(bool calculate_der, double *im0, double *im1, double *points3d, int *bs_counter,
+                  double *bs_ref, int *bs_index_ref, double *pose, double *camera_intrincis, int bin_num,
+                  int bs_degree, int cell_num, int rows, int cols, double *Href, double *pro_target,
+                  double *pro_joint, double *Htarget, double *Hjoint, double *der);
+}
+
+extern "C" {
+struct nid_ctx;
+// 0 = CPU-edge bound (default), 1 = CUDA-kernel bound
+void nid_legacy_set_jacobian_bound(int mode);
+void nid_legacy_set_device(int device);
+// drop every cached context (e.g. before the caller frees its buffers)
+void nid_legacy_reset(void);
+// the context the legacy calls are currently using (NULL before the first call); lets a host
+// mix the legacy operators with the fused C-ABI entry points on the same device state
+nid_ctx *nid_legacy_context(void);
+// number of host->device uploads of frame-pair data done so far (tests: must not grow per call)
+long nid_legacy_upload_count(void);
+}
+
+#endif

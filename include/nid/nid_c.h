@@ -92,6 +92,9 @@ int nid_set_reference_depth(nid_ctx *ctx, const double *depth_m, const uint8_t *
 /* same, from an existing AoS point cloud (NaN xyz = invalid), as handed to
  * CudaComputeHref / CudaComputeH */
 int nid_set_reference_points(nid_ctx *ctx, const double *points3d, const uint8_t *im0);
+/* context-free Calculate3Dpoint (CudaPoints3d.cuh:6): depth f64 metres -> AoS world points, NaN = invalid */
+int nid_backproject(const double *depth_m, const double *T_wc0_colmajor16, double fx, double fy, double cx,
+                    double cy, int32_t rows, int32_t cols, int32_t device, double *points3d);
 /* copy the back-projected points back in Calculate3Dpoint's output layout */
 int nid_get_points3d(nid_ctx *ctx, double *points3d);
 int nid_set_target_u8(nid_ctx *ctx, const uint8_t *im1);

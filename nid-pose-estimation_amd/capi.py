@@ -38,7 +38,7 @@ class NidConfig(C.Structure):
 SYMBOLS = [
     "nid_abi_version", "nid_status_string", "nid_last_error", "nid_device_count", "nid_create",
     "nid_destroy", "nid_set_options", "nid_set_stream", "nid_set_block_threads",
-    "nid_set_reference_depth", "nid_set_reference_points", "nid_get_points3d", "nid_set_target_u8",
+    "nid_set_reference_depth", "nid_set_reference_points", "nid_backproject", "nid_get_points3d", "nid_set_target_u8",
     "nid_set_target_f64", "nid_set_reference_image_f64", "nid_compute_href",
     "nid_compute_href_matrix", "nid_set_href_state", "nid_evaluate", "nid_evaluate_matrix",
     "nid_normal_equations", "nid_launch", "nid_wait", "nid_slot_buffers", "nid_launch_to",
@@ -77,6 +77,7 @@ def load():
     lib.nid_set_reference_depth.argtypes = [vp, c_dp, c_u8p, c_dp]
     lib.nid_set_reference_points.argtypes = [vp, c_dp, c_u8p]
     lib.nid_get_points3d.argtypes = [vp, c_dp]
+    lib.nid_backproject.argtypes = [c_dp, c_dp] + [C.c_double] * 4 + [C.c_int32] * 3 + [c_dp]
     lib.nid_set_target_u8.argtypes = [vp, c_u8p]
     lib.nid_set_target_f64.argtypes = [vp, c_dp]
     lib.nid_set_reference_image_f64.argtypes = [c_dp, C.c_int64, c_u8p]

@@ -529,6 +529,34 @@ int nid_get_points3d(nid_ctx *ctx, double *points3d) {
   return NID_OK;
 }
 
+int nid_backproject(const double *depth_m, const double *T_wc0, double fx, double fy, double cx, double cy,
+                    int32_t rows, int32_t cols, int32_t device, double *points3d) {
+  // context-free twin of Calculate3Dpoint (CudaPoints3d.cu:35-73)
+  if (!depth_m || !T_wc0 || !points3d || rows < 1 || cols < 1) return NID_ERR_INVALID_ARG;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return NID_ERR_NO_DEVICE;
+  if (device < 0 || device >= ndev || hipSetDevice(device) != hipSuccess) return NID_ERR_INVALID_ARG;
+  const size_t N = (size_t)rows * cols;
+  double *d_depth = nullptr, *d_T = nullptr, *d_pts = nullptr;
+  int rc = NID_OK;
+  if (hipMalloc(reinterpret_cast<void **>(&d_depth), N * 8) != hipSuccess ||
+      hipMalloc(reinterpret_cast<void **>(&d_T), 16 * 8) != hipSuccess ||
+      hipMalloc(reinterpret_cast<void **>(&d_pts), 3 * N * 8) != hipSuccess) rc = NID_ERR_NOMEM;
+  if (rc == NID_OK) {
+    Geometry g{};
+    g.rows = rows; g.cols = cols; g.fx = fx; g.fy = fy; g.cx = cx; g.cy = cy;
+    if (hipMemcpy(d_depth, depth_m, N * 8, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(d_T, T_wc0, 16 * 8, hipMemcpyHostToDevice) != hipSuccess) rc = NID_ERR_HIP;
+    if (rc == NID_OK) {
+      hipLaunchKernelGGL(k_backproject_plain, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, 0, g, d_depth, d_T, d_pts);
+      if (hipGetLastError() != hipSuccess ||
+          hipMemcpy(points3d, d_pts, 3 * N * 8, hipMemcpyDeviceToHost) != hipSuccess) rc = NID_ERR_HIP;
+    }
+  }
+  (void)hipFree(d_depth); (void)hipFree(d_T); (void)hipFree(d_pts);
+  return rc;
+}
+
 int nid_set_target_u8(nid_ctx *ctx, const uint8_t *im1) {
   if (!ctx || !im1) return NID_ERR_INVALID_ARG;
   NID_HIP(ctx, hipSetDevice(ctx->cfg.device));

@@ -1,0 +1,143 @@
+// nid_pose_problem.cpp -- the graph that NID_pose_estimation.cpp builds
+// (NID_pose_estimation.cpp:163-366), assembled on the g2o-shaped host API, plus a
+// C entry point so that tests can drive the C++ host stack through ctypes.
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <sstream>
+#include <vector>
+
+#include "g2o_min/g2o_min.h"
+#include "nid/legacy_ops.h"
+#include "nid_pose_problem.h"
+
+int nid_host_run_lm(const nid_pose_problem *pb, double *pose7_inout, nid_host_lm_record *trace,
+                    int max_trace, char *log_buf, int log_cap) {
+  if (!pb || !pose7_inout) return -1;
+  const int rows = pb->rows, cols = pb->cols, cell = pb->cell_num, bin_num = pb->bin_num, bs_degree = 3;
+  const size_t N = (size_t)rows * cols;
+  nid_legacy_reset();
+  nid_legacy_set_jacobian_bound(pb->jac_bound_cuda ? 1 : 0);
+
+  // NID_pose_estimation.cpp:229-251 -- buffers owned by the caller of the operators
+  std::vector<double> intrinscis = {pb->fx, pb->fy, pb->cx, pb->cy, pb->depth_factor};
+  std::vector<double> bs_value(4 * N), Href(cell * cell, 0.0), points_3d_all(3 * N), im0_data(N), im1_data(N);
+  std::vector<int> bin_index(N), bs_counter(cell * cell);
+  for (size_t i = 0; i < N; i++) { im0_data[i] = (double)pb->im0[i]; im1_data[i] = (double)pb->im1[i]; }
+  std::vector<double> depth(N);
+  for (size_t i = 0; i < N; i++) depth[i] = (double)pb->depth_u16[i] * pb->depth_factor;  // convertTo(CV_64F, 1/5000), :106
+  std::vector<double> T_wc0(pb->T_wc0_colmajor, pb->T_wc0_colmajor + 16);
+
+  g2o::SparseOptimizer optimizer;
+  g2o::BlockSolver_6_X::LinearSolverType *linearSolver = new g2o::LinearSolverDense();
+  g2o::BlockSolver_6_X *solver_ptr = new g2o::BlockSolver_6_X(linearSolver);
+  g2o::OptimizationAlgorithmLevenberg *solver = new g2o::OptimizationAlgorithmLevenberg(solver_ptr);
+  solver->setFusedNormalEquations(pb->fused != 0);
+  optimizer.setAlgorithm(solver);
+  optimizer.setVerbose(true);
+  std::ostringstream log;
+  optimizer.setLogStream(&log);
+
+  g2o::VertexSE3Expmap *vSE3 = new g2o::VertexSE3Expmap();
+  vSE3->setEstimate(g2o::SE3Quat::fromPose7(pose7_inout));
+  vSE3->setId(0);
+  vSE3->setFixed(false);
+  optimizer.addVertex(vSE3);
+
+  // :253, :257
+  Calculate3Dpoint(depth.data(), T_wc0.data(), points_3d_all.data(), intrinscis.data(), rows, cols);
+  g2o::Matrix4d M0 = vSE3->estimate().to_homogeneous_matrix();
+  CudaComputeHref(im0_data.data(), points_3d_all.data(), M0.data(), intrinscis.data(), bin_num, bs_degree, cell,
+                  rows, cols, bs_value.data(), bin_index.data(), bs_counter.data(), Href.data());
+
+  // :264-276
+  optimizer.im0_ = im0_data.data(); optimizer.im1_ = im1_data.data(); optimizer.points3d_ = points_3d_all.data();
+  optimizer.rows_ = rows; optimizer.cols_ = cols; optimizer.camera_intrincis_ = intrinscis.data();
+  optimizer.bin_num_ = bin_num; optimizer.bs_degree_ = bs_degree; optimizer.cell_num_ = cell;
+  optimizer.bs_counter_ = bs_counter.data(); optimizer.bs_value_ref_ = bs_value.data();
+  optimizer.bs_index_ref_ = bin_index.data(); optimizer.Href_ = Href.data();
+
+  const double deltaNID = pb->huber_delta > 0 ? pb->huber_delta : std::sqrt(0.95);  // :279
+  for (int i = 0; i < cell; i++)
+    for (int j = 0; j < cell; j++) {  // :283-337 (use_gpu branch)
+      g2o::EdgeSE3ProjectIntensityOnlyPoseNID *e = new g2o::EdgeSE3ProjectIntensityOnlyPoseNID();
+      e->setVertex(0, optimizer.vertex(0));
+      e->use_CPU_ = false;
+      e->set_bspline_relates(bs_degree, bin_num);
+      g2o::RobustKernelHuber *rk = new g2o::RobustKernelHuber;
+      e->setRobustKernel(rk);
+      rk->setDelta(deltaNID);
+      e->setInformation(1.0);
+      if (std::isnan(Href[j + cell * i])) e->setLevel(1);
+      else e->set_href(Href[j + cell * i]);
+      optimizer.addEdge(e);
+    }
+
+  optimizer.initializeOptimization(0);
+  const int done = optimizer.optimize(pb->iterations);  // :349-350
+
+  vSE3->estimate().toPose7(pose7_inout);
+  const std::vector<g2o::IterationRecord> &tr = optimizer.trace();
+  for (int k = 0; k < (int)tr.size() && k < max_trace; k++) {
+    trace[k].iteration = tr[k].iteration; trace[k].chi2 = tr[k].chi2; trace[k].lambda = tr[k].lambda;
+    trace[k].rho = tr[k].rho; trace[k].lm_trials = tr[k].levenbergIter;
+    std::memcpy(trace[k].pose7, tr[k].pose7, sizeof(trace[k].pose7));
+  }
+  if (log_buf && log_cap > 0) {
+    const std::string s = log.str();
+    std::snprintf(log_buf, (size_t)log_cap, "%s", s.c_str());
+  }
+  nid_legacy_reset();
+  return done;
+}
+
+void nid_host_se3_exp(const double *upd6, double *pose7) {
+  g2o::Vector6d u;
+  for (int i = 0; i < 6; i++) u[i] = upd6[i];
+  g2o::SE3Quat::exp(u).toPose7(pose7);
+}
+
+void nid_host_se3_mul(const double *a7, const double *b7, double *out7) {
+  (g2o::SE3Quat::fromPose7(a7) * g2o::SE3Quat::fromPose7(b7)).toPose7(out7);
+}
+
+void nid_host_se3_to_matrix(const double *pose7, double *M16) {
+  g2o::Matrix4d M = g2o::SE3Quat::fromPose7(pose7).to_homogeneous_matrix();
+  std::memcpy(M16, M.data(), 16 * sizeof(double));
+}
+
+int nid_host_ldlt6_solve(const double *H36, const double *b6, double *x6) {
+  g2o::LinearSolverDense ls;
+  return ls.solve(H36, x6, b6) ? 1 : 0;
+}
+
+void nid_host_minimal_vector(const double *pose7, double *v6) {
+  g2o::Vector6d v = g2o::SE3Quat::fromPose7(pose7).toMinimalVector();
+  for (int i = 0; i < 6; i++) v6[i] = v[i];
+}
+
+void nid_host_huber(double e2, double delta, double *rho3) {
+  g2o::RobustKernelHuber rk;
+  rk.setDelta(delta);
+  rk.robustify(e2, rho3);
+}
+
+// ---- C shims of the three legacy C++ operators (tests drive them through ctypes) --------
+void nid_legacy_call_Calculate3Dpoint(double *depth, double *pose_c2w, double *points_3d, double *intr, int rows,
+                                      int cols) {
+  Calculate3Dpoint(depth, pose_c2w, points_3d, intr, rows, cols);
+}
+void nid_legacy_call_CudaComputeHref(double *im0, double *points3d, double *pose, double *intr, int bin_num,
+                                     int bs_degree, int cell_num, int rows, int cols, double *bs_value,
+                                     int *bs_index, int *bs_counter, double *Href) {
+  CudaComputeHref(im0, points3d, pose, intr, bin_num, bs_degree, cell_num, rows, cols, bs_value, bs_index, bs_counter,
+                  Href);
+}
+void nid_legacy_call_CudaComputeH(int calculate_der, double *im0, double *im1, double *points3d, int *bs_counter,
+                                  double *bs_ref, int *bs_index_ref, double *pose, double *intr, int bin_num,
+                                  int bs_degree, int cell_num, int rows, int cols, double *Href, double *Htarget,
+                                  double *Hjoint, double *der) {
+  g2o::CudaComputeH(calculate_der != 0, im0, im1, points3d, bs_counter, bs_ref, bs_index_ref, pose, intr, bin_num,
+                    bs_degree, cell_num, rows, cols, Href, nullptr, nullptr, Htarget, Hjoint, der);
+}

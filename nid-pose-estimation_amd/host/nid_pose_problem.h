@@ -1,0 +1,52 @@
+// nid_pose_problem.h -- C entry points of libnid_host.so: the reference driver's
+// optimisation (NID_pose_estimation.cpp:163-366) on the g2o-shaped host API, and the
+// small host-only routines (SE(3), LDLT, Huber) for CPU unit tests.
+#ifndef NID_POSE_PROBLEM_H
+#define NID_POSE_PROBLEM_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct {
+  int32_t rows, cols, cell_num, bin_num, iterations;
+  int32_t jac_bound_cuda;   /* 0 = CPU-edge bound (parity target), 1 = CUDA-kernel bound */
+  int32_t fused;            /* 1 = fused device normal equations, 0 = per-edge walk like the reference */
+  double fx, fy, cx, cy, depth_factor, huber_delta;
+  const uint8_t *im0, *im1;        /* rows*cols */
+  const uint16_t *depth_u16;       /* rows*cols, metres = value * depth_factor */
+  const double *T_wc0_colmajor;    /* 16 */
+} nid_pose_problem;
+
+typedef struct {
+  int32_t iteration, lm_trials;
+  double chi2, lambda, rho;
+  double pose7[7];
+} nid_host_lm_record;
+
+/* returns the number of outer iterations done (or < 0); pose7 = {qx,qy,qz,qw,tx,ty,tz} in/out */
+int nid_host_run_lm(const nid_pose_problem *pb, double *pose7_inout, nid_host_lm_record *trace, int max_trace,
+                    char *log_buf, int log_cap);
+
+void nid_host_se3_exp(const double *upd6, double *pose7);
+void nid_host_se3_mul(const double *a7, const double *b7, double *out7);
+void nid_host_se3_to_matrix(const double *pose7, double *M16_colmajor);
+int nid_host_ldlt6_solve(const double *H36, const double *b6, double *x6);
+void nid_host_minimal_vector(const double *pose7, double *v6);
+void nid_host_huber(double e2, double delta, double *rho3);
+
+/* C shims of Calculate3Dpoint / CudaComputeHref / g2o::CudaComputeH (include/nid/legacy_ops.h) */
+void nid_legacy_call_Calculate3Dpoint(double *depth, double *pose_c2w, double *points_3d, double *intr, int rows,
+                                      int cols);
+void nid_legacy_call_CudaComputeHref(double *im0, double *points3d, double *pose, double *intr, int bin_num,
+                                     int bs_degree, int cell_num, int rows, int cols, double *bs_value,
+                                     int *bs_index, int *bs_counter, double *Href);
+void nid_legacy_call_CudaComputeH(int calculate_der, double *im0, double *im1, double *points3d, int *bs_counter,
+                                  double *bs_ref, int *bs_index_ref, double *pose, double *intr, int bin_num,
+                                  int bs_degree, int cell_num, int rows, int cols, double *Href, double *Htarget,
+                                  double *Hjoint, double *der);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -2,7 +2,7 @@
 Usage: python tools_stamps.py [A|B] [bins] [block_threads]"""
 import importlib, sys
 import numpy as np
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 capi = importlib.import_module("nid-pose-estimation_amd.capi")
 synth = importlib.import_module("nid-pose-estimation_amd.synth")
 cfg = sys.argv[1] if len(sys.argv) > 1 else "A"
