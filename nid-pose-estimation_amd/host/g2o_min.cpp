@@ -329,7 +329,7 @@ OptimizationAlgorithmLevenberg::SolverResult OptimizationAlgorithmLevenberg::sol
   SparseOptimizer *opt = _optimizer;
   VertexSE3Expmap *vm = opt->_vertices[0];
   nid_ctx *ctx = nid_legacy_context();
-  if (!ctx) {  // first use: let the legacy operator upload the frame-pair state
+  if (!ctx || iteration == 0) {  // first use: let the legacy operator upload the frame-pair state
     const int n2 = opt->cell_num_ * opt->cell_num_;
     std::vector<double> ht(n2, 0.0), hj(n2, 0.0);
     Matrix4d M0 = vm->estimate().to_homogeneous_matrix();

@@ -36,12 +36,12 @@ def main():
         for k, T in enumerate((pair.T_wc0, T_wc1)):
             q = synth.quat_from_R(T[:3, :3])
             t = T[:3, 3]
-            f.write(f"{k} {t[0]!r} {t[1]!r} {t[2]!r} {q[0]!r} {q[1]!r} {q[2]!r} {q[3]!r}\n")
+            f.write(f"{k} " + " ".join(repr(float(x)) for x in (t[0], t[1], t[2], q[0], q[1], q[2], q[3])) + "\n")
     with open(os.path.join(out, "config.yaml"), "w") as f:
         f.write("%YAML:1.0\nimage0_id: '0000'\nimage1_id: '0001'\nimage0_type: rgb\nimage1_type: rgb\n"
                 "use_groundtruth: '1'\ndataset: eth_cvg\n"
                 f"im_address: {os.path.abspath(out)}/\ndepth_factor: 5000.0\n"
-                f"fx: {pair.fx!r}\nfy: {pair.fy!r}\ncx: {pair.cx!r}\ncy: {pair.cy!r}\nuse_gpu: 1\n"
+                f"fx: {float(pair.fx)!r}\nfy: {float(pair.fy)!r}\ncx: {float(pair.cx)!r}\ncy: {float(pair.cy)!r}\nuse_gpu: 1\n"
                 f"cell: {pair.cell}\nbin_num: {bins}\n")
     print(os.path.join(out, "config.yaml"))
 
