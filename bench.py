@@ -42,6 +42,9 @@ def parse():
     ap.add_argument("--block-threads", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl (= RCCL over xGMI) is the product path; gloo lets the multi-rank code path be "
+                         "exercised on a box with fewer GPUs than ranks (ranks then share devices)")
     return ap.parse_args()
 
 
@@ -88,6 +91,17 @@ def cpu_baseline(pair, bins, seconds):
                       f"{el:.1f} s on 1 host core (oracle rebuilt -O3 -march=native -ffp-contract=off)"}
 
 
+def measured_traffic(config, bins):
+    """HBM bytes per launch of the evaluation kernel from the committed rocprofv3 PMC passes
+    (profiles/traffic.json, written by tools/summarize_profile.py); None if that configuration
+    was not profiled.  bench.py cannot run the profiler on itself."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as fh:
+            return float(json.load(fh)[f"{config}:{bins}"]["hbm_bytes_per_launch"])
+    except Exception:
+        return None
+
+
 def main():
     args = parse()
     import torch
@@ -102,10 +116,15 @@ def main():
         import torch.distributed as dist_
         dist = dist_
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback of the product path)")
+    if args.backend == "gloo":
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
@@ -216,7 +235,8 @@ def main():
                             f"histograms, cost+Jacobian+Huber 6x6 reduction per step, "
                             f"{int((cnt[lo:hi] >= 300).sum())} active cells on rank 0",
                 "cells": ncell, "bins": args.bins,
-                "parallelism": f"cells/{world}" + ("" if world == 1 else " + RCCL all-reduce(32 f64)"),
+                "parallelism": f"cells/{world}" + ("" if world == 1 else
+                                                   f" + {'RCCL' if args.backend == 'nccl' else 'gloo'} all-reduce(32 f64)"),
                 "pipelining": f"{nslots} launches in flight, results land in pinned host memory",
             },
             "roofline": {
@@ -225,7 +245,7 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None,
+                "traffic": measured_traffic(args.config, args.bins),
                 "kernel": "nid::k_eval<JAC>",
                 "kernel_ms": eval_ms,
                 "algorithmic_bytes_per_launch": contract,
@@ -233,6 +253,7 @@ def main():
                         "of the evaluation kernel; the tile is L2/MALL-resident after the first launch",
             },
         }
+        out["check"] = {"chi2": chi2, "n_active": int(na), "H00": float(H[0, 0]), "b0": float(b[0])}
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(pair, args.bins, args.cpu_seconds)
         print(json.dumps(out))

@@ -140,3 +140,28 @@ def test_driver_end_to_end(hostlib, synth, pair_S, tmp_path):
     want = synth.pose7_minimal(pair_S.pose_true) - synth.pose7_minimal(pose)
     # the driver re-derives the start pose from groundtruth.txt (printed decimals), so only ~1e-9 agreement
     np.testing.assert_allclose(err, want, rtol=0, atol=1e-5)
+
+
+def test_bench_multi_rank_code_path_on_one_gpu(tmp_path):
+    """bench.py --gpus 2 through torch.distributed.run on ONE box: both ranks share GPU 0 and the
+    32-double partial blocks are summed by gloo instead of RCCL (which refuses two ranks per device).
+    Exercises cell sharding + launch_to + all-reduce + unpack; the sum must equal the 1-rank result."""
+    import json
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    one = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "20", "--warmup", "5",
+                          "--no-cpu-baseline"], capture_output=True, text=True, env=env, timeout=600)
+    assert one.returncode == 0, one.stderr[-2000:]
+    r1 = json.loads(one.stdout.strip().splitlines()[-1])
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29517", os.path.join(root, "bench.py"),
+                          "--gpus", "2", "--steps", "20", "--warmup", "5", "--no-cpu-baseline", "--backend", "gloo"],
+                         capture_output=True, text=True, env=env, timeout=900)
+    assert two.returncode == 0, two.stderr[-3000:]
+    line = [l for l in two.stdout.strip().splitlines() if l.startswith("{")][-1]
+    r2 = json.loads(line)
+    assert r2["n_gpus"] == 2 and r2["scaling"] == "strong"
+    assert r2["check"]["n_active"] == r1["check"]["n_active"]
+    for k in ("chi2", "H00", "b0"):
+        assert abs(r2["check"][k] - r1["check"][k]) <= 1e-12 * abs(r1["check"][k]), k
