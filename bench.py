@@ -40,6 +40,9 @@ def parse():
     ap.add_argument("--config", default="A", choices=["A", "B", "S"])
     ap.add_argument("--bins", type=int, default=8)
     ap.add_argument("--block-threads", type=int, default=0)
+    ap.add_argument("--inflight", type=int, default=0, help="result slots in use (0 = all)")
+    ap.add_argument("--batch", type=int, default=8,
+                    help="candidate poses per kernel launch at N=1 (1 = one launch per step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -146,42 +149,50 @@ def main():
     delta = float(np.sqrt(0.95))
     K, W = args.steps, args.warmup
     poses = pose_trajectory(synth, pair, 256)
-    nslots = capi.NID_SLOTS
+    nslots = capi.NID_SLOTS if not args.inflight else min(capi.NID_SLOTS, args.inflight)
 
     # device-side result ring: one 32-double block per slot (all-reduced when world > 1)
     ring = torch.zeros((nslots, capi.NID_REDUCED_LEN), dtype=torch.float64, device=dev)
     host_ring = torch.zeros((nslots, capi.NID_REDUCED_LEN), dtype=torch.float64).pin_memory()
 
+    B = max(1, min(args.batch, capi.NID_MAX_BATCH)) if world == 1 else 1
+    pose_arr = np.stack(poses)
+
     def step(i):
+        # world > 1: one launch per step on the torch stream, then the RCCL sum of the partial blocks
         s = i % nslots
+        if i >= nslots:
+            ctx.wait(s)
+        ctx.launch(s, poses[i % len(poses)], delta, True, reduced_dev=ring[s].data_ptr())
+        dist.all_reduce(ring[s])             # RCCL sum over xGMI, 256 B
+        host_ring[s].copy_(ring[s], non_blocking=True)
+
+    def run(n):
         if world == 1:
-            if i >= nslots:
-                ctx.wait(s)                      # results of step i-nslots are in host memory
-            ctx.launch(s, poses[i % len(poses)], delta, True)
-        else:
-            if i >= nslots:
-                ctx.wait(s)
-            ctx.launch(s, poses[i % len(poses)], delta, True, reduced_dev=ring[s].data_ptr())
-            dist.all_reduce(ring[s])             # RCCL sum over xGMI, 256 B
-            host_ring[s].copy_(ring[s], non_blocking=True)
+            # the C host loop of the library drives the pipeline (B poses per launch, 16/B launches in
+            # flight); every pose's 6x6 system is collected from pinned host memory
+            seq = pose_arr[np.arange(n) % len(poses)]
+            return ctx.run_sequence(seq, delta, batch=B, want_jac=True)
+        for i in range(n):
+            step(i)
+        drain(n)
+        return None
 
     def drain(n):
         for i in range(max(0, n - nslots), n):
             ctx.wait(i % nslots)
+
+    assert capi.NID_SLOTS % B == 0
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    for i in range(W):
-        step(i)
-    drain(W)
+    run(W)
     barrier()
     t0 = time.perf_counter()
-    for i in range(K):
-        step(i)
-    drain(K)
+    results = run(K)
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
@@ -191,8 +202,10 @@ def main():
 
     # sanity: the last result is finite and every rank agrees after the all-reduce
     if world == 1:
+        assert results.shape == (K, capi.NID_REDUCED_LEN) and np.all(np.isfinite(results))
         ctx.launch(0, poses[0], delta, True)
         H, b, chi2, na = ctx.wait(0)
+        assert np.array_equal(capi.unpack_reduced(results[0])[0], H), "pipelined result differs from a single launch"
     else:
         ctx.launch(0, poses[0], delta, True, reduced_dev=ring[0].data_ptr())
         dist.all_reduce(ring[0])
@@ -201,19 +214,25 @@ def main():
         H, b, chi2, na = capi.unpack_reduced(ring[0].cpu().numpy())
     assert np.isfinite(chi2) and np.all(np.isfinite(H)) and na > 0
 
-    # dominant-kernel duration, HIP events on the launch stream, same launches
+    # dominant-kernel duration: HIP events on the launch stream around the same launches the timed
+    # region issues (B poses per launch at N=1)
     ctx.enable_timing(True)
-    ev_ms, rd_ms = [], []
-    for i in range(min(K, 200)):
-        ctx.launch(0, poses[i % len(poses)], delta, True)
-        ctx.wait(0)
-        a, r = ctx.last_kernel_ms(0)
-        ev_ms.append(a)
-        rd_ms.append(r)
+    ev_ms = []
+    for i in range(min(max(K // B, 20), 200)):
+        if world == 1 and B > 1:
+            idx = [(i * B + k) % len(poses) for k in range(B)]
+            ctx.launch_batch(0, pose_arr[idx], delta, True)
+            for k in range(B):
+                ctx.wait(k)
+        else:
+            ctx.launch(0, poses[i % len(poses)], delta, True)
+            ctx.wait(0)
+        ev_ms.append(ctx.last_kernel_ms(0)[0])
     ctx.enable_timing(False)
+
     if rank == 0:
         eval_ms = float(np.median(ev_ms))
-        contract = ctx.contract_bytes()  # this rank's cells
+        contract = ctx.contract_bytes() * B  # this rank's cells x poses per launch
         achieved = contract / (eval_ms * 1e-3) / 1e9
         out = {
             "metric": "NID GN iterations/sec (640x480 dense pair)" if args.config == "A" else
@@ -237,7 +256,9 @@ def main():
                 "cells": ncell, "bins": args.bins,
                 "parallelism": f"cells/{world}" + ("" if world == 1 else
                                                    f" + {'RCCL' if args.backend == 'nccl' else 'gloo'} all-reduce(32 f64)"),
-                "pipelining": f"{nslots} launches in flight, results land in pinned host memory",
+                "pipelining": (f"{B} candidate poses per kernel launch, {capi.NID_SLOTS // B} launches in flight, "
+                               if world == 1 else f"1 pose per launch, {nslots} launches in flight, ")
+                              + "each pose's 6x6 system lands in pinned host memory",
             },
             "roofline": {
                 "bound": "hbm",
@@ -245,7 +266,8 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": measured_traffic(args.config, args.bins),
+                "traffic": (lambda t: None if t is None else t * B)(measured_traffic(args.config, args.bins)),
+                "poses_per_launch": B,
                 "kernel": "nid::k_eval<JAC>",
                 "kernel_ms": eval_ms,
                 "algorithmic_bytes_per_launch": contract,

@@ -134,10 +134,20 @@ int nid_normal_equations(nid_ctx *ctx, const double *pose7, int want_jac, double
 
 /* Non-blocking forms for pipelining and multi-GPU.  `slot` in [0, NID_SLOTS):
  * results of a launch stay in the slot until nid_wait() collects them. */
-#define NID_SLOTS 8
+#define NID_SLOTS 16
 #define NID_REDUCED_LEN 32 /* [0]=chi2 [1..6]=b [7..27]=H upper triangle row-major [28]=n_active */
 int nid_launch(nid_ctx *ctx, int slot, const double *pose7, int want_jac, double huber_delta);
 int nid_wait(nid_ctx *ctx, int slot, double *H36, double *b6, double *chi2, int32_t *n_active);
+/* n <= NID_SLOTS candidate poses (poses7 = n x 7) in ONE kernel launch, into slots
+ * first_slot .. first_slot+n-1 (e.g. the trial steps of one LM iteration for several lambdas,
+ * or consecutive candidates of a sampling optimiser); collect each with nid_wait() */
+int nid_launch_batch(nid_ctx *ctx, int first_slot, int n, const double *poses7, int want_jac,
+                     double huber_delta);
+/* Host-side pipeline over a sequence of n candidate poses: `batch` poses per launch (batch
+ * divides NID_SLOTS), NID_SLOTS/batch launches in flight; reduced_out (n x NID_REDUCED_LEN,
+ * may be NULL) receives every pose's [chi2, b, H upper, n_active] block.  Blocking. */
+int nid_run_sequence(nid_ctx *ctx, const double *poses7, int n, int batch, int want_jac,
+                     double huber_delta, double *reduced_out);
 /* device address of slot's reduced block (NID_REDUCED_LEN doubles) and of its
  * per-cell block (cells_local x NID_CELL_OUT doubles: Hc,Hj,err,J[6], pad) so
  * that a caller can run a collective on them (RCCL all-reduce / all-gather) */
@@ -157,7 +167,8 @@ int nid_debug_enable_pixel_dump(nid_ctx *ctx, int enable);
 int nid_debug_get_pixel_dump(nid_ctx *ctx, double *u, double *v, double *ic, int32_t *jc,
                              double *wc4);
 /* diagnostic: s_memtime stamps of wave 0 of every workgroup at the phase
- * boundaries of the evaluation kernel, [cells_local][8] */
+ * boundaries of the evaluation kernel, [cells_local][10]: 8 phase stamps, then
+ * s_memrealtime (100 MHz) at kernel start and end of the same wave */
 int nid_debug_enable_stamps(nid_ctx *ctx, int enable);
 int nid_debug_get_stamps(nid_ctx *ctx, int64_t *stamps);
 /* host evaluation of the closed-form B-spline used by the kernels */

@@ -15,7 +15,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libnid_hip.so")
 
 NID_OK = 0
-NID_SLOTS = 8
+NID_SLOTS = 16
+NID_MAX_BATCH = 8
 NID_REDUCED_LEN = 32
 NID_CELL_OUT = 10
 JACBOUND_CPU, JACBOUND_CUDA = 0, 1
@@ -41,7 +42,7 @@ SYMBOLS = [
     "nid_set_reference_depth", "nid_set_reference_points", "nid_backproject", "nid_get_points3d", "nid_set_target_u8",
     "nid_set_target_f64", "nid_set_reference_image_f64", "nid_compute_href",
     "nid_compute_href_matrix", "nid_set_href_state", "nid_evaluate", "nid_evaluate_matrix",
-    "nid_normal_equations", "nid_launch", "nid_wait", "nid_slot_buffers", "nid_launch_to",
+    "nid_normal_equations", "nid_launch", "nid_launch_batch", "nid_run_sequence", "nid_wait", "nid_slot_buffers", "nid_launch_to",
     "nid_unpack_reduced", "nid_debug_enable_pixel_dump", "nid_debug_get_pixel_dump",
     "nid_debug_enable_stamps", "nid_debug_get_stamps", "nid_bspline4_host", "nid_div_small_host", "nid_last_kernel_ms", "nid_enable_timing",
     "nid_contract_bytes",
@@ -88,6 +89,8 @@ def load():
     lib.nid_evaluate_matrix.argtypes = [vp, c_dp, C.c_int, c_dp, c_dp, c_dp, c_dp]
     lib.nid_normal_equations.argtypes = [vp, c_dp, C.c_int, C.c_double, c_dp, c_dp, c_dp, c_ip]
     lib.nid_launch.argtypes = [vp, C.c_int, c_dp, C.c_int, C.c_double]
+    lib.nid_launch_batch.argtypes = [vp, C.c_int, C.c_int, c_dp, C.c_int, C.c_double]
+    lib.nid_run_sequence.argtypes = [vp, c_dp, C.c_int, C.c_int, C.c_int, C.c_double, c_dp]
     lib.nid_launch_to.argtypes = [vp, C.c_int, c_dp, C.c_int, C.c_double, vp]
     lib.nid_wait.argtypes = [vp, C.c_int, c_dp, c_dp, c_dp, c_ip]
     lib.nid_slot_buffers.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(vp)]
@@ -229,6 +232,18 @@ class Context:
                                         C.c_void_p(reduced_dev))
         self._check(rc, "nid_launch")
 
+    def launch_batch(self, first_slot, poses7, delta, want_jac=True):
+        p = _d(np.asarray(poses7).reshape(-1, 7))
+        self._check(self.lib.nid_launch_batch(self.h, first_slot, p.shape[0], _dp(p), 1 if want_jac else 0,
+                                              float(delta)), "nid_launch_batch")
+
+    def run_sequence(self, poses7, delta, batch=8, want_jac=True, collect=True):
+        p = _d(np.asarray(poses7).reshape(-1, 7))
+        out = np.zeros((p.shape[0], NID_REDUCED_LEN)) if collect else None
+        self._check(self.lib.nid_run_sequence(self.h, _dp(p), p.shape[0], int(batch), 1 if want_jac else 0,
+                                              float(delta), _dp(out)), "nid_run_sequence")
+        return out
+
     def wait(self, slot):
         H = np.zeros(36)
         b = np.zeros(6)
@@ -263,7 +278,7 @@ class Context:
 
     def stamps(self):
         n = self.cell_end - self.cell_begin
-        out = np.zeros((n, 8), dtype=np.int64)
+        out = np.zeros((n, 10), dtype=np.int64)
         self._check(self.lib.nid_debug_get_stamps(self.h, out.ctypes.data_as(C.POINTER(C.c_int64))), "nid_debug_get_stamps")
         return out
 

@@ -157,44 +157,34 @@ bool pick_eval_shape(const nid_ctx *ctx, int *nt, int *ppt) {
 }
 
 template <int NT, int PPT>
-void launch_eval_t(const EvalParams &P, bool jac, size_t lds, hipStream_t s) {
+void launch_eval_t(const EvalParams &P, bool jac, size_t lds, hipStream_t s, int batch) {
   if (jac)
-    hipLaunchKernelGGL((k_eval<NT, PPT, true>), dim3(P.g.nloc), dim3(NT), lds, s, P);
+    hipLaunchKernelGGL((k_eval<NT, PPT, true>), dim3(P.g.nloc, batch), dim3(NT), lds, s, P);
   else
-    hipLaunchKernelGGL((k_eval<NT, PPT, false>), dim3(P.g.nloc), dim3(NT), lds, s, P);
+    hipLaunchKernelGGL((k_eval<NT, PPT, false>), dim3(P.g.nloc, batch), dim3(NT), lds, s, P);
 }
 
-int launch_eval(nid_ctx *ctx, const EvalParams &P, bool jac, hipStream_t stream) {
+int launch_eval(nid_ctx *ctx, const EvalParams &P, bool jac, hipStream_t stream, int batch = 1) {
   int nt = 0, ppt = 0;
   if (!pick_eval_shape(ctx, &nt, &ppt)) return NID_ERR_UNSUPPORTED;
   const size_t lds = eval_lds_bytes(P.g, nt);
   if (lds > 160 * 1024) return NID_ERR_UNSUPPORTED;
 #define X(T, PP) \
-  if (nt == T && ppt == PP) { launch_eval_t<T, PP>(P, jac, lds, stream); NID_HIP(ctx, hipGetLastError()); return NID_OK; }
+  if (nt == T && ppt == PP) { launch_eval_t<T, PP>(P, jac, lds, stream, batch); NID_HIP(ctx, hipGetLastError()); return NID_OK; }
   NID_EVAL_CASES(X)
 #undef X
   return NID_ERR_UNSUPPORTED;
 }
 
-void fill_eval_params(nid_ctx *ctx, const Pose &pose, Slot &S, double delta, double *out_reduced,
-                      unsigned long long *host_seq, EvalParams *P) {
-  double *cellout = S.cellout_dev;
+void fill_common_params(nid_ctx *ctx, double delta, EvalParams *P) {
   P->huber_delta = delta;
   P->huber_dsqr = (float)(delta * delta);  // RobustKernelHuber::setDelta, float dsqr (robust_kernel_impl.h:84)
-  P->quad = S.quad_dev;
-  P->ticket = S.ticket_dev;
-  P->gpart = S.gpart_dev;
   P->group_size = ctx->group_size;
-  P->out_reduced = out_reduced;
-  P->host_seq = host_seq;
-  P->launch_seq = S.seq;
   P->g = ctx->g;
-  P->pose = pose;
   P->t = ctx->t;
   P->im1 = ctx->im1_dev;
   P->Nc = ctx->Nc_dev;
   P->Href = ctx->Href_dev;
-  P->cellout = cellout;
   P->jac_cols = (ctx->jac_bound == NID_JACBOUND_CPU) ? ctx->g.cols - 1 : ctx->g.cols;
   P->hist_scale = ctx->hist_scale;
   P->hist_inv_scale = ctx->hist_inv_scale;
@@ -206,6 +196,23 @@ void fill_eval_params(nid_ctx *ctx, const Pose &pose, Slot &S, double delta, dou
     P->dbg_jc = nullptr;
   }
   P->dbg_stamps = ctx->dbg_stamps;
+}
+
+void fill_slot_args(const Pose &pose, Slot &S, double *out_reduced, unsigned long long *host_seq, SlotArgs *A) {
+  A->pose = pose;
+  A->cellout = S.cellout_dev;
+  A->quad = S.quad_dev;
+  A->gpart = S.gpart_dev;
+  A->ticket = S.ticket_dev;
+  A->out_reduced = out_reduced;
+  A->host_seq = host_seq;
+  A->launch_seq = S.seq;
+}
+
+void fill_eval_params(nid_ctx *ctx, const Pose &pose, Slot &S, double delta, double *out_reduced,
+                      unsigned long long *host_seq, EvalParams *P) {
+  fill_common_params(ctx, delta, P);
+  fill_slot_args(pose, S, out_reduced, host_seq, &P->slot[0]);
 }
 
 int check_ready(nid_ctx *ctx) {
@@ -249,6 +256,33 @@ int launch_slot(nid_ctx *ctx, int slot, const Pose &pose, int want_jac, double d
   if (S.timed) NID_HIP(ctx, hipEventRecord(S.e1, st));
   if (S.external_target) NID_HIP(ctx, hipEventRecord(S.done, st));
   S.pending = true;
+  return NID_OK;
+}
+
+// n candidate poses in ONE launch (grid.y = n): each pose uses its own slot (buffers, tickets,
+// pinned result block), so the reduction tails and the launch cost overlap with other poses' work
+// and two workgroups share a CU.  Results are collected per slot with nid_wait().
+int launch_batch(nid_ctx *ctx, int first_slot, int n, const Pose *poses, int want_jac, double delta) {
+  int rc = check_ready(ctx);
+  if (rc) return rc;
+  if (n < 1 || n > kMaxBatch || first_slot < 0 || first_slot + n > NID_SLOTS) return NID_ERR_INVALID_ARG;
+  if (ctx->dbg_enabled) return NID_ERR_STATE;  // the per-pixel dump describes one pose
+  EvalParams P;
+  fill_common_params(ctx, delta, &P);
+  for (int k = 0; k < n; k++) {
+    Slot &S = ctx->slots[first_slot + k];
+    S.seq++;
+    S.external_target = false;
+    fill_slot_args(poses[k], S, S.reduced_host_devptr,
+                   reinterpret_cast<unsigned long long *>(S.reduced_host_devptr + kReducedLen), &P.slot[k]);
+  }
+  Slot &S0 = ctx->slots[first_slot];
+  S0.timed = ctx->timing;
+  if (S0.timed) NID_HIP(ctx, hipEventRecord(S0.e0, ctx->stream));
+  rc = launch_eval(ctx, P, want_jac != 0, ctx->stream, n);
+  if (rc) return rc;
+  if (S0.timed) NID_HIP(ctx, hipEventRecord(S0.e1, ctx->stream));
+  for (int k = 0; k < n; k++) { ctx->slots[first_slot + k].pending = true; if (k) ctx->slots[first_slot + k].timed = false; }
   return NID_OK;
 }
 
@@ -664,6 +698,45 @@ int nid_launch(nid_ctx *ctx, int slot, const double *pose7, int want_jac, double
   return launch_slot(ctx, slot, p, want_jac, delta, nullptr);
 }
 
+int nid_launch_batch(nid_ctx *ctx, int first_slot, int n, const double *poses7, int want_jac, double delta) {
+  if (!ctx || !poses7 || n < 1 || n > kMaxBatch) return NID_ERR_INVALID_ARG;
+  Pose p[kMaxBatch];
+  for (int k = 0; k < n; k++) pose_from_pose7(poses7 + 7 * k, ctx->xform, &p[k]);
+  return launch_batch(ctx, first_slot, n, p, want_jac, delta);
+}
+
+int nid_run_sequence(nid_ctx *ctx, const double *poses7, int n, int batch, int want_jac, double delta,
+                     double *reduced_out) {
+  // host-side pipeline: `batch` poses per launch, NID_SLOTS / batch launches in flight, every
+  // pose's 32-double result block collected from pinned host memory in order
+  if (!ctx || !poses7 || n < 0 || batch < 1 || batch > kMaxBatch || NID_SLOTS % batch) return NID_ERR_INVALID_ARG;
+  NID_HIP(ctx, hipSetDevice(ctx->cfg.device));
+  for (int s = 0; s < NID_SLOTS; s++) if (ctx->slots[s].pending) return NID_ERR_STATE;
+  Pose p[kMaxBatch];
+  int launched = 0, collected = 0;
+  auto collect = [&](int upto) -> int {
+    for (; collected < upto; collected++) {
+      const int slot = collected % NID_SLOTS;
+      int rc = nid_wait(ctx, slot, nullptr, nullptr, nullptr, nullptr);
+      if (rc) return rc;
+      if (reduced_out) std::memcpy(reduced_out + (size_t)collected * kReducedLen, ctx->slots[slot].reduced_host,
+                                   kReducedLen * sizeof(double));
+    }
+    return NID_OK;
+  };
+  while (launched < n) {
+    const int nb = std::min(batch, n - launched);
+    const int first_slot = launched % NID_SLOTS;
+    int rc = collect(launched + nb - NID_SLOTS);  // free the slots this launch will reuse
+    if (rc) return rc;
+    for (int k = 0; k < nb; k++) pose_from_pose7(poses7 + 7 * (size_t)(launched + k), ctx->xform, &p[k]);
+    rc = launch_batch(ctx, first_slot, nb, p, want_jac, delta);
+    if (rc) return rc;
+    launched += nb;
+  }
+  return collect(n);
+}
+
 int nid_launch_to(nid_ctx *ctx, int slot, const double *pose7, int want_jac, double delta, void *reduced_dev) {
   if (!ctx || !pose7 || !reduced_dev) return NID_ERR_INVALID_ARG;
   Pose p; pose_from_pose7(pose7, ctx->xform, &p);
@@ -745,9 +818,9 @@ int nid_debug_enable_stamps(nid_ctx *ctx, int enable) {
   if (!ctx) return NID_ERR_INVALID_ARG;
   NID_HIP(ctx, hipSetDevice(ctx->cfg.device));
   if (enable && !ctx->dbg_stamps) {
-    int rc = dev_alloc(ctx, &ctx->dbg_stamps, (size_t)ctx->g.nloc * 8);
+    int rc = dev_alloc(ctx, &ctx->dbg_stamps, (size_t)ctx->g.nloc * 10);
     if (rc) return rc;
-    NID_HIP(ctx, hipMemset(ctx->dbg_stamps, 0, (size_t)ctx->g.nloc * 8 * sizeof(long long)));
+    NID_HIP(ctx, hipMemset(ctx->dbg_stamps, 0, (size_t)ctx->g.nloc * 10 * sizeof(long long)));
   } else if (!enable && ctx->dbg_stamps) {
     NID_HIP(ctx, hipStreamSynchronize(ctx->stream));
     (void)hipFree(ctx->dbg_stamps);
@@ -760,7 +833,7 @@ int nid_debug_get_stamps(nid_ctx *ctx, int64_t *stamps) {
   if (!ctx || !stamps || !ctx->dbg_stamps) return NID_ERR_STATE;
   NID_HIP(ctx, hipSetDevice(ctx->cfg.device));
   NID_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  NID_HIP(ctx, hipMemcpy(stamps, ctx->dbg_stamps, (size_t)ctx->g.nloc * 8 * sizeof(long long), hipMemcpyDeviceToHost));
+  NID_HIP(ctx, hipMemcpy(stamps, ctx->dbg_stamps, (size_t)ctx->g.nloc * 10 * sizeof(long long), hipMemcpyDeviceToHost));
   return NID_OK;
 }
 

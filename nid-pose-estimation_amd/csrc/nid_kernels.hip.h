@@ -58,30 +58,37 @@ struct Tiles {
   uint8_t *I0;        // reference intensity
 };
 
+constexpr int kMaxBatch = 8;  // candidate poses evaluated by one launch (grid.y)
+
+// what differs between the poses of one launch: the pose and where its results go
+struct SlotArgs {
+  Pose pose;
+  double *cellout;                 // [nloc*kCellOut]
+  double *quad;                    // [nloc*32] per-cell quadratic-form blocks (sc1 traffic)
+  double *gpart;                   // [ngroups*32] group sums (second reduction level)
+  unsigned *ticket;                // [0] top arrival counter, [1+g] group counters; zero between launches
+  double *out_reduced;             // 32 doubles: device memory or pinned host memory
+  unsigned long long *host_seq;    // pinned host word that receives launch_seq (or null)
+  unsigned long long launch_seq;
+};
+
 struct EvalParams {
   Geometry g;
-  Pose pose;
   Tiles t;
   const uint8_t *im1;
   const int *Nc;        // [nloc]
   const double *Href;   // [nloc]
-  double *cellout;      // [nloc*kCellOut]
   int jac_cols;         // cols or cols-1
   double hist_scale, hist_inv_scale;
   // fused Huber + 6x6 reduction
   double huber_delta;
   float huber_dsqr;
-  double *quad;                    // [nloc*32] per-cell quadratic-form blocks (sc1 traffic)
-  double *gpart;                   // [ngroups*32] group sums (second reduction level)
-  unsigned *ticket;                // [0] top arrival counter, [1+g] group counters; zero between launches
   int group_size;                  // cells per first-level group
-  double *out_reduced;             // 32 doubles: device memory or pinned host memory
-  unsigned long long *host_seq;    // pinned host word that receives launch_seq (or null)
-  unsigned long long launch_seq;
+  SlotArgs slot[kMaxBatch];        // indexed by blockIdx.y
   // optional per-pixel dump (image order), null when disabled
   double *dbg_u, *dbg_v, *dbg_ic, *dbg_wc;
   int *dbg_jc;
-  // optional phase stamps (s_memtime) of wave 0 of every workgroup: [nloc][8]; diagnostic runs only
+  // optional phase stamps (s_memtime) of wave 0 of every workgroup: [nloc][10] (8 phase stamps + s_memrealtime at start/end); diagnostic runs only
   long long *dbg_stamps;
 };
 
@@ -91,11 +98,12 @@ __device__ __forceinline__ void nid_stamp(long long *buf, int k, double d0 = 0.0
                                           double d2 = 0.0, double d3 = 0.0) {
   unsigned long long t;
   asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) : "v"(d0), "v"(d1), "v"(d2), "v"(d3) : "memory");
-  if (threadIdx.x == 0) buf[(size_t)blockIdx.x * 8 + k] = (long long)t;
+  if (threadIdx.x == 0) buf[(size_t)blockIdx.x * 10 + k] = (long long)t;
+  if (threadIdx.x == 0 && (k == 0 || k == 7)) buf[(size_t)blockIdx.x * 10 + (k == 0 ? 8 : 9)] = (long long)wall_clock64();
 }
 #define NID_STAMP(k, ...)                                    \
   do {                                                       \
-    if (P.dbg_stamps) nid_stamp(P.dbg_stamps, (k), ##__VA_ARGS__); \
+    if (P.dbg_stamps && blockIdx.y == 0) nid_stamp(P.dbg_stamps, (k), ##__VA_ARGS__); \
   } while (0)
 
 // ---------------------------------------------------------------------------
@@ -459,7 +467,7 @@ __device__ __forceinline__ double sum_blocks(const double *src, int count, doubl
 // P.group_size cells -> total), each level a ticket + last-arriver sum, so the
 // serial read of any one workgroup is <= max(group_size, ngroups) * 256 B.
 template <int NT>
-__device__ __forceinline__ void finish_and_reduce(const EvalParams &P, int cl, int tid,
+__device__ __forceinline__ void finish_and_reduce(const EvalParams &P, const SlotArgs &SA, int cl, int tid,
                                                   double *lds_scratch /* >= NT + 2 doubles */) {
   unsigned *flag = reinterpret_cast<unsigned *>(lds_scratch);
   double *part = lds_scratch + 2;
@@ -471,35 +479,35 @@ __device__ __forceinline__ void finish_and_reduce(const EvalParams &P, int cl, i
   if (tid < 64) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (tid == 0) {
-      const unsigned old = __hip_atomic_fetch_add(P.ticket + 1 + gq, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned old = __hip_atomic_fetch_add(SA.ticket + 1 + gq, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       flag[0] = (old == (unsigned)(gcount - 1)) ? 1u : 0u;
     }
   }
   __syncthreads();
   if (flag[0] == 0u) return;  // uniform
   __syncthreads();            // flag consumed before the scratch is reused
-  double r = sum_blocks<NT>(P.quad + (size_t)gq * gs * kQuad, gcount, part, tid);
+  double r = sum_blocks<NT>(SA.quad + (size_t)gq * gs * kQuad, gcount, part, tid);
   // level 1: publish the group sum, take the top ticket
   if (tid < 64) {
-    if (tid < 32) store_sc1(P.gpart + (size_t)gq * kQuad + tid, r);
+    if (tid < 32) store_sc1(SA.gpart + (size_t)gq * kQuad + tid, r);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (tid == 0) {
-      __hip_atomic_store(P.ticket + 1 + gq, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const unsigned old = __hip_atomic_fetch_add(P.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(SA.ticket + 1 + gq, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned old = __hip_atomic_fetch_add(SA.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       flag[0] = (old == (unsigned)(ngroups - 1)) ? 1u : 0u;
     }
   }
   __syncthreads();
   if (flag[0] == 0u) return;
   __syncthreads();
-  r = sum_blocks<NT>(P.gpart, ngroups, part, tid);
-  if (tid < 32) P.out_reduced[tid] = r;
-  if (tid == 0) __hip_atomic_store(P.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  if (P.host_seq && tid < 64) {  // results live in pinned host memory: publish at system scope
+  r = sum_blocks<NT>(SA.gpart, ngroups, part, tid);
+  if (tid < 32) SA.out_reduced[tid] = r;
+  if (tid == 0) __hip_atomic_store(SA.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (SA.host_seq && tid < 64) {  // results live in pinned host memory: publish at system scope
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (tid == 0) {
       __threadfence_system();
-      __hip_atomic_store(P.host_seq, P.launch_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_store(SA.host_seq, SA.launch_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
   }
 }
@@ -518,14 +526,15 @@ __global__ __launch_bounds__(NT) void k_eval(EvalParams P) {
   double *red = rtab + kMaxBins * kRcpRow;   // max(12*NW, (NT/32)*32 + 2) doubles
 
   const int cl = blockIdx.x, tid = threadIdx.x;
+  const SlotArgs &SA = P.slot[blockIdx.y];
   const int n_c = P.Nc[cl];
   const double href = P.Href[cl];
-  double *out = P.cellout + (size_t)cl * kCellOut;
-  double *quad = P.quad + (size_t)cl * kQuad;
+  double *out = SA.cellout + (size_t)cl * kCellOut;
+  double *quad = SA.quad + (size_t)cl * kQuad;
   if (n_c < 300 || isnan(href)) {  // level-1 edge: never evaluated (computeH.cu:271-275)
     if (tid < kCellOut) out[tid] = (tid == kCellOut - 1) ? (double)n_c : NAN;
     if (tid < kQuad) store_sc1(quad + tid, 0.0);
-    finish_and_reduce<NT>(P, cl, tid, red);
+    finish_and_reduce<NT>(P, SA, cl, tid, red);
     return;
   }
 
@@ -562,7 +571,7 @@ __global__ __launch_bounds__(NT) void k_eval(EvalParams P) {
 #pragma unroll
   for (int i = 0; i < PPT; i++) {
     double qx, qy, qz;
-    xform_point(P.pose, lx[i], ly[i], lz[i], qx, qy, qz);
+    xform_point(SA.pose, lx[i], ly[i], lz[i], qx, qy, qz);
     // types_six_dof_expmap.cpp:562-563: fx * x / z + cx
     const double u = g.fx * qx / qz + g.cx;
     const double v = g.fy * qy / qz + g.cy;
@@ -611,7 +620,7 @@ __global__ __launch_bounds__(NT) void k_eval(EvalParams P) {
         for (int k = 0; k < 4; k++)
           atomicAdd(hj + (size_t)(m * nb + k) * kHistCopies, fx_encode(s_wr[i][m] * wc[k], P.hist_scale));
     }
-    if (P.dbg_u && s_jr[i] >= 0) {
+    if (P.dbg_u && blockIdx.y == 0 && s_jr[i] >= 0) {
       const int s = i * NT + tid;
       const int c = g.cell_begin + cl;
       const int r = (c / g.cell_num) * g.rb + s / g.cb;
@@ -670,7 +679,7 @@ __global__ __launch_bounds__(NT) void k_eval(EvalParams P) {
     if (tid < kQuad) store_sc1(quad + tid, tid == 0 ? rho0 : (tid == 28 ? 1.0 : 0.0));
     __syncthreads();  // `red` is reused by the reduction
     NID_STAMP(6);
-    finish_and_reduce<NT>(P, cl, tid, red);
+    finish_and_reduce<NT>(P, SA, cl, tid, red);
     NID_STAMP(7);
     return;
   }
@@ -776,7 +785,7 @@ __global__ __launch_bounds__(NT) void k_eval(EvalParams P) {
   }
   __syncthreads();  // `red` is reused by the reduction
   NID_STAMP(6);
-  finish_and_reduce<NT>(P, cl, tid, red);
+  finish_and_reduce<NT>(P, SA, cl, tid, red);
   NID_STAMP(7);
 }
 

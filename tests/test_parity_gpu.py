@@ -290,3 +290,21 @@ def test_error_paths(capi, pair_S):
         ctx.compute_href(pair.pose_init)
     with pytest.raises(capi.NidError):
         ctx.set_block_threads(384)                  # shape the kernel is not built for
+
+
+def test_batched_launch_equals_single_launches(capi, synth, pair_A):
+    """nid_launch_batch: n candidate poses in one kernel launch give, slot by slot, the bits of n single launches."""
+    pair, nb = pair_A, 8
+    ctx = capi.from_pair(pair, nb)
+    ctx.compute_href(pair.pose_init)
+    poses = [synth.perturb_pose7(pair.pose_init, [2e-3 * k, -1e-3 * k, 0], [0, 1e-3 * k, 2e-3]) for k in range(8)]
+    ctx.launch_batch(4, poses, DELTA)            # slots 4..11
+    got = [ctx.wait(4 + k) for k in range(8)]
+    for k, p in enumerate(poses):
+        H, b, chi2, na = ctx.normal_equations(p, DELTA)
+        assert np.array_equal(_bits(H), _bits(got[k][0])) and np.array_equal(_bits(b), _bits(got[k][1]))
+        assert chi2 == got[k][2] and na == got[k][3]
+    ctx.launch_batch(0, poses[:3], DELTA, want_jac=False)
+    for k in range(3):
+        _, _, chi2, na = ctx.wait(k)
+        assert chi2 == got[k][2] and na == got[k][3]

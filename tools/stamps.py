@@ -21,7 +21,10 @@ st = ctx.stamps()
 act = cnt >= 300
 s = st[act]
 names = ["zero+loads+warp+sample", "bspline+atomics", "fold+entropy", "phase2(jac)", "blocksum12", "cellquad", "reduce tail"]
-d = np.diff(s, axis=1)
+d = np.diff(s[:, :8], axis=1)
+rt = (s[:, 9] - s[:, 8]) / 100.0   # us (s_memrealtime ticks at 100 MHz)
+cyc = (s[:, 7] - s[:, 0])
+print("in-kernel clock estimate: median %.3f GHz (block time median %.2f us)" % (np.median(cyc / rt) / 1e3, np.median(rt)))
 print("cfg", cfg, "bins", bins, "nt", nt, "active", act.sum())
 for k, n in enumerate(names):
     print(f"{n:26s} median {np.median(d[:,k]):9.0f} cyc   max {d[:,k].max():9.0f}")
