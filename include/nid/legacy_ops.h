@@ -47,6 +47,8 @@ extern "C" {
 struct nid_ctx;
 // 0 = CPU-edge bound (default), 1 = CUDA-kernel bound
 void nid_legacy_set_jacobian_bound(int mode);
+// 0 = FAST arithmetic (default), 1 = STRICT: every rounding of the reference reproduced (nid_c.h)
+void nid_legacy_set_math_mode(int mode);
 void nid_legacy_set_device(int device);
 // drop every cached context (e.g. before the caller frees its buffers)
 void nid_legacy_reset(void);

@@ -56,6 +56,11 @@ typedef enum {
 #define NID_XFORM_QUAT   0  /* quaternion rotate + t, SE3Quat::map se3quat.h:217-220 */
 #define NID_XFORM_MATRIX 1  /* 4x4 matrix rows, computeH.cu:152-154 */
 
+/* arithmetic of the evaluation kernel */
+#define NID_MATH_FAST   0  /* default: same algorithm, cheaper arithmetic; per-cell results inside the stated
+                              tolerances (1e-11 entropies, 1e-9 Jacobian), per-pixel values within a few ulp */
+#define NID_MATH_STRICT 1  /* every rounding of the reference path reproduced: bit-exact per-pixel values */
+
 typedef struct nid_ctx nid_ctx;
 
 typedef struct {
@@ -78,6 +83,7 @@ int nid_device_count(void);                     /* 0 when no GPU; never initiali
 int nid_create(const nid_config *cfg, nid_ctx **out);
 int nid_destroy(nid_ctx *ctx);
 int nid_set_options(nid_ctx *ctx, int jac_bound_mode, int xform_mode);
+int nid_set_math_mode(nid_ctx *ctx, int mode);
 /* run every kernel of this context on a caller-owned hipStream_t (e.g. the
  * current torch stream) instead of the context's own stream; NULL restores it */
 int nid_set_stream(nid_ctx *ctx, void *hip_stream);
@@ -173,6 +179,8 @@ int nid_debug_enable_stamps(nid_ctx *ctx, int enable);
 int nid_debug_get_stamps(nid_ctx *ctx, int64_t *stamps);
 /* host evaluation of the closed-form B-spline used by the kernels */
 void nid_bspline4_host(double u, int bin_num, double *B4, double *D4);
+/* host evaluation of the FAST-mode per-span polynomial B-spline table */
+void nid_bspline4_poly_host(double u, int bin_num, double *B4, double *D4);
 /* host twin of the kernels' division-by-small-constant helper */
 double nid_div_small_host(double x, double d);
 /* timing of the last launch on its stream, ms (hipEvent) */

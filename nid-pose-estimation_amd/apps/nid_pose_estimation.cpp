@@ -175,6 +175,7 @@ int main(int argc, char **argv) {
   pb.fx = fx; pb.fy = fy; pb.cx = cx; pb.cy = cy; pb.depth_factor = depth_factor; pb.huber_delta = std::sqrt(0.95);
   pb.im0 = im0.data(); pb.im1 = im1.data(); pb.depth_u16 = d0.data(); pb.T_wc0_colmajor = T_wc0.data();
   pb.fused = fc.count("fused") ? std::atoi(fc["fused"].c_str()) : 0;
+  pb.strict_math = fc.count("strict_math") ? std::atoi(fc["strict_math"].c_str()) : 0;
 
   double pose7[7];
   start.toPose7(pose7);

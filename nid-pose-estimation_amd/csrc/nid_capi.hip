@@ -66,6 +66,8 @@ struct nid_ctx {
   bool have_ref = false, have_target = false, have_href = false, ref_from_depth = false;
   double hist_scale = 0, hist_inv_scale = 0;
   int group_size = 1, ngroups = 1;
+  int math_mode = NID_MATH_FAST;
+  double *ctab_dev = nullptr;
   Slot slots[NID_SLOTS];
   std::string last_error;
 };
@@ -110,17 +112,69 @@ void pose_from_matrix16(const double *m, Pose *out) {
   out->mode = NID_XFORM_MATRIX;
 }
 
+// FAST mode: polynomial form of the four cubic B-spline basis functions of every span of the
+// clamped knot vector (types_six_dof_expmap.h:283-296), by running the Cox-de Boor recursion
+// (types_six_dof_expmap.cpp:738-764) on polynomials in t = u - knots[j] in long double.
+void build_coef_table(int S, std::vector<double> *out) {
+  typedef long double ld;
+  auto knot = [&](int i) -> ld { int k = i - 3; k = k < 0 ? 0 : k; k = k > S ? S : k; return (ld)k; };
+  out->assign((size_t)S * kCoefRow, 0.0);
+  for (int jj = 0; jj < S; jj++) {
+    const int j = jj + 3;
+    const ld t0 = knot(j);
+    // basis[order][i - (j - order + 1)] as polynomials in t
+    ld cur[4][4] = {{0}}, nxt[4][4];
+    cur[0][0] = 1.0L;  // N_{j,1} = 1 on the span
+    for (int order = 2; order <= 4; order++) {
+      for (int a = 0; a < 4; a++) for (int b = 0; b < 4; b++) nxt[a][b] = 0.0L;
+      for (int n = 0; n < order; n++) {      // basis index i = j - order + 1 + n
+        const int i = j - order + 1 + n;
+        // term 1: (u - t_i)/(t_{i+order-1} - t_i) * B_{i,order-1}      (B_{i,order-1} = cur[n-1])
+        if (n >= 1) {
+          const ld d = knot(i + order - 1) - knot(i);
+          if (d != 0.0L) {
+            const ld a0 = (t0 - knot(i)) / d, a1 = 1.0L / d;
+            for (int p = 0; p < 4; p++) {
+              nxt[n][p] += a0 * cur[n - 1][p];
+              if (p + 1 < 4) nxt[n][p + 1] += a1 * cur[n - 1][p];
+            }
+          }
+        }
+        // term 2: (t_{i+order} - u)/(t_{i+order} - t_{i+1}) * B_{i+1,order-1}  (= cur[n])
+        if (n <= order - 2) {
+          const ld d = knot(i + order) - knot(i + 1);
+          if (d != 0.0L) {
+            const ld a0 = (knot(i + order) - t0) / d, a1 = -1.0L / d;
+            for (int p = 0; p < 4; p++) {
+              nxt[n][p] += a0 * cur[n][p];
+              if (p + 1 < 4) nxt[n][p + 1] += a1 * cur[n][p];
+            }
+          }
+        }
+      }
+      for (int a = 0; a < 4; a++) for (int b = 0; b < 4; b++) cur[a][b] = nxt[a][b];
+    }
+    for (int k = 0; k < 4; k++) {  // basis index j-3+k = jc+k
+      double *row = out->data() + (size_t)jj * kCoefRow + 7 * k;
+      for (int p = 0; p < 4; p++) row[p] = (double)cur[k][p];
+      row[4] = (double)cur[k][1];
+      row[5] = (double)(2.0L * cur[k][2]);
+      row[6] = (double)(3.0L * cur[k][3]);
+    }
+  }
+}
+
 size_t eval_lds_bytes(const Geometry &g, int nt) {
   const int nbins = g.nb * g.nb + g.nb;
   const size_t red = (size_t)std::max(6 * (nt / 64), nt + 2);
   return (size_t)nbins * kHistCopies * 8 + (size_t)((nbins + 1) & ~1) * 8 +
-         (size_t)kMaxBins * kRcpRow * 8 + red * 8;
+         (size_t)kMaxBins * kCoefRow * 8 + red * 8;
 }
 
 // (threads, pixels per thread) pairs the evaluation kernel is instantiated for
 #define NID_EVAL_CASES(X) \
   X(256, 1) X(256, 2) X(256, 3) X(256, 4) X(256, 5) X(256, 6) X(256, 8) \
-  X(512, 3) X(640, 2) X(1024, 2) X(1024, 4) X(1024, 8)
+  X(1024, 2) X(1024, 4) X(1024, 8)
 
 bool pick_eval_shape(const nid_ctx *ctx, int *nt, int *ppt) {
   const int ps = ctx->g.pstride;
@@ -156,12 +210,29 @@ bool pick_eval_shape(const nid_ctx *ctx, int *nt, int *ppt) {
   return false;
 }
 
+template <int NT, int PPT, int NB, bool DBG>
+void launch_eval_v(const EvalParams &P, bool jac, bool strict, size_t lds, hipStream_t s, int batch) {
+  const dim3 grid(P.g.nloc, batch), block(NT);
+  if (strict) {
+    if (jac) hipLaunchKernelGGL((k_eval<NT, PPT, true, true, NB, DBG>), grid, block, lds, s, P);
+    else hipLaunchKernelGGL((k_eval<NT, PPT, false, true, NB, DBG>), grid, block, lds, s, P);
+  } else {
+    if (jac) hipLaunchKernelGGL((k_eval<NT, PPT, true, false, NB, DBG>), grid, block, lds, s, P);
+    else hipLaunchKernelGGL((k_eval<NT, PPT, false, false, NB, DBG>), grid, block, lds, s, P);
+  }
+}
+
 template <int NT, int PPT>
-void launch_eval_t(const EvalParams &P, bool jac, size_t lds, hipStream_t s, int batch) {
-  if (jac)
-    hipLaunchKernelGGL((k_eval<NT, PPT, true>), dim3(P.g.nloc, batch), dim3(NT), lds, s, P);
-  else
-    hipLaunchKernelGGL((k_eval<NT, PPT, false>), dim3(P.g.nloc, batch), dim3(NT), lds, s, P);
+void launch_eval_t(const EvalParams &P, bool jac, bool strict, bool dbg, size_t lds, hipStream_t s, int batch) {
+  if constexpr (NT == 256 && PPT == 5) {
+    // the BASELINE shape (30x40-pixel cells): bin counts 8 / 10 specialised
+    if (!dbg && P.g.nb == 8) return launch_eval_v<256, 5, 8, false>(P, jac, strict, lds, s, batch);
+    if (!dbg && P.g.nb == 10) return launch_eval_v<256, 5, 10, false>(P, jac, strict, lds, s, batch);
+  }
+  if constexpr (NT == 256) {
+    if (dbg) return launch_eval_v<256, PPT, 0, true>(P, jac, strict, lds, s, batch);  // diagnostic build
+  }
+  launch_eval_v<NT, PPT, 0, false>(P, jac, strict, lds, s, batch);
 }
 
 int launch_eval(nid_ctx *ctx, const EvalParams &P, bool jac, hipStream_t stream, int batch = 1) {
@@ -169,8 +240,10 @@ int launch_eval(nid_ctx *ctx, const EvalParams &P, bool jac, hipStream_t stream,
   if (!pick_eval_shape(ctx, &nt, &ppt)) return NID_ERR_UNSUPPORTED;
   const size_t lds = eval_lds_bytes(P.g, nt);
   if (lds > 160 * 1024) return NID_ERR_UNSUPPORTED;
+  const bool dbg = ctx->dbg_enabled || ctx->dbg_stamps != nullptr;
+  if (dbg && nt != 256) { ctx->last_error = "pixel dump / stamps need the 256-thread workgroup shape"; return NID_ERR_UNSUPPORTED; }
 #define X(T, PP) \
-  if (nt == T && ppt == PP) { launch_eval_t<T, PP>(P, jac, lds, stream, batch); NID_HIP(ctx, hipGetLastError()); return NID_OK; }
+  if (nt == T && ppt == PP) { launch_eval_t<T, PP>(P, jac, ctx->math_mode == NID_MATH_STRICT, dbg, lds, stream, batch); NID_HIP(ctx, hipGetLastError()); return NID_OK; }
   NID_EVAL_CASES(X)
 #undef X
   return NID_ERR_UNSUPPORTED;
@@ -180,6 +253,7 @@ void fill_common_params(nid_ctx *ctx, double delta, EvalParams *P) {
   P->huber_delta = delta;
   P->huber_dsqr = (float)(delta * delta);  // RobustKernelHuber::setDelta, float dsqr (robust_kernel_impl.h:84)
   P->group_size = ctx->group_size;
+  P->ctab = ctx->ctab_dev;
   P->g = ctx->g;
   P->t = ctx->t;
   P->im1 = ctx->im1_dev;
@@ -460,6 +534,13 @@ int nid_create(const nid_config *cfg, nid_ctx **out) {
   if ((rc = dev_alloc(ctx, &ctx->Twc_dev, 16))) return fail(rc);
   if ((rc = dev_alloc(ctx, &ctx->Nc_dev, g.nloc))) return fail(rc);
   if ((rc = dev_alloc(ctx, &ctx->Href_dev, g.nloc))) return fail(rc);
+  {
+    std::vector<double> coef;
+    build_coef_table(g.S, &coef);
+    if ((rc = dev_alloc(ctx, &ctx->ctab_dev, coef.size()))) return fail(rc);
+    if (hipMemcpy(ctx->ctab_dev, coef.data(), coef.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess)
+      return fail(NID_ERR_HIP);
+  }
   for (int s = 0; s < NID_SLOTS; s++) {
     Slot &S = ctx->slots[s];
     if ((rc = dev_alloc(ctx, &S.cellout_dev, (size_t)g.nloc * kCellOut))) return fail(rc);
@@ -491,7 +572,7 @@ int nid_destroy(nid_ctx *ctx) {
   (void)hipFree(ctx->t.JR); (void)hipFree(ctx->t.I0);
   (void)hipFree(ctx->im1_dev); (void)hipFree(ctx->im0_dev); (void)hipFree(ctx->depth_dev);
   (void)hipFree(ctx->points_dev); (void)hipFree(ctx->Twc_dev);
-  (void)hipFree(ctx->Nc_dev); (void)hipFree(ctx->Href_dev);
+  (void)hipFree(ctx->Nc_dev); (void)hipFree(ctx->Href_dev); (void)hipFree(ctx->ctab_dev);
   (void)hipFree(ctx->dbg_u); (void)hipFree(ctx->dbg_v); (void)hipFree(ctx->dbg_ic);
   (void)hipFree(ctx->dbg_wc); (void)hipFree(ctx->dbg_jc); (void)hipFree(ctx->dbg_stamps);
   for (int s = 0; s < NID_SLOTS; s++) {
@@ -517,6 +598,27 @@ int nid_set_options(nid_ctx *ctx, int jac_bound_mode, int xform_mode) {
   ctx->jac_bound = jac_bound_mode;
   ctx->xform = xform_mode;
   return NID_OK;
+}
+
+int nid_set_math_mode(nid_ctx *ctx, int mode) {
+  if (!ctx || (mode != NID_MATH_STRICT && mode != NID_MATH_FAST)) return NID_ERR_INVALID_ARG;
+  ctx->math_mode = mode;
+  return NID_OK;
+}
+
+void nid_bspline4_poly_host(double u, int bin_num, double *B4, double *D4) {
+  // host evaluation of the FAST-mode polynomial table (unit tests)
+  std::vector<double> coef;
+  const int S = bin_num - 3;
+  build_coef_table(S, &coef);
+  const int jc = (int)u;
+  const double t = u - (double)jc;
+  const double *c = coef.data() + (size_t)jc * kCoefRow;
+  for (int k = 0; k < 4; k++) {
+    const double *ck = c + 7 * k;
+    if (B4) B4[k] = std::fma(std::fma(std::fma(ck[3], t, ck[2]), t, ck[1]), t, ck[0]);
+    if (D4) D4[k] = (u == 0.0) ? 0.0 : std::fma(std::fma(ck[6], t, ck[5]), t, ck[4]);
+  }
 }
 
 int nid_set_stream(nid_ctx *ctx, void *hip_stream) {

@@ -59,6 +59,9 @@ struct Tiles {
 };
 
 constexpr int kMaxBatch = 8;  // candidate poses evaluated by one launch (grid.y)
+// FAST math mode: per span 4 basis functions x (4 value + 3 derivative) polynomial coefficients in
+// t = u - floor(u):  B_k = ((a3 t + a2) t + a1) t + a0,  B_k' = (d2 t + d1) t + d0
+constexpr int kCoefRow = 28;
 
 // what differs between the poses of one launch: the pose and where its results go
 struct SlotArgs {
@@ -84,6 +87,7 @@ struct EvalParams {
   double huber_delta;
   float huber_dsqr;
   int group_size;                  // cells per first-level group
+  const double *ctab;              // FAST mode: per-span B-spline polynomial coefficients [S][kCoefRow]
   SlotArgs slot[kMaxBatch];        // indexed by blockIdx.y
   // optional per-pixel dump (image order), null when disabled
   double *dbg_u, *dbg_v, *dbg_ic, *dbg_wc;
@@ -103,7 +107,7 @@ __device__ __forceinline__ void nid_stamp(long long *buf, int k, double d0 = 0.0
 }
 #define NID_STAMP(k, ...)                                    \
   do {                                                       \
-    if (P.dbg_stamps && blockIdx.y == 0) nid_stamp(P.dbg_stamps, (k), ##__VA_ARGS__); \
+    if (DBG && P.dbg_stamps && blockIdx.y == 0) nid_stamp(P.dbg_stamps, (k), ##__VA_ARGS__); \
   } while (0)
 
 // ---------------------------------------------------------------------------
@@ -196,6 +200,71 @@ __device__ __forceinline__ double bilinear_rows(const RowPair &r, int wx, double
   const double i00 = win_tap(r.ra, kx), i01 = win_tap(r.ra, kx + 1);
   const double i10 = win_tap(r.rb, kx), i11 = win_tap(r.rb, kx + 1);
   return dxdy * i11 + (dy - dxdy) * i10 + (dx - dxdy) * i01 + (1 - dx - dy + dxdy) * i00;
+}
+
+// ---- FAST math helpers (not rounding-identical to the reference; see k_eval) ----------
+// bilinear sample as two lerps on register taps
+__device__ __forceinline__ double bilinear_rows_fast(const RowPair &r, int wx, double x) {
+  const int ix = (int)x;
+  const double dx = x - ix;
+  int kx = ix - wx;
+  kx = min(max(kx, 0), 3);
+  const double i00 = win_tap(r.ra, kx), i01 = win_tap(r.ra, kx + 1);
+  const double i10 = win_tap(r.rb, kx), i11 = win_tap(r.rb, kx + 1);
+  const double top = fma(dx, i01 - i00, i00);
+  const double bot = fma(dx, i11 - i10, i10);
+  return fma(r.dy, bot - top, top);
+}
+
+__device__ __forceinline__ int tap_i(unsigned row, int k) { return (int)((row >> (k * 8)) & 0xffu); }
+
+// Central-difference image gradient of the bilinear surface at (u, v):
+//   gx = (bil(u+1,v) - bil(u-1,v))/2, gy = (bil(u,v+1) - bil(u,v-1))/2
+// (types_six_dof_expmap.cpp:434-435).  Interior pixels (window origin = (ix-1, iy-1)) use the 12
+// shared taps with exact integer differences; the first row/column falls back to the generic form,
+// which also reproduces the (int)-truncation extrapolation of the reference there.
+__device__ __forceinline__ void gradient_fast(const Win &w, double u, double v, double &gx, double &gy) {
+  const int ix = (int)u, iy = (int)v;
+  const double dx = u - ix, dy = v - iy;
+  if (ix - w.wx == 1 && iy - w.wy == 1) {
+    // gx: rows iy (r1), iy+1 (r2); L(ix+1) - L(ix-1) = (a2 - a0) + dx*((a3 - a2) - (a1 - a0))
+    const int a10 = tap_i(w.r1, 0), a11 = tap_i(w.r1, 1), a12 = tap_i(w.r1, 2), a13 = tap_i(w.r1, 3);
+    const int a20 = tap_i(w.r2, 0), a21 = tap_i(w.r2, 1), a22 = tap_i(w.r2, 2), a23 = tap_i(w.r2, 3);
+    const double g1 = fma(dx, (double)((a13 - a12) - (a11 - a10)), (double)(a12 - a10));
+    const double g2 = fma(dx, (double)((a23 - a22) - (a21 - a20)), (double)(a22 - a20));
+    gx = 0.5 * fma(dy, g2 - g1, g1);
+    // gy: M(j) = a(j,1) + dx*(a(j,2) - a(j,1)) on rows iy-1 .. iy+2;
+    //     bil(v+1) - bil(v-1) = (M2 - M0) + dy*((M3 - M2) - (M1 - M0))
+    const int a01 = tap_i(w.r0, 1), a02 = tap_i(w.r0, 2), a31 = tap_i(w.r3, 1), a32 = tap_i(w.r3, 2);
+    const double m0 = fma(dx, (double)(a02 - a01), (double)a01);
+    const double m1 = fma(dx, (double)(a12 - a11), (double)a11);
+    const double m2 = fma(dx, (double)(a22 - a21), (double)a21);
+    const double m3 = fma(dx, (double)(a32 - a31), (double)a31);
+    gy = 0.5 * fma(dy, (m3 - m2) - (m1 - m0), m2 - m0);
+  } else {
+    const RowPair r0 = win_rows(w, v);
+    gx = 0.5 * (bilinear_rows_fast(r0, w.wx, u + 1) - bilinear_rows_fast(r0, w.wx, u - 1));
+    const RowPair rp = win_rows(w, v + 1), rm = win_rows(w, v - 1);
+    gy = 0.5 * (bilinear_rows_fast(rp, w.wx, u) - bilinear_rows_fast(rm, w.wx, u));
+  }
+}
+
+// B-spline values/derivatives from the per-span polynomial table (kCoefRow doubles per span):
+// row layout [k][a0 a1 a2 a3 d0 d1 d2], k = 0..3.  t = u - jc in [0,1).  The reference's u == 0
+// quirk (derivative identically 0 at exactly 0, Q5) is kept by a select.
+template <bool WANT_DER>
+__device__ __forceinline__ void bspline4_poly(double u, int jc, const double *ctab, double B[4], double D[4]) {
+  const double t = u - (double)jc;
+  const double *c = ctab + jc * kCoefRow;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const double *ck = c + 7 * k;
+    B[k] = fma(fma(fma(ck[3], t, ck[2]), t, ck[1]), t, ck[0]);
+    if (WANT_DER) {
+      const double d = fma(fma(ck[6], t, ck[5]), t, ck[4]);
+      D[k] = (u == 0.0) ? 0.0 : d;
+    }
+  }
 }
 
 // bilinear_u8 on the window: same arithmetic, taps from registers.  A tap index
@@ -512,18 +581,29 @@ __device__ __forceinline__ void finish_and_reduce(const EvalParams &P, const Slo
   }
 }
 
-template <int NT, int PPT, bool JAC>
+// STRICT = true : every rounding of the reference path is reproduced (bit-exact per-pixel
+//                 intermediates; IEEE divisions, quaternion rotate, (int)-truncating bilinear form,
+//                 recursion-identical B-splines, fx*x/z vs fx*(x/z)).
+// STRICT = false: FAST math -- same algorithm, cheaper but not rounding-identical arithmetic
+//                 (3x4 matrix with FMAs, one reciprocal per pixel, lerp bilinear on shared taps,
+//                 per-span polynomial B-splines); per-pixel values differ by a few ulp, per-cell
+//                 results stay inside the stated 1e-11 / 1e-9 tolerances (tests run both modes).
+// NB > 0: bin count known at compile time (LDS offsets of the 20 histogram atomics and the 20
+// weight-table reads fold into instruction immediates); NB == 0: read it from the geometry.
+// DBG: per-pixel dump / phase stamps compiled in (diagnostic launches only).
+template <int NT, int PPT, bool JAC, bool STRICT, int NB, bool DBG>
 __global__ __launch_bounds__(NT) void k_eval(EvalParams P) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const Geometry &g = P.g;
-  const int nb = g.nb;
+  const int nb = NB > 0 ? NB : g.nb;
   const int nbins = nb * nb + nb;  // [0,nb): target histogram, then joint row-major [ref][target]
+  const int S = nb - 3;
   constexpr int NW = NT / 64;
   // LDS carve (all 16-B aligned): hist | tab | rtab | red
   unsigned long long *hist = reinterpret_cast<unsigned long long *>(smem);
   double *tab = reinterpret_cast<double *>(smem + (size_t)nbins * kHistCopies * 8);
-  double *rtab = tab + ((nbins + 1) & ~1);
-  double *red = rtab + kMaxBins * kRcpRow;   // max(12*NW, (NT/32)*32 + 2) doubles
+  double *rtab = tab + ((nbins + 1) & ~1);       // STRICT: reciprocal table; FAST: polynomial table
+  double *red = rtab + kMaxBins * kCoefRow;      // max(6*NW, NT + 2) doubles
 
   const int cl = blockIdx.x, tid = threadIdx.x;
   const SlotArgs &SA = P.slot[blockIdx.y];
@@ -540,14 +620,18 @@ __global__ __launch_bounds__(NT) void k_eval(EvalParams P) {
 
   NID_STAMP(0);
   for (int i = tid; i < nbins * kHistCopies; i += NT) hist[i] = 0ull;
-  if (tid < g.S * 6) {  // RN(1/d) for the six knot differences of every span
-    const int jj = tid / 6, e = tid % 6;
-    rtab[jj * kRcpRow + e] = 1.0 / span_denominator(jj, e, g.S);
+  if (STRICT) {
+    if (tid < S * 6) {  // RN(1/d) for the six knot differences of every span
+      const int jj = tid / 6, e = tid % 6;
+      rtab[jj * kRcpRow + e] = 1.0 / span_denominator(jj, e, S);
+    }
+  } else {
+    for (int i = tid; i < S * kCoefRow; i += NT) rtab[i] = P.ctab[i];
   }
 
   const int copy = tid & (kHistCopies - 1);
-  const size_t base = (size_t)cl * g.pstride;
-  const size_t plane = (size_t)g.nloc * g.pstride;
+  const unsigned base = (unsigned)cl * (unsigned)g.pstride;   // 32-bit element offsets from uniform bases
+  const unsigned plane = (unsigned)g.nloc * (unsigned)g.pstride;
 
   // ---- stage 0: coalesced tile loads (all independent) -----------------------
   double lx[PPT], ly[PPT], lz[PPT], s_wr[PPT][4];
@@ -556,7 +640,7 @@ __global__ __launch_bounds__(NT) void k_eval(EvalParams P) {
   for (int i = 0; i < PPT; i++) {
     const int s = i * NT + tid;
     const bool in_tile = s < g.pstride;
-    const size_t gi = base + (in_tile ? s : 0);
+    const unsigned gi = base + (in_tile ? (unsigned)s : 0u);
     const int jr = P.t.JR[gi];
     s_jr[i] = in_tile ? jr : -1;
     lx[i] = P.t.X[gi]; ly[i] = P.t.Y[gi]; lz[i] = P.t.Z[gi];
@@ -565,26 +649,40 @@ __global__ __launch_bounds__(NT) void k_eval(EvalParams P) {
   }
 
   // ---- stage 1: warp, in-frame test, issue the 4x4 window loads ------------------
-  double s_x[PPT], s_y[PPT], s_z[PPT], s_u[PPT], s_v[PPT];
-  bool s_in[PPT];
+  double s_x[PPT], s_y[PPT], s_z[PPT], s_u[PPT], s_v[PPT];  // FAST: s_z holds 1/z
+  bool s_in[PPT], s_jin[PPT];
   Win s_w[PPT];
 #pragma unroll
   for (int i = 0; i < PPT; i++) {
-    double qx, qy, qz;
-    xform_point(SA.pose, lx[i], ly[i], lz[i], qx, qy, qz);
-    // types_six_dof_expmap.cpp:562-563: fx * x / z + cx
-    const double u = g.fx * qx / qz + g.cx;
-    const double v = g.fy * qy / qz + g.cy;
+    double qx, qy, qz, u, v;
+    if (STRICT) {
+      xform_point(SA.pose, lx[i], ly[i], lz[i], qx, qy, qz);
+      // types_six_dof_expmap.cpp:562-563: fx * x / z + cx
+      u = g.fx * qx / qz + g.cx;
+      v = g.fy * qy / qz + g.cy;
+      s_z[i] = qz;
+      s_jin[i] = false;  // decided in phase 2 from fx*(x/z)+cx (Q6)
+    } else {
+      const double *M = SA.pose.M;
+      qx = fma(M[0], lx[i], fma(M[1], ly[i], fma(M[2], lz[i], M[3])));
+      qy = fma(M[4], lx[i], fma(M[5], ly[i], fma(M[6], lz[i], M[7])));
+      qz = fma(M[8], lx[i], fma(M[9], ly[i], fma(M[10], lz[i], M[11])));
+      const double iz = 1.0 / qz;
+      u = fma(g.fx * qx, iz, g.cx);
+      v = fma(g.fy * qy, iz, g.cy);
+      s_z[i] = iz;
+    }
     s_in[i] = (s_jr[i] >= 0) && (u >= 0 && u + 3 <= g.cols && v >= 0 && v + 3 <= g.rows);
-    s_x[i] = qx; s_y[i] = qy; s_z[i] = qz; s_u[i] = u; s_v[i] = v;
+    if (!STRICT) s_jin[i] = s_in[i] && (u + 3 <= P.jac_cols);
+    s_x[i] = qx; s_y[i] = qy; s_u[i] = u; s_v[i] = v;
     // out-of-frame pixels load the window at (0,0); it is never used
     s_w[i].wx = s_in[i] ? max((int)u - 1, 0) : 0;
     s_w[i].wy = s_in[i] ? max((int)v - 1, 0) : 0;
-    const uint8_t *p = P.im1 + (size_t)s_w[i].wy * g.cols + s_w[i].wx;
-    s_w[i].r0 = load_u32_unaligned(p);
-    s_w[i].r1 = load_u32_unaligned(p + g.cols);
-    s_w[i].r2 = load_u32_unaligned(p + 2 * g.cols);
-    s_w[i].r3 = load_u32_unaligned(p + 3 * g.cols);
+    const unsigned po = (unsigned)s_w[i].wy * (unsigned)g.cols + (unsigned)s_w[i].wx;
+    s_w[i].r0 = load_u32_unaligned(P.im1 + po);
+    s_w[i].r1 = load_u32_unaligned(P.im1 + (po + (unsigned)g.cols));
+    s_w[i].r2 = load_u32_unaligned(P.im1 + (po + 2u * (unsigned)g.cols));
+    s_w[i].r3 = load_u32_unaligned(P.im1 + (po + 3u * (unsigned)g.cols));
   }
   NID_STAMP(1, s_u[0], s_v[PPT - 1]);
   __syncthreads();  // histogram zeroed, rtab ready
@@ -598,29 +696,39 @@ __global__ __launch_bounds__(NT) void k_eval(EvalParams P) {
     double ic = NAN, wc[4] = {NAN, NAN, NAN, NAN};
     if (s_in[i]) {
       const RowPair rp = win_rows(s_w[i], s_v[i]);
-      ic = bilinear_rows(rp, s_w[i].wx, s_u[i]);
-      if (ic >= 255) ic = 254.999;
-      if (ic < 0) ic = 0.0;
-      const double pc = ic * ((double)nb - 3.0) / 255.0;
-      const int jc = (int)floor(pc);
       double dw[4];
-      bspline4_tab<JAC>(pc, jc, g.S, rtab, wc, dw);
+      int jc;
+      if (STRICT) {
+        ic = bilinear_rows(rp, s_w[i].wx, s_u[i]);
+        if (ic >= 255) ic = 254.999;
+        if (ic < 0) ic = 0.0;
+        const double pc = ic * ((double)nb - 3.0) / 255.0;
+        jc = (int)floor(pc);
+        bspline4_tab<JAC>(pc, jc, S, rtab, wc, dw);
+      } else {
+        ic = bilinear_rows_fast(rp, s_w[i].wx, s_u[i]);
+        if (ic >= 255) ic = 254.999;
+        if (ic < 0) ic = 0.0;
+        const double pc = ic * ((double)S / 255.0);
+        jc = (int)pc;
+        bspline4_poly<JAC>(pc, jc, rtab, wc, dw);
+      }
       s_jc[i] = jc;
       if (JAC) {
 #pragma unroll
         for (int k = 0; k < 4; k++) s_dw[i][k] = dw[k];
       }
-      unsigned long long *hc = hist + (size_t)jc * kHistCopies + copy;
+      unsigned long long *hc = hist + (jc * kHistCopies + copy);
 #pragma unroll
       for (int k = 0; k < 4; k++) atomicAdd(hc + k * kHistCopies, fx_encode(wc[k], P.hist_scale));
-      unsigned long long *hj = hist + (size_t)(nb + s_jr[i] * nb + jc) * kHistCopies + copy;
+      unsigned long long *hj = hist + ((nb + s_jr[i] * nb + jc) * kHistCopies + copy);
 #pragma unroll
       for (int m = 0; m < 4; m++)
 #pragma unroll
         for (int k = 0; k < 4; k++)
-          atomicAdd(hj + (size_t)(m * nb + k) * kHistCopies, fx_encode(s_wr[i][m] * wc[k], P.hist_scale));
+          atomicAdd(hj + (m * nb + k) * kHistCopies, fx_encode(s_wr[i][m] * wc[k], P.hist_scale));
     }
-    if (P.dbg_u && blockIdx.y == 0 && s_jr[i] >= 0) {
+    if (DBG && P.dbg_u && blockIdx.y == 0 && s_jr[i] >= 0) {
       const int s = i * NT + tid;
       const int c = g.cell_begin + cl;
       const int r = (c / g.cell_num) * g.rb + s / g.cb;
@@ -696,24 +804,32 @@ __global__ __launch_bounds__(NT) void k_eval(EvalParams P) {
   for (int n = 0; n < 6; n++) acc[n] = 0.0;
 #pragma unroll
   for (int i = 0; i < PPT; i++) {
-    launder(s_x[i]); launder(s_y[i]); launder(s_z[i]);
-    launder(s_w[i].r0); launder(s_w[i].r1); launder(s_w[i].r2); launder(s_w[i].r3);
-    launder(s_w[i].wx); launder(s_w[i].wy);
-  }
-#pragma unroll
-  for (int i = 0; i < PPT; i++) {
     if (s_in[i]) {
-      // linearizeOplus recomputes u as fx*(x/z)+cx (types_six_dof_expmap.cpp:407-422, Q6)
-      const double x = s_x[i], y = s_y[i], zz = s_z[i];
-      const double invz = 1.0 / zz;
-      const double u = g.fx * (x / zz) + g.cx;
-      const double v = g.fy * (y / zz) + g.cy;
-      if (u >= 0 && u + 3 <= P.jac_cols && v >= 0 && v + 3 <= g.rows) {
+      const double x = s_x[i], y = s_y[i];
+      double invz, u, v;
+      bool jin;
+      if (STRICT) {
+        // linearizeOplus recomputes u as fx*(x/z)+cx (types_six_dof_expmap.cpp:407-422, Q6)
+        const double zz = s_z[i];
+        invz = 1.0 / zz;
+        u = g.fx * (x / zz) + g.cx;
+        v = g.fy * (y / zz) + g.cy;
+        jin = (u >= 0 && u + 3 <= P.jac_cols && v >= 0 && v + 3 <= g.rows);
+      } else {
+        invz = s_z[i]; u = s_u[i]; v = s_v[i];
+        jin = s_jin[i];
+      }
+      if (jin) {
         const int wx = s_w[i].wx;
-        const RowPair r0 = win_rows(s_w[i], v);
-        const double gx = (bilinear_rows(r0, wx, u + 1) - bilinear_rows(r0, wx, u - 1)) / 2;
-        const RowPair rp = win_rows(s_w[i], v + 1), rm = win_rows(s_w[i], v - 1);
-        const double gy = (bilinear_rows(rp, wx, u) - bilinear_rows(rm, wx, u)) / 2;
+        double gx, gy;
+        if (STRICT) {
+          const RowPair r0 = win_rows(s_w[i], v);
+          gx = (bilinear_rows(r0, wx, u + 1) - bilinear_rows(r0, wx, u - 1)) / 2;
+          const RowPair rp = win_rows(s_w[i], v + 1), rm = win_rows(s_w[i], v - 1);
+          gy = (bilinear_rows(rp, wx, u) - bilinear_rows(rm, wx, u)) / 2;
+        } else {
+          gradient_fast(s_w[i], u, v, gx, gy);
+        }
         const int jr = s_jr[i], jc = s_jc[i];
         const double *tj = tab + nb + jr * nb + jc;
         double tt = 0.0, ss = 0.0;
@@ -751,7 +867,7 @@ __global__ __launch_bounds__(NT) void k_eval(EvalParams P) {
   if (tid < 64) {
     // CalculateDerKernel tail (computeH.cu:358-366) == types_six_dof_expmap.cpp:486-528:
     // kappa = d_mi_i (:393), 1/N_c (:488,494), 1/Hj^2 (:521)
-    const double kappa = (double)g.S / 255.0;
+    const double kappa = (double)S / 255.0;
     const double scale = (kappa / (double)n_c) * (1.0 / (Hj * Hj));
     double J[6];
 #pragma unroll

@@ -25,6 +25,7 @@ struct LegacyState {
 LegacyState g_state;
 int g_device = 0;
 int g_jac_bound = NID_JACBOUND_CPU;
+int g_math_mode = NID_MATH_FAST;
 long g_uploads = 0;
 
 bool always_upload() {
@@ -55,6 +56,7 @@ nid_ctx *get_ctx(int rows, int cols, int cell, int bins, int deg, const double *
   if (rc != NID_OK) { report("nid_create", rc, nullptr); return nullptr; }
   // the operator signatures carry a 4x4 matrix: computeH.cu:152-154 semantics for the transform
   nid_set_options(ctx, g_jac_bound, NID_XFORM_MATRIX);
+  nid_set_math_mode(ctx, g_math_mode);
   S.ctx = ctx; S.rows = rows; S.cols = cols; S.cell = cell; S.bins = bins;
   std::memcpy(S.intr, intr, sizeof(S.intr));
   return ctx;
@@ -168,6 +170,11 @@ extern "C" {
 void nid_legacy_set_jacobian_bound(int mode) {
   g_jac_bound = mode ? NID_JACBOUND_CUDA : NID_JACBOUND_CPU;
   if (g_state.ctx) nid_set_options(g_state.ctx, g_jac_bound, NID_XFORM_MATRIX);
+}
+
+void nid_legacy_set_math_mode(int mode) {
+  g_math_mode = mode ? NID_MATH_STRICT : NID_MATH_FAST;
+  if (g_state.ctx) nid_set_math_mode(g_state.ctx, g_math_mode);
 }
 
 void nid_legacy_set_device(int device) {

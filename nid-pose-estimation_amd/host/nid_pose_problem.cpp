@@ -19,6 +19,7 @@ int nid_host_run_lm(const nid_pose_problem *pb, double *pose7_inout, nid_host_lm
   const size_t N = (size_t)rows * cols;
   nid_legacy_reset();
   nid_legacy_set_jacobian_bound(pb->jac_bound_cuda ? 1 : 0);
+  nid_legacy_set_math_mode(pb->strict_math ? 1 : 0);
 
   // NID_pose_estimation.cpp:229-251 -- buffers owned by the caller of the operators
   std::vector<double> intrinscis = {pb->fx, pb->fy, pb->cx, pb->cy, pb->depth_factor};

@@ -12,6 +12,8 @@ typedef struct {
   int32_t rows, cols, cell_num, bin_num, iterations;
   int32_t jac_bound_cuda;   /* 0 = CPU-edge bound (parity target), 1 = CUDA-kernel bound */
   int32_t fused;            /* 1 = fused device normal equations, 0 = per-edge walk like the reference */
+  int32_t strict_math;      /* 1 = NID_MATH_STRICT, 0 = NID_MATH_FAST */
+  int32_t pad_;
   double fx, fy, cx, cy, depth_factor, huber_delta;
   const uint8_t *im0, *im1;        /* rows*cols */
   const uint16_t *depth_u16;       /* rows*cols, metres = value * depth_factor */

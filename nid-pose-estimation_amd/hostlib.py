@@ -19,6 +19,7 @@ c_ip = C.POINTER(C.c_int)
 class PoseProblem(C.Structure):
     _fields_ = [("rows", C.c_int32), ("cols", C.c_int32), ("cell_num", C.c_int32), ("bin_num", C.c_int32),
                 ("iterations", C.c_int32), ("jac_bound_cuda", C.c_int32), ("fused", C.c_int32),
+                ("strict_math", C.c_int32), ("pad_", C.c_int32),
                 ("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double), ("cy", C.c_double),
                 ("depth_factor", C.c_double), ("huber_delta", C.c_double),
                 ("im0", C.POINTER(C.c_uint8)), ("im1", C.POINTER(C.c_uint8)),
@@ -53,6 +54,7 @@ def load():
     lib.nid_legacy_reset.restype = None
     lib.nid_legacy_set_jacobian_bound.argtypes = [C.c_int]
     lib.nid_legacy_upload_count.restype = C.c_long
+    lib.nid_legacy_set_math_mode.argtypes = [C.c_int]
     _lib = lib
     return lib
 
@@ -101,7 +103,8 @@ def huber(e2, delta):
     return rho
 
 
-def run_lm(pair, bin_num, pose7, iterations=10, jac_bound_cuda=False, fused=False, huber_delta=None, synth=None):
+def run_lm(pair, bin_num, pose7, iterations=10, jac_bound_cuda=False, fused=False, huber_delta=None, synth=None,
+           strict=False):
     """The reference driver's optimisation (NID_pose_estimation.cpp:163-366) on the C++ host stack."""
     import importlib
     synth = synth or importlib.import_module("nid-pose-estimation_amd.synth")
@@ -110,7 +113,7 @@ def run_lm(pair, bin_num, pose7, iterations=10, jac_bound_cuda=False, fused=Fals
     dep = np.ascontiguousarray(pair.depth_u16, dtype=np.uint16)
     T = _d(synth.matrix_colmajor16(pair.T_wc0))
     pb = PoseProblem(pair.rows, pair.cols, pair.cell, bin_num, iterations, 1 if jac_bound_cuda else 0,
-                     1 if fused else 0, pair.fx, pair.fy, pair.cx, pair.cy, 1.0 / 5000,
+                     1 if fused else 0, 1 if strict else 0, 0, pair.fx, pair.fy, pair.cx, pair.cy, 1.0 / 5000,
                      float(huber_delta) if huber_delta else 0.0,
                      im0.ctypes.data_as(C.POINTER(C.c_uint8)), im1.ctypes.data_as(C.POINTER(C.c_uint8)),
                      dep.ctypes.data_as(C.POINTER(C.c_uint16)), _dp(T))

@@ -47,3 +47,25 @@ def test_div_small_is_correctly_rounded(capi):
     for d in (1.0, 2.0, 3.0):
         got = np.array([lib.nid_div_small_host(float(x), d) for x in xs[:60000]])
         assert np.array_equal(_bits(got), _bits(xs[:60000] / d)), d
+
+
+@pytest.mark.parametrize("nb", [4, 6, 8, 10, 14, 16])
+def test_fast_mode_polynomial_table(capi, oracle, nb):
+    """FAST math: the per-span polynomial form of the basis (built in long double from the knot
+    vector) agrees with the reference recursion to a few ulp, including at knots and the u == 0 quirk."""
+    S = nb - 3
+    rng = np.random.default_rng(100 + nb)
+    us = np.concatenate([rng.uniform(0, S, 5000), np.arange(0, S, 1.0), np.nextafter(np.arange(1, S + 1, 1.0), -np.inf)])
+    us = us[(us >= 0) & (us < S)]
+    lib = oracle.load()
+    worst_b = worst_d = 0.0
+    for u in us:
+        j = int(math.floor(u))
+        B, D = capi.bspline4_poly_host(u, nb)
+        Bo = np.array([lib.nid_oracle_bspline(nb, j + k, 4, float(u)) for k in range(4)])
+        Do = np.array([lib.nid_oracle_bspline_der(nb, j + k, 4, float(u)) for k in range(4)])
+        worst_b = max(worst_b, np.abs(B - Bo).max())
+        worst_d = max(worst_d, np.abs(D - Do).max())
+    assert worst_b < 1e-15 and worst_d < 4e-15, (worst_b, worst_d)
+    B, D = capi.bspline4_poly_host(0.0, nb)
+    assert list(B) == [1.0, 0.0, 0.0, 0.0] and list(D) == [0.0, 0.0, 0.0, 0.0]
