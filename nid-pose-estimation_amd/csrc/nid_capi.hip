@@ -235,7 +235,35 @@ void launch_eval_t(const EvalParams &P, bool jac, bool strict, bool dbg, size_t 
   launch_eval_v<NT, PPT, 0, false>(P, jac, strict, lds, s, batch);
 }
 
+// k_eval2 (occupancy-organised, runtime pixel loop): one workgroup shape for every cell size
+template <int NB, bool DBG>
+void launch_eval2_v(const EvalParams &P, bool jac, bool strict, size_t lds, hipStream_t s, int batch) {
+  const dim3 grid(P.g.nloc, batch), block(256);
+  if (strict) {
+    if (jac) hipLaunchKernelGGL((k_eval2<256, true, true, NB, DBG>), grid, block, lds, s, P);
+    else hipLaunchKernelGGL((k_eval2<256, false, true, NB, DBG>), grid, block, lds, s, P);
+  } else {
+    if (jac) hipLaunchKernelGGL((k_eval2<256, true, false, NB, DBG>), grid, block, lds, s, P);
+    else hipLaunchKernelGGL((k_eval2<256, false, false, NB, DBG>), grid, block, lds, s, P);
+  }
+}
+
+int launch_eval2(nid_ctx *ctx, const EvalParams &P, bool jac, hipStream_t stream, int batch) {
+  const size_t lds = eval_lds_bytes(P.g, 256);
+  if (lds > 160 * 1024) return NID_ERR_UNSUPPORTED;
+  const bool dbg = ctx->dbg_enabled || ctx->dbg_stamps != nullptr;
+  const bool strict = ctx->math_mode == NID_MATH_STRICT;
+  if (dbg) launch_eval2_v<0, true>(P, jac, strict, lds, stream, batch);
+  else if (P.g.nb == 8) launch_eval2_v<8, false>(P, jac, strict, lds, stream, batch);
+  else if (P.g.nb == 10) launch_eval2_v<10, false>(P, jac, strict, lds, stream, batch);
+  else launch_eval2_v<0, false>(P, jac, strict, lds, stream, batch);
+  NID_HIP(ctx, hipGetLastError());
+  return NID_OK;
+}
+
 int launch_eval(nid_ctx *ctx, const EvalParams &P, bool jac, hipStream_t stream, int batch = 1) {
+  static const bool v1 = getenv("NID_KERNEL_V1") != nullptr;  // A/B switch: register-resident variant
+  if (!v1 && ctx->block_threads == 0) return launch_eval2(ctx, P, jac, stream, batch);
   int nt = 0, ppt = 0;
   if (!pick_eval_shape(ctx, &nt, &ppt)) return NID_ERR_UNSUPPORTED;
   const size_t lds = eval_lds_bytes(P.g, nt);

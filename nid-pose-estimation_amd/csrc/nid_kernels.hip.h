@@ -591,8 +591,11 @@ __device__ __forceinline__ void finish_and_reduce(const EvalParams &P, const Slo
 // NB > 0: bin count known at compile time (LDS offsets of the 20 histogram atomics and the 20
 // weight-table reads fold into instruction immediates); NB == 0: read it from the geometry.
 // DBG: per-pixel dump / phase stamps compiled in (diagnostic launches only).
+#ifndef NID_MIN_WAVES
+#define NID_MIN_WAVES 1
+#endif
 template <int NT, int PPT, bool JAC, bool STRICT, int NB, bool DBG>
-__global__ __launch_bounds__(NT) void k_eval(EvalParams P) {
+__global__ __launch_bounds__(NT, (NT == 256 && NB > 0) ? NID_MIN_WAVES : 1) void k_eval(EvalParams P) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const Geometry &g = P.g;
   const int nb = NB > 0 ? NB : g.nb;
@@ -900,6 +903,304 @@ __global__ __launch_bounds__(NT) void k_eval(EvalParams P) {
     }
   }
   __syncthreads();  // `red` is reused by the reduction
+  NID_STAMP(6);
+  finish_and_reduce<NT>(P, SA, cl, tid, red);
+  NID_STAMP(7);
+}
+
+// ---------------------------------------------------------------------------
+// k_eval2: the same computation organised for OCCUPANCY instead of per-thread ILP.
+// Nothing is carried in registers from the cost phase to the Jacobian phase: the Jacobian
+// phase re-reads the pixel's tile entry (L2-resident) and its 4x4 window and recomputes
+// the warp / sample / B-spline derivative with the identical instruction sequence (so the
+// reference's Q7 "Jacobian reuses the cost pass's intensities" holds by construction).  The
+// pixel loops are NOT unrolled: ~100 VGPRs instead of ~220, so 4-5 workgroups share a CU
+// and the scheduler hides the load / LDS latencies that one wave per SIMD exposes.
+struct PixelFront {
+  bool in, jin;
+  int jr;
+  double x, y, zq, u, v;  // zq = z (STRICT) or 1/z (FAST)
+  Win w;
+  double wr[4];
+};
+
+template <bool STRICT>
+__device__ __forceinline__ void pixel_front(const EvalParams &P, const SlotArgs &SA, unsigned gi, unsigned plane,
+                                            bool in_tile, PixelFront &f) {
+  const Geometry &g = P.g;
+  const int jr = P.t.JR[gi];
+  f.jr = in_tile ? jr : -1;
+  const double lx = P.t.X[gi], ly = P.t.Y[gi], lz = P.t.Z[gi];
+#pragma unroll
+  for (int k = 0; k < 4; k++) f.wr[k] = P.t.W[k * plane + gi];
+  double qx, qy, qz, u, v;
+  if (STRICT) {
+    xform_point(SA.pose, lx, ly, lz, qx, qy, qz);
+    u = g.fx * qx / qz + g.cx;  // types_six_dof_expmap.cpp:562-563
+    v = g.fy * qy / qz + g.cy;
+    f.zq = qz;
+  } else {
+    const double *M = SA.pose.M;
+    qx = fma(M[0], lx, fma(M[1], ly, fma(M[2], lz, M[3])));
+    qy = fma(M[4], lx, fma(M[5], ly, fma(M[6], lz, M[7])));
+    qz = fma(M[8], lx, fma(M[9], ly, fma(M[10], lz, M[11])));
+    const double iz = 1.0 / qz;
+    u = fma(g.fx * qx, iz, g.cx);
+    v = fma(g.fy * qy, iz, g.cy);
+    f.zq = iz;
+  }
+  f.in = (f.jr >= 0) && (u >= 0 && u + 3 <= g.cols && v >= 0 && v + 3 <= g.rows);
+  f.jin = f.in && (u + 3 <= P.jac_cols);  // FAST; STRICT re-decides from fx*(x/z)+cx (Q6)
+  f.x = qx; f.y = qy; f.u = u; f.v = v;
+  f.w.wx = f.in ? max((int)u - 1, 0) : 0;  // out-of-frame pixels load the window at (0,0); never used
+  f.w.wy = f.in ? max((int)v - 1, 0) : 0;
+  const unsigned po = (unsigned)f.w.wy * (unsigned)g.cols + (unsigned)f.w.wx;
+  f.w.r0 = load_u32_unaligned(P.im1 + po);
+  f.w.r1 = load_u32_unaligned(P.im1 + (po + (unsigned)g.cols));
+  f.w.r2 = load_u32_unaligned(P.im1 + (po + 2u * (unsigned)g.cols));
+  f.w.r3 = load_u32_unaligned(P.im1 + (po + 3u * (unsigned)g.cols));
+}
+
+// centre sample -> clamped intensity -> bin position -> B-spline weights (and derivatives)
+template <bool STRICT, bool WANT_DER>
+__device__ __forceinline__ int pixel_sample(const PixelFront &f, int nb, int S, const double *rtab, double &ic,
+                                            double wc[4], double dw[4]) {
+  const RowPair rp = win_rows(f.w, f.v);
+  int jc;
+  if (STRICT) {
+    ic = bilinear_rows(rp, f.w.wx, f.u);
+    if (ic >= 255) ic = 254.999;
+    if (ic < 0) ic = 0.0;
+    const double pc = ic * ((double)nb - 3.0) / 255.0;
+    jc = (int)floor(pc);
+    bspline4_tab<WANT_DER>(pc, jc, S, rtab, wc, dw);
+  } else {
+    ic = bilinear_rows_fast(rp, f.w.wx, f.u);
+    if (ic >= 255) ic = 254.999;
+    if (ic < 0) ic = 0.0;
+    const double pc = ic * ((double)S / 255.0);
+    jc = (int)pc;
+    bspline4_poly<WANT_DER>(pc, jc, rtab, wc, dw);
+  }
+  return jc;
+}
+
+template <int NT, bool JAC, bool STRICT, int NB, bool DBG>
+__global__ __launch_bounds__(NT) void k_eval2(EvalParams P) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const Geometry &g = P.g;
+  const int nb = NB > 0 ? NB : g.nb;
+  const int nbins = nb * nb + nb;
+  const int S = nb - 3;
+  unsigned long long *hist = reinterpret_cast<unsigned long long *>(smem);
+  double *tab = reinterpret_cast<double *>(smem + (size_t)nbins * kHistCopies * 8);
+  double *rtab = tab + ((nbins + 1) & ~1);
+  double *red = rtab + kMaxBins * kCoefRow;
+
+  const int cl = blockIdx.x, tid = threadIdx.x;
+  const SlotArgs &SA = P.slot[blockIdx.y];
+  const int n_c = P.Nc[cl];
+  const double href = P.Href[cl];
+  double *out = SA.cellout + (size_t)cl * kCellOut;
+  double *quad = SA.quad + (size_t)cl * kQuad;
+  if (n_c < 300 || isnan(href)) {  // level-1 edge: never evaluated (computeH.cu:271-275)
+    if (tid < kCellOut) out[tid] = (tid == kCellOut - 1) ? (double)n_c : NAN;
+    if (tid < kQuad) store_sc1(quad + tid, 0.0);
+    finish_and_reduce<NT>(P, SA, cl, tid, red);
+    return;
+  }
+  NID_STAMP(0);
+  for (int i = tid; i < nbins * kHistCopies; i += NT) hist[i] = 0ull;
+  if (STRICT) {
+    if (tid < S * 6) {
+      const int jj = tid / 6, e = tid % 6;
+      rtab[jj * kRcpRow + e] = 1.0 / span_denominator(jj, e, S);
+    }
+  } else {
+    for (int i = tid; i < S * kCoefRow; i += NT) rtab[i] = P.ctab[i];
+  }
+  const int copy = tid & (kHistCopies - 1);
+  const unsigned base = (unsigned)cl * (unsigned)g.pstride;
+  const unsigned plane = (unsigned)g.nloc * (unsigned)g.pstride;
+  const int rounds = (g.pstride + NT - 1) / NT;
+  __syncthreads();
+  NID_STAMP(1);
+
+  // ---- phase 1: cost ---------------------------------------------------------------
+#pragma clang loop unroll(disable)
+  for (int i = 0; i < rounds; i++) {
+    const int s = i * NT + tid;
+    const bool in_tile = s < g.pstride;
+    PixelFront f;
+    pixel_front<STRICT>(P, SA, base + (in_tile ? (unsigned)s : 0u), plane, in_tile, f);
+    double ic = NAN, wc[4] = {NAN, NAN, NAN, NAN}, dw[4];
+    int jc = -1;
+    if (f.in) {
+      jc = pixel_sample<STRICT, false>(f, nb, S, rtab, ic, wc, dw);
+      unsigned long long *hc = hist + (jc * kHistCopies + copy);
+#pragma unroll
+      for (int k = 0; k < 4; k++) atomicAdd(hc + k * kHistCopies, fx_encode(wc[k], P.hist_scale));
+      unsigned long long *hj = hist + ((nb + f.jr * nb + jc) * kHistCopies + copy);
+#pragma unroll
+      for (int m = 0; m < 4; m++)
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+          atomicAdd(hj + (m * nb + k) * kHistCopies, fx_encode(f.wr[m] * wc[k], P.hist_scale));
+    }
+    if (DBG && P.dbg_u && blockIdx.y == 0 && f.jr >= 0) {
+      const int c = g.cell_begin + cl;
+      const int r = (c / g.cell_num) * g.rb + s / g.cb;
+      const int col = (c % g.cell_num) * g.cb + s % g.cb;
+      const size_t id = (size_t)r * g.cols + col;
+      P.dbg_u[id] = f.u; P.dbg_v[id] = f.v; P.dbg_ic[id] = ic; P.dbg_jc[id] = jc;
+#pragma unroll
+      for (int k = 0; k < 4; k++) P.dbg_wc[4 * id + k] = wc[k];
+    }
+  }
+  NID_STAMP(2);
+  __syncthreads();
+
+  // ---- fold the copies, probabilities, entropies, weight tables ----------------------
+  double ent[2] = {0.0, 0.0};
+  for (int b = tid; b < nbins; b += NT) {
+    const uint4 *hv = reinterpret_cast<const uint4 *>(hist + (size_t)b * kHistCopies);
+    unsigned long long acc = 0;
+#pragma unroll
+    for (int c = 0; c < kHistCopies / 2; c++) {
+      const uint4 q = hv[(c + b) & (kHistCopies / 2 - 1)];
+      acc += ((unsigned long long)q.y << 32 | q.x) + ((unsigned long long)q.w << 32 | q.z);
+    }
+    const double p = ((double)(long long)acc * P.hist_inv_scale) / (double)n_c;  // Q1: N_c of the initial pose
+    double w = 0.0;
+    if (!(p < kSigma)) {
+      const double l = log2(p);
+      w = -(1.0 + l);  // Q9
+      if (b < nb) ent[0] += p * l; else ent[1] += p * l;
+    }
+    tab[b] = w;
+  }
+  block_sum<NT, 2>(ent, red, tid);
+  NID_STAMP(3, ent[0], ent[1]);
+  const double Hc = 0.0 - ent[0];
+  const double Hj = 0.0 - ent[1];
+  const double err = (2 * Hj - href - Hc) / Hj;  // types_six_dof_expmap.h:227
+  const double e2 = err * err;                   // Huber, robust_kernel_impl.cpp:77-91 (float dsqr)
+  double rho0 = e2, rho1 = 1.0;
+  if (!(e2 <= P.huber_dsqr)) {
+    const double sqrte = sqrt(e2);
+    rho0 = 2 * sqrte * P.huber_delta - P.huber_dsqr;
+    rho1 = P.huber_delta / sqrte;
+  }
+  if (!JAC) {
+    if (tid == 0) { out[0] = Hc; out[1] = Hj; out[2] = err; out[kCellOut - 1] = (double)n_c; }
+    if (tid < kQuad) store_sc1(quad + tid, tid == 0 ? rho0 : (tid == 28 ? 1.0 : 0.0));
+    __syncthreads();
+    NID_STAMP(6);
+    finish_and_reduce<NT>(P, SA, cl, tid, red);
+    NID_STAMP(7);
+    return;
+  }
+
+  // ---- phase 2: Jacobian (recompute, see header comment) -------------------------------
+  const double cA = Hc + href, cB = Hj;
+  double acc[6];
+#pragma unroll
+  for (int n = 0; n < 6; n++) acc[n] = 0.0;
+#pragma clang loop unroll(disable)
+  for (int i = 0; i < rounds; i++) {
+    const int s = i * NT + tid;
+    const bool in_tile = s < g.pstride;
+    PixelFront f;
+    pixel_front<STRICT>(P, SA, base + (in_tile ? (unsigned)s : 0u), plane, in_tile, f);
+    if (f.in) {
+      double invz, u, v;
+      bool jin;
+      if (STRICT) {  // linearizeOplus: fx*(x/z)+cx (types_six_dof_expmap.cpp:407-422, Q6)
+        invz = 1.0 / f.zq;
+        u = g.fx * (f.x / f.zq) + g.cx;
+        v = g.fy * (f.y / f.zq) + g.cy;
+        jin = (u >= 0 && u + 3 <= P.jac_cols && v >= 0 && v + 3 <= g.rows);
+      } else {
+        invz = f.zq; u = f.u; v = f.v; jin = f.jin;
+      }
+      if (jin) {
+        double ic, wc[4], dw[4];
+        const int jc = pixel_sample<STRICT, true>(f, nb, S, rtab, ic, wc, dw);
+        double gx, gy;
+        if (STRICT) {
+          const RowPair r0 = win_rows(f.w, v);
+          gx = (bilinear_rows(r0, f.w.wx, u + 1) - bilinear_rows(r0, f.w.wx, u - 1)) / 2;
+          const RowPair rp = win_rows(f.w, v + 1), rm = win_rows(f.w, v - 1);
+          gy = (bilinear_rows(rp, f.w.wx, u) - bilinear_rows(rm, f.w.wx, u)) / 2;
+        } else {
+          gradient_fast(f.w, u, v, gx, gy);
+        }
+        const double *tj = tab + nb + f.jr * nb + jc;
+        double tt = 0.0, ss = 0.0;
+#pragma unroll
+        for (int m = 0; m < 4; m++) tt = fma(tab[jc + m], dw[m], tt);
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          double inner = 0.0;
+#pragma unroll
+          for (int m = 0; m < 4; m++) inner = fma(tj[k * nb + m], dw[m], inner);
+          ss = fma(f.wr[k], inner, ss);
+        }
+        const double c = fma(ss, cA, -(tt * cB));
+        const double cgx = c * gx, cgy = c * gy;
+        const double x = f.x, y = f.y;
+        const double invz_2 = invz * invz;
+        // rows of d(u,v)/d(xi), types_six_dof_expmap.cpp:438-450 (omega first, then upsilon)
+        const double ju0 = -x * y * invz_2 * g.fx, ju1 = (1 + (x * x * invz_2)) * g.fx;
+        const double ju2 = -y * invz * g.fx, ju3 = invz * g.fx, ju5 = -x * invz_2 * g.fx;
+        const double jv0 = -(1 + y * y * invz_2) * g.fy, jv1 = x * y * invz_2 * g.fy;
+        const double jv2 = x * invz * g.fy, jv4 = invz * g.fy, jv5 = -y * invz_2 * g.fy;
+        acc[0] = fma(cgx, ju0, fma(cgy, jv0, acc[0]));
+        acc[1] = fma(cgx, ju1, fma(cgy, jv1, acc[1]));
+        acc[2] = fma(cgx, ju2, fma(cgy, jv2, acc[2]));
+        acc[3] = fma(cgx, ju3, acc[3]);
+        acc[4] = fma(cgy, jv4, acc[4]);
+        acc[5] = fma(cgx, ju5, fma(cgy, jv5, acc[5]));
+      }
+    }
+  }
+  NID_STAMP(4, acc[0], acc[2], acc[3], acc[5]);
+  __syncthreads();
+  block_sum<NT, 6>(acc, red, tid);
+  NID_STAMP(5, acc[0], acc[2], acc[3], acc[5]);
+  if (tid < 64) {
+    const double kappa = (double)S / 255.0;  // d_mi_i (:393), 1/N_c (:488,494), 1/Hj^2 (:521)
+    const double scale = (kappa / (double)n_c) * (1.0 / (Hj * Hj));
+    double J[6];
+#pragma unroll
+    for (int n = 0; n < 6; n++) J[n] = acc[n] * scale;
+    if (tid == 0) {
+      out[0] = Hc; out[1] = Hj; out[2] = err;
+#pragma unroll
+      for (int n = 0; n < 6; n++) out[3 + n] = J[n];
+      out[kCellOut - 1] = (double)n_c;
+    }
+    if (tid < kQuad) {  // constructQuadraticForm (base_unary_edge.hpp:56-63)
+      double val = 0.0;
+      if (tid == 0) val = rho0;
+      else if (tid == 28) val = 1.0;
+      else if (tid < 7) {
+        double Jn = 0.0;
+#pragma unroll
+        for (int n = 0; n < 6; n++) if (n == tid - 1) Jn = J[n];
+        val = 0.0 - (rho1 * Jn) * err;
+      } else if (tid < 28) {
+        int a, b;
+        quad_ab(tid, a, b);
+        double Ja = 0.0, Jb = 0.0;
+#pragma unroll
+        for (int n = 0; n < 6; n++) { if (n == a) Ja = J[n]; if (n == b) Jb = J[n]; }
+        val = (Ja * rho1) * Jb;
+      }
+      store_sc1(quad + tid, val);
+    }
+  }
+  __syncthreads();
   NID_STAMP(6);
   finish_and_reduce<NT>(P, SA, cl, tid, red);
   NID_STAMP(7);
