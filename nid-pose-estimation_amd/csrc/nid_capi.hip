@@ -171,70 +171,6 @@ size_t eval_lds_bytes(const Geometry &g, int nt) {
          (size_t)kMaxBins * kCoefRow * 8 + red * 8;
 }
 
-// (threads, pixels per thread) pairs the evaluation kernel is instantiated for
-#define NID_EVAL_CASES(X) \
-  X(256, 1) X(256, 2) X(256, 3) X(256, 4) X(256, 5) X(256, 6) X(256, 8) \
-  X(1024, 2) X(1024, 4) X(1024, 8)
-
-bool pick_eval_shape(const nid_ctx *ctx, int *nt, int *ppt) {
-  const int ps = ctx->g.pstride;
-  auto instantiated = [](int t, int p) {
-#define X(T, P) if (t == T && p == P) return true;
-    NID_EVAL_CASES(X)
-#undef X
-    return false;
-  };
-  int want = ctx->block_threads;
-  if (want == 0) {
-    const char *env = getenv("NID_BLOCK_THREADS");
-    if (env) want = atoi(env);
-  }
-  if (want > 0) {
-    int p = (ps + want - 1) / want;
-    if (want == 256 && p == 7) p = 8;
-    if (instantiated(want, p)) { *nt = want; *ppt = p; return true; }
-    return false;
-  }
-  if (ps <= 2048) {
-    int p = (ps + 255) / 256;
-    if (p == 7) p = 8;
-    *nt = 256; *ppt = p;
-    return instantiated(256, p);
-  }
-  if (ps <= 8192) {
-    int p = (ps + 1023) / 1024;
-    p = p <= 2 ? 2 : (p <= 4 ? 4 : 8);
-    *nt = 1024; *ppt = p;
-    return true;
-  }
-  return false;
-}
-
-template <int NT, int PPT, int NB, bool DBG>
-void launch_eval_v(const EvalParams &P, bool jac, bool strict, size_t lds, hipStream_t s, int batch) {
-  const dim3 grid(P.g.nloc, batch), block(NT);
-  if (strict) {
-    if (jac) hipLaunchKernelGGL((k_eval<NT, PPT, true, true, NB, DBG>), grid, block, lds, s, P);
-    else hipLaunchKernelGGL((k_eval<NT, PPT, false, true, NB, DBG>), grid, block, lds, s, P);
-  } else {
-    if (jac) hipLaunchKernelGGL((k_eval<NT, PPT, true, false, NB, DBG>), grid, block, lds, s, P);
-    else hipLaunchKernelGGL((k_eval<NT, PPT, false, false, NB, DBG>), grid, block, lds, s, P);
-  }
-}
-
-template <int NT, int PPT>
-void launch_eval_t(const EvalParams &P, bool jac, bool strict, bool dbg, size_t lds, hipStream_t s, int batch) {
-  if constexpr (NT == 256 && PPT == 5) {
-    // the BASELINE shape (30x40-pixel cells): bin counts 8 / 10 specialised
-    if (!dbg && P.g.nb == 8) return launch_eval_v<256, 5, 8, false>(P, jac, strict, lds, s, batch);
-    if (!dbg && P.g.nb == 10) return launch_eval_v<256, 5, 10, false>(P, jac, strict, lds, s, batch);
-  }
-  if constexpr (NT == 256) {
-    if (dbg) return launch_eval_v<256, PPT, 0, true>(P, jac, strict, lds, s, batch);  // diagnostic build
-  }
-  launch_eval_v<NT, PPT, 0, false>(P, jac, strict, lds, s, batch);
-}
-
 // k_eval2 (occupancy-organised, runtime pixel loop): one workgroup shape for every cell size
 template <int NB, bool DBG>
 void launch_eval2_v(const EvalParams &P, bool jac, bool strict, size_t lds, hipStream_t s, int batch) {
@@ -262,19 +198,7 @@ int launch_eval2(nid_ctx *ctx, const EvalParams &P, bool jac, hipStream_t stream
 }
 
 int launch_eval(nid_ctx *ctx, const EvalParams &P, bool jac, hipStream_t stream, int batch = 1) {
-  static const bool v1 = getenv("NID_KERNEL_V1") != nullptr;  // A/B switch: register-resident variant
-  if (!v1 && ctx->block_threads == 0) return launch_eval2(ctx, P, jac, stream, batch);
-  int nt = 0, ppt = 0;
-  if (!pick_eval_shape(ctx, &nt, &ppt)) return NID_ERR_UNSUPPORTED;
-  const size_t lds = eval_lds_bytes(P.g, nt);
-  if (lds > 160 * 1024) return NID_ERR_UNSUPPORTED;
-  const bool dbg = ctx->dbg_enabled || ctx->dbg_stamps != nullptr;
-  if (dbg && nt != 256) { ctx->last_error = "pixel dump / stamps need the 256-thread workgroup shape"; return NID_ERR_UNSUPPORTED; }
-#define X(T, PP) \
-  if (nt == T && ppt == PP) { launch_eval_t<T, PP>(P, jac, ctx->math_mode == NID_MATH_STRICT, dbg, lds, stream, batch); NID_HIP(ctx, hipGetLastError()); return NID_OK; }
-  NID_EVAL_CASES(X)
-#undef X
-  return NID_ERR_UNSUPPORTED;
+  return launch_eval2(ctx, P, jac, stream, batch);
 }
 
 void fill_common_params(nid_ctx *ctx, double delta, EvalParams *P) {
@@ -657,11 +581,10 @@ int nid_set_stream(nid_ctx *ctx, void *hip_stream) {
 }
 
 int nid_set_block_threads(nid_ctx *ctx, int threads) {
+  // the evaluation kernel has one workgroup shape (256 threads, runtime pixel loop)
   if (!ctx || threads < 0) return NID_ERR_INVALID_ARG;
-  const int old = ctx->block_threads;
+  if (threads != 0 && threads != 256) return NID_ERR_UNSUPPORTED;
   ctx->block_threads = threads;
-  int nt, ppt;
-  if (!pick_eval_shape(ctx, &nt, &ppt)) { ctx->block_threads = old; return NID_ERR_UNSUPPORTED; }
   return NID_OK;
 }
 

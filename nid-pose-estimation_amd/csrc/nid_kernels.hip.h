@@ -97,7 +97,7 @@ struct EvalParams {
 };
 
 // Stamp k: ordered AFTER the values passed as dependencies and BEFORE any later
-// volatile asm (launder) / memory operation.  One asm statement per the guide.
+// volatile asm / memory operation.  One asm statement per the guide.
 __device__ __forceinline__ void nid_stamp(long long *buf, int k, double d0 = 0.0, double d1 = 0.0,
                                           double d2 = 0.0, double d3 = 0.0) {
   unsigned long long t;
@@ -223,7 +223,21 @@ __device__ __forceinline__ int tap_i(unsigned row, int k) { return (int)((row >>
 // (types_six_dof_expmap.cpp:434-435).  Interior pixels (window origin = (ix-1, iy-1)) use the 12
 // shared taps with exact integer differences; the first row/column falls back to the generic form,
 // which also reproduces the (int)-truncation extrapolation of the reference there.
-__device__ __forceinline__ void gradient_fast(const Win &w, double u, double v, double &gx, double &gy) {
+// Centre sample only (cost phase): interior pixels read the four fixed taps.
+__device__ __forceinline__ double sample_fast(const Win &w, double u, double v) {
+  const int ix = (int)u, iy = (int)v;
+  const double dx = u - ix, dy = v - iy;
+  if (ix - w.wx == 1 && iy - w.wy == 1) {
+    const int a11 = tap_i(w.r1, 1), a12 = tap_i(w.r1, 2), a21 = tap_i(w.r2, 1), a22 = tap_i(w.r2, 2);
+    const double m1 = fma(dx, (double)(a12 - a11), (double)a11);
+    const double m2 = fma(dx, (double)(a22 - a21), (double)a21);
+    return fma(dy, m2 - m1, m1);
+  }
+  return bilinear_rows_fast(win_rows(w, v), w.wx, u);
+}
+
+// `ic` receives the centre sample bil(u,v) (same arithmetic as sample_fast).
+__device__ __forceinline__ void gradient_fast(const Win &w, double u, double v, double &gx, double &gy, double &ic) {
   const int ix = (int)u, iy = (int)v;
   const double dx = u - ix, dy = v - iy;
   if (ix - w.wx == 1 && iy - w.wy == 1) {
@@ -241,8 +255,10 @@ __device__ __forceinline__ void gradient_fast(const Win &w, double u, double v, 
     const double m2 = fma(dx, (double)(a22 - a21), (double)a21);
     const double m3 = fma(dx, (double)(a32 - a31), (double)a31);
     gy = 0.5 * fma(dy, (m3 - m2) - (m1 - m0), m2 - m0);
+    ic = fma(dy, m2 - m1, m1);
   } else {
     const RowPair r0 = win_rows(w, v);
+    ic = bilinear_rows_fast(r0, w.wx, u);
     gx = 0.5 * (bilinear_rows_fast(r0, w.wx, u + 1) - bilinear_rows_fast(r0, w.wx, u - 1));
     const RowPair rp = win_rows(w, v + 1), rm = win_rows(w, v - 1);
     gy = 0.5 * (bilinear_rows_fast(rp, w.wx, u) - bilinear_rows_fast(rm, w.wx, u));
@@ -267,6 +283,27 @@ __device__ __forceinline__ void bspline4_poly(double u, int jc, const double *ct
   }
 }
 
+// derivative-only form of bspline4_poly (Jacobian phase of k_eval2)
+__device__ __forceinline__ void bspline4_poly_der(double u, int jc, const double *ctab, double D[4]) {
+  const double t = u - (double)jc;
+  const double *c = ctab + jc * kCoefRow;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const double *ck = c + 7 * k;
+    const double d = fma(fma(ck[6], t, ck[5]), t, ck[4]);
+    D[k] = (u == 0.0) ? 0.0 : d;
+  }
+}
+
+// 1/z to ~1 ulp from the hardware estimate and two Newton steps (FAST math only)
+__device__ __forceinline__ double rcp_fast(double z) {
+  double r = __builtin_amdgcn_rcp(z);
+  double e = fma(-z, r, 1.0);
+  r = fma(r, e, r);
+  e = fma(-z, r, 1.0);
+  return fma(r, e, r);
+}
+
 // bilinear_u8 on the window: same arithmetic, taps from registers.  A tap index
 // that leaves the window can only belong to a tap whose weight is exactly 0
 // (x or y rounded up to an integer) -- any finite byte is then correct.
@@ -284,13 +321,6 @@ __device__ __forceinline__ double bilinear_w(const Win &w, double x, double y) {
   const double i10 = win_tap(rb, kx), i11 = win_tap(rb, kx + 1);
   return dxdy * i11 + (dy - dxdy) * i10 + (dx - dxdy) * i01 + (1 - dx - dy + dxdy) * i00;
 }
-
-// Opaque re-definition of a register value: code that depends on the result
-// cannot be hoisted above this point (keeps phase-2 arithmetic out of phase 1,
-// where it would only lengthen live ranges).
-__device__ __forceinline__ void launder(double &v) { asm volatile("" : "+v"(v)); }
-__device__ __forceinline__ void launder(unsigned &v) { asm volatile("" : "+v"(v)); }
-__device__ __forceinline__ void launder(int &v) { asm volatile("" : "+v"(v)); }
 
 // Wave64 sum by DPP (VALU cross-lane moves, no LDS traffic): quad swaps, row
 // (half-)mirror, then row_bcast15 / row_bcast31.  The total ends in lane 63.
@@ -581,6 +611,7 @@ __device__ __forceinline__ void finish_and_reduce(const EvalParams &P, const Slo
   }
 }
 
+// Math modes of the evaluation kernel:
 // STRICT = true : every rounding of the reference path is reproduced (bit-exact per-pixel
 //                 intermediates; IEEE divisions, quaternion rotate, (int)-truncating bilinear form,
 //                 recursion-identical B-splines, fx*x/z vs fx*(x/z)).
@@ -591,325 +622,11 @@ __device__ __forceinline__ void finish_and_reduce(const EvalParams &P, const Slo
 // NB > 0: bin count known at compile time (LDS offsets of the 20 histogram atomics and the 20
 // weight-table reads fold into instruction immediates); NB == 0: read it from the geometry.
 // DBG: per-pixel dump / phase stamps compiled in (diagnostic launches only).
-#ifndef NID_MIN_WAVES
-#define NID_MIN_WAVES 1
-#endif
-template <int NT, int PPT, bool JAC, bool STRICT, int NB, bool DBG>
-__global__ __launch_bounds__(NT, (NT == 256 && NB > 0) ? NID_MIN_WAVES : 1) void k_eval(EvalParams P) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const Geometry &g = P.g;
-  const int nb = NB > 0 ? NB : g.nb;
-  const int nbins = nb * nb + nb;  // [0,nb): target histogram, then joint row-major [ref][target]
-  const int S = nb - 3;
-  constexpr int NW = NT / 64;
-  // LDS carve (all 16-B aligned): hist | tab | rtab | red
-  unsigned long long *hist = reinterpret_cast<unsigned long long *>(smem);
-  double *tab = reinterpret_cast<double *>(smem + (size_t)nbins * kHistCopies * 8);
-  double *rtab = tab + ((nbins + 1) & ~1);       // STRICT: reciprocal table; FAST: polynomial table
-  double *red = rtab + kMaxBins * kCoefRow;      // max(6*NW, NT + 2) doubles
-
-  const int cl = blockIdx.x, tid = threadIdx.x;
-  const SlotArgs &SA = P.slot[blockIdx.y];
-  const int n_c = P.Nc[cl];
-  const double href = P.Href[cl];
-  double *out = SA.cellout + (size_t)cl * kCellOut;
-  double *quad = SA.quad + (size_t)cl * kQuad;
-  if (n_c < 300 || isnan(href)) {  // level-1 edge: never evaluated (computeH.cu:271-275)
-    if (tid < kCellOut) out[tid] = (tid == kCellOut - 1) ? (double)n_c : NAN;
-    if (tid < kQuad) store_sc1(quad + tid, 0.0);
-    finish_and_reduce<NT>(P, SA, cl, tid, red);
-    return;
-  }
-
-  NID_STAMP(0);
-  for (int i = tid; i < nbins * kHistCopies; i += NT) hist[i] = 0ull;
-  if (STRICT) {
-    if (tid < S * 6) {  // RN(1/d) for the six knot differences of every span
-      const int jj = tid / 6, e = tid % 6;
-      rtab[jj * kRcpRow + e] = 1.0 / span_denominator(jj, e, S);
-    }
-  } else {
-    for (int i = tid; i < S * kCoefRow; i += NT) rtab[i] = P.ctab[i];
-  }
-
-  const int copy = tid & (kHistCopies - 1);
-  const unsigned base = (unsigned)cl * (unsigned)g.pstride;   // 32-bit element offsets from uniform bases
-  const unsigned plane = (unsigned)g.nloc * (unsigned)g.pstride;
-
-  // ---- stage 0: coalesced tile loads (all independent) -----------------------
-  double lx[PPT], ly[PPT], lz[PPT], s_wr[PPT][4];
-  int s_jr[PPT];
-#pragma unroll
-  for (int i = 0; i < PPT; i++) {
-    const int s = i * NT + tid;
-    const bool in_tile = s < g.pstride;
-    const unsigned gi = base + (in_tile ? (unsigned)s : 0u);
-    const int jr = P.t.JR[gi];
-    s_jr[i] = in_tile ? jr : -1;
-    lx[i] = P.t.X[gi]; ly[i] = P.t.Y[gi]; lz[i] = P.t.Z[gi];
-#pragma unroll
-    for (int k = 0; k < 4; k++) s_wr[i][k] = P.t.W[k * plane + gi];
-  }
-
-  // ---- stage 1: warp, in-frame test, issue the 4x4 window loads ------------------
-  double s_x[PPT], s_y[PPT], s_z[PPT], s_u[PPT], s_v[PPT];  // FAST: s_z holds 1/z
-  bool s_in[PPT], s_jin[PPT];
-  Win s_w[PPT];
-#pragma unroll
-  for (int i = 0; i < PPT; i++) {
-    double qx, qy, qz, u, v;
-    if (STRICT) {
-      xform_point(SA.pose, lx[i], ly[i], lz[i], qx, qy, qz);
-      // types_six_dof_expmap.cpp:562-563: fx * x / z + cx
-      u = g.fx * qx / qz + g.cx;
-      v = g.fy * qy / qz + g.cy;
-      s_z[i] = qz;
-      s_jin[i] = false;  // decided in phase 2 from fx*(x/z)+cx (Q6)
-    } else {
-      const double *M = SA.pose.M;
-      qx = fma(M[0], lx[i], fma(M[1], ly[i], fma(M[2], lz[i], M[3])));
-      qy = fma(M[4], lx[i], fma(M[5], ly[i], fma(M[6], lz[i], M[7])));
-      qz = fma(M[8], lx[i], fma(M[9], ly[i], fma(M[10], lz[i], M[11])));
-      const double iz = 1.0 / qz;
-      u = fma(g.fx * qx, iz, g.cx);
-      v = fma(g.fy * qy, iz, g.cy);
-      s_z[i] = iz;
-    }
-    s_in[i] = (s_jr[i] >= 0) && (u >= 0 && u + 3 <= g.cols && v >= 0 && v + 3 <= g.rows);
-    if (!STRICT) s_jin[i] = s_in[i] && (u + 3 <= P.jac_cols);
-    s_x[i] = qx; s_y[i] = qy; s_u[i] = u; s_v[i] = v;
-    // out-of-frame pixels load the window at (0,0); it is never used
-    s_w[i].wx = s_in[i] ? max((int)u - 1, 0) : 0;
-    s_w[i].wy = s_in[i] ? max((int)v - 1, 0) : 0;
-    const unsigned po = (unsigned)s_w[i].wy * (unsigned)g.cols + (unsigned)s_w[i].wx;
-    s_w[i].r0 = load_u32_unaligned(P.im1 + po);
-    s_w[i].r1 = load_u32_unaligned(P.im1 + (po + (unsigned)g.cols));
-    s_w[i].r2 = load_u32_unaligned(P.im1 + (po + 2u * (unsigned)g.cols));
-    s_w[i].r3 = load_u32_unaligned(P.im1 + (po + 3u * (unsigned)g.cols));
-  }
-  NID_STAMP(1, s_u[0], s_v[PPT - 1]);
-  __syncthreads();  // histogram zeroed, rtab ready
-
-  // ---- stage 2: sample, target B-spline weights, histogram accumulation ---------
-  double s_dw[PPT][4];
-  int s_jc[PPT];
-#pragma unroll
-  for (int i = 0; i < PPT; i++) {
-    s_jc[i] = 0;
-    double ic = NAN, wc[4] = {NAN, NAN, NAN, NAN};
-    if (s_in[i]) {
-      const RowPair rp = win_rows(s_w[i], s_v[i]);
-      double dw[4];
-      int jc;
-      if (STRICT) {
-        ic = bilinear_rows(rp, s_w[i].wx, s_u[i]);
-        if (ic >= 255) ic = 254.999;
-        if (ic < 0) ic = 0.0;
-        const double pc = ic * ((double)nb - 3.0) / 255.0;
-        jc = (int)floor(pc);
-        bspline4_tab<JAC>(pc, jc, S, rtab, wc, dw);
-      } else {
-        ic = bilinear_rows_fast(rp, s_w[i].wx, s_u[i]);
-        if (ic >= 255) ic = 254.999;
-        if (ic < 0) ic = 0.0;
-        const double pc = ic * ((double)S / 255.0);
-        jc = (int)pc;
-        bspline4_poly<JAC>(pc, jc, rtab, wc, dw);
-      }
-      s_jc[i] = jc;
-      if (JAC) {
-#pragma unroll
-        for (int k = 0; k < 4; k++) s_dw[i][k] = dw[k];
-      }
-      unsigned long long *hc = hist + (jc * kHistCopies + copy);
-#pragma unroll
-      for (int k = 0; k < 4; k++) atomicAdd(hc + k * kHistCopies, fx_encode(wc[k], P.hist_scale));
-      unsigned long long *hj = hist + ((nb + s_jr[i] * nb + jc) * kHistCopies + copy);
-#pragma unroll
-      for (int m = 0; m < 4; m++)
-#pragma unroll
-        for (int k = 0; k < 4; k++)
-          atomicAdd(hj + (m * nb + k) * kHistCopies, fx_encode(s_wr[i][m] * wc[k], P.hist_scale));
-    }
-    if (DBG && P.dbg_u && blockIdx.y == 0 && s_jr[i] >= 0) {
-      const int s = i * NT + tid;
-      const int c = g.cell_begin + cl;
-      const int r = (c / g.cell_num) * g.rb + s / g.cb;
-      const int col = (c % g.cell_num) * g.cb + s % g.cb;
-      const size_t id = (size_t)r * g.cols + col;
-      P.dbg_u[id] = s_u[i]; P.dbg_v[id] = s_v[i];
-      P.dbg_ic[id] = ic;
-      P.dbg_jc[id] = s_in[i] ? s_jc[i] : -1;
-#pragma unroll
-      for (int k = 0; k < 4; k++) P.dbg_wc[4 * id + k] = wc[k];
-    }
-    __builtin_amdgcn_sched_barrier(0);  // one pixel at a time: bounds the live register set
-  }
-  NID_STAMP(2);
-  __syncthreads();
-
-  // ---- fold the copies, probabilities, entropies, weight tables ---------------
-  double ent[2] = {0.0, 0.0};  // sum p*log2(p): target, joint
-  for (int b = tid; b < nbins; b += NT) {
-    const uint4 *hv = reinterpret_cast<const uint4 *>(hist + (size_t)b * kHistCopies);
-    unsigned long long acc = 0;
-#pragma unroll
-    for (int c = 0; c < kHistCopies / 2; c++) {  // 16-byte reads, start rotated per bin (bank spread)
-      const uint4 q = hv[(c + b) & (kHistCopies / 2 - 1)];
-      acc += ((unsigned long long)q.y << 32 | q.x) + ((unsigned long long)q.w << 32 | q.z);
-    }
-    // CalculateHKernel: pro /= bs_counter (computeH.cu:277-291), N_c of the initial pose (Q1)
-    const double p = ((double)(long long)acc * P.hist_inv_scale) / (double)n_c;
-    double w = 0.0;
-    if (!(p < kSigma)) {
-      const double l = log2(p);
-      w = -(1.0 + l);  // Q9: (1 + log2 p)
-      if (b < nb) ent[0] += p * l; else ent[1] += p * l;
-    }
-    tab[b] = w;
-  }
-  block_sum<NT, 2>(ent, red, tid);  // contains the barrier that publishes tab[]
-  NID_STAMP(3, ent[0], ent[1]);
-  const double Hc = 0.0 - ent[0];
-  const double Hj = 0.0 - ent[1];
-  const double err = (2 * Hj - href - Hc) / Hj;  // types_six_dof_expmap.h:227
-  // Huber (robust_kernel_impl.cpp:77-91, float dsqr)
-  const double e2 = err * err;
-  double rho0 = e2, rho1 = 1.0;
-  if (!(e2 <= P.huber_dsqr)) {
-    const double sqrte = sqrt(e2);
-    rho0 = 2 * sqrte * P.huber_delta - P.huber_dsqr;
-    rho1 = P.huber_delta / sqrte;
-  }
-
-  if (!JAC) {
-    if (tid == 0) {
-      out[0] = Hc; out[1] = Hj; out[2] = err;
-      out[kCellOut - 1] = (double)n_c;
-    }
-    if (tid < kQuad) store_sc1(quad + tid, tid == 0 ? rho0 : (tid == 28 ? 1.0 : 0.0));
-    __syncthreads();  // `red` is reused by the reduction
-    NID_STAMP(6);
-    finish_and_reduce<NT>(P, SA, cl, tid, red);
-    NID_STAMP(7);
-    return;
-  }
-
-  // ---- phase 2: Jacobian --------------------------------------------------------
-  // J[n] = (dHj[n]*(Hc+Href) - dHc[n]*Hj)/Hj^2 with dHj = sum s*dI/N_c, dHc = sum t*dI/N_c
-  // (types_six_dof_expmap.cpp:486-528) is linear in the per-pixel contributions, so one
-  // coefficient c = s*(Hc+Href) - t*Hj per pixel and six sums G[n] = sum c*dI[n] suffice;
-  // s = sum_k wr[k] * (sum_m Wj[jr+k][jc+m] dw[m]), t = sum_m Wc[jc+m] dw[m] contract the
-  // reference's 6*bin^2 tensor per pixel.  Smooth algebra: FMAs allowed.
-  const double cA = Hc + href, cB = Hj;
-  double acc[6];
-#pragma unroll
-  for (int n = 0; n < 6; n++) acc[n] = 0.0;
-#pragma unroll
-  for (int i = 0; i < PPT; i++) {
-    if (s_in[i]) {
-      const double x = s_x[i], y = s_y[i];
-      double invz, u, v;
-      bool jin;
-      if (STRICT) {
-        // linearizeOplus recomputes u as fx*(x/z)+cx (types_six_dof_expmap.cpp:407-422, Q6)
-        const double zz = s_z[i];
-        invz = 1.0 / zz;
-        u = g.fx * (x / zz) + g.cx;
-        v = g.fy * (y / zz) + g.cy;
-        jin = (u >= 0 && u + 3 <= P.jac_cols && v >= 0 && v + 3 <= g.rows);
-      } else {
-        invz = s_z[i]; u = s_u[i]; v = s_v[i];
-        jin = s_jin[i];
-      }
-      if (jin) {
-        const int wx = s_w[i].wx;
-        double gx, gy;
-        if (STRICT) {
-          const RowPair r0 = win_rows(s_w[i], v);
-          gx = (bilinear_rows(r0, wx, u + 1) - bilinear_rows(r0, wx, u - 1)) / 2;
-          const RowPair rp = win_rows(s_w[i], v + 1), rm = win_rows(s_w[i], v - 1);
-          gy = (bilinear_rows(rp, wx, u) - bilinear_rows(rm, wx, u)) / 2;
-        } else {
-          gradient_fast(s_w[i], u, v, gx, gy);
-        }
-        const int jr = s_jr[i], jc = s_jc[i];
-        const double *tj = tab + nb + jr * nb + jc;
-        double tt = 0.0, ss = 0.0;
-#pragma unroll
-        for (int m = 0; m < 4; m++) tt = fma(tab[jc + m], s_dw[i][m], tt);
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-          double inner = 0.0;
-#pragma unroll
-          for (int m = 0; m < 4; m++) inner = fma(tj[k * nb + m], s_dw[i][m], inner);
-          ss = fma(s_wr[i][k], inner, ss);
-        }
-        const double c = fma(ss, cA, -(tt * cB));
-        const double cgx = c * gx, cgy = c * gy;
-        const double invz_2 = invz * invz;
-        // rows of d(u,v)/d(xi), types_six_dof_expmap.cpp:438-450 (omega first, then upsilon)
-        const double ju0 = -x * y * invz_2 * g.fx, ju1 = (1 + (x * x * invz_2)) * g.fx;
-        const double ju2 = -y * invz * g.fx, ju3 = invz * g.fx, ju5 = -x * invz_2 * g.fx;
-        const double jv0 = -(1 + y * y * invz_2) * g.fy, jv1 = x * y * invz_2 * g.fy;
-        const double jv2 = x * invz * g.fy, jv4 = invz * g.fy, jv5 = -y * invz_2 * g.fy;
-        acc[0] = fma(cgx, ju0, fma(cgy, jv0, acc[0]));
-        acc[1] = fma(cgx, ju1, fma(cgy, jv1, acc[1]));
-        acc[2] = fma(cgx, ju2, fma(cgy, jv2, acc[2]));
-        acc[3] = fma(cgx, ju3, acc[3]);
-        acc[4] = fma(cgy, jv4, acc[4]);
-        acc[5] = fma(cgx, ju5, fma(cgy, jv5, acc[5]));
-      }
-    }
-    __builtin_amdgcn_sched_barrier(0);  // one pixel at a time: bounds the live register set
-  }
-  NID_STAMP(4, acc[0], acc[2], acc[3], acc[5]);
-  __syncthreads();  // `red` is reused
-  block_sum<NT, 6>(acc, red, tid);
-  NID_STAMP(5, acc[0], acc[2], acc[3], acc[5]);
-  if (tid < 64) {
-    // CalculateDerKernel tail (computeH.cu:358-366) == types_six_dof_expmap.cpp:486-528:
-    // kappa = d_mi_i (:393), 1/N_c (:488,494), 1/Hj^2 (:521)
-    const double kappa = (double)S / 255.0;
-    const double scale = (kappa / (double)n_c) * (1.0 / (Hj * Hj));
-    double J[6];
-#pragma unroll
-    for (int n = 0; n < 6; n++) J[n] = acc[n] * scale;
-    if (tid == 0) {
-      out[0] = Hc; out[1] = Hj; out[2] = err;
-#pragma unroll
-      for (int n = 0; n < 6; n++) out[3 + n] = J[n];
-      out[kCellOut - 1] = (double)n_c;
-    }
-    if (tid < kQuad) {
-      // constructQuadraticForm (base_unary_edge.hpp:56-63): b -= (rho1*J)*e ; H += (J*rho1)*J^T
-      double val = 0.0;
-      if (tid == 0) val = rho0;
-      else if (tid == 28) val = 1.0;
-      else if (tid < 7) {
-        double Jn = 0.0;
-#pragma unroll
-        for (int n = 0; n < 6; n++) if (n == tid - 1) Jn = J[n];
-        val = 0.0 - (rho1 * Jn) * err;
-      } else if (tid < 28) {
-        int a, b;
-        quad_ab(tid, a, b);
-        double Ja = 0.0, Jb = 0.0;
-#pragma unroll
-        for (int n = 0; n < 6; n++) { if (n == a) Ja = J[n]; if (n == b) Jb = J[n]; }
-        val = (Ja * rho1) * Jb;
-      }
-      store_sc1(quad + tid, val);
-    }
-  }
-  __syncthreads();  // `red` is reused by the reduction
-  NID_STAMP(6);
-  finish_and_reduce<NT>(P, SA, cl, tid, red);
-  NID_STAMP(7);
-}
 
 // ---------------------------------------------------------------------------
-// k_eval2: the same computation organised for OCCUPANCY instead of per-thread ILP.
+// k_eval2: the hot kernel, organised for OCCUPANCY instead of per-thread ILP (an earlier
+// variant that kept 5 pixels per thread in registers across both phases needed ~220 VGPRs,
+// fit 2 workgroups per CU and measured 10 % slower).
 // Nothing is carried in registers from the cost phase to the Jacobian phase: the Jacobian
 // phase re-reads the pixel's tile entry (L2-resident) and its 4x4 window and recomputes
 // the warp / sample / B-spline derivative with the identical instruction sequence (so the
@@ -944,7 +661,7 @@ __device__ __forceinline__ void pixel_front(const EvalParams &P, const SlotArgs 
     qx = fma(M[0], lx, fma(M[1], ly, fma(M[2], lz, M[3])));
     qy = fma(M[4], lx, fma(M[5], ly, fma(M[6], lz, M[7])));
     qz = fma(M[8], lx, fma(M[9], ly, fma(M[10], lz, M[11])));
-    const double iz = 1.0 / qz;
+    const double iz = rcp_fast(qz);
     u = fma(g.fx * qx, iz, g.cx);
     v = fma(g.fy * qy, iz, g.cy);
     f.zq = iz;
@@ -965,9 +682,9 @@ __device__ __forceinline__ void pixel_front(const EvalParams &P, const SlotArgs 
 template <bool STRICT, bool WANT_DER>
 __device__ __forceinline__ int pixel_sample(const PixelFront &f, int nb, int S, const double *rtab, double &ic,
                                             double wc[4], double dw[4]) {
-  const RowPair rp = win_rows(f.w, f.v);
   int jc;
   if (STRICT) {
+    const RowPair rp = win_rows(f.w, f.v);
     ic = bilinear_rows(rp, f.w.wx, f.u);
     if (ic >= 255) ic = 254.999;
     if (ic < 0) ic = 0.0;
@@ -975,7 +692,7 @@ __device__ __forceinline__ int pixel_sample(const PixelFront &f, int nb, int S, 
     jc = (int)floor(pc);
     bspline4_tab<WANT_DER>(pc, jc, S, rtab, wc, dw);
   } else {
-    ic = bilinear_rows_fast(rp, f.w.wx, f.u);
+    ic = sample_fast(f.w, f.u, f.v);
     if (ic >= 255) ic = 254.999;
     if (ic < 0) ic = 0.0;
     const double pc = ic * ((double)S / 255.0);
@@ -1037,15 +754,20 @@ __global__ __launch_bounds__(NT) void k_eval2(EvalParams P) {
     int jc = -1;
     if (f.in) {
       jc = pixel_sample<STRICT, false>(f, nb, S, rtab, ic, wc, dw);
+      // fixed-point encode: the scale is a power of two, so wcs = wc*scale is exact and
+      // fma(wr, wcs, 2^52) rounds wr*wc*scale once
+      double wcs[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) wcs[k] = wc[k] * P.hist_scale;
       unsigned long long *hc = hist + (jc * kHistCopies + copy);
 #pragma unroll
-      for (int k = 0; k < 4; k++) atomicAdd(hc + k * kHistCopies, fx_encode(wc[k], P.hist_scale));
+      for (int k = 0; k < 4; k++) atomicAdd(hc + k * kHistCopies, fx_encode(wcs[k], 1.0));
       unsigned long long *hj = hist + ((nb + f.jr * nb + jc) * kHistCopies + copy);
 #pragma unroll
       for (int m = 0; m < 4; m++)
 #pragma unroll
         for (int k = 0; k < 4; k++)
-          atomicAdd(hj + (m * nb + k) * kHistCopies, fx_encode(f.wr[m] * wc[k], P.hist_scale));
+          atomicAdd(hj + (m * nb + k) * kHistCopies, fx_encode(f.wr[m], wcs[k]));
     }
     if (DBG && P.dbg_u && blockIdx.y == 0 && f.jr >= 0) {
       const int c = g.cell_begin + cl;
@@ -1124,16 +846,21 @@ __global__ __launch_bounds__(NT) void k_eval2(EvalParams P) {
         invz = f.zq; u = f.u; v = f.v; jin = f.jin;
       }
       if (jin) {
-        double ic, wc[4], dw[4];
-        const int jc = pixel_sample<STRICT, true>(f, nb, S, rtab, ic, wc, dw);
-        double gx, gy;
+        double ic, wc[4], dw[4], gx, gy;
+        int jc;
         if (STRICT) {
+          jc = pixel_sample<STRICT, true>(f, nb, S, rtab, ic, wc, dw);
           const RowPair r0 = win_rows(f.w, v);
           gx = (bilinear_rows(r0, f.w.wx, u + 1) - bilinear_rows(r0, f.w.wx, u - 1)) / 2;
           const RowPair rp = win_rows(f.w, v + 1), rm = win_rows(f.w, v - 1);
           gy = (bilinear_rows(rp, f.w.wx, u) - bilinear_rows(rm, f.w.wx, u)) / 2;
         } else {
-          gradient_fast(f.w, u, v, gx, gy);
+          gradient_fast(f.w, u, v, gx, gy, ic);  // centre sample shares the gradient's taps
+          if (ic >= 255) ic = 254.999;
+          if (ic < 0) ic = 0.0;
+          const double pc = ic * ((double)S / 255.0);
+          jc = (int)pc;
+          bspline4_poly_der(pc, jc, rtab, dw);
         }
         const double *tj = tab + nb + f.jr * nb + jc;
         double tt = 0.0, ss = 0.0;
