@@ -174,7 +174,7 @@ size_t eval_lds_bytes(const Geometry &g, int nt) {
 // k_eval2 (occupancy-organised, runtime pixel loop): one workgroup shape for every cell size
 template <int NB, bool DBG>
 void launch_eval2_v(const EvalParams &P, bool jac, bool strict, size_t lds, hipStream_t s, int batch) {
-  const dim3 grid(P.g.nloc, batch), block(256);
+  const dim3 grid((unsigned)(((P.g.nloc + 7) / 8) * 8 * batch)), block(256);
   if (strict) {
     if (jac) hipLaunchKernelGGL((k_eval2<256, true, true, NB, DBG>), grid, block, lds, s, P);
     else hipLaunchKernelGGL((k_eval2<256, false, true, NB, DBG>), grid, block, lds, s, P);
@@ -184,7 +184,8 @@ void launch_eval2_v(const EvalParams &P, bool jac, bool strict, size_t lds, hipS
   }
 }
 
-int launch_eval2(nid_ctx *ctx, const EvalParams &P, bool jac, hipStream_t stream, int batch) {
+int launch_eval2(nid_ctx *ctx, EvalParams &P, bool jac, hipStream_t stream, int batch) {
+  P.batch = batch;
   const size_t lds = eval_lds_bytes(P.g, 256);
   if (lds > 160 * 1024) return NID_ERR_UNSUPPORTED;
   const bool dbg = ctx->dbg_enabled || ctx->dbg_stamps != nullptr;
@@ -197,7 +198,7 @@ int launch_eval2(nid_ctx *ctx, const EvalParams &P, bool jac, hipStream_t stream
   return NID_OK;
 }
 
-int launch_eval(nid_ctx *ctx, const EvalParams &P, bool jac, hipStream_t stream, int batch = 1) {
+int launch_eval(nid_ctx *ctx, EvalParams &P, bool jac, hipStream_t stream, int batch = 1) {
   return launch_eval2(ctx, P, jac, stream, batch);
 }
 

@@ -87,6 +87,7 @@ struct EvalParams {
   double huber_delta;
   float huber_dsqr;
   int group_size;                  // cells per first-level group
+  int batch;                       // poses in this launch (slot[0..batch-1])
   const double *ctab;              // FAST mode: per-span B-spline polynomial coefficients [S][kCoefRow]
   SlotArgs slot[kMaxBatch];        // indexed by blockIdx.y
   // optional per-pixel dump (image order), null when disabled
@@ -98,16 +99,16 @@ struct EvalParams {
 
 // Stamp k: ordered AFTER the values passed as dependencies and BEFORE any later
 // volatile asm / memory operation.  One asm statement per the guide.
-__device__ __forceinline__ void nid_stamp(long long *buf, int k, double d0 = 0.0, double d1 = 0.0,
+__device__ __forceinline__ void nid_stamp(long long *buf, int cell, int k, double d0 = 0.0, double d1 = 0.0,
                                           double d2 = 0.0, double d3 = 0.0) {
   unsigned long long t;
   asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) : "v"(d0), "v"(d1), "v"(d2), "v"(d3) : "memory");
-  if (threadIdx.x == 0) buf[(size_t)blockIdx.x * 10 + k] = (long long)t;
-  if (threadIdx.x == 0 && (k == 0 || k == 7)) buf[(size_t)blockIdx.x * 10 + (k == 0 ? 8 : 9)] = (long long)wall_clock64();
+  if (threadIdx.x == 0) buf[(size_t)cell * 10 + k] = (long long)t;
+  if (threadIdx.x == 0 && (k == 0 || k == 7)) buf[(size_t)cell * 10 + (k == 0 ? 8 : 9)] = (long long)wall_clock64();
 }
 #define NID_STAMP(k, ...)                                    \
   do {                                                       \
-    if (DBG && P.dbg_stamps && blockIdx.y == 0) nid_stamp(P.dbg_stamps, (k), ##__VA_ARGS__); \
+    if (DBG && P.dbg_stamps && pose_idx == 0) nid_stamp(P.dbg_stamps, cl, (k), ##__VA_ARGS__); \
   } while (0)
 
 // ---------------------------------------------------------------------------
@@ -714,8 +715,18 @@ __global__ __launch_bounds__(NT) void k_eval2(EvalParams P) {
   double *rtab = tab + ((nbins + 1) & ~1);
   double *red = rtab + kMaxBins * kCoefRow;
 
-  const int cl = blockIdx.x, tid = threadIdx.x;
-  const SlotArgs &SA = P.slot[blockIdx.y];
+  // XCD-aware block -> (cell, pose) map: workgroups are dealt round-robin over the 8 XCDs, so
+  // id % 8 fixes the XCD; all `batch` poses of a cell get the same id % 8 and consecutive slots
+  // of that XCD's stream, i.e. they run together on one XCD and share the cell's tile rows in its
+  // L2 (measured on the 1280x960 config: HBM/MALL traffic per launch 1.13 GB -> see DESIGN.md).
+  // Speed only: nothing depends on the placement.
+  const int tid = threadIdx.x;
+  const int bid = blockIdx.x;
+  const int q = bid >> 3;
+  const int pose_idx = q % P.batch;
+  const int cl = (q / P.batch) * 8 + (bid & 7);
+  if (cl >= g.nloc) return;  // padding of the last group of 8 cells
+  const SlotArgs &SA = P.slot[pose_idx];
   const int n_c = P.Nc[cl];
   const double href = P.Href[cl];
   double *out = SA.cellout + (size_t)cl * kCellOut;
@@ -769,7 +780,7 @@ __global__ __launch_bounds__(NT) void k_eval2(EvalParams P) {
         for (int k = 0; k < 4; k++)
           atomicAdd(hj + (m * nb + k) * kHistCopies, fx_encode(f.wr[m], wcs[k]));
     }
-    if (DBG && P.dbg_u && blockIdx.y == 0 && f.jr >= 0) {
+    if (DBG && P.dbg_u && pose_idx == 0 && f.jr >= 0) {
       const int c = g.cell_begin + cl;
       const int r = (c / g.cell_num) * g.rb + s / g.cb;
       const int col = (c % g.cell_num) * g.cb + s % g.cb;
