@@ -140,32 +140,41 @@ def main():
     ctx = capi.from_pair(pair, args.bins, device=local_rank, cell_begin=lo, cell_end=hi)
     if args.block_threads:
         ctx.set_block_threads(args.block_threads)
-    stream = torch.cuda.current_stream(dev)
+    side = None
     if world > 1:
-        ctx.set_stream(stream.cuda_stream)   # RCCL ops are ordered against torch's stream
-    # world == 1: the context alternates its two own streams so that launch N+1 overlaps the
-    # reduction tail of launch N; torch.cuda.synchronize() below still fences the whole device
+        # The evaluation kernel, the RCCL all-reduce and the D2H copy of a step must be ordered on ONE
+        # stream.  torch's default stream has the null handle, which nid_set_stream() reads as "use the
+        # context's own stream", so run the multi-rank path on an explicit side stream.
+        side = torch.cuda.Stream(device=dev)
+        ctx.set_stream(side.cuda_stream)
+    # world == 1: the library's own in-order stream; torch.cuda.synchronize() below fences the whole device
     cnt, href = ctx.compute_href(pair.pose_init)
     delta = float(np.sqrt(0.95))
     K, W = args.steps, args.warmup
     poses = pose_trajectory(synth, pair, 256)
     nslots = capi.NID_SLOTS if not args.inflight else min(capi.NID_SLOTS, args.inflight)
 
-    # device-side result ring: one 32-double block per slot (all-reduced when world > 1)
-    ring = torch.zeros((nslots, capi.NID_REDUCED_LEN), dtype=torch.float64, device=dev)
-    host_ring = torch.zeros((nslots, capi.NID_REDUCED_LEN), dtype=torch.float64).pin_memory()
-
-    B = max(1, min(args.batch, capi.NID_MAX_BATCH)) if world == 1 else 1
+    # device-side result ring (world > 1): one [B, 32] group per launch, summed by ONE all-reduce
+    B = max(1, min(args.batch, capi.NID_MAX_BATCH))
+    assert capi.NID_SLOTS % B == 0
+    ngroups = nslots // B
+    ring = torch.zeros((ngroups, B, capi.NID_REDUCED_LEN), dtype=torch.float64, device=dev)
+    host_ring = torch.zeros((ngroups, B, capi.NID_REDUCED_LEN), dtype=torch.float64).pin_memory()
     pose_arr = np.stack(poses)
 
-    def step(i):
-        # world > 1: one launch per step on the torch stream, then the RCCL sum of the partial blocks
-        s = i % nslots
-        if i >= nslots:
-            ctx.wait(s)
-        ctx.launch(s, poses[i % len(poses)], delta, True, reduced_dev=ring[s].data_ptr())
-        dist.all_reduce(ring[s])             # RCCL sum over xGMI, 256 B
-        host_ring[s].copy_(ring[s], non_blocking=True)
+    def launch_group(j, n):
+        """world > 1: poses j*B .. j*B+n-1 in one kernel launch per rank, then the RCCL sum of the
+        [n, 32] partial blocks over xGMI and the copy to pinned host memory, all on `side`."""
+        gidx = j % ngroups
+        first = gidx * B
+        if j >= ngroups:
+            for k in range(B):
+                ctx.wait(first + k)              # the launch that last used these slots has finished
+        idx = [(j * B + k) % len(poses) for k in range(n)]
+        with torch.cuda.stream(side):
+            ctx.launch_batch(first, pose_arr[idx], delta, True, reduced_dev=ring[gidx].data_ptr())
+            dist.all_reduce(ring[gidx])
+            host_ring[gidx].copy_(ring[gidx], non_blocking=True)
 
     def run(n):
         if world == 1:
@@ -173,16 +182,16 @@ def main():
             # flight); every pose's 6x6 system is collected from pinned host memory
             seq = pose_arr[np.arange(n) % len(poses)]
             return ctx.run_sequence(seq, delta, batch=B, want_jac=True)
-        for i in range(n):
-            step(i)
-        drain(n)
+        nlaunch = (n + B - 1) // B
+        for j in range(nlaunch):
+            launch_group(j, min(B, n - j * B))
+        for j in range(max(0, nlaunch - ngroups), nlaunch):
+            for k in range(B):
+                try:
+                    ctx.wait((j % ngroups) * B + k)
+                except capi.NidError:
+                    pass                         # slot not used by a short last group
         return None
-
-    def drain(n):
-        for i in range(max(0, n - nslots), n):
-            ctx.wait(i % nslots)
-
-    assert capi.NID_SLOTS % B == 0
 
     def barrier():
         if dist is not None:
@@ -203,15 +212,21 @@ def main():
     # sanity: the last result is finite and every rank agrees after the all-reduce
     if world == 1:
         assert results.shape == (K, capi.NID_REDUCED_LEN) and np.all(np.isfinite(results))
-        ctx.launch(0, poses[0], delta, True)
+        ctx.launch(0, poses[(K - 1) % len(poses)], delta, True)
         H, b, chi2, na = ctx.wait(0)
-        assert np.array_equal(capi.unpack_reduced(results[0])[0], H), "pipelined result differs from a single launch"
+        assert np.array_equal(capi.unpack_reduced(results[K - 1])[0], H), "pipelined result differs from a single launch"
     else:
-        ctx.launch(0, poses[0], delta, True, reduced_dev=ring[0].data_ptr())
-        dist.all_reduce(ring[0])
+        # the pipelined result of the last step must equal a synchronous evaluation of the same pose
+        jl, kl = (K - 1) // B, (K - 1) % B
+        piped = host_ring[jl % ngroups, kl].clone().numpy()
+        with torch.cuda.stream(side):
+            ctx.launch(0, poses[(K - 1) % len(poses)], delta, True, reduced_dev=ring[0, 0].data_ptr())
+            dist.all_reduce(ring[0, 0])
         torch.cuda.synchronize(dev)
         ctx.wait(0)
-        H, b, chi2, na = capi.unpack_reduced(ring[0].cpu().numpy())
+        sync = ring[0, 0].cpu().numpy()
+        assert np.array_equal(piped, sync), "pipelined multi-rank result differs from the synchronous one"
+        H, b, chi2, na = capi.unpack_reduced(sync)
     assert np.isfinite(chi2) and np.all(np.isfinite(H)) and na > 0
 
     # dominant-kernel duration: HIP events on the launch stream around the same launches the timed
@@ -219,14 +234,10 @@ def main():
     ctx.enable_timing(True)
     ev_ms = []
     for i in range(min(max(K // B, 20), 200)):
-        if world == 1 and B > 1:
-            idx = [(i * B + k) % len(poses) for k in range(B)]
-            ctx.launch_batch(0, pose_arr[idx], delta, True)
-            for k in range(B):
-                ctx.wait(k)
-        else:
-            ctx.launch(0, poses[i % len(poses)], delta, True)
-            ctx.wait(0)
+        idx = [(i * B + k) % len(poses) for k in range(B)]
+        ctx.launch_batch(0, pose_arr[idx], delta, True)   # this rank's cells, B poses, results to pinned host
+        for k in range(B):
+            ctx.wait(k)
         ev_ms.append(ctx.last_kernel_ms(0)[0])
     ctx.enable_timing(False)
 
@@ -255,10 +266,10 @@ def main():
                             f"{int((cnt[lo:hi] >= 300).sum())} active cells on rank 0",
                 "cells": ncell, "bins": args.bins,
                 "parallelism": f"cells/{world}" + ("" if world == 1 else
-                                                   f" + {'RCCL' if args.backend == 'nccl' else 'gloo'} all-reduce(32 f64)"),
-                "pipelining": (f"{B} candidate poses per kernel launch, {capi.NID_SLOTS // B} launches in flight, "
-                               if world == 1 else f"1 pose per launch, {nslots} launches in flight, ")
-                              + "each pose's 6x6 system lands in pinned host memory",
+                                                   f" + {'RCCL' if args.backend == 'nccl' else 'gloo'} all-reduce([{B},32] f64)"),
+                "pipelining": f"{B} candidate poses per kernel launch, {nslots // B} launches in flight, "
+                              + ("each pose's 6x6 system lands in pinned host memory" if world == 1 else
+                                 f"one all-reduce of [{B},32] f64 per launch, then D2H to pinned memory"),
             },
             "roofline": {
                 "bound": "hbm",

@@ -149,6 +149,11 @@ int nid_wait(nid_ctx *ctx, int slot, double *H36, double *b6, double *chi2, int3
  * or consecutive candidates of a sampling optimiser); collect each with nid_wait() */
 int nid_launch_batch(nid_ctx *ctx, int first_slot, int n, const double *poses7, int want_jac,
                      double huber_delta);
+/* same, with the n result blocks written to a caller-owned DEVICE buffer (n x NID_REDUCED_LEN doubles,
+ * pose k at offset k*NID_REDUCED_LEN) so that ONE collective can sum the partial blocks of all n poses
+ * across the cell shards of several GPUs; nid_wait(slot) then only waits for the launch */
+int nid_launch_batch_to(nid_ctx *ctx, int first_slot, int n, const double *poses7, int want_jac,
+                        double huber_delta, void *reduced_dev);
 /* Host-side pipeline over a sequence of n candidate poses: `batch` poses per launch (batch
  * divides NID_SLOTS), NID_SLOTS/batch launches in flight; reduced_out (n x NID_REDUCED_LEN,
  * may be NULL) receives every pose's [chi2, b, H upper, n_active] block.  Blocking. */

@@ -43,7 +43,7 @@ SYMBOLS = [
     "nid_set_reference_depth", "nid_set_reference_points", "nid_backproject", "nid_get_points3d", "nid_set_target_u8",
     "nid_set_target_f64", "nid_set_reference_image_f64", "nid_compute_href",
     "nid_compute_href_matrix", "nid_set_href_state", "nid_evaluate", "nid_evaluate_matrix",
-    "nid_normal_equations", "nid_launch", "nid_launch_batch", "nid_run_sequence", "nid_wait", "nid_slot_buffers", "nid_launch_to",
+    "nid_normal_equations", "nid_launch", "nid_launch_batch", "nid_launch_batch_to", "nid_run_sequence", "nid_wait", "nid_slot_buffers", "nid_launch_to",
     "nid_unpack_reduced", "nid_debug_enable_pixel_dump", "nid_debug_get_pixel_dump",
     "nid_debug_enable_stamps", "nid_debug_get_stamps", "nid_bspline4_host", "nid_bspline4_poly_host", "nid_div_small_host", "nid_last_kernel_ms", "nid_enable_timing",
     "nid_contract_bytes",
@@ -92,6 +92,7 @@ def load():
     lib.nid_normal_equations.argtypes = [vp, c_dp, C.c_int, C.c_double, c_dp, c_dp, c_dp, c_ip]
     lib.nid_launch.argtypes = [vp, C.c_int, c_dp, C.c_int, C.c_double]
     lib.nid_launch_batch.argtypes = [vp, C.c_int, C.c_int, c_dp, C.c_int, C.c_double]
+    lib.nid_launch_batch_to.argtypes = [vp, C.c_int, C.c_int, c_dp, C.c_int, C.c_double, vp]
     lib.nid_run_sequence.argtypes = [vp, c_dp, C.c_int, C.c_int, C.c_int, C.c_double, c_dp]
     lib.nid_launch_to.argtypes = [vp, C.c_int, c_dp, C.c_int, C.c_double, vp]
     lib.nid_wait.argtypes = [vp, C.c_int, c_dp, c_dp, c_dp, c_ip]
@@ -236,10 +237,14 @@ class Context:
                                         C.c_void_p(reduced_dev))
         self._check(rc, "nid_launch")
 
-    def launch_batch(self, first_slot, poses7, delta, want_jac=True):
+    def launch_batch(self, first_slot, poses7, delta, want_jac=True, reduced_dev=None):
         p = _d(np.asarray(poses7).reshape(-1, 7))
-        self._check(self.lib.nid_launch_batch(self.h, first_slot, p.shape[0], _dp(p), 1 if want_jac else 0,
-                                              float(delta)), "nid_launch_batch")
+        if reduced_dev is None:
+            rc = self.lib.nid_launch_batch(self.h, first_slot, p.shape[0], _dp(p), 1 if want_jac else 0, float(delta))
+        else:
+            rc = self.lib.nid_launch_batch_to(self.h, first_slot, p.shape[0], _dp(p), 1 if want_jac else 0,
+                                              float(delta), C.c_void_p(reduced_dev))
+        self._check(rc, "nid_launch_batch")
 
     def run_sequence(self, poses7, delta, batch=8, want_jac=True, collect=True):
         p = _d(np.asarray(poses7).reshape(-1, 7))

@@ -289,7 +289,8 @@ int launch_slot(nid_ctx *ctx, int slot, const Pose &pose, int want_jac, double d
 // n candidate poses in ONE launch (grid.y = n): each pose uses its own slot (buffers, tickets,
 // pinned result block), so the reduction tails and the launch cost overlap with other poses' work
 // and two workgroups share a CU.  Results are collected per slot with nid_wait().
-int launch_batch(nid_ctx *ctx, int first_slot, int n, const Pose *poses, int want_jac, double delta) {
+int launch_batch(nid_ctx *ctx, int first_slot, int n, const Pose *poses, int want_jac, double delta,
+                 double *reduced_dev_base = nullptr) {
   int rc = check_ready(ctx);
   if (rc) return rc;
   if (n < 1 || n > kMaxBatch || first_slot < 0 || first_slot + n > NID_SLOTS) return NID_ERR_INVALID_ARG;
@@ -299,9 +300,12 @@ int launch_batch(nid_ctx *ctx, int first_slot, int n, const Pose *poses, int wan
   for (int k = 0; k < n; k++) {
     Slot &S = ctx->slots[first_slot + k];
     S.seq++;
-    S.external_target = false;
-    fill_slot_args(poses[k], S, S.reduced_host_devptr,
-                   reinterpret_cast<unsigned long long *>(S.reduced_host_devptr + kReducedLen), &P.slot[k]);
+    S.external_target = reduced_dev_base != nullptr;
+    if (S.external_target)  // caller-owned device buffer: pose k's block at base + k*32 (multi-GPU all-reduce)
+      fill_slot_args(poses[k], S, reduced_dev_base + (size_t)k * kReducedLen, nullptr, &P.slot[k]);
+    else
+      fill_slot_args(poses[k], S, S.reduced_host_devptr,
+                     reinterpret_cast<unsigned long long *>(S.reduced_host_devptr + kReducedLen), &P.slot[k]);
   }
   Slot &S0 = ctx->slots[first_slot];
   S0.timed = ctx->timing;
@@ -309,7 +313,12 @@ int launch_batch(nid_ctx *ctx, int first_slot, int n, const Pose *poses, int wan
   rc = launch_eval(ctx, P, want_jac != 0, ctx->stream, n);
   if (rc) return rc;
   if (S0.timed) NID_HIP(ctx, hipEventRecord(S0.e1, ctx->stream));
-  for (int k = 0; k < n; k++) { ctx->slots[first_slot + k].pending = true; if (k) ctx->slots[first_slot + k].timed = false; }
+  for (int k = 0; k < n; k++) {
+    Slot &S = ctx->slots[first_slot + k];
+    S.pending = true;
+    if (k) S.timed = false;
+    if (S.external_target) NID_HIP(ctx, hipEventRecord(S.done, ctx->stream));
+  }
   return NID_OK;
 }
 
@@ -757,6 +766,14 @@ int nid_launch_batch(nid_ctx *ctx, int first_slot, int n, const double *poses7, 
   Pose p[kMaxBatch];
   for (int k = 0; k < n; k++) pose_from_pose7(poses7 + 7 * k, ctx->xform, &p[k]);
   return launch_batch(ctx, first_slot, n, p, want_jac, delta);
+}
+
+int nid_launch_batch_to(nid_ctx *ctx, int first_slot, int n, const double *poses7, int want_jac, double delta,
+                        void *reduced_dev) {
+  if (!ctx || !poses7 || !reduced_dev || n < 1 || n > kMaxBatch) return NID_ERR_INVALID_ARG;
+  Pose p[kMaxBatch];
+  for (int k = 0; k < n; k++) pose_from_pose7(poses7 + 7 * k, ctx->xform, &p[k]);
+  return launch_batch(ctx, first_slot, n, p, want_jac, delta, static_cast<double *>(reduced_dev));
 }
 
 int nid_run_sequence(nid_ctx *ctx, const double *poses7, int n, int batch, int want_jac, double delta,
