@@ -94,13 +94,14 @@ def cpu_baseline(pair, bins, seconds):
                       f"{el:.1f} s on 1 host core (oracle rebuilt -O3 -march=native -ffp-contract=off)"}
 
 
-def measured_traffic(config, bins):
+def measured_traffic(config, bins, poses_per_launch):
     """HBM bytes per launch of the evaluation kernel from the committed rocprofv3 PMC passes
-    (profiles/traffic.json, written by tools/summarize_profile.py); None if that configuration
-    was not profiled.  bench.py cannot run the profiler on itself."""
+    (profiles/traffic.json, written from tools/summarize_profile.py output); None if that
+    configuration / launch shape was not profiled.  bench.py cannot run the profiler on itself."""
     try:
         with open(os.path.join(ROOT, "profiles", "traffic.json")) as fh:
-            return float(json.load(fh)[f"{config}:{bins}"]["hbm_bytes_per_launch"])
+            e = json.load(fh)[f"{config}:{bins}"]
+        return float(e["hbm_bytes_per_launch"]) if int(e["poses_per_launch"]) == poses_per_launch else None
     except Exception:
         return None
 
@@ -277,9 +278,9 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": (lambda t: None if t is None else t * B)(measured_traffic(args.config, args.bins)),
+                "traffic": measured_traffic(args.config, args.bins, B) if world == 1 else None,
                 "poses_per_launch": B,
-                "kernel": "nid::k_eval<JAC>",
+                "kernel": "nid::k_eval2<256, JAC=true, FAST, NB, false>",
                 "kernel_ms": eval_ms,
                 "algorithmic_bytes_per_launch": contract,
                 "note": "achieved = contract bytes (68 B/px + 64 B/cell, SURVEY 8d) / median HIP-event duration "
