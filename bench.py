@@ -94,6 +94,48 @@ def cpu_baseline(pair, bins, seconds):
                       f"{el:.1f} s on 1 host core (oracle rebuilt -O3 -march=native -ffp-contract=off)"}
 
 
+def pose_error_vs_ref(pair, bins):
+    """The second half of the BASELINE metric: the reference driver's optimisation (10 LM iterations
+    from the disturbed start, NID_pose_estimation.cpp:163-366) on the C++ host stack + HIP kernels,
+    against the CPU oracle's LM on the same pair; also the wall time of both."""
+    from oracle import oracle_py
+    hostlib = importlib.import_module("nid-pose-estimation_amd.hostlib")
+    synth = importlib.import_module("nid-pose-estimation_amd.synth")
+    t0 = time.perf_counter()
+    pose_gpu, recs, _ = hostlib.run_lm(pair, bins, pair.pose_init, 10)
+    t_gpu = time.perf_counter() - t0
+    o_gpu = hostlib.last_optimize_seconds()
+    t0 = time.perf_counter()
+    pose_fused, recs_f, _ = hostlib.run_lm(pair, bins, pair.pose_init, 10, fused=1)
+    t_fused = time.perf_counter() - t0
+    o_fused = hostlib.last_optimize_seconds()
+    t0 = time.perf_counter()
+    pose_spec, recs_s, _ = hostlib.run_lm(pair, bins, pair.pose_init, 10, fused=2)
+    t_spec = time.perf_counter() - t0
+    o_spec = hostlib.last_optimize_seconds()
+    o = oracle_py.from_pair(pair, bins, jac_bound="cpu", xform="matrix")
+    o.compute_href(pair.pose_init)
+    t0 = time.perf_counter()
+    pose_cpu, recs_o = o.lm(pair.pose_init, 10)
+    t_cpu = time.perf_counter() - t0
+    mv = synth.pose7_minimal
+    return {
+        "max_abs_minimal_vector_diff": float(np.abs(mv(pose_gpu) - mv(pose_cpu)).max()),
+        "fused_path_diff": float(np.abs(mv(pose_fused) - mv(pose_cpu)).max()),
+        "tolerance": 1e-6,
+        "same_lm_trace": [r["lm_trials"] for r in recs] == [r["lm_trials"] for r in recs_o],
+        "lm_outer_iterations": len(recs),
+        "error_vs_truth_start": float(np.linalg.norm(mv(pair.pose_true) - mv(pair.pose_init))),
+        "error_vs_truth_end": float(np.linalg.norm(mv(pair.pose_true) - mv(pose_gpu))),
+        "speculative_path_diff": float(np.abs(mv(pose_spec) - mv(pose_cpu)).max()),
+        "lm_wall_s": {"hip_reference_flow": t_gpu, "hip_fused": t_fused, "hip_fused_batched_trials": t_spec,
+                      "cpu_oracle_1core": t_cpu},
+        "optimize_only_s": {"hip_reference_flow": o_gpu, "hip_fused": o_fused, "hip_fused_batched_trials": o_spec},
+        "note": "lm_wall_s includes the per-pair setup (upload, back-projection, reference weights); "
+                "reference schedule = 1 Jacobian + k cost-only + 1 verbose evaluation per outer iteration",
+    }
+
+
 def measured_traffic(config, bins, poses_per_launch):
     """HBM bytes per launch of the evaluation kernel from the committed rocprofv3 PMC passes
     (profiles/traffic.json, written from tools/summarize_profile.py output); None if that
@@ -290,6 +332,8 @@ def main():
         out["check"] = {"chi2": chi2, "n_active": int(na), "H00": float(H[0, 0]), "b0": float(b[0])}
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(pair, args.bins, args.cpu_seconds)
+            if world == 1:
+                out["pose_error_vs_ref"] = pose_error_vs_ref(pair, args.bins)
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()

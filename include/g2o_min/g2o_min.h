@@ -229,6 +229,9 @@ class OptimizationAlgorithmLevenberg {
   // fast path (not in the reference): take H, b, chi2 from the fused device reduction
   // (nid_normal_equations) instead of the per-edge set_h/set_j walk
   void setFusedNormalEquations(bool on) { _fused = on; }
+  // with the fused path: evaluate the whole rejection chain of an outer iteration (up to 8
+  // candidate poses) in one batched launch; decisions identical to the sequential trials
+  void setSpeculativeTrials(bool on) { _speculative = on; }
   bool fused() const { return _fused; }
   double fusedChi() const { return _fusedChi; }
  private:
@@ -240,6 +243,7 @@ class OptimizationAlgorithmLevenberg {
   double _currentLambda, _tau, _goodStepLowerScale, _goodStepUpperScale, _ni, _lastRho;
   int _maxTrialsAfterFailure, _levenbergIterations, _nBad;
   bool _fused;
+  bool _speculative = false;
   double _fusedChi = 0.0;
 };
 

@@ -355,6 +355,70 @@ OptimizationAlgorithmLevenberg::SolverResult OptimizationAlgorithmLevenberg::sol
   double rho = 0;
   int &qmax = _levenbergIterations;
   qmax = 0;
+  if (_speculative) {
+    // The trial chain of one outer iteration is known in advance IF every trial is rejected:
+    // lambda_{k+1} = lambda_k * ni_k, ni_{k+1} = 2 ni_k (:196-197).  Solve all of them on the host
+    // (6x6, microseconds), evaluate the candidate poses in ONE batched cost-only launch, then replay
+    // the reference's accept/reject scan over the results.  Same poses, same chi2 bits, same
+    // decisions as the sequential loop below -- only the number of launches changes.
+    const SE3Quat T0 = vm->estimate();
+    while (qmax < _maxTrialsAfterFailure) {
+      const int nb = std::min((int)NID_SLOTS / 2, _maxTrialsAfterFailure - qmax);
+      double lam[NID_SLOTS], nis[NID_SLOTS], xs[NID_SLOTS][6], poses[NID_SLOTS * 7];
+      bool oks[NID_SLOTS];
+      SE3Quat cand[NID_SLOTS];
+      double l = _currentLambda, n_i = _ni;
+      for (int k = 0; k < nb; k++) {
+        lam[k] = l; nis[k] = n_i;
+        double Hl[36];
+        std::memcpy(Hl, H, sizeof(Hl));
+        for (int j = 0; j < 6; j++) Hl[j * 6 + j] += l;
+        LinearSolverDense ls;
+        for (int j = 0; j < 6; j++) xs[k][j] = (k ? xs[k - 1][j] : _solver->x()[j]);  // failed solve leaves x untouched
+        oks[k] = ls.solve(Hl, xs[k], b);
+        Vector6d u;
+        for (int j = 0; j < 6; j++) u[j] = xs[k][j];
+        cand[k] = SE3Quat::exp(u) * T0;
+        cand[k].toPose7(poses + 7 * k);
+        l *= n_i; n_i *= 2;
+      }
+      if (nid_launch_batch(ctx, 0, nb, poses, 0, delta) != NID_OK) return Fail;
+      double chis[NID_SLOTS];
+      for (int k = 0; k < nb; k++)
+        if (nid_wait(ctx, k, nullptr, nullptr, &chis[k], &na) != NID_OK) return Fail;
+      bool accepted = false;
+      for (int k = 0; k < nb; k++) {
+        tempChi = oks[k] ? chis[k] : std::numeric_limits<double>::max();
+        rho = (currentChi - tempChi);
+        double scale = 0.;
+        for (int j = 0; j < 6; j++) scale += xs[k][j] * (lam[k] * xs[k][j] + b[j]);
+        scale += 1e-3;
+        rho /= scale;
+        qmax++;
+        if (rho > 0 && std::isfinite(tempChi)) {
+          double alpha = 1. - std::pow((2 * rho - 1), 3);
+          alpha = (std::min)(alpha, _goodStepUpperScale);
+          const double scaleFactor = (std::max)(_goodStepLowerScale, alpha);
+          _currentLambda = lam[k] * scaleFactor;
+          _ni = 2;
+          currentChi = tempChi;
+          vm->setEstimate(cand[k]);
+          accepted = true;
+          break;
+        }
+        _currentLambda = lam[k] * nis[k];
+        _ni = nis[k] * 2;
+        if (!(rho < 0)) break;  // rho == 0 (or NaN): the reference's do/while stops here
+      }
+      if (accepted || !(rho < 0)) break;
+    }
+    _lastRho = rho;
+    _fusedChi = currentChi;
+    if (qmax == _maxTrialsAfterFailure || rho == 0) return Terminate;
+    if ((iniChi - currentChi) * 1e3 < iniChi) _nBad++; else _nBad = 0;
+    if (_nBad >= 3) return Terminate;
+    return OK;
+  }
   do {
     opt->push();
     _solver->setLambda(_currentLambda, true);

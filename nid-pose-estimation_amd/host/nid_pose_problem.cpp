@@ -1,6 +1,7 @@
 // nid_pose_problem.cpp -- the graph that NID_pose_estimation.cpp builds
 // (NID_pose_estimation.cpp:163-366), assembled on the g2o-shaped host API, plus a
 // C entry point so that tests can drive the C++ host stack through ctypes.
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -11,6 +12,9 @@
 #include "g2o_min/g2o_min.h"
 #include "nid/legacy_ops.h"
 #include "nid_pose_problem.h"
+
+static double g_last_optimize_s = 0.0;
+double nid_host_last_optimize_seconds(void) { return g_last_optimize_s; }
 
 int nid_host_run_lm(const nid_pose_problem *pb, double *pose7_inout, nid_host_lm_record *trace,
                     int max_trace, char *log_buf, int log_cap) {
@@ -35,6 +39,7 @@ int nid_host_run_lm(const nid_pose_problem *pb, double *pose7_inout, nid_host_lm
   g2o::BlockSolver_6_X *solver_ptr = new g2o::BlockSolver_6_X(linearSolver);
   g2o::OptimizationAlgorithmLevenberg *solver = new g2o::OptimizationAlgorithmLevenberg(solver_ptr);
   solver->setFusedNormalEquations(pb->fused != 0);
+  solver->setSpeculativeTrials(pb->fused == 2);
   optimizer.setAlgorithm(solver);
   optimizer.setVerbose(true);
   std::ostringstream log;
@@ -76,7 +81,9 @@ int nid_host_run_lm(const nid_pose_problem *pb, double *pose7_inout, nid_host_lm
     }
 
   optimizer.initializeOptimization(0);
+  const auto t_opt0 = std::chrono::steady_clock::now();
   const int done = optimizer.optimize(pb->iterations);  // :349-350
+  g_last_optimize_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_opt0).count();
 
   vSE3->estimate().toPose7(pose7_inout);
   const std::vector<g2o::IterationRecord> &tr = optimizer.trace();

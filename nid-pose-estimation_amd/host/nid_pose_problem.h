@@ -11,7 +11,8 @@ extern "C" {
 typedef struct {
   int32_t rows, cols, cell_num, bin_num, iterations;
   int32_t jac_bound_cuda;   /* 0 = CPU-edge bound (parity target), 1 = CUDA-kernel bound */
-  int32_t fused;            /* 1 = fused device normal equations, 0 = per-edge walk like the reference */
+  int32_t fused;            /* 0 = per-edge walk like the reference, 1 = fused device normal equations,
+                               2 = fused + the LM rejection chain evaluated in one batched launch */
   int32_t strict_math;      /* 1 = NID_MATH_STRICT, 0 = NID_MATH_FAST */
   int32_t pad_;
   double fx, fy, cx, cy, depth_factor, huber_delta;
@@ -29,6 +30,9 @@ typedef struct {
 /* returns the number of outer iterations done (or < 0); pose7 = {qx,qy,qz,qw,tx,ty,tz} in/out */
 int nid_host_run_lm(const nid_pose_problem *pb, double *pose7_inout, nid_host_lm_record *trace, int max_trace,
                     char *log_buf, int log_cap);
+
+/* wall time of the optimize() call of the last nid_host_run_lm (setup excluded) */
+double nid_host_last_optimize_seconds(void);
 
 void nid_host_se3_exp(const double *upd6, double *pose7);
 void nid_host_se3_mul(const double *a7, const double *b7, double *out7);

@@ -40,6 +40,8 @@ def load():
     lib = C.CDLL(LIB_PATH)
     lib.nid_host_run_lm.restype = C.c_int
     lib.nid_host_run_lm.argtypes = [C.POINTER(PoseProblem), c_dp, C.POINTER(LmRecord), C.c_int, C.c_char_p, C.c_int]
+    lib.nid_host_last_optimize_seconds.restype = C.c_double
+    lib.nid_host_last_optimize_seconds.argtypes = []
     lib.nid_host_se3_exp.argtypes = [c_dp, c_dp]
     lib.nid_host_se3_mul.argtypes = [c_dp, c_dp, c_dp]
     lib.nid_host_se3_to_matrix.argtypes = [c_dp, c_dp]
@@ -113,7 +115,7 @@ def run_lm(pair, bin_num, pose7, iterations=10, jac_bound_cuda=False, fused=Fals
     dep = np.ascontiguousarray(pair.depth_u16, dtype=np.uint16)
     T = _d(synth.matrix_colmajor16(pair.T_wc0))
     pb = PoseProblem(pair.rows, pair.cols, pair.cell, bin_num, iterations, 1 if jac_bound_cuda else 0,
-                     1 if fused else 0, 1 if strict else 0, 0, pair.fx, pair.fy, pair.cx, pair.cy, 1.0 / 5000,
+                     int(fused), 1 if strict else 0, 0, pair.fx, pair.fy, pair.cx, pair.cy, 1.0 / 5000,
                      float(huber_delta) if huber_delta else 0.0,
                      im0.ctypes.data_as(C.POINTER(C.c_uint8)), im1.ctypes.data_as(C.POINTER(C.c_uint8)),
                      dep.ctypes.data_as(C.POINTER(C.c_uint16)), _dp(T))
@@ -126,3 +128,8 @@ def run_lm(pair, bin_num, pose7, iterations=10, jac_bound_cuda=False, fused=Fals
     recs = [dict(iteration=t.iteration, chi2=t.chi2, lambda_=t.lambda_, lm_trials=t.lm_trials, rho=t.rho,
                  pose7=np.array(list(t.pose7))) for t in trace[:n]]
     return p, recs, log.value.decode(errors="replace")
+
+
+def last_optimize_seconds():
+    """Wall time of optimize() inside the last run_lm (per-pair setup excluded)."""
+    return float(load().nid_host_last_optimize_seconds())

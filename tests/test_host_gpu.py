@@ -119,6 +119,11 @@ def test_lm_fused_path_equals_per_edge_path(hostlib, synth, pair_A):
     pose_b, recs_b, _ = hostlib.run_lm(pair, nb, pair.pose_init, 10, fused=True)
     assert [r["lm_trials"] for r in recs_a] == [r["lm_trials"] for r in recs_b]
     np.testing.assert_allclose(synth.pose7_minimal(pose_a), synth.pose7_minimal(pose_b), rtol=0, atol=1e-8)
+    # speculative batched trials: same decisions and, pose for pose, the same bits as the sequential fused path
+    pose_c, recs_c, _ = hostlib.run_lm(pair, nb, pair.pose_init, 10, fused=2)
+    assert [r["lm_trials"] for r in recs_c] == [r["lm_trials"] for r in recs_b]
+    assert [r["chi2"] for r in recs_c] == [r["chi2"] for r in recs_b]
+    assert np.array_equal(pose_c, pose_b)
 
 
 def test_lm_cuda_bound_mode(hostlib, oracle, synth, pair_S):
