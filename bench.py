@@ -325,8 +325,12 @@ def main():
                 "kernel": "nid::k_eval2<256, JAC=true, FAST, NB, false>",
                 "kernel_ms": eval_ms,
                 "algorithmic_bytes_per_launch": contract,
+                "achieved_pipelined": (contract / B) * (K / elapsed) / 1e9,
                 "note": "achieved = contract bytes (68 B/px + 64 B/cell, SURVEY 8d) / median HIP-event duration "
-                        "of the evaluation kernel; the tile is L2/MALL-resident after the first launch",
+                        "of ONE evaluation launch running alone on the device (what rocprofv3 reports per kernel); "
+                        "achieved_pipelined = the same bytes / (timed region / launches): the timed pipeline keeps "
+                        "launches on two streams in flight, so the next launch fills the tail of the previous one; "
+                        "the tile is L2/MALL-resident after the first launch",
             },
         }
         out["check"] = {"chi2": chi2, "n_active": int(na), "H00": float(H[0, 0]), "b0": float(b[0])}

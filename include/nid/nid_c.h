@@ -140,11 +140,12 @@ int nid_normal_equations(nid_ctx *ctx, const double *pose7, int want_jac, double
 
 /* Non-blocking forms for pipelining and multi-GPU.  `slot` in [0, NID_SLOTS):
  * results of a launch stay in the slot until nid_wait() collects them. */
-#define NID_SLOTS 16
+#define NID_SLOTS 32
+#define NID_MAX_BATCH 8 /* poses per launch */
 #define NID_REDUCED_LEN 32 /* [0]=chi2 [1..6]=b [7..27]=H upper triangle row-major [28]=n_active */
 int nid_launch(nid_ctx *ctx, int slot, const double *pose7, int want_jac, double huber_delta);
 int nid_wait(nid_ctx *ctx, int slot, double *H36, double *b6, double *chi2, int32_t *n_active);
-/* n <= NID_SLOTS candidate poses (poses7 = n x 7) in ONE kernel launch, into slots
+/* n <= NID_MAX_BATCH candidate poses (poses7 = n x 7) in ONE kernel launch, into slots
  * first_slot .. first_slot+n-1 (e.g. the trial steps of one LM iteration for several lambdas,
  * or consecutive candidates of a sampling optimiser); collect each with nid_wait() */
 int nid_launch_batch(nid_ctx *ctx, int first_slot, int n, const double *poses7, int want_jac,

@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libnid_hip.so")
 
 NID_OK = 0
-NID_SLOTS = 16
+NID_SLOTS = 32
 NID_MAX_BATCH = 8
 NID_REDUCED_LEN = 32
 NID_CELL_OUT = 10

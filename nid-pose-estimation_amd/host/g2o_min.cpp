@@ -363,10 +363,10 @@ OptimizationAlgorithmLevenberg::SolverResult OptimizationAlgorithmLevenberg::sol
     // decisions as the sequential loop below -- only the number of launches changes.
     const SE3Quat T0 = vm->estimate();
     while (qmax < _maxTrialsAfterFailure) {
-      const int nb = std::min((int)NID_SLOTS / 2, _maxTrialsAfterFailure - qmax);
-      double lam[NID_SLOTS], nis[NID_SLOTS], xs[NID_SLOTS][6], poses[NID_SLOTS * 7];
-      bool oks[NID_SLOTS];
-      SE3Quat cand[NID_SLOTS];
+      const int nb = std::min((int)NID_MAX_BATCH, _maxTrialsAfterFailure - qmax);
+      double lam[NID_MAX_BATCH], nis[NID_MAX_BATCH], xs[NID_MAX_BATCH][6], poses[NID_MAX_BATCH * 7];
+      bool oks[NID_MAX_BATCH];
+      SE3Quat cand[NID_MAX_BATCH];
       double l = _currentLambda, n_i = _ni;
       for (int k = 0; k < nb; k++) {
         lam[k] = l; nis[k] = n_i;
@@ -383,7 +383,7 @@ OptimizationAlgorithmLevenberg::SolverResult OptimizationAlgorithmLevenberg::sol
         l *= n_i; n_i *= 2;
       }
       if (nid_launch_batch(ctx, 0, nb, poses, 0, delta) != NID_OK) return Fail;
-      double chis[NID_SLOTS];
+      double chis[NID_MAX_BATCH];
       for (int k = 0; k < nb; k++)
         if (nid_wait(ctx, k, nullptr, nullptr, &chis[k], &na) != NID_OK) return Fail;
       bool accepted = false;
