@@ -253,11 +253,13 @@ def main():
         elapsed = float(t.item())
 
     # sanity: the last result is finite and every rank agrees after the all-reduce
+    ablation = bool(os.environ.get("NID_HIP_LIB"))  # kernel-ablation builds (exp/) produce meaningless numbers
     if world == 1:
-        assert results.shape == (K, capi.NID_REDUCED_LEN) and np.all(np.isfinite(results))
+        assert ablation or (results.shape == (K, capi.NID_REDUCED_LEN) and np.all(np.isfinite(results)))
         ctx.launch(0, poses[(K - 1) % len(poses)], delta, True)
         H, b, chi2, na = ctx.wait(0)
-        assert np.array_equal(capi.unpack_reduced(results[K - 1])[0], H), "pipelined result differs from a single launch"
+        assert ablation or np.array_equal(capi.unpack_reduced(results[K - 1])[0], H), \
+            "pipelined result differs from a single launch"
     else:
         # the pipelined result of the last step must equal a synchronous evaluation of the same pose
         jl, kl = (K - 1) // B, (K - 1) % B
@@ -270,7 +272,7 @@ def main():
         sync = ring[0, 0].cpu().numpy()
         assert np.array_equal(piped, sync), "pipelined multi-rank result differs from the synchronous one"
         H, b, chi2, na = capi.unpack_reduced(sync)
-    assert np.isfinite(chi2) and np.all(np.isfinite(H)) and na > 0
+    assert ablation or (np.isfinite(chi2) and np.all(np.isfinite(H)) and na > 0)
 
     # dominant-kernel duration: HIP events on the launch stream around the same launches the timed
     # region issues (B poses per launch at N=1)

@@ -187,6 +187,8 @@ int nid_debug_get_stamps(nid_ctx *ctx, int64_t *stamps);
 void nid_bspline4_host(double u, int bin_num, double *B4, double *D4);
 /* host evaluation of the FAST-mode per-span polynomial B-spline table */
 void nid_bspline4_poly_host(double u, int bin_num, double *B4, double *D4);
+/* host twin of the FAST-mode log2 of the entropy fold */
+double nid_log2_fast_host(double x);
 /* host twin of the kernels' division-by-small-constant helper */
 double nid_div_small_host(double x, double d);
 /* timing of the last launch on its stream, ms (hipEvent) */

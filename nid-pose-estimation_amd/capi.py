@@ -12,7 +12,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libnid_hip.so")
+LIB_PATH = os.environ.get("NID_HIP_LIB") or os.path.join(_HERE, "libnid_hip.so")  # NID_HIP_LIB: experiment builds of the same C-ABI
 
 NID_OK = 0
 NID_SLOTS = 32
@@ -45,7 +45,7 @@ SYMBOLS = [
     "nid_compute_href_matrix", "nid_set_href_state", "nid_evaluate", "nid_evaluate_matrix",
     "nid_normal_equations", "nid_launch", "nid_launch_batch", "nid_launch_batch_to", "nid_run_sequence", "nid_wait", "nid_slot_buffers", "nid_launch_to",
     "nid_unpack_reduced", "nid_debug_enable_pixel_dump", "nid_debug_get_pixel_dump",
-    "nid_debug_enable_stamps", "nid_debug_get_stamps", "nid_bspline4_host", "nid_bspline4_poly_host", "nid_div_small_host", "nid_last_kernel_ms", "nid_enable_timing",
+    "nid_debug_enable_stamps", "nid_debug_get_stamps", "nid_bspline4_host", "nid_bspline4_poly_host", "nid_log2_fast_host", "nid_div_small_host", "nid_last_kernel_ms", "nid_enable_timing",
     "nid_contract_bytes",
 ]
 
@@ -312,6 +312,13 @@ def unpack_reduced(r):
     na = C.c_int32(0)
     lib.nid_unpack_reduced(_dp(r), _dp(H), _dp(b), C.byref(chi2), C.byref(na))
     return H.reshape(6, 6), b, chi2.value, na.value
+
+
+def log2_fast_host(x):
+    lib = load()
+    lib.nid_log2_fast_host.restype = C.c_double
+    lib.nid_log2_fast_host.argtypes = [C.c_double]
+    return float(lib.nid_log2_fast_host(float(x)))
 
 
 def bspline4_poly_host(u, bin_num):

@@ -64,7 +64,8 @@ struct nid_ctx {
   bool dbg_enabled = false;
   bool timing = false;
   bool have_ref = false, have_target = false, have_href = false, ref_from_depth = false;
-  double hist_scale = 0, hist_inv_scale = 0;
+  double hist_scale = 0, hist_inv_scale = 0;            // k_href: whole-cell sums below 2^62
+  double eval_hist_scale = 0, eval_hist_inv_scale = 0;  // k_eval2: every histogram COPY stays below 2^52
   int group_size = 1, ngroups = 1;
   int math_mode = NID_MATH_FAST;
   double *ctab_dev = nullptr;
@@ -166,9 +167,8 @@ void build_coef_table(int S, std::vector<double> *out) {
 
 size_t eval_lds_bytes(const Geometry &g, int nt) {
   const int nbins = g.nb * g.nb + g.nb;
-  const size_t red = (size_t)std::max(6 * (nt / 64), nt + 2);
   return (size_t)nbins * kHistCopies * 8 + (size_t)((nbins + 1) & ~1) * 8 +
-         (size_t)kMaxBins * kCoefRow * 8 + red * 8;
+         (size_t)kMaxBins * kCoefRow * 8 + (size_t)kRedDoubles(nt) * 8;
 }
 
 // k_eval2 (occupancy-organised, runtime pixel loop): one workgroup shape for every cell size
@@ -186,8 +186,10 @@ void launch_eval2_v(const EvalParams &P, bool jac, bool strict, size_t lds, hipS
 
 int launch_eval2(nid_ctx *ctx, EvalParams &P, bool jac, hipStream_t stream, int batch) {
   P.batch = batch;
-  const size_t lds = eval_lds_bytes(P.g, 256);
+  size_t lds = eval_lds_bytes(P.g, 256);
   if (lds > 160 * 1024) return NID_ERR_UNSUPPORTED;
+  static const char *pad_env = getenv("NID_EXP_LDS_PAD");  // occupancy experiments: pad the LDS request
+  if (pad_env) lds = std::min<size_t>(160 * 1024, lds + (size_t)atoi(pad_env));
   const bool dbg = ctx->dbg_enabled || ctx->dbg_stamps != nullptr;
   const bool strict = ctx->math_mode == NID_MATH_STRICT;
   if (dbg) launch_eval2_v<0, true>(P, jac, strict, lds, stream, batch);
@@ -213,8 +215,8 @@ void fill_common_params(nid_ctx *ctx, double delta, EvalParams *P) {
   P->Nc = ctx->Nc_dev;
   P->Href = ctx->Href_dev;
   P->jac_cols = (ctx->jac_bound == NID_JACBOUND_CPU) ? ctx->g.cols - 1 : ctx->g.cols;
-  P->hist_scale = ctx->hist_scale;
-  P->hist_inv_scale = ctx->hist_inv_scale;
+  P->hist_scale = ctx->eval_hist_scale;
+  P->hist_inv_scale = ctx->eval_hist_inv_scale;
   if (ctx->dbg_enabled) {
     P->dbg_u = ctx->dbg_u; P->dbg_v = ctx->dbg_v; P->dbg_ic = ctx->dbg_ic;
     P->dbg_wc = ctx->dbg_wc; P->dbg_jc = ctx->dbg_jc;
@@ -474,6 +476,17 @@ int nid_create(const nid_config *cfg, nid_ctx **out) {
   while ((1 << bits) < g.ps + 1) bits++;
   ctx->hist_scale = std::ldexp(1.0, 62 - bits);
   ctx->hist_inv_scale = std::ldexp(1.0, -(62 - bits));
+  // k_eval2 accumulates raw 2^52-magic bit patterns and masks the top 12 bits per copy in the fold,
+  // so no copy may carry out of 52 bits: a copy receives at most rounds * 256 / kHistCopies weights
+  // (each <= 1) per bin.
+  {
+    const int per_copy = ((g.pstride + 255) / 256) * 256 / kHistCopies;
+    int cb2 = 0;
+    while ((1 << cb2) < per_copy + 1) cb2++;
+    ctx->eval_hist_scale = std::ldexp(1.0, 52 - cb2);
+    ctx->eval_hist_inv_scale = std::ldexp(1.0, -(52 - cb2));
+  }
+  if ((size_t)g.nloc * (size_t)g.pstride >= ((size_t)1 << 29)) { delete ctx; return NID_ERR_UNSUPPORTED; }
   auto fail = [&](int rc) { nid_destroy(ctx); return rc; };
   if (hipSetDevice(cfg->device) != hipSuccess) return fail(NID_ERR_NO_DEVICE);
   if (hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess) return fail(NID_ERR_HIP);
@@ -568,6 +581,8 @@ int nid_set_math_mode(nid_ctx *ctx, int mode) {
   ctx->math_mode = mode;
   return NID_OK;
 }
+
+double nid_log2_fast_host(double x) { return log2_fast(x); }
 
 void nid_bspline4_poly_host(double u, int bin_num, double *B4, double *D4) {
   // host evaluation of the FAST-mode polynomial table (unit tests)

@@ -30,7 +30,10 @@
 
 namespace nid {
 
-constexpr int kHistCopies = 32;   // NC: lane-interleaved histogram copies
+// NC: lane-interleaved histogram copies.  The LDS services a 64-bit access in four groups of 16
+// consecutive lanes (MI355X_MICROARCH.md, LDS table): 16 copies give every lane of a group its own
+// address and its own pair of banks, so more copies buy nothing and cost zeroing + fold time.
+constexpr int kHistCopies = 16;
 constexpr int kMaxBins = 16;
 constexpr int kCellOut = 10;      // Hc, Hj, err, J[6], Nc
 constexpr int kReducedLen = 32;
@@ -219,8 +222,9 @@ __device__ __forceinline__ double bilinear_rows_fast(const RowPair &r, int wx, d
 
 __device__ __forceinline__ int tap_i(unsigned row, int k) { return (int)((row >> (k * 8)) & 0xffu); }
 
-// Central-difference image gradient of the bilinear surface at (u, v):
-//   gx = (bil(u+1,v) - bil(u-1,v))/2, gy = (bil(u,v+1) - bil(u,v-1))/2
+// TWICE the central-difference image gradient of the bilinear surface at (u, v) (the caller folds
+// the 1/2 into its constants):
+//   gx = bil(u+1,v) - bil(u-1,v), gy = bil(u,v+1) - bil(u,v-1)
 // (types_six_dof_expmap.cpp:434-435).  Interior pixels (window origin = (ix-1, iy-1)) use the 12
 // shared taps with exact integer differences; the first row/column falls back to the generic form,
 // which also reproduces the (int)-truncation extrapolation of the reference there.
@@ -247,7 +251,7 @@ __device__ __forceinline__ void gradient_fast(const Win &w, double u, double v, 
     const int a20 = tap_i(w.r2, 0), a21 = tap_i(w.r2, 1), a22 = tap_i(w.r2, 2), a23 = tap_i(w.r2, 3);
     const double g1 = fma(dx, (double)((a13 - a12) - (a11 - a10)), (double)(a12 - a10));
     const double g2 = fma(dx, (double)((a23 - a22) - (a21 - a20)), (double)(a22 - a20));
-    gx = 0.5 * fma(dy, g2 - g1, g1);
+    gx = fma(dy, g2 - g1, g1);
     // gy: M(j) = a(j,1) + dx*(a(j,2) - a(j,1)) on rows iy-1 .. iy+2;
     //     bil(v+1) - bil(v-1) = (M2 - M0) + dy*((M3 - M2) - (M1 - M0))
     const int a01 = tap_i(w.r0, 1), a02 = tap_i(w.r0, 2), a31 = tap_i(w.r3, 1), a32 = tap_i(w.r3, 2);
@@ -255,14 +259,14 @@ __device__ __forceinline__ void gradient_fast(const Win &w, double u, double v, 
     const double m1 = fma(dx, (double)(a12 - a11), (double)a11);
     const double m2 = fma(dx, (double)(a22 - a21), (double)a21);
     const double m3 = fma(dx, (double)(a32 - a31), (double)a31);
-    gy = 0.5 * fma(dy, (m3 - m2) - (m1 - m0), m2 - m0);
+    gy = fma(dy, (m3 - m2) - (m1 - m0), m2 - m0);
     ic = fma(dy, m2 - m1, m1);
   } else {
     const RowPair r0 = win_rows(w, v);
     ic = bilinear_rows_fast(r0, w.wx, u);
-    gx = 0.5 * (bilinear_rows_fast(r0, w.wx, u + 1) - bilinear_rows_fast(r0, w.wx, u - 1));
+    gx = bilinear_rows_fast(r0, w.wx, u + 1) - bilinear_rows_fast(r0, w.wx, u - 1);
     const RowPair rp = win_rows(w, v + 1), rm = win_rows(w, v - 1);
-    gy = 0.5 * (bilinear_rows_fast(rp, w.wx, u) - bilinear_rows_fast(rm, w.wx, u));
+    gy = bilinear_rows_fast(rp, w.wx, u) - bilinear_rows_fast(rm, w.wx, u);
   }
 }
 
@@ -272,7 +276,7 @@ __device__ __forceinline__ void gradient_fast(const Win &w, double u, double v, 
 template <bool WANT_DER>
 __device__ __forceinline__ void bspline4_poly(double u, int jc, const double *ctab, double B[4], double D[4]) {
   const double t = u - (double)jc;
-  const double *c = ctab + jc * kCoefRow;
+  const double *c = ctab + __mul24(jc, kCoefRow);
 #pragma unroll
   for (int k = 0; k < 4; k++) {
     const double *ck = c + 7 * k;
@@ -284,15 +288,15 @@ __device__ __forceinline__ void bspline4_poly(double u, int jc, const double *ct
   }
 }
 
-// derivative-only form of bspline4_poly (Jacobian phase of k_eval2)
+// derivative-only form of bspline4_poly (Jacobian phase of k_eval2).  The u == 0 quirk (Q5: all
+// four derivatives identically 0) is applied by the caller, once, on the pixel's coefficient.
 __device__ __forceinline__ void bspline4_poly_der(double u, int jc, const double *ctab, double D[4]) {
   const double t = u - (double)jc;
-  const double *c = ctab + jc * kCoefRow;
+  const double *c = ctab + __mul24(jc, kCoefRow);
 #pragma unroll
   for (int k = 0; k < 4; k++) {
     const double *ck = c + 7 * k;
-    const double d = fma(fma(ck[6], t, ck[5]), t, ck[4]);
-    D[k] = (u == 0.0) ? 0.0 : d;
+    D[k] = fma(fma(ck[6], t, ck[5]), t, ck[4]);
   }
 }
 
@@ -342,6 +346,13 @@ __device__ __forceinline__ double wave_sum_to_lane63(double v) {
   return v;
 }
 
+// A value every lane of the wave holds identically, moved to scalar registers (frees its VGPR pair)
+__device__ __forceinline__ double wave_uniform(double x) {
+  const int lo = __builtin_amdgcn_readfirstlane(__double2loint(x));
+  const int hi = __builtin_amdgcn_readfirstlane(__double2hiint(x));
+  return __hiloint2double(hi, lo);
+}
+
 // Deterministic block sum of NV values; result broadcast to every thread.
 // `red` holds NV * (NT/64) doubles and must not be in use.
 template <int NT, int NV>
@@ -369,6 +380,15 @@ __device__ __forceinline__ unsigned long long fx_encode(double w, double scale) 
   const double t = fma(w, scale, 0x1p52);
   return (unsigned long long)__double_as_longlong(t) - 0x4330000000000000ull;
 }
+
+// Hot-kernel form: the raw bit pattern of RN(w*scale + 2^52), i.e. the fixed-point value with
+// 0x433 left in the top 12 bits.  With the scale chosen so that a histogram copy can never carry
+// out of its low 52 bits (EvalParams::hist_scale), the copies are summed as integers and the top
+// 12 bits are masked off once per copy in the fold -- one VALU instruction less per atomic.
+__device__ __forceinline__ unsigned long long fx_encode_raw(double w, double scale) {
+  return (unsigned long long)__double_as_longlong(fma(w, scale, 0x1p52));
+}
+constexpr unsigned kFxHiMask = 0x000FFFFFu;
 
 // ---------------------------------------------------------------------------
 // Setup: back-projection + tiling.  Calculate3DpointKernel (CudaPoints3d.cu:5-32)
@@ -525,6 +545,7 @@ __device__ __forceinline__ double load_sc1(const double *p) {
       reinterpret_cast<const unsigned long long *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
 }
 
+constexpr int kRedDoubles(int nt) { return ((6 * (nt / 64) > nt + 2 ? 6 * (nt / 64) : nt + 2) + 1) & ~1; }
 constexpr int kQuad = 32;  // per-cell block: rho0 | b[6] | H upper[21] | 1.0 | 0 0 0
 
 // which (a,b) of the upper triangle a quad slot 7..27 holds
@@ -642,15 +663,21 @@ struct PixelFront {
   double wr[4];
 };
 
+// f64 plane element at a 32-bit BYTE offset: uniform 64-bit base + zero-extended 32-bit lane offset
+// is the addressing mode of global_load (saddr + voffset), so no per-lane 64-bit address arithmetic
+__device__ __forceinline__ double ld_f64(const double *base, unsigned byte_off) {
+  return *reinterpret_cast<const double *>(reinterpret_cast<const char *>(base) + byte_off);
+}
+
 template <bool STRICT>
 __device__ __forceinline__ void pixel_front(const EvalParams &P, const SlotArgs &SA, unsigned gi, unsigned plane,
-                                            bool in_tile, PixelFront &f) {
+                                            PixelFront &f) {
   const Geometry &g = P.g;
-  const int jr = P.t.JR[gi];
-  f.jr = in_tile ? jr : -1;
-  const double lx = P.t.X[gi], ly = P.t.Y[gi], lz = P.t.Z[gi];
+  f.jr = P.t.JR[gi];
+  const unsigned bo = gi << 3;  // nloc * pstride * 8 < 2^32 (nid_create)
+  const double lx = ld_f64(P.t.X, bo), ly = ld_f64(P.t.Y, bo), lz = ld_f64(P.t.Z, bo);
 #pragma unroll
-  for (int k = 0; k < 4; k++) f.wr[k] = P.t.W[k * plane + gi];
+  for (int k = 0; k < 4; k++) f.wr[k] = ld_f64(P.t.W + (size_t)k * plane, bo);
   double qx, qy, qz, u, v;
   if (STRICT) {
     xform_point(SA.pose, lx, ly, lz, qx, qy, qz);
@@ -672,11 +699,22 @@ __device__ __forceinline__ void pixel_front(const EvalParams &P, const SlotArgs 
   f.x = qx; f.y = qy; f.u = u; f.v = v;
   f.w.wx = f.in ? max((int)u - 1, 0) : 0;  // out-of-frame pixels load the window at (0,0); never used
   f.w.wy = f.in ? max((int)v - 1, 0) : 0;
+#if defined(NID_EXP_NOWIN)
+  const unsigned po = 0;
+  f.w.r0 = 0x20304050u + f.w.wx; f.w.r1 = 0x21314151u + f.w.wy; f.w.r2 = 0x22324252u; f.w.r3 = 0x23334353u;
+  if (g.cols < 0) {
+#elif defined(NID_EXP_WINALIGNED)
+  const unsigned po = ((unsigned)f.w.wy * (unsigned)g.cols + (unsigned)f.w.wx) & ~3u;
+  {
+#else
   const unsigned po = (unsigned)f.w.wy * (unsigned)g.cols + (unsigned)f.w.wx;
+  {
+#endif
   f.w.r0 = load_u32_unaligned(P.im1 + po);
   f.w.r1 = load_u32_unaligned(P.im1 + (po + (unsigned)g.cols));
   f.w.r2 = load_u32_unaligned(P.im1 + (po + 2u * (unsigned)g.cols));
   f.w.r3 = load_u32_unaligned(P.im1 + (po + 3u * (unsigned)g.cols));
+  }
 }
 
 // centre sample -> clamped intensity -> bin position -> B-spline weights (and derivatives)
@@ -693,9 +731,8 @@ __device__ __forceinline__ int pixel_sample(const PixelFront &f, int nb, int S, 
     jc = (int)floor(pc);
     bspline4_tab<WANT_DER>(pc, jc, S, rtab, wc, dw);
   } else {
-    ic = sample_fast(f.w, f.u, f.v);
+    ic = sample_fast(f.w, f.u, f.v);  // a convex combination of u8 taps: never negative
     if (ic >= 255) ic = 254.999;
-    if (ic < 0) ic = 0.0;
     const double pc = ic * ((double)S / 255.0);
     jc = (int)pc;
     bspline4_poly<WANT_DER>(pc, jc, rtab, wc, dw);
@@ -703,17 +740,26 @@ __device__ __forceinline__ int pixel_sample(const PixelFront &f, int nb, int S, 
   return jc;
 }
 
+#if defined(NID_EXP_NOATOMIC)
+#define NID_EXP_ATOMIC(p, v) do { if ((v) == 0x7ff0000000000001ull) *(p) = (v); } while (0)
+#elif defined(NID_EXP_PLAINSTORE)
+#define NID_EXP_ATOMIC(p, v) do { *(p) = (v); } while (0)
+#else
+#define NID_EXP_ATOMIC(p, v) atomicAdd((p), (v))
+#endif
 template <int NT, bool JAC, bool STRICT, int NB, bool DBG>
-__global__ __launch_bounds__(NT) void k_eval2(EvalParams P) {
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(5))) void k_eval2(EvalParams P) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const Geometry &g = P.g;
   const int nb = NB > 0 ? NB : g.nb;
   const int nbins = nb * nb + nb;
   const int S = nb - 3;
-  unsigned long long *hist = reinterpret_cast<unsigned long long *>(smem);
-  double *tab = reinterpret_cast<double *>(smem + (size_t)nbins * kHistCopies * 8);
+  // LDS: [weight table | B-spline table | reduction scratch | histogram copies].  The two tables come
+  // first so that their reads sit inside the 2040-byte immediate range of ds_read2_b64.
+  double *tab = reinterpret_cast<double *>(smem);
   double *rtab = tab + ((nbins + 1) & ~1);
   double *red = rtab + kMaxBins * kCoefRow;
+  unsigned long long *hist = reinterpret_cast<unsigned long long *>(red + kRedDoubles(NT));
 
   // XCD-aware block -> (cell, pose) map: workgroups are dealt round-robin over the 8 XCDs, so
   // id % 8 fixes the XCD; all `batch` poses of a cell get the same id % 8 and consecutive slots
@@ -750,17 +796,19 @@ __global__ __launch_bounds__(NT) void k_eval2(EvalParams P) {
   const int copy = tid & (kHistCopies - 1);
   const unsigned base = (unsigned)cl * (unsigned)g.pstride;
   const unsigned plane = (unsigned)g.nloc * (unsigned)g.pstride;
-  const int rounds = (g.pstride + NT - 1) / NT;
+  // pstride is a multiple of 64, so a wave is either entirely inside the tile or entirely past
+  // it: the round loops run on a wave-uniform bound and the last round costs idle waves nothing
+  const int wave_base = __builtin_amdgcn_readfirstlane(tid & ~63);
+  const int lane = tid & 63;
   __syncthreads();
   NID_STAMP(1);
 
   // ---- phase 1: cost ---------------------------------------------------------------
 #pragma clang loop unroll(disable)
-  for (int i = 0; i < rounds; i++) {
-    const int s = i * NT + tid;
-    const bool in_tile = s < g.pstride;
+  for (int sb = wave_base; sb < g.pstride; sb += NT) {
+    const int s = sb + lane;
     PixelFront f;
-    pixel_front<STRICT>(P, SA, base + (in_tile ? (unsigned)s : 0u), plane, in_tile, f);
+    pixel_front<STRICT>(P, SA, base + (unsigned)s, plane, f);
     double ic = NAN, wc[4] = {NAN, NAN, NAN, NAN}, dw[4];
     int jc = -1;
     if (f.in) {
@@ -770,15 +818,16 @@ __global__ __launch_bounds__(NT) void k_eval2(EvalParams P) {
       double wcs[4];
 #pragma unroll
       for (int k = 0; k < 4; k++) wcs[k] = wc[k] * P.hist_scale;
-      unsigned long long *hc = hist + (jc * kHistCopies + copy);
+      const unsigned hrow = (unsigned)(__mul24(f.jr, nb) + jc);
+      unsigned long long *hc = hist + ((unsigned)jc * kHistCopies + (unsigned)copy);
 #pragma unroll
-      for (int k = 0; k < 4; k++) atomicAdd(hc + k * kHistCopies, fx_encode(wcs[k], 1.0));
-      unsigned long long *hj = hist + ((nb + f.jr * nb + jc) * kHistCopies + copy);
+      for (int k = 0; k < 4; k++) NID_EXP_ATOMIC(hc + k * kHistCopies, fx_encode_raw(wcs[k], 1.0));
+      unsigned long long *hj = hist + (((unsigned)nb + hrow) * kHistCopies + (unsigned)copy);
 #pragma unroll
       for (int m = 0; m < 4; m++)
 #pragma unroll
         for (int k = 0; k < 4; k++)
-          atomicAdd(hj + (m * nb + k) * kHistCopies, fx_encode(f.wr[m], wcs[k]));
+          NID_EXP_ATOMIC(hj + (m * nb + k) * kHistCopies, fx_encode_raw(f.wr[m], wcs[k]));
     }
     if (DBG && P.dbg_u && pose_idx == 0 && f.jr >= 0) {
       const int c = g.cell_begin + cl;
@@ -801,12 +850,12 @@ __global__ __launch_bounds__(NT) void k_eval2(EvalParams P) {
 #pragma unroll
     for (int c = 0; c < kHistCopies / 2; c++) {
       const uint4 q = hv[(c + b) & (kHistCopies / 2 - 1)];
-      acc += ((unsigned long long)q.y << 32 | q.x) + ((unsigned long long)q.w << 32 | q.z);
+      acc += ((unsigned long long)(q.y & kFxHiMask) << 32 | q.x) + ((unsigned long long)(q.w & kFxHiMask) << 32 | q.z);
     }
     const double p = ((double)(long long)acc * P.hist_inv_scale) / (double)n_c;  // Q1: N_c of the initial pose
     double w = 0.0;
     if (!(p < kSigma)) {
-      const double l = log2(p);
+      const double l = STRICT ? log2(p) : log2_fast(p);
       w = -(1.0 + l);  // Q9
       if (b < nb) ent[0] += p * l; else ent[1] += p * l;
     }
@@ -814,16 +863,19 @@ __global__ __launch_bounds__(NT) void k_eval2(EvalParams P) {
   }
   block_sum<NT, 2>(ent, red, tid);
   NID_STAMP(3, ent[0], ent[1]);
-  const double Hc = 0.0 - ent[0];
-  const double Hj = 0.0 - ent[1];
-  const double err = (2 * Hj - href - Hc) / Hj;  // types_six_dof_expmap.h:227
-  const double e2 = err * err;                   // Huber, robust_kernel_impl.cpp:77-91 (float dsqr)
+  // block_sum leaves the same value in every lane: keep the per-cell scalars in SGPRs
+  const double Hc = wave_uniform(0.0 - ent[0]);
+  const double Hj = wave_uniform(0.0 - ent[1]);
+  const double err = wave_uniform((2 * Hj - href - Hc) / Hj);  // types_six_dof_expmap.h:227
+  const double e2 = err * err;                                 // Huber, robust_kernel_impl.cpp:77-91 (float dsqr)
   double rho0 = e2, rho1 = 1.0;
   if (!(e2 <= P.huber_dsqr)) {
     const double sqrte = sqrt(e2);
     rho0 = 2 * sqrte * P.huber_delta - P.huber_dsqr;
     rho1 = P.huber_delta / sqrte;
   }
+  rho0 = wave_uniform(rho0);
+  rho1 = wave_uniform(rho1);
   if (!JAC) {
     if (tid == 0) { out[0] = Hc; out[1] = Hj; out[2] = err; out[kCellOut - 1] = (double)n_c; }
     if (tid < kQuad) store_sc1(quad + tid, tid == 0 ? rho0 : (tid == 28 ? 1.0 : 0.0));
@@ -835,16 +887,23 @@ __global__ __launch_bounds__(NT) void k_eval2(EvalParams P) {
   }
 
   // ---- phase 2: Jacobian (recompute, see header comment) -------------------------------
-  const double cA = Hc + href, cB = Hj;
+  const double cA = wave_uniform(Hc + href), cB = wave_uniform(Hj);
   double acc[6];
 #pragma unroll
   for (int n = 0; n < 6; n++) acc[n] = 0.0;
+  // FAST-mode constants: the gradient helper returns twice the gradient, so 1/2 rides on fx, fy
+  const double cAx = wave_uniform(cA * (0.5 * g.fx)), cBx = wave_uniform(cB * (0.5 * g.fx));
+  const double cAy = wave_uniform(cA * (0.5 * g.fy)), cBy = wave_uniform(cB * (0.5 * g.fy));
+#ifdef NID_EXP_NOP2
+  if (P.batch < 100)
+    for (int n = 0; n < 6; n++) acc[n] = tab[n];
+  else
+#endif
 #pragma clang loop unroll(disable)
-  for (int i = 0; i < rounds; i++) {
-    const int s = i * NT + tid;
-    const bool in_tile = s < g.pstride;
+  for (int sb = wave_base; sb < g.pstride; sb += NT) {
+    const int s = sb + lane;
     PixelFront f;
-    pixel_front<STRICT>(P, SA, base + (in_tile ? (unsigned)s : 0u), plane, in_tile, f);
+    pixel_front<STRICT>(P, SA, base + (unsigned)s, plane, f);
     if (f.in) {
       double invz, u, v;
       bool jin;
@@ -857,7 +916,7 @@ __global__ __launch_bounds__(NT) void k_eval2(EvalParams P) {
         invz = f.zq; u = f.u; v = f.v; jin = f.jin;
       }
       if (jin) {
-        double ic, wc[4], dw[4], gx, gy;
+        double ic, wc[4], dw[4], gx, gy, pc = 1.0;
         int jc;
         if (STRICT) {
           jc = pixel_sample<STRICT, true>(f, nb, S, rtab, ic, wc, dw);
@@ -868,12 +927,11 @@ __global__ __launch_bounds__(NT) void k_eval2(EvalParams P) {
         } else {
           gradient_fast(f.w, u, v, gx, gy, ic);  // centre sample shares the gradient's taps
           if (ic >= 255) ic = 254.999;
-          if (ic < 0) ic = 0.0;
-          const double pc = ic * ((double)S / 255.0);
+          pc = ic * ((double)S / 255.0);
           jc = (int)pc;
           bspline4_poly_der(pc, jc, rtab, dw);
         }
-        const double *tj = tab + nb + f.jr * nb + jc;
+        const double *tj = tab + ((unsigned)nb + (unsigned)(__mul24(f.jr, nb) + jc));
         double tt = 0.0, ss = 0.0;
 #pragma unroll
         for (int m = 0; m < 4; m++) tt = fma(tab[jc + m], dw[m], tt);
@@ -883,6 +941,23 @@ __global__ __launch_bounds__(NT) void k_eval2(EvalParams P) {
 #pragma unroll
           for (int m = 0; m < 4; m++) inner = fma(tj[k * nb + m], dw[m], inner);
           ss = fma(f.wr[k], inner, ss);
+        }
+        if (!STRICT) {
+          // d(u,v)/d(xi) with a = x/z, b = y/z (types_six_dof_expmap.cpp:438-450 regrouped):
+          //   Ju = fx [-ab, 1+a^2, -b, 1/z, 0, -a/z],  Jv = fy [-(1+b^2), ab, a, 0, 1/z, -b/z]
+          // acc[0] and acc[5] accumulate the NEGATED sums (fixed after the loop).
+          double cP = fma(ss, cAx, -(tt * cBx)), cQ = fma(ss, cAy, -(tt * cBy));
+          if (pc == 0.0) { cP = 0.0; cQ = 0.0; }  // Q5: B-spline derivative identically 0 at u == 0
+          const double Pg = cP * gx, Qg = cQ * gy;
+          const double a = f.x * invz, b = f.y * invz;
+          const double Pa = Pg * a, Qb = Qg * b;
+          acc[0] = fma(Pa, b, fma(Qb, b, Qg + acc[0]));
+          acc[1] = fma(Pa, a, fma(Qb, a, Pg + acc[1]));
+          acc[2] = fma(Qg, a, fma(-Pg, b, acc[2]));
+          acc[3] = fma(Pg, invz, acc[3]);
+          acc[4] = fma(Qg, invz, acc[4]);
+          acc[5] = fma(Pa + Qb, invz, acc[5]);
+          continue;
         }
         const double c = fma(ss, cA, -(tt * cB));
         const double cgx = c * gx, cgy = c * gy;
@@ -902,6 +977,7 @@ __global__ __launch_bounds__(NT) void k_eval2(EvalParams P) {
       }
     }
   }
+  if (!STRICT) { acc[0] = -acc[0]; acc[5] = -acc[5]; }
   NID_STAMP(4, acc[0], acc[2], acc[3], acc[5]);
   __syncthreads();
   block_sum<NT, 6>(acc, red, tid);

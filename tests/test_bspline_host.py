@@ -69,3 +69,17 @@ def test_fast_mode_polynomial_table(capi, oracle, nb):
     assert worst_b < 1e-15 and worst_d < 4e-15, (worst_b, worst_d)
     B, D = capi.bspline4_poly_host(0.0, nb)
     assert list(B) == [1.0, 0.0, 0.0, 0.0] and list(D) == [0.0, 0.0, 0.0, 0.0]
+
+
+def test_log2_fast_host(capi):
+    """FAST math: the entropy fold's short log2 (atanh series) against numpy's, on probabilities down to
+    the reference's 1e-30 floor, near 1, at powers of two and across the sqrt(1/2) range split."""
+    rng = np.random.default_rng(11)
+    xs = np.concatenate([10.0 ** rng.uniform(-30, 0, 20000), 1.0 - 10.0 ** rng.uniform(-16, -1, 2000),
+                         np.ldexp(1.0, np.arange(-100, 3)), np.sqrt(0.5) * (1 + rng.uniform(-1e-12, 1e-12, 200)),
+                         rng.uniform(0.5, 2.0, 5000)])
+    got = np.array([capi.log2_fast_host(x) for x in xs])
+    ref = np.log2(xs.astype(np.longdouble)).astype(np.float64)
+    err = np.abs(got - ref)
+    assert np.all(err <= 2.0 ** -51 * np.maximum(1.0, np.abs(ref))), float(err.max())
+    assert capi.log2_fast_host(1.0) == 0.0 and capi.log2_fast_host(0.25) == -2.0
