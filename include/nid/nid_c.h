@@ -194,6 +194,10 @@ double nid_div_small_host(double x, double d);
 /* timing of the last launch on its stream, ms (hipEvent) */
 int nid_last_kernel_ms(nid_ctx *ctx, int slot, float *eval_ms, float *reduce_ms);
 int nid_enable_timing(nid_ctx *ctx, int enable);
+/* average duration (ms) of `repeats` identical n-pose launches issued back to back on the context's
+ * stream, from one pair of HIP events around the whole group (what a kernel trace reports per launch) */
+int nid_time_launches(nid_ctx *ctx, int n, const double *poses7, int want_jac, double delta, int repeats,
+                      float *ms_per_launch);
 /* algorithmic (contract) bytes of one evaluation over this context's cells:
  * 68 B per pixel + 64 B per cell */
 int64_t nid_contract_bytes(const nid_ctx *ctx);

@@ -45,7 +45,7 @@ SYMBOLS = [
     "nid_compute_href_matrix", "nid_set_href_state", "nid_evaluate", "nid_evaluate_matrix",
     "nid_normal_equations", "nid_launch", "nid_launch_batch", "nid_launch_batch_to", "nid_run_sequence", "nid_wait", "nid_slot_buffers", "nid_launch_to",
     "nid_unpack_reduced", "nid_debug_enable_pixel_dump", "nid_debug_get_pixel_dump",
-    "nid_debug_enable_stamps", "nid_debug_get_stamps", "nid_bspline4_host", "nid_bspline4_poly_host", "nid_log2_fast_host", "nid_div_small_host", "nid_last_kernel_ms", "nid_enable_timing",
+    "nid_debug_enable_stamps", "nid_debug_get_stamps", "nid_bspline4_host", "nid_bspline4_poly_host", "nid_log2_fast_host", "nid_div_small_host", "nid_last_kernel_ms", "nid_enable_timing", "nid_time_launches",
     "nid_contract_bytes",
 ]
 
@@ -110,6 +110,7 @@ def load():
     lib.nid_div_small_host.argtypes = [C.c_double, C.c_double]
     lib.nid_last_kernel_ms.argtypes = [vp, C.c_int, c_fp, c_fp]
     lib.nid_enable_timing.argtypes = [vp, C.c_int]
+    lib.nid_time_launches.argtypes = [vp, C.c_int, c_dp, C.c_int, C.c_double, C.c_int, c_fp]
     lib.nid_contract_bytes.restype = C.c_int64
     lib.nid_contract_bytes.argtypes = [vp]
     _lib = lib
@@ -277,6 +278,14 @@ class Context:
         a, b = C.c_float(0), C.c_float(0)
         self._check(self.lib.nid_last_kernel_ms(self.h, slot, C.byref(a), C.byref(b)), "nid_last_kernel_ms")
         return a.value, b.value
+
+    def time_launches(self, poses7, delta, repeats=10, want_jac=True):
+        """ms per launch of `repeats` back-to-back launches of these poses (one HIP event pair)."""
+        ps = np.ascontiguousarray(np.asarray(poses7, dtype=np.float64).reshape(-1, 7))
+        ms = C.c_float(0)
+        self._check(self.lib.nid_time_launches(self.h, ps.shape[0], _dp(ps), int(want_jac), float(delta), int(repeats),
+                                               C.byref(ms)), "nid_time_launches")
+        return float(ms.value)
 
     def contract_bytes(self):
         return int(self.lib.nid_contract_bytes(self.h))

@@ -188,7 +188,7 @@ int launch_eval2(nid_ctx *ctx, EvalParams &P, bool jac, hipStream_t stream, int 
   P.batch = batch;
   size_t lds = eval_lds_bytes(P.g, 256);
   if (lds > 160 * 1024) return NID_ERR_UNSUPPORTED;
-  static const char *pad_env = getenv("NID_EXP_LDS_PAD");  // occupancy experiments: pad the LDS request
+  static const char *pad_env = getenv("NID_EXP_LDS_PAD");  // occupancy experiments (DESIGN.md 7): pad the LDS request
   if (pad_env) lds = std::min<size_t>(160 * 1024, lds + (size_t)atoi(pad_env));
   const bool dbg = ctx->dbg_enabled || ctx->dbg_stamps != nullptr;
   const bool strict = ctx->math_mode == NID_MATH_STRICT;
@@ -951,6 +951,34 @@ int nid_last_kernel_ms(nid_ctx *ctx, int slot, float *eval_ms, float *reduce_ms)
   NID_HIP(ctx, hipEventSynchronize(S.e1));
   if (eval_ms) NID_HIP(ctx, hipEventElapsedTime(eval_ms, S.e0, S.e1));
   if (reduce_ms) *reduce_ms = 0.0f;  // the reduction is fused into the evaluation kernel
+  return NID_OK;
+}
+
+int nid_time_launches(nid_ctx *ctx, int n, const double *poses7, int want_jac, double delta, int repeats,
+                      float *ms_per_launch) {
+  // `repeats` identical n-pose launches back to back on the context's stream between two events: the
+  // per-launch duration a kernel trace reports (event pairs around ONE launch add ~5 us of marker and
+  // dispatch latency to a ~50 us kernel).  Same-stream launches are serialised, so reusing the slots is safe.
+  if (!ctx || !poses7 || !ms_per_launch || n < 1 || n > kMaxBatch || repeats < 1) return NID_ERR_INVALID_ARG;
+  NID_HIP(ctx, hipSetDevice(ctx->cfg.device));
+  for (int s = 0; s < NID_SLOTS; s++) if (ctx->slots[s].pending) return NID_ERR_STATE;
+  Pose p[kMaxBatch];
+  for (int k = 0; k < n; k++) pose_from_pose7(poses7 + 7 * k, ctx->xform, &p[k]);
+  Slot &S0 = ctx->slots[0];
+  NID_HIP(ctx, hipEventRecord(S0.e0, ctx->stream));
+  for (int r = 0; r < repeats; r++) {
+    int rc = launch_batch(ctx, 0, n, p, want_jac, delta);
+    if (rc) return rc;
+  }
+  NID_HIP(ctx, hipEventRecord(S0.e1, ctx->stream));
+  for (int k = 0; k < n; k++) {
+    int rc = nid_wait(ctx, k, nullptr, nullptr, nullptr, nullptr);
+    if (rc) return rc;
+  }
+  NID_HIP(ctx, hipEventSynchronize(S0.e1));
+  float ms = 0.f;
+  NID_HIP(ctx, hipEventElapsedTime(&ms, S0.e0, S0.e1));
+  *ms_per_launch = ms / (float)repeats;
   return NID_OK;
 }
 

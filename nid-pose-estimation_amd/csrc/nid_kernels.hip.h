@@ -669,15 +669,36 @@ __device__ __forceinline__ double ld_f64(const double *base, unsigned byte_off) 
   return *reinterpret_cast<const double *>(reinterpret_cast<const char *>(base) + byte_off);
 }
 
-template <bool STRICT>
-__device__ __forceinline__ void pixel_front(const EvalParams &P, const SlotArgs &SA, unsigned gi, unsigned plane,
-                                            PixelFront &f) {
-  const Geometry &g = P.g;
-  f.jr = P.t.JR[gi];
+// one pixel's tile entry, as loaded (the round loops fetch the NEXT round's entry before they work on
+// the current one, so the L2 / Infinity-Cache latency of the tile stream overlaps the arithmetic)
+struct TileIn {
+  double x, y, z;
+  double wr[4];
+  int jr;
+};
+
+__device__ __forceinline__ void load_tile_xyz(const EvalParams &P, unsigned gi, TileIn &t) {
+  t.jr = P.t.JR[gi];
   const unsigned bo = gi << 3;  // nloc * pstride * 8 < 2^32 (nid_create)
-  const double lx = ld_f64(P.t.X, bo), ly = ld_f64(P.t.Y, bo), lz = ld_f64(P.t.Z, bo);
+  t.x = ld_f64(P.t.X, bo); t.y = ld_f64(P.t.Y, bo); t.z = ld_f64(P.t.Z, bo);
+}
+__device__ __forceinline__ void load_tile_w(const EvalParams &P, unsigned gi, unsigned plane, TileIn &t) {
+  const unsigned bo = gi << 3;
 #pragma unroll
-  for (int k = 0; k < 4; k++) f.wr[k] = ld_f64(P.t.W + (size_t)k * plane, bo);
+  for (int k = 0; k < 4; k++) t.wr[k] = ld_f64(P.t.W + (size_t)k * plane, bo);
+}
+__device__ __forceinline__ void load_tile(const EvalParams &P, unsigned gi, unsigned plane, TileIn &t) {
+  load_tile_xyz(P, gi, t);
+  load_tile_w(P, gi, plane, t);
+}
+
+template <bool STRICT>
+__device__ __forceinline__ void pixel_front(const EvalParams &P, const SlotArgs &SA, const TileIn &t, PixelFront &f) {
+  const Geometry &g = P.g;
+  f.jr = t.jr;
+  const double lx = t.x, ly = t.y, lz = t.z;
+#pragma unroll
+  for (int k = 0; k < 4; k++) f.wr[k] = t.wr[k];
   double qx, qy, qz, u, v;
   if (STRICT) {
     xform_point(SA.pose, lx, ly, lz, qx, qy, qz);
@@ -699,22 +720,11 @@ __device__ __forceinline__ void pixel_front(const EvalParams &P, const SlotArgs 
   f.x = qx; f.y = qy; f.u = u; f.v = v;
   f.w.wx = f.in ? max((int)u - 1, 0) : 0;  // out-of-frame pixels load the window at (0,0); never used
   f.w.wy = f.in ? max((int)v - 1, 0) : 0;
-#if defined(NID_EXP_NOWIN)
-  const unsigned po = 0;
-  f.w.r0 = 0x20304050u + f.w.wx; f.w.r1 = 0x21314151u + f.w.wy; f.w.r2 = 0x22324252u; f.w.r3 = 0x23334353u;
-  if (g.cols < 0) {
-#elif defined(NID_EXP_WINALIGNED)
-  const unsigned po = ((unsigned)f.w.wy * (unsigned)g.cols + (unsigned)f.w.wx) & ~3u;
-  {
-#else
   const unsigned po = (unsigned)f.w.wy * (unsigned)g.cols + (unsigned)f.w.wx;
-  {
-#endif
   f.w.r0 = load_u32_unaligned(P.im1 + po);
   f.w.r1 = load_u32_unaligned(P.im1 + (po + (unsigned)g.cols));
   f.w.r2 = load_u32_unaligned(P.im1 + (po + 2u * (unsigned)g.cols));
   f.w.r3 = load_u32_unaligned(P.im1 + (po + 3u * (unsigned)g.cols));
-  }
 }
 
 // centre sample -> clamped intensity -> bin position -> B-spline weights (and derivatives)
@@ -740,15 +750,23 @@ __device__ __forceinline__ int pixel_sample(const PixelFront &f, int nb, int S, 
   return jc;
 }
 
-#if defined(NID_EXP_NOATOMIC)
-#define NID_EXP_ATOMIC(p, v) do { if ((v) == 0x7ff0000000000001ull) *(p) = (v); } while (0)
-#elif defined(NID_EXP_PLAINSTORE)
-#define NID_EXP_ATOMIC(p, v) do { *(p) = (v); } while (0)
-#else
-#define NID_EXP_ATOMIC(p, v) atomicAdd((p), (v))
+// Tuning switches; defaults = the measured best on MI355X (640x480, 8 bins, 8 poses per launch, two
+// launches in flight; tools/build_variant.sh + tools/power_probe.sh, results in DESIGN.md section 7):
+// NID_PREFETCH_P1 / _P2 (cost / Jacobian phase): 0 = load the tile entry at the top of the round,
+// 1 = request the NEXT round's entry during the current round, 2 = as 1 for the point, the current
+// round's reference weights behind the window loads.  NID_FAST_WAVES: occupancy target of the FAST
+// kernels (5 waves/SIMD = 96 VGPRs; 6 measured equal, 7-8 spill inside the loops and lose 17-35 %).
+#ifndef NID_PREFETCH_P1
+#define NID_PREFETCH_P1 2
+#endif
+#ifndef NID_PREFETCH_P2
+#define NID_PREFETCH_P2 2
+#endif
+#ifndef NID_FAST_WAVES
+#define NID_FAST_WAVES 5
 #endif
 template <int NT, bool JAC, bool STRICT, int NB, bool DBG>
-__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(5))) void k_eval2(EvalParams P) {
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(STRICT ? 4 : NID_FAST_WAVES))) void k_eval2(EvalParams P) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const Geometry &g = P.g;
   const int nb = NB > 0 ? NB : g.nb;
@@ -804,11 +822,36 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(5))) void k_
   NID_STAMP(1);
 
   // ---- phase 1: cost ---------------------------------------------------------------
+  // Tile entry of the round being worked on.  PF = NID_PREFETCH_P1: 0 load at the top of the round;
+  // 1 the NEXT round's entry is requested during the current round (unconditionally -- the last round
+  // re-requests its own entry -- so that the vmcnt bookkeeping stays exact), fenced so that it is
+  // issued AFTER the window loads: vector memory returns in order, and the window is then waited for
+  // with the eight tile loads still outstanding; 2 as 1 for the point, the reference weights of the
+  // current round are requested behind the window (they are used last).
+  TileIn tin;
+#if NID_PREFETCH_P1 == 1
+  if (wave_base < g.pstride) load_tile(P, base + (unsigned)(wave_base + lane), plane, tin);
+#elif NID_PREFETCH_P1 == 2
+  if (wave_base < g.pstride) load_tile_xyz(P, base + (unsigned)(wave_base + lane), tin);
+#endif
 #pragma clang loop unroll(disable)
   for (int sb = wave_base; sb < g.pstride; sb += NT) {
     const int s = sb + lane;
     PixelFront f;
-    pixel_front<STRICT>(P, SA, base + (unsigned)s, plane, f);
+#if NID_PREFETCH_P1 == 0
+    load_tile(P, base + (unsigned)s, plane, tin);
+#endif
+    pixel_front<STRICT>(P, SA, tin, f);
+#if NID_PREFETCH_P1 == 1
+    asm volatile("" ::: "memory");
+    load_tile(P, base + (unsigned)(sb + NT < g.pstride ? s + NT : s), plane, tin);
+#elif NID_PREFETCH_P1 == 2
+    asm volatile("" ::: "memory");
+    load_tile_w(P, base + (unsigned)s, plane, tin);
+#pragma unroll
+    for (int k = 0; k < 4; k++) f.wr[k] = tin.wr[k];
+    load_tile_xyz(P, base + (unsigned)(sb + NT < g.pstride ? s + NT : s), tin);
+#endif
     double ic = NAN, wc[4] = {NAN, NAN, NAN, NAN}, dw[4];
     int jc = -1;
     if (f.in) {
@@ -821,13 +864,13 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(5))) void k_
       const unsigned hrow = (unsigned)(__mul24(f.jr, nb) + jc);
       unsigned long long *hc = hist + ((unsigned)jc * kHistCopies + (unsigned)copy);
 #pragma unroll
-      for (int k = 0; k < 4; k++) NID_EXP_ATOMIC(hc + k * kHistCopies, fx_encode_raw(wcs[k], 1.0));
+      for (int k = 0; k < 4; k++) atomicAdd(hc + k * kHistCopies, fx_encode_raw(wcs[k], 1.0));
       unsigned long long *hj = hist + (((unsigned)nb + hrow) * kHistCopies + (unsigned)copy);
 #pragma unroll
       for (int m = 0; m < 4; m++)
 #pragma unroll
         for (int k = 0; k < 4; k++)
-          NID_EXP_ATOMIC(hj + (m * nb + k) * kHistCopies, fx_encode_raw(f.wr[m], wcs[k]));
+          atomicAdd(hj + (m * nb + k) * kHistCopies, fx_encode_raw(f.wr[m], wcs[k]));
     }
     if (DBG && P.dbg_u && pose_idx == 0 && f.jr >= 0) {
       const int c = g.cell_begin + cl;
@@ -894,16 +937,29 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(5))) void k_
   // FAST-mode constants: the gradient helper returns twice the gradient, so 1/2 rides on fx, fy
   const double cAx = wave_uniform(cA * (0.5 * g.fx)), cBx = wave_uniform(cB * (0.5 * g.fx));
   const double cAy = wave_uniform(cA * (0.5 * g.fy)), cBy = wave_uniform(cB * (0.5 * g.fy));
-#ifdef NID_EXP_NOP2
-  if (P.batch < 100)
-    for (int n = 0; n < 6; n++) acc[n] = tab[n];
-  else
+#if NID_PREFETCH_P2 == 1
+  if (wave_base < g.pstride) load_tile(P, base + (unsigned)(wave_base + lane), plane, tin);
+#elif NID_PREFETCH_P2 == 2
+  if (wave_base < g.pstride) load_tile_xyz(P, base + (unsigned)(wave_base + lane), tin);
 #endif
 #pragma clang loop unroll(disable)
   for (int sb = wave_base; sb < g.pstride; sb += NT) {
     const int s = sb + lane;
     PixelFront f;
-    pixel_front<STRICT>(P, SA, base + (unsigned)s, plane, f);
+#if NID_PREFETCH_P2 == 0
+    load_tile(P, base + (unsigned)s, plane, tin);
+#endif
+    pixel_front<STRICT>(P, SA, tin, f);
+#if NID_PREFETCH_P2 == 1
+    asm volatile("" ::: "memory");
+    load_tile(P, base + (unsigned)(sb + NT < g.pstride ? s + NT : s), plane, tin);
+#elif NID_PREFETCH_P2 == 2
+    asm volatile("" ::: "memory");
+    load_tile_w(P, base + (unsigned)s, plane, tin);
+#pragma unroll
+    for (int k = 0; k < 4; k++) f.wr[k] = tin.wr[k];
+    load_tile_xyz(P, base + (unsigned)(sb + NT < g.pstride ? s + NT : s), tin);
+#endif
     if (f.in) {
       double invz, u, v;
       bool jin;
