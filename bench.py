@@ -41,7 +41,7 @@ def parse():
     ap.add_argument("--bins", type=int, default=8)
     ap.add_argument("--block-threads", type=int, default=0)
     ap.add_argument("--inflight", type=int, default=0, help="result slots in use (0 = all)")
-    ap.add_argument("--batch", type=int, default=8,
+    ap.add_argument("--batch", type=int, default=16,
                     help="candidate poses per kernel launch at N=1 (1 = one launch per step)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)

@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get("NID_HIP_LIB") or os.path.join(_HERE, "libnid_hip.so")
 
 NID_OK = 0
 NID_SLOTS = 32
-NID_MAX_BATCH = 8
+NID_MAX_BATCH = 16
 NID_REDUCED_LEN = 32
 NID_CELL_OUT = 10
 JACBOUND_CPU, JACBOUND_CUDA = 0, 1

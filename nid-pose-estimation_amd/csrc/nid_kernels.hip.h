@@ -61,7 +61,7 @@ struct Tiles {
   uint8_t *I0;        // reference intensity
 };
 
-constexpr int kMaxBatch = 8;  // candidate poses evaluated by one launch (grid.y)
+constexpr int kMaxBatch = 16;  // candidate poses evaluated by one launch (grid.y)
 // FAST math mode: per span 4 basis functions x (4 value + 3 derivative) polynomial coefficients in
 // t = u - floor(u):  B_k = ((a3 t + a2) t + a1) t + a0,  B_k' = (d2 t + d1) t + d0
 constexpr int kCoefRow = 28;
@@ -113,6 +113,8 @@ __device__ __forceinline__ void nid_stamp(long long *buf, int cell, int k, doubl
   do {                                                       \
     if (DBG && P.dbg_stamps && pose_idx == 0) nid_stamp(P.dbg_stamps, cl, (k), ##__VA_ARGS__); \
   } while (0)
+
+static_assert(sizeof(EvalParams) <= 4096, "kernel arguments are limited to 4 KiB: lower kMaxBatch");
 
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ void xform_point(const Pose &P, double x, double y, double z,

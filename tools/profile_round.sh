@@ -9,7 +9,7 @@ tag=$1
 R=$(pwd)
 cd /tmp && export TMPDIR=/tmp
 for cfg in A B; do
-  steps=2000; [ $cfg = B ] && steps=800
+  steps=4000; [ $cfg = B ] && steps=1600
   O=$R/gpurun_out/${tag}_$cfg
   rm -rf $O
   export NID_ONE_STREAM=1
