@@ -43,6 +43,8 @@ def parse():
     ap.add_argument("--inflight", type=int, default=0, help="result slots in use (0 = all)")
     ap.add_argument("--batch", type=int, default=16,
                     help="candidate poses per kernel launch at N=1 (1 = one launch per step)")
+    ap.add_argument("--group", type=int, default=4,
+                    help="N>1: kernel launches per all-reduce (group of GROUP*BATCH poses)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -183,13 +185,14 @@ def main():
     ctx = capi.from_pair(pair, args.bins, device=local_rank, cell_begin=lo, cell_end=hi)
     if args.block_threads:
         ctx.set_block_threads(args.block_threads)
-    side = None
+    sides = None
     if world > 1:
-        # The evaluation kernel, the RCCL all-reduce and the D2H copy of a step must be ordered on ONE
-        # stream.  torch's default stream has the null handle, which nid_set_stream() reads as "use the
-        # context's own stream", so run the multi-rank path on an explicit side stream.
-        side = torch.cuda.Stream(device=dev)
-        ctx.set_stream(side.cuda_stream)
+        # The evaluation kernels of a group, its RCCL all-reduce and its D2H copy must be ordered on ONE
+        # stream; two groups are kept in flight on TWO side streams so that group j+1's kernels run
+        # while group j's (latency-bound) all-reduce and copy are in progress.  torch's default stream has
+        # the null handle, which nid_set_stream() reads as "use the context's own stream": use explicit ones.
+        sides = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
+        ctx.set_stream(sides[0].cuda_stream)
     # world == 1: the library's own in-order stream; torch.cuda.synchronize() below fences the whole device
     cnt, href = ctx.compute_href(pair.pose_init)
     delta = float(np.sqrt(0.95))
@@ -197,27 +200,34 @@ def main():
     poses = pose_trajectory(synth, pair, 256)
     nslots = capi.NID_SLOTS if not args.inflight else min(capi.NID_SLOTS, args.inflight)
 
-    # device-side result ring (world > 1): one [B, 32] group per launch, summed by ONE all-reduce
+    # device-side result ring (world > 1): a group = G launches of B poses on one stream, summed by ONE
+    # all-reduce of [G*B, 32] doubles (the collective is latency-bound: fewer, larger ones)
     B = max(1, min(args.batch, capi.NID_MAX_BATCH))
-    assert capi.NID_SLOTS % B == 0
-    ngroups = nslots // B
-    ring = torch.zeros((ngroups, B, capi.NID_REDUCED_LEN), dtype=torch.float64, device=dev)
-    host_ring = torch.zeros((ngroups, B, capi.NID_REDUCED_LEN), dtype=torch.float64).pin_memory()
+    assert capi.NID_SLOTS % B == 0 and capi.NID_SLOTS >= 2 * B
+    G = max(1, args.group)
+    ngroups = 2
+    ring = torch.zeros((ngroups, G * B, capi.NID_REDUCED_LEN), dtype=torch.float64, device=dev)
+    host_ring = torch.zeros((ngroups, G * B, capi.NID_REDUCED_LEN), dtype=torch.float64).pin_memory()
+    done = [torch.cuda.Event() for _ in range(ngroups)] if world > 1 else None
     pose_arr = np.stack(poses)
 
     def launch_group(j, n):
-        """world > 1: poses j*B .. j*B+n-1 in one kernel launch per rank, then the RCCL sum of the
-        [n, 32] partial blocks over xGMI and the copy to pinned host memory, all on `side`."""
+        """world > 1: poses j*G*B .. +n-1 as up to G kernel launches per rank on side stream j % 2 (its own
+        B slots, reused launch after launch: a stream runs them in order), then the RCCL sum of the
+        partial blocks over xGMI and the copy to pinned host memory on the same stream."""
         gidx = j % ngroups
-        first = gidx * B
         if j >= ngroups:
-            for k in range(B):
-                ctx.wait(first + k)              # the launch that last used these slots has finished
-        idx = [(j * B + k) % len(poses) for k in range(n)]
-        with torch.cuda.stream(side):
-            ctx.launch_batch(first, pose_arr[idx], delta, True, reduced_dev=ring[gidx].data_ptr())
+            done[gidx].synchronize()             # the group that last used this ring entry has been delivered
+        st = sides[gidx]
+        ctx.set_stream(st.cuda_stream)
+        with torch.cuda.stream(st):
+            for l in range((n + B - 1) // B):
+                m = min(B, n - l * B)
+                idx = [(j * G * B + l * B + k) % len(poses) for k in range(m)]
+                ctx.launch_batch(gidx * B, pose_arr[idx], delta, True, reduced_dev=ring[gidx, l * B].data_ptr())
             dist.all_reduce(ring[gidx])
             host_ring[gidx].copy_(ring[gidx], non_blocking=True)
+            done[gidx].record(st)
 
     def run(n):
         if world == 1:
@@ -225,15 +235,16 @@ def main():
             # flight); every pose's 6x6 system is collected from pinned host memory
             seq = pose_arr[np.arange(n) % len(poses)]
             return ctx.run_sequence(seq, delta, batch=B, want_jac=True)
-        nlaunch = (n + B - 1) // B
-        for j in range(nlaunch):
-            launch_group(j, min(B, n - j * B))
-        for j in range(max(0, nlaunch - ngroups), nlaunch):
-            for k in range(B):
-                try:
-                    ctx.wait((j % ngroups) * B + k)
-                except capi.NidError:
-                    pass                         # slot not used by a short last group
+        ngr = (n + G * B - 1) // (G * B)
+        for j in range(ngr):
+            launch_group(j, min(G * B, n - j * G * B))
+        for j in range(max(0, ngr - ngroups), ngr):
+            done[j % ngroups].synchronize()
+        for k in range(capi.NID_SLOTS):
+            try:
+                ctx.wait(k)                      # clear the slots' pending marks (their kernels are long done)
+            except capi.NidError:
+                pass
         return None
 
     def barrier():
@@ -262,9 +273,10 @@ def main():
             "pipelined result differs from a single launch"
     else:
         # the pipelined result of the last step must equal a synchronous evaluation of the same pose
-        jl, kl = (K - 1) // B, (K - 1) % B
+        jl, kl = (K - 1) // (G * B), (K - 1) % (G * B)
         piped = host_ring[jl % ngroups, kl].clone().numpy()
-        with torch.cuda.stream(side):
+        ctx.set_stream(sides[0].cuda_stream)
+        with torch.cuda.stream(sides[0]):
             ctx.launch(0, poses[(K - 1) % len(poses)], delta, True, reduced_dev=ring[0, 0].data_ptr())
             dist.all_reduce(ring[0, 0])
         torch.cuda.synchronize(dev)
@@ -307,10 +319,11 @@ def main():
                             f"{int((cnt[lo:hi] >= 300).sum())} active cells on rank 0",
                 "cells": ncell, "bins": args.bins,
                 "parallelism": f"cells/{world}" + ("" if world == 1 else
-                                                   f" + {'RCCL' if args.backend == 'nccl' else 'gloo'} all-reduce([{B},32] f64)"),
-                "pipelining": f"{B} candidate poses per kernel launch, {nslots // B} launches in flight, "
+                                                   f" + {'RCCL' if args.backend == 'nccl' else 'gloo'} all-reduce([{G * B},32] f64)"),
+                "pipelining": f"{B} candidate poses per kernel launch, 2 launches in flight on 2 streams, "
                               + ("each pose's 6x6 system lands in pinned host memory" if world == 1 else
-                                 f"one all-reduce of [{B},32] f64 per launch, then D2H to pinned memory"),
+                                 f"one all-reduce of [{G * B},32] f64 per {G} launches, then D2H to pinned memory; "
+                                 f"2 groups in flight on 2 streams"),
             },
             "roofline": {
                 "bound": "hbm",
