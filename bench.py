@@ -121,7 +121,23 @@ def pose_error_vs_ref(pair, bins):
     pose_cpu, recs_o = o.lm(pair.pose_init, 10)
     t_cpu = time.perf_counter() - t0
     mv = synth.pose7_minimal
+    # BASELINE configs[4]: 3-level pyramid, 10 iterations per level (own coarse-to-fine definition)
+    t0 = time.perf_counter()
+    pose_pyr, per_pyr, _ = hostlib.run_pyramid_lm(pair, bins, pair.pose_init, levels=3, iterations=10, fused=2)
+    t_pyr = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    pose_pyr_o, per_pyr_o = oracle_py.pyramid_lm(pair, bins, pair.pose_init, levels=3, iterations=10)
+    t_pyr_o = time.perf_counter() - t0
+    pyramid = {
+        "levels": 3, "iterations_per_level": 10,
+        "max_abs_minimal_vector_diff": float(np.abs(mv(pose_pyr) - mv(pose_pyr_o)).max()),
+        "same_lm_trace": [[r["lm_trials"] for r in lv] for lv in per_pyr] == [[r["lm_trials"] for r in lv] for lv in per_pyr_o],
+        "lm_outer_iterations": [len(lv) for lv in per_pyr],
+        "error_vs_truth_end": float(np.linalg.norm(mv(pair.pose_true) - mv(pose_pyr))),
+        "wall_s": {"hip_fused_batched_trials": t_pyr, "cpu_oracle_1core": t_pyr_o},
+    }
     return {
+        "pyramid_3_levels": pyramid,
         "max_abs_minimal_vector_diff": float(np.abs(mv(pose_gpu) - mv(pose_cpu)).max()),
         "fused_path_diff": float(np.abs(mv(pose_fused) - mv(pose_cpu)).max()),
         "tolerance": 1e-6,

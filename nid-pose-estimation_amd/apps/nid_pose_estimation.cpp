@@ -7,7 +7,7 @@
 //
 // Inputs: the config keys of config_eth_cvg.yaml (image0_id, image1_id,
 // image0_type, image1_type, dataset, im_address, depth_factor, fx, fy, cx, cy,
-// use_gpu) plus optional cell / bin_num / iterations.  Images are read from
+// use_gpu) plus optional cell / bin_num / iterations / fused / strict_math / pyramid_levels.  Images are read from
 // <im_address><type>/<id>.pgm and <im_address>depth/<id>.pgm (binary PGM, 8-bit
 // grey / 16-bit depth): this image has neither OpenCV nor libpng, so the ETH-CVG
 // PNGs must be converted once (tools/make_dataset.py writes the same layout for
@@ -180,9 +180,13 @@ int main(int argc, char **argv) {
   double pose7[7];
   start.toPose7(pose7);
   std::vector<nid_host_lm_record> trace(iterations);
-  std::vector<char> log(16384);
+  std::vector<char> log(65536);
   std::cout << "enter optimization ............. 0" << std::endl;
-  const int done = nid_host_run_lm(&pb, pose7, trace.data(), iterations, log.data(), (int)log.size());
+  // optional coarse-to-fine schedule (not in the reference; host/nid_pyramid.cpp): pyramid_levels > 1
+  const int levels = fc.count("pyramid_levels") ? std::atoi(fc["pyramid_levels"].c_str()) : 1;
+  const int done = levels > 1
+                       ? nid_host_run_pyramid_lm(&pb, levels, pose7, nullptr, 0, nullptr, log.data(), (int)log.size())
+                       : nid_host_run_lm(&pb, pose7, trace.data(), iterations, log.data(), (int)log.size());
   std::cerr << log.data();
   if (done < 0) { std::cerr << "optimisation failed" << std::endl; return 1; }
 

@@ -31,6 +31,15 @@ typedef struct {
 int nid_host_run_lm(const nid_pose_problem *pb, double *pose7_inout, nid_host_lm_record *trace, int max_trace,
                     char *log_buf, int log_cap);
 
+/* Coarse-to-fine schedule (own definition, see nid_pyramid.cpp): `levels`
+ * pyramid levels, `pb->iterations` LM iterations on each from the coarsest to level 0 (= *pb).  trace holds
+ * levels * max_trace_per_level records (coarsest level first), done_per_level[levels] the iterations done.
+ * Returns the total number of outer iterations, < 0 on failure (-2: sizes not divisible). */
+int nid_host_run_pyramid_lm(const nid_pose_problem *pb, int levels, double *pose7_inout, nid_host_lm_record *trace,
+                            int max_trace_per_level, int *done_per_level, char *log_buf, int log_cap);
+void nid_pyr_down_u8(const uint8_t *src, int rows, int cols, uint8_t *dst);
+void nid_pyr_down_depth_u16(const uint16_t *src, int rows, int cols, double depth_factor, uint16_t *dst);
+
 /* wall time of the optimize() call of the last nid_host_run_lm (setup excluded) */
 double nid_host_last_optimize_seconds(void);
 

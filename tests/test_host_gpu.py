@@ -126,6 +126,28 @@ def test_lm_fused_path_equals_per_edge_path(hostlib, synth, pair_A):
     assert np.array_equal(pose_c, pose_b)
 
 
+def test_pyramid_lm_pose_parity(hostlib, oracle, synth, pair_A):
+    """Coarse-to-fine schedule (BASELINE configs[4]; own definition): 3 levels x 10 LM iterations on the
+    C++ host stack + HIP kernels against the oracle's restatement of the same schedule: same accept/reject trace
+    on every level, same pose to the 1e-6 tolerance of the north star."""
+    pair, nb = pair_A, 8
+    pose_o, per_o = oracle.pyramid_lm(pair, nb, pair.pose_init, levels=3, iterations=10)
+    pose, per, log = hostlib.run_pyramid_lm(pair, nb, pair.pose_init, levels=3, iterations=10, fused=2)
+    assert "pyramid level 2: 160x120, 4x4 cells" in log and "pyramid level 0: 640x480, 16x16 cells" in log
+    assert [[r["lm_trials"] for r in lv] for lv in per] == [[r["lm_trials"] for r in lv] for lv in per_o]
+    for lv, lv_o in zip(per, per_o):
+        np.testing.assert_allclose([r["chi2"] for r in lv], [r["chi2"] for r in lv_o], rtol=1e-9)
+    d = np.abs(synth.pose7_minimal(pose) - synth.pose7_minimal(pose_o)).max()
+    print(f"pyramid: max |pose_gpu - pose_oracle| = {d:.3e}")
+    assert d < 1e-8
+    # the reference call schedule (per-edge walk) gives the same result as the fused path
+    pose_r, per_r, _ = hostlib.run_pyramid_lm(pair, nb, pair.pose_init, levels=3, iterations=10, fused=0)
+    np.testing.assert_allclose(synth.pose7_minimal(pose_r), synth.pose7_minimal(pose), rtol=0, atol=1e-8)
+    # sizes that do not divide are refused
+    with pytest.raises(RuntimeError):
+        hostlib.run_pyramid_lm(pair, nb, pair.pose_init, levels=6, iterations=2)
+
+
 def test_lm_cuda_bound_mode(hostlib, oracle, synth, pair_S):
     pair, nb = pair_S, 10
     o = oracle.from_pair(pair, nb, jac_bound="cuda", xform="matrix")
