@@ -203,11 +203,13 @@ def main():
         ctx.set_block_threads(args.block_threads)
     sides = None
     if world > 1:
-        # The evaluation kernels of a group, its RCCL all-reduce and its D2H copy must be ordered on ONE
-        # stream; two groups are kept in flight on TWO side streams so that group j+1's kernels run
-        # while group j's (latency-bound) all-reduce and copy are in progress.  torch's default stream has
-        # the null handle, which nid_set_stream() reads as "use the context's own stream": use explicit ones.
+        # Three explicit streams (torch's default stream has the null handle, which nid_set_stream() reads
+        # as "use the context's own stream"): consecutive kernel launches alternate between two COMPUTE
+        # streams, so two launches are resident at once (a shard of 32 cells x 16 poses fills only 2
+        # workgroups per CU); a COMM stream waits for a group's launches, runs its RCCL all-reduce and the
+        # D2H copy, while the compute streams already work on the next group.
         sides = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
+        comm = torch.cuda.Stream(device=dev)
         ctx.set_stream(sides[0].cuda_stream)
     # world == 1: the library's own in-order stream; torch.cuda.synchronize() below fences the whole device
     cnt, href = ctx.compute_href(pair.pose_init)
@@ -228,22 +230,27 @@ def main():
     pose_arr = np.stack(poses)
 
     def launch_group(j, n):
-        """world > 1: poses j*G*B .. +n-1 as up to G kernel launches per rank on side stream j % 2 (its own
-        B slots, reused launch after launch: a stream runs them in order), then the RCCL sum of the
-        partial blocks over xGMI and the copy to pinned host memory on the same stream."""
+        """world > 1: poses j*G*B .. +n-1 as up to G kernel launches per rank, alternating between the two
+        compute streams (each with its own B result slots, reused launch after launch: a stream runs its
+        launches in order); then, on the comm stream, the RCCL sum of the [G*B, 32] partial blocks over xGMI
+        and the copy to pinned host memory."""
         gidx = j % ngroups
         if j >= ngroups:
             done[gidx].synchronize()             # the group that last used this ring entry has been delivered
-        st = sides[gidx]
-        ctx.set_stream(st.cuda_stream)
-        with torch.cuda.stream(st):
-            for l in range((n + B - 1) // B):
-                m = min(B, n - l * B)
-                idx = [(j * G * B + l * B + k) % len(poses) for k in range(m)]
-                ctx.launch_batch(gidx * B, pose_arr[idx], delta, True, reduced_dev=ring[gidx, l * B].data_ptr())
+        nl = (n + B - 1) // B
+        for l in range(nl):
+            m = min(B, n - l * B)
+            idx = [(j * G * B + l * B + k) % len(poses) for k in range(m)]
+            st = sides[l % 2]
+            ctx.set_stream(st.cuda_stream)
+            with torch.cuda.stream(st):
+                ctx.launch_batch((l % 2) * B, pose_arr[idx], delta, True, reduced_dev=ring[gidx, l * B].data_ptr())
+        for st in sides[:min(nl, 2)]:
+            comm.wait_stream(st)
+        with torch.cuda.stream(comm):
             dist.all_reduce(ring[gidx])
             host_ring[gidx].copy_(ring[gidx], non_blocking=True)
-            done[gidx].record(st)
+            done[gidx].record(comm)
 
     def run(n):
         if world == 1:
@@ -291,6 +298,7 @@ def main():
         # the pipelined result of the last step must equal a synchronous evaluation of the same pose
         jl, kl = (K - 1) // (G * B), (K - 1) % (G * B)
         piped = host_ring[jl % ngroups, kl].clone().numpy()
+        torch.cuda.synchronize(dev)
         ctx.set_stream(sides[0].cuda_stream)
         with torch.cuda.stream(sides[0]):
             ctx.launch(0, poses[(K - 1) % len(poses)], delta, True, reduced_dev=ring[0, 0].data_ptr())
@@ -338,8 +346,8 @@ def main():
                                                    f" + {'RCCL' if args.backend == 'nccl' else 'gloo'} all-reduce([{G * B},32] f64)"),
                 "pipelining": f"{B} candidate poses per kernel launch, 2 launches in flight on 2 streams, "
                               + ("each pose's 6x6 system lands in pinned host memory" if world == 1 else
-                                 f"one all-reduce of [{G * B},32] f64 per {G} launches, then D2H to pinned memory; "
-                                 f"2 groups in flight on 2 streams"),
+                                 f"launches alternate between 2 compute streams; one all-reduce of [{G * B},32] f64 per "
+                                 f"{G} launches + D2H to pinned memory on a comm stream, 2 groups in flight"),
             },
             "roofline": {
                 "bound": "hbm",
