@@ -187,6 +187,13 @@ int nid_debug_get_stamps(nid_ctx *ctx, int64_t *stamps);
 void nid_bspline4_host(double u, int bin_num, double *B4, double *D4);
 /* host evaluation of the FAST-mode per-span polynomial B-spline table */
 void nid_bspline4_poly_host(double u, int bin_num, double *B4, double *D4);
+/* Plain-histogram NID per cell at pose7 (T_cw1): NID::ComputeHref + NID::ComputeH of the reference's second
+ * program (NID_standard_property.cpp:342-485): hard binning floor(I*bins/255), no B-spline, no Jacobian.
+ * Arrays are indexed by global cell id (only this context's cells are written), any may be NULL; cells
+ * with fewer than 300 in-frame pixels get NaN in Hcur / Hjoint / nid / mi.  *total = sqrt(sum nid^2) over
+ * this context's cells (the program's "final nid").  Needs the reference and the target, not the href state. */
+int nid_plain_nid(nid_ctx *ctx, const double *pose7, int bins, double *Href, double *Hcur, double *Hjoint,
+                  double *nid, double *mi, int32_t *n_in, double *total);
 /* host twin of the FAST-mode log2 of the entropy fold */
 double nid_log2_fast_host(double x);
 /* host twin of the kernels' division-by-small-constant helper */

@@ -177,6 +177,21 @@ int main(int argc, char **argv) {
   pb.fused = fc.count("fused") ? std::atoi(fc["fused"].c_str()) : 0;
   pb.strict_math = fc.count("strict_math") ? std::atoi(fc["strict_math"].c_str()) : 0;
 
+  if (fc.count("mode") && fc["mode"] == "standard_property") {
+    // the reference's second program (NID_standard_property.cpp): plain-histogram NID of every cell at the
+    // ground-truth relative pose, "final nid is ..." on stdout
+    pb.bin_num = fc.count("bin_num") ? bin_num : 8;  // :11
+    double gt7[7], final_nid = 0.0;
+    T_cw1_g2o.toPose7(gt7);
+    std::vector<char> out(1 << 18);
+    if (nid_host_standard_property(&pb, gt7, &final_nid, out.data(), (int)out.size()) != 0) {
+      std::cerr << out.data();
+      return 1;
+    }
+    std::cout << out.data();
+    return 0;
+  }
+
   double pose7[7];
   start.toPose7(pose7);
   std::vector<nid_host_lm_record> trace(iterations);

@@ -42,7 +42,7 @@ SYMBOLS = [
     "nid_destroy", "nid_set_options", "nid_set_math_mode", "nid_set_stream", "nid_set_block_threads",
     "nid_set_reference_depth", "nid_set_reference_points", "nid_backproject", "nid_get_points3d", "nid_set_target_u8",
     "nid_set_target_f64", "nid_set_reference_image_f64", "nid_compute_href",
-    "nid_compute_href_matrix", "nid_set_href_state", "nid_evaluate", "nid_evaluate_matrix",
+    "nid_compute_href_matrix", "nid_set_href_state", "nid_plain_nid", "nid_evaluate", "nid_evaluate_matrix",
     "nid_normal_equations", "nid_launch", "nid_launch_batch", "nid_launch_batch_to", "nid_run_sequence", "nid_wait", "nid_slot_buffers", "nid_launch_to",
     "nid_unpack_reduced", "nid_debug_enable_pixel_dump", "nid_debug_get_pixel_dump",
     "nid_debug_enable_stamps", "nid_debug_get_stamps", "nid_bspline4_host", "nid_bspline4_poly_host", "nid_log2_fast_host", "nid_div_small_host", "nid_last_kernel_ms", "nid_enable_timing", "nid_time_launches",
@@ -201,6 +201,20 @@ class Context:
         return (cnt, href, bsv, bsi) if dump else (cnt, href)
 
     # ---- per iteration --------------------------------------------------------
+    def plain_nid(self, pose7, bins=8):
+        """Plain-histogram NID per cell (NID_standard_property.cpp): dict of per-cell arrays + 'total'."""
+        n = self.ncell
+        out = {k: np.full(n, np.nan) for k in ("Href", "Hcur", "Hjoint", "nid", "mi")}
+        n_in = np.zeros(n, dtype=np.int32)
+        total = C.c_double(0)
+        self.lib.nid_plain_nid.argtypes = [C.c_void_p, c_dp, C.c_int, c_dp, c_dp, c_dp, c_dp, c_dp, c_ip, C.POINTER(C.c_double)]
+        self._check(self.lib.nid_plain_nid(self.h, _dp(_d(pose7)), int(bins), _dp(out["Href"]), _dp(out["Hcur"]),
+                                           _dp(out["Hjoint"]), _dp(out["nid"]), _dp(out["mi"]), _ip(n_in),
+                                           C.byref(total)), "nid_plain_nid")
+        out["n_in"] = n_in
+        out["total"] = float(total.value)
+        return out
+
     def evaluate(self, pose7, want_jac=True):
         Hc = np.full(self.ncell, np.nan)
         Hj = np.full(self.ncell, np.nan)

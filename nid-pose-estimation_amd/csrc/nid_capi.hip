@@ -715,6 +715,39 @@ int nid_compute_href_matrix(nid_ctx *ctx, const double *pose16, int32_t *bs_coun
   return href_common(ctx, p, bs_counter, Href, bs_value, bs_index);
 }
 
+int nid_plain_nid(nid_ctx *ctx, const double *pose7, int bins, double *Href, double *Hcur, double *Hjoint,
+                  double *nid, double *mi, int32_t *n_in, double *total) {
+  if (!ctx || !pose7 || bins < 1 || bins > kMaxPlainBins) return NID_ERR_INVALID_ARG;
+  if (!ctx->have_ref || !ctx->have_target) { ctx->last_error = "reference / target not set"; return NID_ERR_STATE; }
+  NID_HIP(ctx, hipSetDevice(ctx->cfg.device));
+  Pose p; pose_from_pose7(pose7, NID_XFORM_MATRIX, &p);  // T_cw1 * pw as a 4x4 product (:353-354)
+  const int nloc = ctx->g.nloc;
+  double *out_dev = nullptr;
+  NID_HIP(ctx, hipMalloc(&out_dev, (size_t)nloc * 6 * sizeof(double)));
+  hipLaunchKernelGGL((k_plain_nid<256>), dim3(nloc), dim3(256), 0, ctx->stream, ctx->g, p, ctx->t, ctx->im1_dev, bins,
+                     out_dev);
+  std::vector<double> o((size_t)nloc * 6);
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) e = hipMemcpyAsync(o.data(), out_dev, o.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  (void)hipFree(out_dev);
+  NID_HIP(ctx, e);
+  double sum = 0.0;
+  for (int cl = 0; cl < nloc; cl++) {
+    const int c = ctx->g.cell_begin + cl;
+    const double *r = o.data() + (size_t)cl * 6;
+    if (Href) Href[c] = r[0];
+    if (Hcur) Hcur[c] = r[1];
+    if (Hjoint) Hjoint[c] = r[2];
+    if (nid) nid[c] = r[3];
+    if (mi) mi[c] = r[4];
+    if (n_in) n_in[c] = (int32_t)r[5];
+    if (!std::isnan(r[3])) sum += r[3] * r[3];  // total_nid += nid*nid (:196), cells in row-major order
+  }
+  if (total) *total = std::sqrt(sum);  // "final nid" (:201); with cell sharding: this rank's cells only
+  return NID_OK;
+}
+
 int nid_set_href_state(nid_ctx *ctx, const int32_t *bs_counter, const double *Href,
                        const double *bs_value, const int32_t *bs_index) {
   (void)bs_index;  // the reference bin index is recomputed from im0 for every pixel (Appendix A.2)

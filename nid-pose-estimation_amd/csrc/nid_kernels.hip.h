@@ -35,6 +35,7 @@ namespace nid {
 // address and its own pair of banks, so more copies buy nothing and cost zeroing + fold time.
 constexpr int kHistCopies = 16;
 constexpr int kMaxBins = 16;
+constexpr int kMaxPlainBins = 32;  // plain-histogram mode (k_plain_nid)
 constexpr int kCellOut = 10;      // Hc, Hj, err, J[6], Nc
 constexpr int kReducedLen = 32;
 constexpr double kSigma = 1e-30;  // types_six_dof_expmap.h:281
@@ -522,6 +523,78 @@ __global__ __launch_bounds__(NT) void k_href(Geometry g, Pose pose, Tiles t, int
   if (tid == 0) {
     Nc[cl] = n_c;
     Href[cl] = (n_c < 300) ? NAN : (0.0 - v1[0]);  // CudaComputeHref.cu:206-209
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Plain-histogram NID of one cell per workgroup: NID::ComputeHref + NID::ComputeH of the reference's
+// second program (NID_standard_property.cpp:342-485) -- same warp and bilinear sample, HARD binning
+// floor(I * bins / 255), no B-spline, no Jacobian.  Counts are integers (u32 LDS atomics), so the
+// histograms are exact; the entropies are summed by one thread in the reference's bin order.
+// out[cell*6 + {0..5}] = H_ref, H_current, H_joint, nid, MI, n_in.  Cells with fewer than 300 in-frame
+// pixels get NaN for H_current / H_joint / nid / MI (the reference returns early there and then reads an
+// uninitialised nid_: not reproduced).
+template <int NT>
+__global__ __launch_bounds__(NT) void k_plain_nid(Geometry g, Pose pose, Tiles t, const uint8_t *__restrict__ im1,
+                                                  int bins, double *__restrict__ out) {
+  __shared__ unsigned h_ref[kMaxPlainBins], h_cur[kMaxPlainBins], h_joint[kMaxPlainBins * kMaxPlainBins];
+  __shared__ unsigned n_in_s;
+  const int cl = blockIdx.x, tid = threadIdx.x;
+  for (int i = tid; i < bins; i += NT) { h_ref[i] = 0u; h_cur[i] = 0u; }
+  for (int i = tid; i < bins * bins; i += NT) h_joint[i] = 0u;
+  if (tid == 0) n_in_s = 0u;
+  __syncthreads();
+  const size_t base = (size_t)cl * g.pstride;
+  for (int s = tid; s < g.pstride; s += NT) {
+    const size_t gi = base + s;
+    if (t.JR[gi] < 0) continue;  // invalid depth / padding: Get3dPointAndIntensity skips the pixel (:226-227)
+    double qx, qy, qz;
+    xform_point(pose, t.X[gi], t.Y[gi], t.Z[gi], qx, qy, qz);
+    const double u = g.fx * qx / qz + g.cx;  // :357-358
+    const double v = g.fy * qy / qz + g.cy;
+    if (!(u >= 0 && u + 3 <= g.cols && v >= 0 && v + 3 <= g.rows)) continue;  // ob++
+    double i0 = (double)t.I0[gi];
+    if (i0 >= 255) i0 = 254.999;  // :370-373
+    const int br = (int)floor(i0 * bins / 255.0);
+    double ic = bilinear_u8(im1, g.cols, u, v);
+    if (ic >= 255) ic = 254.999;  // :432-435
+    if (ic < 0) ic = 0.0;
+    const int bc = (int)floor(ic * bins / 255.0);
+    atomicAdd(&h_ref[br], 1u);
+    atomicAdd(&h_cur[bc], 1u);
+    atomicAdd(&h_joint[br * bins + bc], 1u);
+    atomicAdd(&n_in_s, 1u);
+  }
+  __syncthreads();
+  if (tid == 0) {
+    const unsigned n_in = n_in_s;
+    const double n = (double)n_in;
+    double Href = 0.0, Hc = 0.0, Hj = 0.0;
+    for (int i = 0; i < bins; i++) {
+      const double p = (double)h_ref[i] / n;
+      if (p < kSigma) continue;
+      Href -= p * log2(p);
+    }
+    double nid = NAN, mi = NAN;
+    if (n_in >= 300u) {
+      for (int i = 0; i < bins; i++) {
+        const double p = (double)h_cur[i] / n;
+        if (p < kSigma) continue;
+        Hc -= p * log2(p);
+      }
+      for (int i = 0; i < bins * bins; i++) {
+        const double p = (double)h_joint[i] / n;
+        if (p < kSigma) continue;
+        Hj -= p * log2(p);
+      }
+      nid = (2 * Hj - Href - Hc) / Hj;  // :469-470
+      mi = Href + Hc - Hj;
+      if (Href == 0.0 && Hc == 0.0 && Hj == 0.0) { mi = 0.0; nid = 0.0; }  // :474-477
+    } else {
+      Hc = NAN; Hj = NAN;
+    }
+    double *o = out + (size_t)cl * 6;
+    o[0] = Href; o[1] = Hc; o[2] = Hj; o[3] = nid; o[4] = mi; o[5] = n;
   }
 }
 

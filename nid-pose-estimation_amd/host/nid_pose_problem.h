@@ -31,6 +31,12 @@ typedef struct {
 int nid_host_run_lm(const nid_pose_problem *pb, double *pose7_inout, nid_host_lm_record *trace, int max_trace,
                     char *log_buf, int log_cap);
 
+/* The reference's second program (NID_standard_property.cpp:150-201) on the HIP library: plain-histogram NID of
+ * every cell at pose7 (T_cw1), printed per cell in the reference's format into log_buf; returns 0 and
+ * *final_nid = sqrt(sum nid^2), < 0 on failure.  pb->bin_num = number of hard bins (8 in the reference). */
+int nid_host_standard_property(const nid_pose_problem *pb, const double *pose7, double *final_nid, char *log_buf,
+                               int log_cap);
+
 /* Coarse-to-fine schedule (own definition, see nid_pyramid.cpp): `levels`
  * pyramid levels, `pb->iterations` LM iterations on each from the coarsest to level 0 (= *pb).  trace holds
  * levels * max_trace_per_level records (coarsest level first), done_per_level[levels] the iterations done.

@@ -22,6 +22,7 @@
 #include <string>
 #include <vector>
 
+#include "nid/nid_c.h"
 #include "nid_pose_problem.h"
 
 extern "C" {
@@ -104,6 +105,44 @@ int nid_host_run_pyramid_lm(const nid_pose_problem *pb, int levels, double *pose
   }
   if (log_buf && log_cap > 0) std::snprintf(log_buf, (size_t)log_cap, "%s", log.c_str());
   return total;
+}
+
+int nid_host_standard_property(const nid_pose_problem *pb, const double *pose7, double *final_nid, char *log_buf,
+                               int log_cap) {
+  if (!pb || !pose7) return -1;
+  nid_config cfg;
+  std::memset(&cfg, 0, sizeof(cfg));
+  cfg.rows = pb->rows; cfg.cols = pb->cols; cfg.cell_num = pb->cell_num; cfg.bin_num = 8; cfg.bs_degree = 3;
+  cfg.fx = pb->fx; cfg.fy = pb->fy; cfg.cx = pb->cx; cfg.cy = pb->cy;
+  nid_ctx *ctx = nullptr;
+  if (nid_create(&cfg, &ctx) != NID_OK) return -3;
+  const size_t N = (size_t)pb->rows * pb->cols;
+  std::vector<double> depth(N);
+  for (size_t i = 0; i < N; i++) depth[i] = (double)pb->depth_u16[i] * pb->depth_factor;  // convertTo(CV_64F, 1/5000), :106
+  int rc = nid_set_reference_depth(ctx, depth.data(), pb->im0, pb->T_wc0_colmajor);
+  if (rc == NID_OK) rc = nid_set_target_u8(ctx, pb->im1);
+  const int ncell = pb->cell_num * pb->cell_num;
+  std::vector<double> hr(ncell), hc(ncell), hj(ncell), nid(ncell), mi(ncell);
+  double total = 0.0;
+  if (rc == NID_OK) rc = nid_plain_nid(ctx, pose7, pb->bin_num, hr.data(), hc.data(), hj.data(), nid.data(), mi.data(), nullptr, &total);
+  std::string log;
+  if (rc == NID_OK) {
+    char line[256];
+    for (int c = 0; c < ncell; c++) {
+      if (nid[c] != nid[c]) continue;  // < 300 in-frame pixels: the reference prints nothing for the cell
+      std::snprintf(line, sizeof(line), "Href, current, joint from standard method is %g,%g,%g, MI %g, NID %g\n", hr[c], hc[c],
+                    hj[c], mi[c], nid[c]);  // :481
+      log += line;
+    }
+    std::snprintf(line, sizeof(line), "final nid is %g\n", total);  // :201
+    log += line;
+  } else {
+    log = std::string("nid_plain_nid failed: ") + nid_last_error(ctx) + "\n";
+  }
+  nid_destroy(ctx);
+  if (final_nid) *final_nid = total;
+  if (log_buf && log_cap > 0) std::snprintf(log_buf, (size_t)log_cap, "%s", log.c_str());
+  return rc == NID_OK ? 0 : -4;
 }
 
 }  // extern "C"

@@ -4,6 +4,7 @@ the oracle's LM (pose tolerance 1e-6 per minimal-vector
 component given an identical accept/reject sequence; the trace is compared too)."""
 import importlib
 import os
+import re
 import subprocess
 
 import numpy as np
@@ -170,6 +171,23 @@ def test_driver_end_to_end(hostlib, synth, pair_S, tmp_path):
     want = synth.pose7_minimal(pair_S.pose_true) - synth.pose7_minimal(pose)
     # the driver re-derives the start pose from groundtruth.txt (printed decimals), so only ~1e-9 agreement
     np.testing.assert_allclose(err, want, rtol=0, atol=1e-5)
+
+
+def test_driver_standard_property_mode(capi, synth, pair_S, tmp_path):
+    """The reference's second program (NID_standard_property.cpp) as a driver mode: per-cell lines in its
+    print format and "final nid is X" at the ground-truth relative pose."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["python", os.path.join(root, "tools", "make_dataset.py"), str(tmp_path), "S", "8"])
+    with open(tmp_path / "config.yaml", "a") as f:
+        f.write("mode: standard_property\n")
+    exe = os.path.join(root, "nid-pose-estimation_amd", "nid_pose_estimation")
+    r = subprocess.run([exe, str(tmp_path / "config.yaml")], capture_output=True, text=True, cwd=tmp_path, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert "Href, current, joint from standard method is" in r.stdout
+    final = float(re.search(r"final nid is ([0-9.eE+-]+)", r.stdout).group(1))
+    ctx = capi.from_pair(pair_S, 8)
+    want = ctx.plain_nid(pair_S.pose_true, 8)["total"]
+    assert abs(final - want) < 1e-4 * max(1.0, want)   # %g print + pose re-derived from groundtruth.txt
 
 
 def test_bench_multi_rank_code_path_on_one_gpu(tmp_path):

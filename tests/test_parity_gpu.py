@@ -377,3 +377,25 @@ def test_batched_launch_equals_single_launches(capi, synth, pair_A):
     for k in range(3):
         _, _, chi2, na = ctx.wait(k)
         assert chi2 == got[k][2] and na == got[k][3]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg,bins", [("S", 8), ("A", 8), ("A", 16)])
+def test_plain_histogram_nid_mode(capi, oracle, synth, cfg, bins):
+    """the reference's second program (NID_standard_property.cpp) -- hard-binned histograms, no
+    B-spline.  Counts are integers, so n_in is exact and the entropies agree to rounding."""
+    pair = synth.make_pair(cfg, edge_cases=(cfg == "S"))
+    ctx = capi.from_pair(pair, 8)
+    for pose in (pair.pose_init, pair.pose_true):
+        got = ctx.plain_nid(pose, bins)
+        ref = oracle.plain_nid(pair, pose, bins)
+        assert np.array_equal(got["n_in"], ref["n_in"])
+        act = ref["n_in"] >= 300
+        assert act.any()
+        for k in ("Href", "Hcur", "Hjoint", "nid", "mi"):
+            assert np.array_equal(np.isnan(got[k]), np.isnan(ref[k])), k
+            fin = ~np.isnan(ref[k])
+            np.testing.assert_allclose(got[k][fin], ref[k][fin], rtol=0, atol=1e-12, err_msg=k)
+        assert abs(got["total"] - ref["total"]) < 1e-11
+    # NID is lower at the true pose than at the disturbed start (the metric means something)
+    assert ctx.plain_nid(pair.pose_true, bins)["total"] < ctx.plain_nid(pair.pose_init, bins)["total"]
