@@ -8,10 +8,10 @@
 // Inputs: the config keys of config_eth_cvg.yaml (image0_id, image1_id,
 // image0_type, image1_type, dataset, im_address, depth_factor, fx, fy, cx, cy,
 // use_gpu) plus optional cell / bin_num / iterations / fused / strict_math / pyramid_levels.  Images are read from
-// <im_address><type>/<id>.pgm and <im_address>depth/<id>.pgm (binary PGM, 8-bit
-// grey / 16-bit depth): this image has neither OpenCV nor libpng, so the ETH-CVG
-// PNGs must be converted once (tools/make_dataset.py writes the same layout for
-// the synthetic pair).  Grey conversion of colour PNGs is out of scope.
+// <im_address><type>/<id>.png and <im_address>depth/<id>.png as in the reference (decoded
+// by host/nid_png.cpp on zlib; colour -> grey with the reference's imread/cvtColor channel
+// order), or the same stems with .pgm (binary PGM, 8-bit grey / 16-bit depth;
+// tools/make_dataset.py writes either for the synthetic pair).
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -81,6 +81,23 @@ bool read_pgm(const std::string &path, int *rows, int *cols, int *maxval, std::v
   return (bool)f;
 }
 
+// <stem>.png (host/nid_png.cpp) if it exists, else <stem>.pgm; depth = 16-bit grey
+bool read_image(const std::string &stem, bool depth, int *rows, int *cols, std::vector<uint16_t> *out) {
+  const std::string png = stem + ".png";
+  int r = 0, c = 0;
+  if (nid_png_info(png.c_str(), &r, &c, nullptr, nullptr) == 0) {
+    out->resize((size_t)r * c);
+    *rows = r; *cols = c;
+    if (depth) return nid_png_read_u16(png.c_str(), &r, &c, out->data(), out->size()) == 0;
+    std::vector<uint8_t> g((size_t)r * c);
+    if (nid_png_read_gray_u8(png.c_str(), 0, &r, &c, g.data(), g.size()) != 0) return false;
+    for (size_t i = 0; i < g.size(); i++) (*out)[i] = g[i];
+    return true;
+  }
+  int mv = 0;
+  return read_pgm(stem + ".pgm", rows, cols, &mv, out);
+}
+
 // ReadGroundtruth, NID_pose_estimation.cpp:434-530: "ts tx ty tz qx qy qz qw", line index = frame id
 std::vector<g2o::Matrix4d> read_groundtruth(const std::string &path) {
   std::vector<g2o::Matrix4d> all;
@@ -133,11 +150,12 @@ int main(int argc, char **argv) {
   const int pose_id0 = std::atoi(id0.c_str()), pose_id1 = std::atoi(id1.c_str());
   std::cout << "optimize relative pose between " << pose_id0 << " and " << pose_id1 << std::endl;
 
-  int rows = 0, cols = 0, r2 = 0, c2 = 0, mv = 0;
+  int rows = 0, cols = 0, r2 = 0, c2 = 0;
   std::vector<uint16_t> g0, g1, d0;
-  if (!read_pgm(im_add + type0 + "/" + id0 + ".pgm", &rows, &cols, &mv, &g0) ||
-      !read_pgm(im_add + type1 + "/" + id1 + ".pgm", &r2, &c2, &mv, &g1) || r2 != rows || c2 != cols ||
-      !read_pgm(im_add + "depth/" + id0 + ".pgm", &r2, &c2, &mv, &d0) || r2 != rows || c2 != cols) {
+  // <id>.png as in the reference (:84-113; colour -> grey with its imread/cvtColor channel quirk), else <id>.pgm
+  if (!read_image(im_add + type0 + "/" + id0, false, &rows, &cols, &g0) ||
+      !read_image(im_add + type1 + "/" + id1, false, &r2, &c2, &g1) || r2 != rows || c2 != cols ||
+      !read_image(im_add + "depth/" + id0, true, &r2, &c2, &d0) || r2 != rows || c2 != cols) {
     std::cerr << "cannot read the image pair / depth under " << im_add << std::endl;
     return 1;
   }

@@ -3,6 +3,7 @@
 // small host-only routines (SE(3), LDLT, Huber) for CPU unit tests.
 #ifndef NID_POSE_PROBLEM_H
 #define NID_POSE_PROBLEM_H
+#include <stddef.h>
 #include <stdint.h>
 #ifdef __cplusplus
 extern "C" {
@@ -30,6 +31,13 @@ typedef struct {
 /* returns the number of outer iterations done (or < 0); pose7 = {qx,qy,qz,qw,tx,ty,tz} in/out */
 int nid_host_run_lm(const nid_pose_problem *pb, double *pose7_inout, nid_host_lm_record *trace, int max_trace,
                     char *log_buf, int log_cap);
+
+/* PNG input of the reference's driver (host/nid_png.cpp; zlib only).  Return 0, or -1 cannot open, -2 not a
+ * PNG / corrupt, -3 unsupported variant, -4 inflate failed, -5 buffer too small.  With out == NULL only the
+ * size is returned.  swap_rb = 0 reproduces the driver's imread(UNCHANGED) + CV_RGB2GRAY (blue weighted as red). */
+int nid_png_info(const char *path, int *rows, int *cols, int *channels, int *bit_depth);
+int nid_png_read_gray_u8(const char *path, int swap_rb, int *rows, int *cols, uint8_t *out, size_t cap);
+int nid_png_read_u16(const char *path, int *rows, int *cols, uint16_t *out, size_t cap);
 
 /* The reference's second program (NID_standard_property.cpp:150-201) on the HIP library: plain-histogram NID of
  * every cell at pose7 (T_cw1), printed per cell in the reference's format into log_buf; returns 0 and

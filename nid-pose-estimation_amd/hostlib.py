@@ -191,6 +191,36 @@ def pyr_down_depth_u16(dep, depth_factor=1.0 / 5000):
     return out
 
 
+def png_read_gray_u8(path, swap_rb=False):
+    """Grey u8 image from a PNG the way the reference's driver gets it (imread UNCHANGED + CV_RGB2GRAY)."""
+    lib = load()
+    lib.nid_png_read_gray_u8.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_uint8), C.c_size_t]
+    r, c = C.c_int(0), C.c_int(0)
+    rc = lib.nid_png_read_gray_u8(os.fsencode(path), int(swap_rb), C.byref(r), C.byref(c), None, 0)
+    if rc:
+        raise RuntimeError(f"nid_png_read_gray_u8({path}) -> {rc}")
+    out = np.zeros((r.value, c.value), dtype=np.uint8)
+    rc = lib.nid_png_read_gray_u8(os.fsencode(path), int(swap_rb), C.byref(r), C.byref(c),
+                                  out.ctypes.data_as(C.POINTER(C.c_uint8)), out.size)
+    if rc:
+        raise RuntimeError(f"nid_png_read_gray_u8({path}) -> {rc}")
+    return out
+
+
+def png_read_u16(path):
+    lib = load()
+    lib.nid_png_read_u16.argtypes = [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_uint16), C.c_size_t]
+    r, c = C.c_int(0), C.c_int(0)
+    rc = lib.nid_png_read_u16(os.fsencode(path), C.byref(r), C.byref(c), None, 0)
+    if rc:
+        raise RuntimeError(f"nid_png_read_u16({path}) -> {rc}")
+    out = np.zeros((r.value, c.value), dtype=np.uint16)
+    rc = lib.nid_png_read_u16(os.fsencode(path), C.byref(r), C.byref(c), out.ctypes.data_as(C.POINTER(C.c_uint16)), out.size)
+    if rc:
+        raise RuntimeError(f"nid_png_read_u16({path}) -> {rc}")
+    return out
+
+
 def last_optimize_seconds():
     """Wall time of optimize() inside the last run_lm (per-pair setup excluded)."""
     return float(load().nid_host_last_optimize_seconds())

@@ -72,7 +72,7 @@ def test_huber_float_threshold(hostlib):
 def test_host_library_exports(hostlib):
     nm = subprocess.run(["nm", "-D", "--defined-only", hostlib.LIB_PATH], capture_output=True, text=True).stdout
     for sym in ("nid_host_run_lm", "nid_host_run_pyramid_lm", "nid_pyr_down_u8", "nid_pyr_down_depth_u16",
-                "nid_host_standard_property", "nid_legacy_reset", "nid_legacy_context", "nid_legacy_upload_count",
+                "nid_host_standard_property", "nid_png_info", "nid_png_read_gray_u8", "nid_png_read_u16", "nid_legacy_reset", "nid_legacy_context", "nid_legacy_upload_count",
                 "nid_legacy_set_jacobian_bound"):
         assert re.search(rf" T {sym}\b", nm), sym
     # the three legacy operators keep their C++ linkage (mangled), as in the reference
@@ -109,6 +109,107 @@ def test_pyramid_downsampling_matches_oracle(hostlib, oracle):
     assert [(p.rows, p.cols, p.cell) for p in lv] == [(480, 640, 16), (240, 320, 8), (120, 160, 4)]
     assert lv[1].fx == lv[0].fx / 2 and lv[1].cx == (lv[0].cx - 0.5) / 2
     assert np.array_equal(hostlib.pyr_down_u8(lv[0].im1), lv[1].im1)
+
+
+def _png_bytes(img, depth, colour, filters, palette=None, split=1, interlace=0):
+    """Reference PNG encoder for the reader test: every scanline filtered with the type the caller asks for."""
+    import struct
+    import zlib
+    img = np.ascontiguousarray(img)
+    raw = img.astype(">u2").tobytes() if depth == 16 else img.astype(np.uint8).tobytes()
+    ch = {0: 1, 2: 3, 3: 1, 4: 2, 6: 4}[colour]
+    bpp = ch * depth // 8
+    stride = img.shape[1] * bpp
+    rows = [bytearray(raw[r * stride:(r + 1) * stride]) for r in range(img.shape[0])]
+    out = bytearray()
+    for r, cur in enumerate(rows):
+        ft = filters[r % len(filters)]
+        up = rows[r - 1] if r else bytearray(stride)
+        line = bytearray(stride)
+        for i in range(stride):
+            a = cur[i - bpp] if i >= bpp else 0
+            b = up[i]
+            c = up[i - bpp] if i >= bpp else 0
+            if ft == 0: pred = 0
+            elif ft == 1: pred = a
+            elif ft == 2: pred = b
+            elif ft == 3: pred = (a + b) >> 1
+            else:
+                p = a + b - c
+                pa, pb, pc = abs(p - a), abs(p - b), abs(p - c)
+                pred = a if (pa <= pb and pa <= pc) else (b if pb <= pc else c)
+            line[i] = (cur[i] - pred) & 0xFF
+        out += bytes([ft]) + line
+
+    def chunk(t, d):
+        return struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d) & 0xffffffff)
+    z = zlib.compress(bytes(out), 6)
+    parts = [z[i * len(z) // split:(i + 1) * len(z) // split] for i in range(split)]
+    body = chunk(b"IHDR", struct.pack(">IIBBBBB", img.shape[1], img.shape[0], depth, colour, 0, 0, interlace))
+    if palette is not None:
+        body += chunk(b"PLTE", np.asarray(palette, dtype=np.uint8).tobytes())
+    body += chunk(b"tEXt", b"Comment\x00ancillary chunks are skipped")
+    for part in parts:
+        body += chunk(b"IDAT", part)
+    return b"\x89PNG\r\n\x1a\n" + body + chunk(b"IEND", b"")
+
+
+def _cv_gray(rgb, swap_rb):
+    r, g, b = (rgb[..., k].astype(np.int64) for k in range(3))
+    c0, c2 = (r, b) if swap_rb else (b, r)
+    return ((c0 * 4899 + g * 9617 + c2 * 1868 + 8192) >> 14).astype(np.uint8)
+
+
+def test_png_reader_and_grey_conversion(hostlib, tmp_path):
+    """PNG decoding on zlib (all five scanline filters, 8/16 bit, grey / RGB / RGBA / palette,
+    split IDAT) and the driver's colour -> grey conversion (OpenCV fixed point with the reference's channel
+    order quirk).  OpenCV itself is not available: the conversion is checked against its published formula."""
+    rng = np.random.default_rng(3)
+    rgb = rng.integers(0, 256, (13, 17, 3), dtype=np.uint8)
+    rgb[0, 0] = (255, 255, 255); rgb[0, 1] = (0, 0, 0); rgb[0, 2] = (255, 0, 0); rgb[0, 3] = (0, 0, 255)
+    for filters, split in (([0], 1), ([1], 1), ([2], 2), ([3], 1), ([4], 3), ([0, 1, 2, 3, 4], 2)):
+        p = tmp_path / "rgb.png"
+        p.write_bytes(_png_bytes(rgb, 8, 2, filters, split=split))
+        assert np.array_equal(hostlib.png_read_gray_u8(str(p)), _cv_gray(rgb, False)), filters
+        assert np.array_equal(hostlib.png_read_gray_u8(str(p), swap_rb=True), _cv_gray(rgb, True)), filters
+    assert _cv_gray(rgb, False)[0, 2] == 29 and _cv_gray(rgb, True)[0, 2] == 76   # pure red: quirk vs luma
+    rgba = np.concatenate([rgb, rng.integers(0, 256, (13, 17, 1), dtype=np.uint8)], axis=2)
+    (tmp_path / "rgba.png").write_bytes(_png_bytes(rgba, 8, 6, [4, 3]))
+    assert np.array_equal(hostlib.png_read_gray_u8(str(tmp_path / "rgba.png")), _cv_gray(rgb, False))
+    grey = rng.integers(0, 256, (9, 11), dtype=np.uint8)
+    (tmp_path / "g8.png").write_bytes(_png_bytes(grey, 8, 0, [1, 4]))
+    assert np.array_equal(hostlib.png_read_gray_u8(str(tmp_path / "g8.png")), grey)
+    assert np.array_equal(hostlib.png_read_u16(str(tmp_path / "g8.png")), grey.astype(np.uint16))
+    d16 = rng.integers(0, 65536, (9, 11)).astype(np.uint16)
+    for filters in ([0], [2, 4, 1, 3]):
+        (tmp_path / "d16.png").write_bytes(_png_bytes(d16, 16, 0, filters))
+        assert np.array_equal(hostlib.png_read_u16(str(tmp_path / "d16.png")), d16)
+    pal = rng.integers(0, 256, (16, 3), dtype=np.uint8)
+    idx = rng.integers(0, 16, (7, 5), dtype=np.uint8)
+    (tmp_path / "pal.png").write_bytes(_png_bytes(idx, 8, 3, [0, 1], palette=pal))
+    assert np.array_equal(hostlib.png_read_gray_u8(str(tmp_path / "pal.png")), _cv_gray(pal[idx], False))
+    # interop with a real encoder, when one is around
+    try:
+        from PIL import Image
+    except Exception:
+        Image = None
+    if Image is not None:
+        Image.fromarray(rgb, "RGB").save(tmp_path / "pil_rgb.png")
+        assert np.array_equal(hostlib.png_read_gray_u8(str(tmp_path / "pil_rgb.png")), _cv_gray(rgb, False))
+        Image.fromarray(d16.astype(np.uint16)).save(tmp_path / "pil_d16.png")
+        assert np.array_equal(hostlib.png_read_u16(str(tmp_path / "pil_d16.png")), d16)
+    # refusals
+    lib = hostlib.load()
+    bad = tmp_path / "bad.png"
+    bad.write_bytes(_png_bytes(rgb, 8, 2, [0])[:60])
+    assert lib.nid_png_info(os.fsencode(str(bad)), None, None, None, None) in (-2, -4)
+    bad.write_bytes(_png_bytes(rgb, 8, 2, [0], interlace=1))
+    assert lib.nid_png_info(os.fsencode(str(bad)), None, None, None, None) == -3
+    bad.write_bytes(b"P5\n2 2\n255\n1234")
+    assert lib.nid_png_info(os.fsencode(str(bad)), None, None, None, None) == -2
+    assert lib.nid_png_info(os.fsencode(str(tmp_path / "missing.png")), None, None, None, None) == -1
+    with pytest.raises(RuntimeError):
+        hostlib.png_read_u16(str(tmp_path / "rgb.png"))      # depth must be single-channel
 
 
 def test_driver_refuses_cpu_mode(tmp_path):

@@ -2,7 +2,7 @@
 """Write the synthetic pair in the ETH-CVG directory layout the driver reads
 (<dir>/rgb/<id>.pgm, <dir>/depth/<id>.pgm 16-bit, <dir>/groundtruth.txt) plus a
 config in the format of the reference's config_eth_cvg.yaml.
-Usage: tools/make_dataset.py OUT_DIR [A|B|S] [bins]"""
+Usage: tools/make_dataset.py OUT_DIR [A|B|S] [bins] [pgm|png]"""
 import importlib
 import os
 import sys
@@ -21,16 +21,44 @@ def write_pgm(path, img):
         f.write(img.tobytes() if img.dtype == np.uint8 else img.astype(">u2").tobytes())
 
 
+def write_png(path, img):
+    """Minimal PNG writer (zlib only): u8 [r,c] or [r,c,3] -> 8-bit grey / RGB, u16 [r,c] -> 16-bit grey."""
+    import struct
+    import zlib
+    img = np.ascontiguousarray(img)
+    if img.dtype == np.uint16:
+        depth, colour, raw = 16, 0, img.astype(">u2").tobytes()
+        stride = img.shape[1] * 2
+    else:
+        depth, colour = 8, (2 if img.ndim == 3 else 0)
+        raw = img.tobytes()
+        stride = img.shape[1] * (3 if img.ndim == 3 else 1)
+    rows = [b"\x00" + raw[r * stride:(r + 1) * stride] for r in range(img.shape[0])]
+
+    def chunk(t, d):
+        return struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d) & 0xffffffff)
+    with open(path, "wb") as f:
+        f.write(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", img.shape[1], img.shape[0], depth, colour, 0, 0, 0))
+                + chunk(b"IDAT", zlib.compress(b"".join(rows), 6)) + chunk(b"IEND", b""))
+
+
 def main():
     out = sys.argv[1]
     cfg = sys.argv[2] if len(sys.argv) > 2 else "A"
     bins = int(sys.argv[3]) if len(sys.argv) > 3 else 10
+    fmt = sys.argv[4] if len(sys.argv) > 4 else "pgm"
     pair = synth.make_pair(cfg)
     os.makedirs(os.path.join(out, "rgb"), exist_ok=True)
     os.makedirs(os.path.join(out, "depth"), exist_ok=True)
-    write_pgm(os.path.join(out, "rgb", "0000.pgm"), pair.im0)
-    write_pgm(os.path.join(out, "rgb", "0001.pgm"), pair.im1)
-    write_pgm(os.path.join(out, "depth", "0000.pgm"), pair.depth_u16)
+    if fmt == "png":
+        # grey value in all three channels: the driver's colour -> grey conversion returns it unchanged
+        write_png(os.path.join(out, "rgb", "0000.png"), np.repeat(pair.im0[:, :, None], 3, axis=2))
+        write_png(os.path.join(out, "rgb", "0001.png"), np.repeat(pair.im1[:, :, None], 3, axis=2))
+        write_png(os.path.join(out, "depth", "0000.png"), pair.depth_u16)
+    else:
+        write_pgm(os.path.join(out, "rgb", "0000.pgm"), pair.im0)
+        write_pgm(os.path.join(out, "rgb", "0001.pgm"), pair.im1)
+        write_pgm(os.path.join(out, "depth", "0000.pgm"), pair.depth_u16)
     T_wc1 = np.linalg.inv(synth.pose7_to_matrix(pair.pose_true))
     with open(os.path.join(out, "groundtruth.txt"), "w") as f:
         for k, T in enumerate((pair.T_wc0, T_wc1)):
