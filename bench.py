@@ -370,10 +370,9 @@ def main():
             },
         }
         out["check"] = {"chi2": chi2, "n_active": int(na), "H00": float(H[0, 0]), "b0": float(b[0])}
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:   # CPU legs: rank 0 at N=1 only
             out["cpu_baseline"] = cpu_baseline(pair, args.bins, args.cpu_seconds)
-            if world == 1:
-                out["pose_error_vs_ref"] = pose_error_vs_ref(pair, args.bins)
+            out["pose_error_vs_ref"] = pose_error_vs_ref(pair, args.bins)
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()
