@@ -474,8 +474,10 @@ int nid_create(const nid_config *cfg, nid_ctx **out) {
   if (g.ps > 8192) { delete ctx; return NID_ERR_UNSUPPORTED; }
   int bits = 0;
   while ((1 << bits) < g.ps + 1) bits++;
-  ctx->hist_scale = std::ldexp(1.0, 62 - bits);
-  ctx->hist_inv_scale = std::ldexp(1.0, -(62 - bits));
+  // whole-cell sums stay below 2^62 and every single weight (<= 1) below the 2^52 of the magic-number encode
+  const int hs = std::min(62 - bits, 51);
+  ctx->hist_scale = std::ldexp(1.0, hs);
+  ctx->hist_inv_scale = std::ldexp(1.0, -hs);
   // k_eval2 accumulates raw 2^52-magic bit patterns and masks the top 12 bits per copy in the fold,
   // so no copy may carry out of 52 bits: a copy receives at most rounds * 256 / kHistCopies weights
   // (each <= 1) per bin.

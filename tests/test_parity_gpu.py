@@ -399,3 +399,117 @@ def test_plain_histogram_nid_mode(capi, oracle, synth, cfg, bins):
         assert abs(got["total"] - ref["total"]) < 1e-11
     # NID is lower at the true pose than at the disturbed start (the metric means something)
     assert ctx.plain_nid(pair.pose_true, bins)["total"] < ctx.plain_nid(pair.pose_init, bins)["total"]
+
+
+GEOMETRIES = {
+    # rows, cols, cell: trailing rows / columns that belong to no cell (Q11), one huge cell (24 pixel rounds per
+    # wave), cells of exactly 300 pixels (the activity threshold), a single row of cells
+    "ragged": (123, 166, 4),
+    "one_cell": (64, 96, 1),
+    "threshold_cells": (120, 160, 8),
+    "wide": (60, 320, 2),
+}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("math", MODES)
+@pytest.mark.parametrize("geom", sorted(GEOMETRIES))
+def test_edge_geometries(capi, oracle, synth, geom, math):
+    rows, cols, cell = GEOMETRIES[geom]
+    pair = synth.make_pair("S", rows=rows, cols=cols, cell=cell, edge_cases=geom in ("ragged", "wide"))
+    nb = 8
+    ctx = capi.from_pair(pair, nb, math=_mode(capi, math))
+    o = oracle.from_pair(pair, nb)
+    pts = ctx.get_points3d()                       # Calculate3Dpoint covers the pixels outside every cell too
+    m = ~np.isnan(o.points3d)
+    assert np.array_equal(np.isnan(pts), np.isnan(o.points3d))
+    assert np.array_equal(_bits(pts[m]), _bits(o.points3d[m]))
+    cnt, href = ctx.compute_href(pair.pose_init)
+    cnt_o, href_o = o.compute_href(pair.pose_init)
+    assert np.array_equal(cnt, cnt_o)
+    act = cnt_o >= 300
+    assert act.any()
+    if geom == "threshold_cells":                  # 15x20-pixel cells: active only if every pixel is in frame
+        assert (cnt_o == 300).any() and (~act).any()
+    np.testing.assert_allclose(href[act], href_o[act], rtol=0, atol=ATOL_H)
+    for name, pose in _poses(synth, pair).items():
+        got = ctx.evaluate(pose, True)
+        ref = o.evaluate(pose, True)
+        _compare_cells(got, ref, cnt_o, loose=_saturated_cells(o, pair) if math == "fast" else None)
+        H, b, chi2, na = ctx.normal_equations(pose, DELTA)
+        assert na == int(act.sum())
+        H_o, b_o, chi2_o, na_o = oracle.normal_equations(ref[2], ref[3], DELTA)
+        assert na_o == na
+        if np.isfinite(chi2_o):
+            # FAST math on cells with saturation-clamp samples is only good to 1e-4 per cell (_saturated_cells)
+            sat = math == "fast" and (_saturated_cells(o, pair) & act).any()
+            assert abs(chi2 - chi2_o) <= (1e-3 if sat else 1e-9) * max(1.0, abs(chi2_o))
+            np.testing.assert_allclose(H, H_o, rtol=0, atol=(5e-2 if sat else 1e-7) * max(1.0, np.abs(H_o).max()))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nb", [4, 5, 16])
+def test_extreme_bin_counts(capi, oracle, synth, pair_S_edge, nb):
+    """bin_num = 4 is a single B-spline span (S = 1), 16 is the LDS-table maximum."""
+    pair = pair_S_edge
+    for math in MODES:
+        ctx = capi.from_pair(pair, nb, math=_mode(capi, math))
+        o = oracle.from_pair(pair, nb)
+        cnt, href = ctx.compute_href(pair.pose_init)
+        cnt_o, href_o = o.compute_href(pair.pose_init)
+        assert np.array_equal(cnt, cnt_o)
+        act = cnt_o >= 300
+        np.testing.assert_allclose(href[act], href_o[act], rtol=0, atol=ATOL_H)
+        for pose in (pair.pose_init, pair.pose_true):
+            _compare_cells(ctx.evaluate(pose, True), o.evaluate(pose, True), cnt_o,
+                           loose=_saturated_cells(o, pair) if math == "fast" else None)
+    with pytest.raises(capi.NidError):
+        capi.Context(pair.rows, pair.cols, pair.cell, 17, pair.fx, pair.fy, pair.cx, pair.cy)
+    with pytest.raises(capi.NidError):
+        capi.Context(pair.rows, pair.cols, pair.cell, 3, pair.fx, pair.fy, pair.cx, pair.cy)
+
+
+@pytest.mark.gpu
+def test_degenerate_inputs(capi, oracle, synth, pair_S):
+    """No valid depth at all (every cell inactive) and a pose that throws every pixel out of the frame (cells
+    stay active by their initial-pose count, Q1, but their histograms are empty)."""
+    import dataclasses
+    nb = 8
+    empty = dataclasses.replace(pair_S, depth_u16=np.zeros_like(pair_S.depth_u16))
+    ctx = capi.from_pair(empty, nb)
+    cnt, href = ctx.compute_href(empty.pose_init)
+    assert not cnt.any() and np.isnan(href).all()
+    Hc, Hj, err, J = ctx.evaluate(empty.pose_init, True)
+    assert np.isnan(err).all() and np.isnan(J).all()
+    H, b, chi2, na = ctx.normal_equations(empty.pose_init, DELTA)
+    assert na == 0 and chi2 == 0.0 and not H.any() and not b.any()
+
+    ctx = capi.from_pair(pair_S, nb)
+    o = oracle.from_pair(pair_S, nb)
+    cnt, _ = ctx.compute_href(pair_S.pose_init)
+    cnt_o, _ = o.compute_href(pair_S.pose_init)
+    away = synth.perturb_pose7(pair_S.pose_init, [0.0, 0.0, 0.0], [50.0, 0.0, 0.0])
+    got, ref = ctx.evaluate(away, True), o.evaluate(away, True)
+    act = cnt_o >= 300
+    for a, r in zip(got[:3], ref[:3]):
+        assert np.array_equal(np.isnan(a[act]), np.isnan(r[act]))
+        fin = np.isfinite(r[act])
+        assert np.array_equal(np.isfinite(a[act]), fin)
+        np.testing.assert_allclose(a[act][fin], r[act][fin], rtol=0, atol=ATOL_H)
+
+
+@pytest.mark.gpu
+def test_full_batch_of_sixteen(capi, synth, pair_S):
+    """NID_MAX_BATCH poses in one launch (3.7 KB of kernel arguments) == the single launches, bit for bit."""
+    ctx = capi.from_pair(pair_S, 8)
+    ctx.compute_href(pair_S.pose_init)
+    assert capi.NID_MAX_BATCH == 16
+    poses = [synth.perturb_pose7(pair_S.pose_init, [1e-3 * k, -5e-4 * k, 0], [0, 1e-3 * k, 1e-3]) for k in range(16)]
+    ctx.launch_batch(16, poses, DELTA)
+    got = [ctx.wait(16 + k) for k in range(16)]
+    for k, p in enumerate(poses):
+        H, b, chi2, na = ctx.normal_equations(p, DELTA)
+        assert np.array_equal(_bits(H), _bits(got[k][0])) and np.array_equal(_bits(b), _bits(got[k][1]))
+        assert chi2 == got[k][2] and na == got[k][3]
+    with pytest.raises(capi.NidError):
+        ctx.launch_batch(0, poses + poses[:1], DELTA)
