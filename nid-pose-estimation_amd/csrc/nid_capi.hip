@@ -471,7 +471,7 @@ int nid_create(const nid_config *cfg, nid_ctx **out) {
   g.cell_begin = cb_; g.nloc = ce_ - cb_;
   g.nb = cfg->bin_num; g.S = cfg->bin_num - 3;
   g.fx = cfg->fx; g.fy = cfg->fy; g.cx = cfg->cx; g.cy = cfg->cy;
-  if (g.ps > 8192) { delete ctx; return NID_ERR_UNSUPPORTED; }
+  if (g.ps > (1 << 20)) { delete ctx; return NID_ERR_UNSUPPORTED; }  // fixed-point head-room of the histograms
   int bits = 0;
   while ((1 << bits) < g.ps + 1) bits++;
   // whole-cell sums stay below 2^62 and every single weight (<= 1) below the 2^52 of the magic-number encode

@@ -406,6 +406,7 @@ GEOMETRIES = {
     # wave), cells of exactly 300 pixels (the activity threshold), a single row of cells
     "ragged": (123, 166, 4),
     "one_cell": (64, 96, 1),
+    "one_big_cell": (120, 160, 1),   # 19 200 pixels in one workgroup: 75 rounds
     "threshold_cells": (120, 160, 8),
     "wide": (60, 320, 2),
 }
@@ -416,7 +417,7 @@ GEOMETRIES = {
 @pytest.mark.parametrize("geom", sorted(GEOMETRIES))
 def test_edge_geometries(capi, oracle, synth, geom, math):
     rows, cols, cell = GEOMETRIES[geom]
-    pair = synth.make_pair("S", rows=rows, cols=cols, cell=cell, edge_cases=geom in ("ragged", "wide"))
+    pair = synth.make_pair("S", rows=rows, cols=cols, cell=cell, edge_cases=geom in ("ragged", "wide", "one_big_cell"))
     nb = 8
     ctx = capi.from_pair(pair, nb, math=_mode(capi, math))
     o = oracle.from_pair(pair, nb)
