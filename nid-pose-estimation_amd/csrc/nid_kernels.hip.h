@@ -630,78 +630,59 @@ __device__ __forceinline__ void quad_ab(int slot, int &a, int &b) {
   a = aa; b = aa + k;
 }
 
-// Sum `count` 32-double blocks (stride kQuad) starting at `src` in a fixed order:
-// thread (v = tid & 31, sub = tid >> 5) adds blocks sub, sub+SUB, ... with all of
-// its (sc1) loads in flight, then the SUB partial sums are combined in order.
-// Result: lanes tid < 32 hold element tid.
-template <int NT>
-__device__ __forceinline__ double sum_blocks(const double *src, int count, double *part, int tid) {
-  constexpr int SUB = NT / 32;
-  const int v = tid & 31, sub = tid >> 5;
+// Two-level in-launch reduction of the per-cell blocks (cells -> groups of P.group_size cells -> total),
+// each level a ticket + last-arriver sum, so the serial read of any one wave is
+// <= max(group_size, ngroups) * 256 B.
+// Run by ONE wave (wave 0 of the workgroup; the other waves have retired by then).
+// 64 lanes: v = lane & 31 selects the element, half = lane >> 5 the even / odd blocks; eight sc1 loads in
+// flight per lane, the two halves are combined with one cross-lane read.  Result in lanes 0..31.
+__device__ __forceinline__ double sum_blocks_w0(const double *src, int count, int lane) {
+  const int v = lane & 31, half = lane >> 5;
   double x[8];
   double s = 0.0;
-  for (int c0 = sub; c0 < count; c0 += 8 * SUB) {
+  for (int c0 = half; c0 < count; c0 += 16) {
 #pragma unroll
     for (int k = 0; k < 8; k++) {
-      const int c = c0 + k * SUB;
+      const int c = c0 + 2 * k;
       x[k] = (c < count) ? load_sc1(src + (size_t)c * kQuad + v) : 0.0;
     }
 #pragma unroll
     for (int k = 0; k < 8; k++) s += x[k];
   }
-  part[sub * 32 + v] = s;
-  __syncthreads();
-  double r = 0.0;
-  if (tid < 32) {
-    r = part[tid];
-    for (int k = 1; k < SUB; k++) r += part[k * 32 + tid];
-  }
-  return r;
+  return s + __shfl_down(s, 32, 64);
 }
 
-// Two-level in-launch reduction of the per-cell blocks (cells -> groups of
-// P.group_size cells -> total), each level a ticket + last-arriver sum, so the
-// serial read of any one workgroup is <= max(group_size, ngroups) * 256 B.
-template <int NT>
-__device__ __forceinline__ void finish_and_reduce(const EvalParams &P, const SlotArgs &SA, int cl, int tid,
-                                                  double *lds_scratch /* >= NT + 2 doubles */) {
-  unsigned *flag = reinterpret_cast<unsigned *>(lds_scratch);
-  double *part = lds_scratch + 2;
+// Called by wave 0 only, all 64 lanes active, after it has stored (sc1) this cell's 32-double block.
+__device__ __forceinline__ void finish_and_reduce_w0(const EvalParams &P, const SlotArgs &SA, int cl, int lane) {
   const int gs = P.group_size;
   const int gq = cl / gs;
   const int ngroups = (P.g.nloc + gs - 1) / gs;
   const int gcount = min(gs, P.g.nloc - gq * gs);
-  // level 0: this cell's block has been stored (sc1) by wave 0 -- drain, take a group ticket
-  if (tid < 64) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (tid == 0) {
-      const unsigned old = __hip_atomic_fetch_add(SA.ticket + 1 + gq, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      flag[0] = (old == (unsigned)(gcount - 1)) ? 1u : 0u;
-    }
+  // level 0: drain the block's stores, take a group ticket
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  unsigned last = 0u;
+  if (lane == 0) {
+    const unsigned old = __hip_atomic_fetch_add(SA.ticket + 1 + gq, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    last = (old == (unsigned)(gcount - 1)) ? 1u : 0u;
   }
-  __syncthreads();
-  if (flag[0] == 0u) return;  // uniform
-  __syncthreads();            // flag consumed before the scratch is reused
-  double r = sum_blocks<NT>(SA.quad + (size_t)gq * gs * kQuad, gcount, part, tid);
+  if (__builtin_amdgcn_readfirstlane(last) == 0u) return;
+  double r = sum_blocks_w0(SA.quad + (size_t)gq * gs * kQuad, gcount, lane);
   // level 1: publish the group sum, take the top ticket
-  if (tid < 64) {
-    if (tid < 32) store_sc1(SA.gpart + (size_t)gq * kQuad + tid, r);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (tid == 0) {
-      __hip_atomic_store(SA.ticket + 1 + gq, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const unsigned old = __hip_atomic_fetch_add(SA.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      flag[0] = (old == (unsigned)(ngroups - 1)) ? 1u : 0u;
-    }
+  if (lane < 32) store_sc1(SA.gpart + (size_t)gq * kQuad + lane, r);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  last = 0u;
+  if (lane == 0) {
+    __hip_atomic_store(SA.ticket + 1 + gq, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned old = __hip_atomic_fetch_add(SA.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    last = (old == (unsigned)(ngroups - 1)) ? 1u : 0u;
   }
-  __syncthreads();
-  if (flag[0] == 0u) return;
-  __syncthreads();
-  r = sum_blocks<NT>(SA.gpart, ngroups, part, tid);
-  if (tid < 32) SA.out_reduced[tid] = r;
-  if (tid == 0) __hip_atomic_store(SA.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  if (SA.host_seq && tid < 64) {  // results live in pinned host memory: publish at system scope
+  if (__builtin_amdgcn_readfirstlane(last) == 0u) return;
+  r = sum_blocks_w0(SA.gpart, ngroups, lane);
+  if (lane < 32) SA.out_reduced[lane] = r;
+  if (lane == 0) __hip_atomic_store(SA.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (SA.host_seq) {  // results live in pinned host memory: publish at system scope
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (tid == 0) {
+    if (lane == 0) {
       __threadfence_system();
       __hip_atomic_store(SA.host_seq, SA.launch_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
@@ -871,9 +852,10 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(STRICT ? 4 :
   double *out = SA.cellout + (size_t)cl * kCellOut;
   double *quad = SA.quad + (size_t)cl * kQuad;
   if (n_c < 300 || isnan(href)) {  // level-1 edge: never evaluated (computeH.cu:271-275)
+    if (tid >= 64) return;
     if (tid < kCellOut) out[tid] = (tid == kCellOut - 1) ? (double)n_c : NAN;
     if (tid < kQuad) store_sc1(quad + tid, 0.0);
-    finish_and_reduce<NT>(P, SA, cl, tid, red);
+    finish_and_reduce_w0(P, SA, cl, tid);
     return;
   }
   NID_STAMP(0);
@@ -995,11 +977,11 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(STRICT ? 4 :
   rho0 = wave_uniform(rho0);
   rho1 = wave_uniform(rho1);
   if (!JAC) {
+    if (tid >= 64) return;  // the cell's tail is wave 0's business: the other waves free their slots now
     if (tid == 0) { out[0] = Hc; out[1] = Hj; out[2] = err; out[kCellOut - 1] = (double)n_c; }
     if (tid < kQuad) store_sc1(quad + tid, tid == 0 ? rho0 : (tid == 28 ? 1.0 : 0.0));
-    __syncthreads();
     NID_STAMP(6);
-    finish_and_reduce<NT>(P, SA, cl, tid, red);
+    finish_and_reduce_w0(P, SA, cl, tid);
     NID_STAMP(7);
     return;
   }
@@ -1110,10 +1092,29 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(STRICT ? 4 :
   }
   if (!STRICT) { acc[0] = -acc[0]; acc[5] = -acc[5]; }
   NID_STAMP(4, acc[0], acc[2], acc[3], acc[5]);
-  __syncthreads();
-  block_sum<NT, 6>(acc, red, tid);
+  __syncthreads();  // the fold's use of `red` is over
+  // Block sum of the six accumulators: every wave reduces its own (DPP), lane 63 leaves the partials in LDS;
+  // after the barrier waves 1..3 retire -- the cell's tail (quadratic form, hand-off, reductions) is
+  // wave 0's business, and the retired waves' slots go to the next workgroup ~5 k cycles earlier.
+  {
+    constexpr int NW = NT / 64;
+#pragma unroll
+    for (int k = 0; k < 6; k++) acc[k] = wave_sum_to_lane63(acc[k]);
+    if ((tid & 63) == 63) {
+#pragma unroll
+      for (int k = 0; k < 6; k++) red[(tid >> 6) * 6 + k] = acc[k];
+    }
+    __syncthreads();
+    if (tid >= 64) return;
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+      double sum = red[k];
+      for (int w = 1; w < NW; w++) sum += red[w * 6 + k];
+      acc[k] = sum;
+    }
+  }
   NID_STAMP(5, acc[0], acc[2], acc[3], acc[5]);
-  if (tid < 64) {
+  {
     const double kappa = (double)S / 255.0;  // d_mi_i (:393), 1/N_c (:488,494), 1/Hj^2 (:521)
     const double scale = (kappa / (double)n_c) * (1.0 / (Hj * Hj));
     double J[6];
@@ -1145,9 +1146,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(STRICT ? 4 :
       store_sc1(quad + tid, val);
     }
   }
-  __syncthreads();
   NID_STAMP(6);
-  finish_and_reduce<NT>(P, SA, cl, tid, red);
+  finish_and_reduce_w0(P, SA, cl, tid);
   NID_STAMP(7);
 }
 
