@@ -12,8 +12,8 @@ pair = synth.make_pair(cfg)
 ctx = capi.from_pair(pair, bins)
 ctx.compute_href(pair.pose_init)
 delta = float(np.sqrt(0.95))
-poses = np.stack([synth.perturb_pose7(pair.pose_init, [1e-4 * k, 0, 0], [0, 1e-4 * k, 0]) for k in range(8)])
+poses = np.stack([synth.perturb_pose7(pair.pose_init, [1e-4 * k, 0, 0], [0, 1e-4 * k, 0]) for k in range(16)])
 for _ in range(n):
     ctx.launch_batch(0, poses, delta)
-    for k in range(8):
+    for k in range(16):
         ctx.wait(k)

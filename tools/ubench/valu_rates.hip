@@ -5,6 +5,7 @@
 // Build: hipcc --offload-arch=gfx950 -O2 -o valu_rates valu_rates.hip ; run: ./valu_rates
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
 #include <string>
 
@@ -75,13 +76,14 @@ static const char *names[] = {"v_fma_f64", "v_add_f64", "v_mul_f64", "v_cvt_f64_
                               "v_mul_lo_u32", "v_mad_u64_u32", "v_fma_f32", "ds_add_u64", "ds_write_b64", "ds_read_b64",
                               "ds_read2_b64", "ds_read_b128", "v_max_i32", "v_mad_i32_i24", "v_fmac_f64", "cndmask_e64_sgpr", "cmp_f64_e64_sgpr", "cmp_f64+cndmask", "v_mov_dpp", "readfirstlane", "v_and_b32", "saveexec+or", "cmp_i32+cndmask", "s_nop", "cndmask_3op"};
 
+static int g_grid = 1;
 template <int OP>
 void run(long long *d) {
   const int iters = 4096;
   for (int threads : {256, 512, 1024}) {
     long long h[3];
     for (int rep = 0; rep < 3; rep++) {
-      hipLaunchKernelGGL(k<OP>, dim3(1), dim3(threads), 0, 0, d, iters, 1.5);
+      hipLaunchKernelGGL(k<OP>, dim3(g_grid), dim3(threads), 0, 0, d, iters, 1.5);
       hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost);
     }
     const int wps = threads / 256;  // waves per SIMD
@@ -95,7 +97,8 @@ void run(long long *d) {
 template <int OP> struct Runner { static void go(long long *d) { run<OP>(d); Runner<OP + 1>::go(d); } };
 template <> struct Runner<33> { static void go(long long *) {} };
 
-int main() {
+int main(int argc, char **argv) {
+  if (argc > 1) g_grid = atoi(argv[1]);  // 256*k blocks: k blocks per CU (block 0 is the one timed)
   long long *d;
   hipMalloc(&d, 64); hipMemset(d, 0, 64);
   Runner<0>::go(d);
