@@ -40,7 +40,6 @@ def parse():
     ap.add_argument("--config", default="A", choices=["A", "B", "S"])
     ap.add_argument("--bins", type=int, default=8)
     ap.add_argument("--block-threads", type=int, default=0)
-    ap.add_argument("--inflight", type=int, default=0, help="result slots in use (0 = all)")
     ap.add_argument("--batch", type=int, default=16,
                     help="candidate poses per kernel launch at N=1 (1 = one launch per step)")
     ap.add_argument("--group", type=int, default=4,
@@ -216,7 +215,6 @@ def main():
     delta = float(np.sqrt(0.95))
     K, W = args.steps, args.warmup
     poses = pose_trajectory(synth, pair, 256)
-    nslots = capi.NID_SLOTS if not args.inflight else min(capi.NID_SLOTS, args.inflight)
 
     # device-side result ring (world > 1): a group = G launches of B poses on one stream, summed by ONE
     # all-reduce of [G*B, 32] doubles (the collective is latency-bound: fewer, larger ones)

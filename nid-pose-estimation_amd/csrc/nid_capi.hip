@@ -274,10 +274,9 @@ int launch_slot(nid_ctx *ctx, int slot, const Pose &pose, int want_jac, double d
     NID_HIP(ctx, hipMemsetAsync(ctx->dbg_wc, 0xFF, N * 32, ctx->stream));
     NID_HIP(ctx, hipMemsetAsync(ctx->dbg_jc, 0xFF, N * 4, ctx->stream));
   }
-  // Measured on MI355X (round 1): alternating two streams per launch is 2.2x SLOWER (52 vs 24 us
-  // per step) than one in-order stream, so the aux stream is opt-in (NID_TWO_STREAMS=1).
-  static const bool two_streams = getenv("NID_TWO_STREAMS") != nullptr;
-  hipStream_t st = (two_streams && !ctx->external_stream && !ctx->dbg_enabled && (slot & 1)) ? ctx->aux_stream : ctx->stream;
+  // single-pose launches stay on one in-order stream (alternating streams per single-pose launch measured
+  // 2.2x slower); the batched pipeline of nid_run_sequence is the one that alternates
+  hipStream_t st = ctx->stream;
   S.timed = ctx->timing;
   if (S.timed) NID_HIP(ctx, hipEventRecord(S.e0, st));
   rc = launch_eval(ctx, P, want_jac != 0, st);
