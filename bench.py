@@ -42,6 +42,7 @@ def parse():
     ap.add_argument("--block-threads", type=int, default=0)
     ap.add_argument("--batch", type=int, default=16,
                     help="candidate poses per kernel launch at N=1 (1 = one launch per step)")
+    ap.add_argument("--compute-streams", type=int, default=0, help="N>1: 1, 2 or 4 (0 = 2 for N<=2, else 4)")
     ap.add_argument("--group", type=int, default=4,
                     help="N>1: kernel launches per all-reduce (group of GROUP*BATCH poses)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -202,12 +203,13 @@ def main():
         ctx.set_block_threads(args.block_threads)
     sides = None
     if world > 1:
-        # Three explicit streams (torch's default stream has the null handle, which nid_set_stream() reads
-        # as "use the context's own stream"): consecutive kernel launches alternate between two COMPUTE
-        # streams, so two launches are resident at once (a shard of 32 cells x 16 poses fills only 2
-        # workgroups per CU); a COMM stream waits for a group's launches, runs its RCCL all-reduce and the
-        # D2H copy, while the compute streams already work on the next group.
-        sides = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
+        # Explicit streams (torch's default stream has the null handle, which nid_set_stream() reads as "use
+        # the context's own stream"): consecutive kernel launches rotate over 2 (N <= 2) or 4 COMPUTE
+        # streams, so that many launches are resident at once (at N = 8 a shard of 32 cells x 16 poses is
+        # only 2 workgroups per CU, and the kernel wants 5); a COMM stream waits for a group's launches,
+        # runs its RCCL all-reduce and the D2H copy, while the compute streams already work on the next group.
+        ncomp = args.compute_streams if args.compute_streams in (1, 2, 4) else (2 if world <= 2 else 4)
+        sides = [torch.cuda.Stream(device=dev) for _ in range(ncomp)]
         comm = torch.cuda.Stream(device=dev)
         ctx.set_stream(sides[0].cuda_stream)
     # world == 1: the library's own in-order stream; torch.cuda.synchronize() below fences the whole device
@@ -219,7 +221,7 @@ def main():
     # device-side result ring (world > 1): a group = G launches of B poses on one stream, summed by ONE
     # all-reduce of [G*B, 32] doubles (the collective is latency-bound: fewer, larger ones)
     B = max(1, min(args.batch, capi.NID_MAX_BATCH))
-    assert capi.NID_SLOTS % B == 0 and capi.NID_SLOTS >= 2 * B
+    assert capi.NID_SLOTS % B == 0 and capi.NID_SLOTS >= 4 * B
     G = max(1, args.group)
     ngroups = 2
     ring = torch.zeros((ngroups, G * B, capi.NID_REDUCED_LEN), dtype=torch.float64, device=dev)
@@ -239,11 +241,12 @@ def main():
         for l in range(nl):
             m = min(B, n - l * B)
             idx = [(j * G * B + l * B + k) % len(poses) for k in range(m)]
-            st = sides[l % 2]
+            st = sides[l % len(sides)]
             ctx.set_stream(st.cuda_stream)
             with torch.cuda.stream(st):
-                ctx.launch_batch((l % 2) * B, pose_arr[idx], delta, True, reduced_dev=ring[gidx, l * B].data_ptr())
-        for st in sides[:min(nl, 2)]:
+                ctx.launch_batch((l % len(sides)) * B, pose_arr[idx], delta, True,
+                                 reduced_dev=ring[gidx, l * B].data_ptr())
+        for st in sides[:min(nl, len(sides))]:
             comm.wait_stream(st)
         with torch.cuda.stream(comm):
             dist.all_reduce(ring[gidx])
@@ -344,7 +347,7 @@ def main():
                                                    f" + {'RCCL' if args.backend == 'nccl' else 'gloo'} all-reduce([{G * B},32] f64)"),
                 "pipelining": f"{B} candidate poses per kernel launch, 2 launches in flight on 2 streams, "
                               + ("each pose's 6x6 system lands in pinned host memory" if world == 1 else
-                                 f"launches alternate between 2 compute streams; one all-reduce of [{G * B},32] f64 per "
+                                 f"launches rotate over {len(sides) if sides else 2} compute streams; one all-reduce of [{G * B},32] f64 per "
                                  f"{G} launches + D2H to pinned memory on a comm stream, 2 groups in flight"),
             },
             "roofline": {

@@ -221,14 +221,20 @@ def test_bench_multi_rank_code_path_on_one_gpu(tmp_path):
                           "--no-cpu-baseline"], capture_output=True, text=True, env=env, timeout=600)
     assert one.returncode == 0, one.stderr[-2000:]
     r1 = json.loads(one.stdout.strip().splitlines()[-1])
-    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                          "--master-addr", "127.0.0.1", "--master-port", "29517", os.path.join(root, "bench.py"),
-                          "--gpus", "2", "--steps", "20", "--warmup", "5", "--no-cpu-baseline", "--backend", "gloo"],
-                         capture_output=True, text=True, env=env, timeout=900)
-    assert two.returncode == 0, two.stderr[-3000:]
-    line = [l for l in two.stdout.strip().splitlines() if l.startswith("{")][-1]
-    r2 = json.loads(line)
-    assert r2["n_gpus"] == 2 and r2["scaling"] == "strong"
-    assert r2["check"]["n_active"] == r1["check"]["n_active"]
-    for k in ("chi2", "H00", "b0"):
-        assert abs(r2["check"][k] - r1["check"][k]) <= 1e-12 * abs(r1["check"][k]), k
+    # (steps, warmup, extra): one short partial group; several groups + a partial one on 2 compute streams;
+    # the 4-compute-stream rotation the bench uses from N = 4 on, with 8 launches per all-reduce
+    for port, extra in ((29517, ["--steps", "20", "--warmup", "5"]),
+                        (29518, ["--steps", "300", "--warmup", "70"]),
+                        (29519, ["--steps", "300", "--warmup", "70", "--compute-streams", "4", "--group", "8"])):
+        two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                              "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"),
+                              "--gpus", "2", "--no-cpu-baseline", "--backend", "gloo"] + extra,
+                             capture_output=True, text=True, env=env, timeout=900)
+        assert two.returncode == 0, two.stderr[-3000:]
+        line = [l for l in two.stdout.strip().splitlines() if l.startswith("{")][-1]
+        r2 = json.loads(line)
+        assert r2["n_gpus"] == 2 and r2["scaling"] == "strong"
+        if extra[1] == "20":     # same last pose as the 1-rank run: the all-reduced sums must agree
+            assert r2["check"]["n_active"] == r1["check"]["n_active"]
+            for k in ("chi2", "H00", "b0"):
+                assert abs(r2["check"][k] - r1["check"][k]) <= 1e-12 * abs(r1["check"][k]), k
