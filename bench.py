@@ -45,6 +45,8 @@ def parse():
     ap.add_argument("--compute-streams", type=int, default=0, help="N>1: 1, 2 or 4 (0 = 2 for N<=2, else 4)")
     ap.add_argument("--group", type=int, default=4,
                     help="N>1: kernel launches per all-reduce (group of GROUP*BATCH poses)")
+    ap.add_argument("--cost-only", action="store_true",
+                    help="time cost-only evaluations (what LM trial poses need) instead of cost+Jacobian; not the metric")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -258,7 +260,7 @@ def main():
             # the C host loop of the library drives the pipeline (B poses per launch, 16/B launches in
             # flight); every pose's 6x6 system is collected from pinned host memory
             seq = pose_arr[np.arange(n) % len(poses)]
-            return ctx.run_sequence(seq, delta, batch=B, want_jac=True)
+            return ctx.run_sequence(seq, delta, batch=B, want_jac=not args.cost_only)
         ngr = (n + G * B - 1) // (G * B)
         for j in range(ngr):
             launch_group(j, min(G * B, n - j * G * B))
@@ -291,9 +293,10 @@ def main():
     ablation = bool(os.environ.get("NID_HIP_LIB"))  # kernel-ablation builds (exp/) produce meaningless numbers
     if world == 1:
         assert ablation or (results.shape == (K, capi.NID_REDUCED_LEN) and np.all(np.isfinite(results)))
-        ctx.launch(0, poses[(K - 1) % len(poses)], delta, True)
+        ctx.launch(0, poses[(K - 1) % len(poses)], delta, not args.cost_only)
         H, b, chi2, na = ctx.wait(0)
-        assert ablation or np.array_equal(capi.unpack_reduced(results[K - 1])[0], H), \
+        assert ablation or (np.array_equal(capi.unpack_reduced(results[K - 1])[0], H)
+                            and capi.unpack_reduced(results[K - 1])[2] == chi2), \
             "pipelined result differs from a single launch"
     else:
         # the pipelined result of the last step must equal a synchronous evaluation of the same pose
@@ -310,6 +313,8 @@ def main():
         assert np.array_equal(piped, sync), "pipelined multi-rank result differs from the synchronous one"
         H, b, chi2, na = capi.unpack_reduced(sync)
     assert ablation or (np.isfinite(chi2) and np.all(np.isfinite(H)) and na > 0)
+    if args.cost_only and rank == 0:
+        print("[bench] --cost-only: cost evaluations without the Jacobian phase; not the BASELINE metric", file=sys.stderr)
 
     # dominant-kernel duration: groups of 10 identical launches (B poses each, this rank's cells) back to
     # back on the launch stream between ONE pair of HIP events -- the per-launch duration a kernel trace
@@ -317,7 +322,7 @@ def main():
     ev_ms = []
     for i in range(min(max(K // (10 * B), 5), 40)):
         idx = [(i * B + k) % len(poses) for k in range(B)]
-        ev_ms.append(ctx.time_launches(pose_arr[idx], delta, repeats=10))
+        ev_ms.append(ctx.time_launches(pose_arr[idx], delta, repeats=10, want_jac=not args.cost_only))
 
     if rank == 0:
         eval_ms = float(np.median(ev_ms))
