@@ -87,7 +87,7 @@ int nid_set_math_mode(nid_ctx *ctx, int mode);
 /* run every kernel of this context on a caller-owned hipStream_t (e.g. the
  * current torch stream) instead of the context's own stream; NULL restores it */
 int nid_set_stream(nid_ctx *ctx, void *hip_stream);
-/* tuning knob: threads per workgroup of the evaluation kernel (0 = default) */
+/* tuning knob: threads per workgroup of the evaluation kernel: 128 or 256 (0 = default = 128) */
 int nid_set_block_threads(nid_ctx *ctx, int threads);
 
 /* ---- once per frame pair ------------------------------------------------ */

@@ -65,7 +65,6 @@ struct nid_ctx {
   bool timing = false;
   bool have_ref = false, have_target = false, have_href = false, ref_from_depth = false;
   double hist_scale = 0, hist_inv_scale = 0;            // k_href: whole-cell sums below 2^62
-  double eval_hist_scale = 0, eval_hist_inv_scale = 0;  // k_eval2: every histogram COPY stays below 2^52
   int group_size = 1, ngroups = 1;
   int math_mode = NID_MATH_FAST;
   double *ctab_dev = nullptr;
@@ -167,35 +166,57 @@ void build_coef_table(int S, std::vector<double> *out) {
 
 size_t eval_lds_bytes(const Geometry &g, int nt) {
   const int nbins = g.nb * g.nb + g.nb;
-  return (size_t)nbins * kHistCopies * 8 + (size_t)((nbins + 1) & ~1) * 8 +
-         (size_t)kMaxBins * kCoefRow * 8 + (size_t)kRedDoubles(nt) * 8;
+  return (size_t)nbins * eval_hist_copies(nt) * 8 + (size_t)((nbins + 1) & ~1) * 8 +
+         (size_t)g.S * kCoefRow * 8 + (size_t)kRedDoubles(nt) * 8;
 }
 
 // k_eval2 (occupancy-organised, runtime pixel loop): one workgroup shape for every cell size
-template <int NB, bool DBG>
+template <int NT, int NB, bool DBG>
 void launch_eval2_v(const EvalParams &P, bool jac, bool strict, size_t lds, hipStream_t s, int batch) {
-  const dim3 grid((unsigned)(((P.g.nloc + 7) / 8) * 8 * batch)), block(256);
+  const dim3 grid((unsigned)(((P.g.nloc + 7) / 8) * 8 * batch)), block(NT);
   if (strict) {
-    if (jac) hipLaunchKernelGGL((k_eval2<256, true, true, NB, DBG>), grid, block, lds, s, P);
-    else hipLaunchKernelGGL((k_eval2<256, false, true, NB, DBG>), grid, block, lds, s, P);
+    if (jac) hipLaunchKernelGGL((k_eval2<NT, true, true, NB, DBG>), grid, block, lds, s, P);
+    else hipLaunchKernelGGL((k_eval2<NT, false, true, NB, DBG>), grid, block, lds, s, P);
   } else {
-    if (jac) hipLaunchKernelGGL((k_eval2<256, true, false, NB, DBG>), grid, block, lds, s, P);
-    else hipLaunchKernelGGL((k_eval2<256, false, false, NB, DBG>), grid, block, lds, s, P);
+    if (jac) hipLaunchKernelGGL((k_eval2<NT, true, false, NB, DBG>), grid, block, lds, s, P);
+    else hipLaunchKernelGGL((k_eval2<NT, false, false, NB, DBG>), grid, block, lds, s, P);
   }
 }
 
 int launch_eval2(nid_ctx *ctx, EvalParams &P, bool jac, hipStream_t stream, int batch) {
   P.batch = batch;
-  size_t lds = eval_lds_bytes(P.g, 256);
+  // Workgroup shape: 128 threads by default.  Measured on MI355X (16 poses per launch, two launches in flight):
+  // 640x480 / 8 bins 237k (256 threads) -> 260k (128) evaluations/s, 1280x960 63.8k -> 70.5k; one-wave
+  // workgroups with 8 histogram copies measured 248k / 66.5k and were dropped.  Two waves per workgroup halve the wave-time lost at the workgroup's barriers and in its serial
+  // phases (fold, block sums, tail), and ten workgroups still fit a CU (LDS 14 KB, 96 VGPRs).
+  const int nt = ctx->block_threads == 256 ? 256 : 128;
+  size_t lds = eval_lds_bytes(P.g, nt);
+  {
+    // k_eval2 accumulates raw 2^52-magic bit patterns and masks the top 12 bits per copy in the fold, so no
+    // copy may carry out of 52 bits: a copy receives at most ceil(pstride / copies) weights (each <= 1) per bin
+    const int per_copy = (P.g.pstride + eval_hist_copies(nt) - 1) / eval_hist_copies(nt);
+    int cb2 = 0;
+    while ((1 << cb2) < per_copy + 1) cb2++;
+    P.hist_scale = std::ldexp(1.0, 52 - cb2);
+    P.hist_inv_scale = std::ldexp(1.0, -(52 - cb2));
+  }
   if (lds > 160 * 1024) return NID_ERR_UNSUPPORTED;
   static const char *pad_env = getenv("NID_EXP_LDS_PAD");  // occupancy experiments: pad the LDS request
   if (pad_env) lds = std::min<size_t>(160 * 1024, lds + (size_t)atoi(pad_env));
   const bool dbg = ctx->dbg_enabled || ctx->dbg_stamps != nullptr;
   const bool strict = ctx->math_mode == NID_MATH_STRICT;
-  if (dbg) launch_eval2_v<0, true>(P, jac, strict, lds, stream, batch);
-  else if (P.g.nb == 8) launch_eval2_v<8, false>(P, jac, strict, lds, stream, batch);
-  else if (P.g.nb == 10) launch_eval2_v<10, false>(P, jac, strict, lds, stream, batch);
-  else launch_eval2_v<0, false>(P, jac, strict, lds, stream, batch);
+  if (dbg) {  // diagnostics keep the workgroup shape: the Jacobian sums depend on it in their last bits
+    if (nt == 128) launch_eval2_v<128, 0, true>(P, jac, strict, lds, stream, batch);
+    else launch_eval2_v<256, 0, true>(P, jac, strict, lds, stream, batch);
+  } else if (nt == 128) {
+    if (P.g.nb == 8) launch_eval2_v<128, 8, false>(P, jac, strict, lds, stream, batch);
+    else if (P.g.nb == 10) launch_eval2_v<128, 10, false>(P, jac, strict, lds, stream, batch);
+    else launch_eval2_v<128, 0, false>(P, jac, strict, lds, stream, batch);
+  } else {
+    if (P.g.nb == 8) launch_eval2_v<256, 8, false>(P, jac, strict, lds, stream, batch);
+    else if (P.g.nb == 10) launch_eval2_v<256, 10, false>(P, jac, strict, lds, stream, batch);
+    else launch_eval2_v<256, 0, false>(P, jac, strict, lds, stream, batch);
+  }
   NID_HIP(ctx, hipGetLastError());
   return NID_OK;
 }
@@ -215,8 +236,7 @@ void fill_common_params(nid_ctx *ctx, double delta, EvalParams *P) {
   P->Nc = ctx->Nc_dev;
   P->Href = ctx->Href_dev;
   P->jac_cols = (ctx->jac_bound == NID_JACBOUND_CPU) ? ctx->g.cols - 1 : ctx->g.cols;
-  P->hist_scale = ctx->eval_hist_scale;
-  P->hist_inv_scale = ctx->eval_hist_inv_scale;
+  P->hist_scale = P->hist_inv_scale = 0.0;  // set by launch_eval2 (depends on the workgroup shape)
   if (ctx->dbg_enabled) {
     P->dbg_u = ctx->dbg_u; P->dbg_v = ctx->dbg_v; P->dbg_ic = ctx->dbg_ic;
     P->dbg_wc = ctx->dbg_wc; P->dbg_jc = ctx->dbg_jc;
@@ -477,17 +497,11 @@ int nid_create(const nid_config *cfg, nid_ctx **out) {
   const int hs = std::min(62 - bits, 51);
   ctx->hist_scale = std::ldexp(1.0, hs);
   ctx->hist_inv_scale = std::ldexp(1.0, -hs);
-  // k_eval2 accumulates raw 2^52-magic bit patterns and masks the top 12 bits per copy in the fold,
-  // so no copy may carry out of 52 bits: a copy receives at most rounds * 256 / kHistCopies weights
-  // (each <= 1) per bin.
-  {
-    const int per_copy = ((g.pstride + 255) / 256) * 256 / kHistCopies;
-    int cb2 = 0;
-    while ((1 << cb2) < per_copy + 1) cb2++;
-    ctx->eval_hist_scale = std::ldexp(1.0, 52 - cb2);
-    ctx->eval_hist_inv_scale = std::ldexp(1.0, -(52 - cb2));
-  }
   if ((size_t)g.nloc * (size_t)g.pstride >= ((size_t)1 << 29)) { delete ctx; return NID_ERR_UNSUPPORTED; }
+  if (const char *bt = getenv("NID_BLOCK_THREADS")) {  // tuning
+    const int v = atoi(bt);
+    ctx->block_threads = (v == 256) ? 256 : 128;
+  }
   auto fail = [&](int rc) { nid_destroy(ctx); return rc; };
   if (hipSetDevice(cfg->device) != hipSuccess) return fail(NID_ERR_NO_DEVICE);
   if (hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess) return fail(NID_ERR_HIP);
@@ -610,7 +624,7 @@ int nid_set_stream(nid_ctx *ctx, void *hip_stream) {
 int nid_set_block_threads(nid_ctx *ctx, int threads) {
   // the evaluation kernel has one workgroup shape (256 threads, runtime pixel loop)
   if (!ctx || threads < 0) return NID_ERR_INVALID_ARG;
-  if (threads != 0 && threads != 256) return NID_ERR_UNSUPPORTED;
+  if (threads != 0 && threads != 256 && threads != 128) return NID_ERR_UNSUPPORTED;
   ctx->block_threads = threads;
   return NID_OK;
 }

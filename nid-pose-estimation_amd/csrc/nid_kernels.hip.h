@@ -34,6 +34,7 @@ namespace nid {
 // consecutive lanes (MI355X_MICROARCH.md, LDS table): 16 copies give every lane of a group its own
 // address and its own pair of banks, so more copies buy nothing and cost zeroing + fold time.
 constexpr int kHistCopies = 16;
+constexpr int eval_hist_copies(int nt) { return nt >= 128 ? kHistCopies : 8; }  // k_eval2, by workgroup shape
 constexpr int kMaxBins = 16;
 constexpr int kMaxPlainBins = 32;  // plain-histogram mode (k_plain_nid)
 constexpr int kCellOut = 10;      // Hc, Hj, err, J[6], Nc
@@ -824,6 +825,7 @@ __device__ __forceinline__ int pixel_sample(const PixelFront &f, int nb, int S, 
 template <int NT, bool JAC, bool STRICT, int NB, bool DBG>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(STRICT ? 4 : NID_FAST_WAVES))) void k_eval2(EvalParams P) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int NC = eval_hist_copies(NT);
   const Geometry &g = P.g;
   const int nb = NB > 0 ? NB : g.nb;
   const int nbins = nb * nb + nb;
@@ -832,7 +834,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(STRICT ? 4 :
   // first so that their reads sit inside the 2040-byte immediate range of ds_read2_b64.
   double *tab = reinterpret_cast<double *>(smem);
   double *rtab = tab + ((nbins + 1) & ~1);
-  double *red = rtab + kMaxBins * kCoefRow;
+  double *red = rtab + S * kCoefRow;  // S rows of kCoefRow (FAST) or kRcpRow <= kCoefRow (STRICT) doubles
   unsigned long long *hist = reinterpret_cast<unsigned long long *>(red + kRedDoubles(NT));
 
   // XCD-aware block -> (cell, pose) map: workgroups are dealt round-robin over the 8 XCDs, so
@@ -859,7 +861,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(STRICT ? 4 :
     return;
   }
   NID_STAMP(0);
-  for (int i = tid; i < nbins * kHistCopies; i += NT) hist[i] = 0ull;
+  for (int i = tid; i < nbins * NC; i += NT) hist[i] = 0ull;
   if (STRICT) {
     if (tid < S * 6) {
       const int jj = tid / 6, e = tid % 6;
@@ -868,7 +870,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(STRICT ? 4 :
   } else {
     for (int i = tid; i < S * kCoefRow; i += NT) rtab[i] = P.ctab[i];
   }
-  const int copy = tid & (kHistCopies - 1);
+  const int copy = tid & (NC - 1);
   const unsigned base = (unsigned)cl * (unsigned)g.pstride;
   const unsigned plane = (unsigned)g.nloc * (unsigned)g.pstride;
   // pstride is a multiple of 64, so a wave is either entirely inside the tile or entirely past
@@ -919,15 +921,15 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(STRICT ? 4 :
 #pragma unroll
       for (int k = 0; k < 4; k++) wcs[k] = wc[k] * P.hist_scale;
       const unsigned hrow = (unsigned)(__mul24(f.jr, nb) + jc);
-      unsigned long long *hc = hist + ((unsigned)jc * kHistCopies + (unsigned)copy);
+      unsigned long long *hc = hist + ((unsigned)jc * NC + (unsigned)copy);
 #pragma unroll
-      for (int k = 0; k < 4; k++) atomicAdd(hc + k * kHistCopies, fx_encode_raw(wcs[k], 1.0));
-      unsigned long long *hj = hist + (((unsigned)nb + hrow) * kHistCopies + (unsigned)copy);
+      for (int k = 0; k < 4; k++) atomicAdd(hc + k * NC, fx_encode_raw(wcs[k], 1.0));
+      unsigned long long *hj = hist + (((unsigned)nb + hrow) * NC + (unsigned)copy);
 #pragma unroll
       for (int m = 0; m < 4; m++)
 #pragma unroll
         for (int k = 0; k < 4; k++)
-          atomicAdd(hj + (m * nb + k) * kHistCopies, fx_encode_raw(f.wr[m], wcs[k]));
+          atomicAdd(hj + (m * nb + k) * NC, fx_encode_raw(f.wr[m], wcs[k]));
     }
     if (DBG && P.dbg_u && pose_idx == 0 && f.jr >= 0) {
       const int c = g.cell_begin + cl;
@@ -945,11 +947,11 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(STRICT ? 4 :
   // ---- fold the copies, probabilities, entropies, weight tables ----------------------
   double ent[2] = {0.0, 0.0};
   for (int b = tid; b < nbins; b += NT) {
-    const uint4 *hv = reinterpret_cast<const uint4 *>(hist + (size_t)b * kHistCopies);
+    const uint4 *hv = reinterpret_cast<const uint4 *>(hist + (size_t)b * NC);
     unsigned long long acc = 0;
 #pragma unroll
-    for (int c = 0; c < kHistCopies / 2; c++) {
-      const uint4 q = hv[(c + b) & (kHistCopies / 2 - 1)];
+    for (int c = 0; c < NC / 2; c++) {
+      const uint4 q = hv[(c + b) & (NC / 2 - 1)];
       acc += ((unsigned long long)(q.y & kFxHiMask) << 32 | q.x) + ((unsigned long long)(q.w & kFxHiMask) << 32 | q.z);
     }
     const double p = ((double)(long long)acc * P.hist_inv_scale) / (double)n_c;  // Q1: N_c of the initial pose

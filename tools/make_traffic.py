@@ -3,7 +3,7 @@
 HBM bytes per launch of the hot kernel = (2*FETCH_SIZE + WRITE_SIZE)*1024 (MI355X_MICROARCH.md, HBM
 section: counters in KB, gfx950 FETCH_SIZE reports half of a wide coalesced read).
 Usage: tools/make_traffic.py TAG POSES_PER_LAUNCH [BINS]"""
-import json, os, sys
+import json, os, re, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag, ppl = sys.argv[1], int(sys.argv[2])
 bins = int(sys.argv[3]) if len(sys.argv) > 3 else 8
@@ -11,7 +11,7 @@ out = {}
 for c in "AB":
     d = json.load(open(os.path.join(ROOT, "profiles", f"{tag}_{c}_summary.json")))
     for k, e in d["kernels"].items():
-        if f"k_eval2<256, true, false, {bins}, false>" in k and "hbm_bytes_per_dispatch_corrected" in e:
+        if re.search(rf"k_eval2<\d+, true, false, {bins}, false>", k) and "hbm_bytes_per_dispatch_corrected" in e:
             out[f"{c}:{bins}"] = {
                 "kernel": k, "poses_per_launch": ppl,
                 "hbm_bytes_per_launch": e["hbm_bytes_per_dispatch_corrected"],
