@@ -807,17 +807,18 @@ __device__ __forceinline__ int pixel_sample(const PixelFront &f, int nb, int S, 
   return jc;
 }
 
-// Tuning switches; defaults = the measured best on MI355X (640x480, 8 bins, 8 poses per launch, two
-// launches in flight; tools/build_variant.sh + tools/power_probe.sh, results in DESIGN.md section 7):
+// Tuning switches (tools/build_variant.sh + tools/power_probe.sh; results in DESIGN.md section 7).
 // NID_PREFETCH_P1 / _P2 (cost / Jacobian phase): 0 = load the tile entry at the top of the round,
 // 1 = request the NEXT round's entry during the current round, 2 = as 1 for the point, the current
-// round's reference weights behind the window loads.  NID_FAST_WAVES: occupancy target of the FAST
-// kernels (5 waves/SIMD = 96 VGPRs; 6 measured equal, 7-8 spill inside the loops and lose 17-35 %).
+// round's reference weights behind the window loads.  With 256-thread workgroups 2/2 measured +6 %; with
+// the default 128-thread workgroups (ten per CU) the latency is hidden anyway: 0/0 258.8 k it/s at 1 272 W,
+// 2/2 256.4 k at 1 335 W, 1/1 250.8 k -- so the default is 0/0.  NID_FAST_WAVES: occupancy target of the
+// FAST kernels (5 waves/SIMD = 96 VGPRs; 6 spills inside the loops: 216.8 k).
 #ifndef NID_PREFETCH_P1
-#define NID_PREFETCH_P1 2
+#define NID_PREFETCH_P1 0
 #endif
 #ifndef NID_PREFETCH_P2
-#define NID_PREFETCH_P2 2
+#define NID_PREFETCH_P2 0
 #endif
 #ifndef NID_FAST_WAVES
 #define NID_FAST_WAVES 5

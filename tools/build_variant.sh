@@ -14,8 +14,8 @@ f = glob.glob('/tmp/nidv_%s/*gfx950*.s' % sys.argv[1])
 txt = open(f[0]).read()
 for m in re.finditer(r'\.name:\s+(\S*k_eval2\S*)\n(.*?)\.wavefront_size', txt, re.S):
     body = m.group(2)
-    t = re.search(r'k_eval2ILi256ELb(\d)ELb(\d)ELi(\d+)ELb(\d)', m.group(1))
-    if t.group(3) == '8' and t.group(2) == '0' and t.group(1) == '1':
+    t = re.search(r'k_eval2ILi128ELb(\d)ELb(\d)ELi(\d+)ELb(\d)', m.group(1))
+    if t and t.group(3) == '8' and t.group(2) == '0' and t.group(1) == '1' and t.group(4) == '0':
         print(sys.argv[1], "hot kernel vgpr", re.search(r'\.vgpr_count:\s+(\d+)', body).group(1), "spill",
               re.search(r'\.vgpr_spill_count:\s+(\d+)', body).group(1))
 PY
