@@ -209,6 +209,34 @@ def test_driver_standard_property_mode(capi, synth, pair_S, tmp_path):
     assert abs(final - want) < 1e-4 * max(1.0, want)   # %g print + pose re-derived from groundtruth.txt
 
 
+def test_sharded_lm_matches_single_gpu_lm(hostlib, synth, pair_A):
+    """BASELINE configs[3]: the LM optimisation on cell shards (parallel.ShardedProblem: one launch over the
+    rank's cells per batch of candidate poses + one all-reduce of the partial blocks) against the single-context
+    C++ host LM: same accept/reject trace, same pose (the reduced sums differ only in their summation tree).
+    Two ranks share the GPU and sum with gloo here; one rank per GPU and RCCL in production."""
+    import json
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    worker = os.path.join(root, "tests", "_sharded_lm_worker.py")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    pose_ref, recs_ref, _ = hostlib.run_lm(pair_A, 8, pair_A.pose_init, 10, fused=2)
+    outs = []
+    for world, port in ((1, 0), (2, 29541), (4, 29542)):
+        if world == 1:
+            cmd = [sys.executable, worker, "A", "8", "gloo"]
+        else:
+            cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+                   "--master-addr", "127.0.0.1", "--master-port", str(port), worker, "A", "8", "gloo"]
+        r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900)
+        assert r.returncode == 0, r.stderr[-3000:]
+        outs.append(json.loads([l for l in r.stdout.strip().splitlines() if l.startswith("{")][-1]))
+    for o in outs:
+        assert o["lm_trials"] == [r["lm_trials"] for r in recs_ref], o["world"]
+        np.testing.assert_allclose(o["chi2"], [r["chi2"] for r in recs_ref], rtol=1e-11)
+        np.testing.assert_allclose(synth.pose7_minimal(np.array(o["pose"])), synth.pose7_minimal(pose_ref), rtol=0,
+                                   atol=1e-9)
+
+
 def test_bench_multi_rank_code_path_on_one_gpu(tmp_path):
     """bench.py --gpus 2 through torch.distributed.run on ONE box: both ranks share GPU 0 and the
     32-double partial blocks are summed by gloo instead of RCCL (which refuses two ranks per device).
