@@ -1,4 +1,4 @@
-"""Quick validity gate for an experiment build (NID_HIP_LIB=...): config S and A evaluations against the
+"""Quick validity gate for an experiment build (NID_HIP_LIB=exp/libnid_X.so python tests/variant_check.py): config S and A evaluations against the
 CPU oracle at the FAST-mode tolerances.  Exit code 1 on mismatch."""
 import importlib, os, sys
 import numpy as np

@@ -1,6 +1,6 @@
 #!/bin/bash
 # tools/build_variant.sh NAME -DFLAG=... : an experiment build of the HIP library into exp/libnid_NAME.so
-# (load it with NID_HIP_LIB=exp/libnid_NAME.so); prints VGPR / spill counts of the hot kernel.
+# (load it with NID_HIP_LIB=exp/libnid_NAME.so; gate it with tests/variant_check.py); prints VGPR / spill counts of the hot kernel.
 set -e
 name=$1; shift
 root=$(cd "$(dirname "$0")/.." && pwd)
