@@ -247,6 +247,16 @@ class OptimizationAlgorithmLevenberg {
   double _fusedChi = 0.0;
 };
 
+// the fields of batch_stats.h:39-78 that exist for a one-vertex dense problem (no Schur complement, no
+// symbolic decomposition); filled per outer iteration when setComputeBatchStatistics(true)
+// (sparse_optimizer.cpp:372-446, optimization_algorithm_levenberg.cpp:118-162)
+struct G2OBatchStatistics {
+  int iteration = 0, numVertices = 0, numEdges = 0, levenbergIterations = 0;
+  double chi2 = 0.0, timeIteration = 0.0;  // seconds
+  size_t hessianDimension = 0;
+};
+typedef std::vector<G2OBatchStatistics> BatchStatisticsContainer;
+
 struct IterationRecord {  // one line of the verbose output (sparse_optimizer.cpp:434-440)
   int iteration;
   double chi2, lambda, rho;
@@ -275,6 +285,8 @@ class SparseOptimizer {
   const std::vector<VertexSE3Expmap *> &activeVertices() const { return _vertices; }
   const double *activeRobustChi2His() const { return robustchi2_his_.data(); }
   const std::vector<IterationRecord> &trace() const { return _trace; }
+  void setComputeBatchStatistics(bool on) { _computeBatchStatistics = on; }
+  const BatchStatisticsContainer &batchStatistics() const { return _batchStatistics; }
   void setLogStream(std::ostream *os) { _log = os; }
 
   // public NID fields, sparse_optimizer.h:299-313
@@ -298,6 +310,8 @@ class SparseOptimizer {
   bool _verbose;
   std::ostream *_log;
   std::vector<IterationRecord> _trace;
+  bool _computeBatchStatistics = false;
+  BatchStatisticsContainer _batchStatistics;
 };
 
 }  // namespace g2o

@@ -4,6 +4,7 @@
 #include "g2o_min/g2o_min.h"
 
 #include <cfloat>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <iostream>
@@ -600,8 +601,23 @@ int SparseOptimizer::optimize(int iterations) {  // sparse_optimizer.cpp:356-450
   bool ok = true;
   robustchi2_his_.assign(iterations, 0.0);
   _trace.clear();
+  _batchStatistics.clear();
   OptimizationAlgorithmLevenberg::SolverResult result = OptimizationAlgorithmLevenberg::OK;
   for (int i = 0; i < iterations && ok; i++) {
+    const auto t_it0 = std::chrono::steady_clock::now();
+    struct StatScope {  // one G2OBatchStatistics entry per outer iteration, whichever branch ends it
+      SparseOptimizer *o; int it; std::chrono::steady_clock::time_point t0;
+      ~StatScope() {
+        if (!o->_computeBatchStatistics) return;
+        G2OBatchStatistics st;
+        st.iteration = it; st.numVertices = (int)o->_vertices.size(); st.numEdges = (int)o->_activeEdges.size();
+        st.levenbergIterations = o->_algorithm->levenbergIteration();
+        st.chi2 = o->_trace.empty() ? 0.0 : o->_trace.back().chi2;
+        st.hessianDimension = 6;
+        st.timeIteration = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        o->_batchStatistics.push_back(st);
+      }
+    } stat_scope{this, i, t_it0};
     result = _algorithm->solve(i);
     ok = (result == OptimizationAlgorithmLevenberg::OK);
     if (verbose() && _algorithm->fused()) {

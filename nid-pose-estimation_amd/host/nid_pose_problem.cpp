@@ -42,6 +42,7 @@ int nid_host_run_lm(const nid_pose_problem *pb, double *pose7_inout, nid_host_lm
   solver->setSpeculativeTrials(pb->fused == 2);
   optimizer.setAlgorithm(solver);
   optimizer.setVerbose(true);
+  optimizer.setComputeBatchStatistics(true);
   std::ostringstream log;
   optimizer.setLogStream(&log);
 
@@ -91,6 +92,7 @@ int nid_host_run_lm(const nid_pose_problem *pb, double *pose7_inout, nid_host_lm
     trace[k].iteration = tr[k].iteration; trace[k].chi2 = tr[k].chi2; trace[k].lambda = tr[k].lambda;
     trace[k].rho = tr[k].rho; trace[k].lm_trials = tr[k].levenbergIter;
     std::memcpy(trace[k].pose7, tr[k].pose7, sizeof(trace[k].pose7));
+    trace[k].time_s = k < (int)optimizer.batchStatistics().size() ? optimizer.batchStatistics()[k].timeIteration : 0.0;
   }
   if (log_buf && log_cap > 0) {
     const std::string s = log.str();

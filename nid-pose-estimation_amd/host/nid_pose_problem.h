@@ -26,6 +26,7 @@ typedef struct {
   int32_t iteration, lm_trials;
   double chi2, lambda, rho;
   double pose7[7];
+  double time_s;            /* wall time of the outer iteration (G2OBatchStatistics::timeIteration) */
 } nid_host_lm_record;
 
 /* returns the number of outer iterations done (or < 0); pose7 = {qx,qy,qz,qw,tx,ty,tz} in/out */

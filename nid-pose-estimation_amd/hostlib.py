@@ -28,7 +28,7 @@ class PoseProblem(C.Structure):
 
 class LmRecord(C.Structure):
     _fields_ = [("iteration", C.c_int32), ("lm_trials", C.c_int32), ("chi2", C.c_double),
-                ("lambda_", C.c_double), ("rho", C.c_double), ("pose7", C.c_double * 7)]
+                ("lambda_", C.c_double), ("rho", C.c_double), ("pose7", C.c_double * 7), ("time_s", C.c_double)]
 
 
 def load():
@@ -126,7 +126,7 @@ def run_lm(pair, bin_num, pose7, iterations=10, jac_bound_cuda=False, fused=Fals
     if n < 0:
         raise RuntimeError("nid_host_run_lm failed: " + log.value.decode(errors="replace"))
     recs = [dict(iteration=t.iteration, chi2=t.chi2, lambda_=t.lambda_, lm_trials=t.lm_trials, rho=t.rho,
-                 pose7=np.array(list(t.pose7))) for t in trace[:n]]
+                 pose7=np.array(list(t.pose7)), time_s=t.time_s) for t in trace[:n]]
     return p, recs, log.value.decode(errors="replace")
 
 
@@ -164,7 +164,8 @@ def run_pyramid_lm(pair, bin_num, pose7, levels=3, iterations=10, jac_bound_cuda
     per_level = []
     for l in range(levels):
         per_level.append([dict(iteration=t.iteration, chi2=t.chi2, lambda_=t.lambda_, lm_trials=t.lm_trials, rho=t.rho,
-                               pose7=np.array(list(t.pose7))) for t in trace[l * iterations:l * iterations + done[l]]])
+                               pose7=np.array(list(t.pose7)), time_s=t.time_s)
+                          for t in trace[l * iterations:l * iterations + done[l]]])
     del keep
     return p, per_level, log.value.decode(errors="replace")
 

@@ -104,6 +104,8 @@ def test_lm_pose_parity_config_A(hostlib, oracle, synth, pair_A, nb, strict):
     pose, recs, log = hostlib.run_lm(pair, nb, pair.pose_init, 10, strict=strict)
     assert "levenbergIter" in log
     _compare_traces(recs, recs_o, pose, pose_o, synth)
+    # batch statistics (batch_stats.h): one timed entry per outer iteration
+    assert all(0.0 < r["time_s"] < 1.0 for r in recs)
     # report how close the two really are (well inside the 1e-6 tolerance)
     d = np.abs(synth.pose7_minimal(pose) - synth.pose7_minimal(pose_o)).max()
     print(f"[{'STRICT' if strict else 'FAST'} nb={nb}] max |pose_gpu - pose_oracle| = {d:.3e}")
