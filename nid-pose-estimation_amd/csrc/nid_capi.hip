@@ -54,6 +54,14 @@ struct nid_ctx {
   hipStream_t own_stream = nullptr, aux_stream = nullptr, stream = nullptr;
   bool external_stream = false;
   Tiles t{};
+  // launches of more than kMaxBatch poses: per-pose argument records travel through a small ring of device
+  // arrays (host fills the pinned mirror, one in-stream copy, then the kernel)
+  static constexpr int kExtRing = 4;
+  SlotArgs *ext_dev[kExtRing] = {nullptr, nullptr, nullptr, nullptr};
+  SlotArgs *ext_host[kExtRing] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t ext_done[kExtRing] = {nullptr, nullptr, nullptr, nullptr};
+  bool ext_busy[kExtRing] = {false, false, false, false};
+  int ext_next = 0;
   uint8_t *im1_dev = nullptr, *im0_dev = nullptr;
   double *depth_dev = nullptr, *points_dev = nullptr, *Twc_dev = nullptr;
   int *Nc_dev = nullptr;
@@ -174,7 +182,15 @@ size_t eval_lds_bytes(const Geometry &g, int nt) {
 template <int NT, int NB, bool DBG>
 void launch_eval2_v(const EvalParams &P, bool jac, bool strict, size_t lds, hipStream_t s, int batch) {
   const dim3 grid((unsigned)(((P.g.nloc + 7) / 8) * 8 * batch)), block(NT);
-  if (strict) {
+  if (P.slots_ext && !DBG) {  // more than kMaxBatch poses: per-pose records in device memory
+    if (strict) {
+      if (jac) hipLaunchKernelGGL((k_eval2<NT, true, true, NB, false, true>), grid, block, lds, s, P);
+      else hipLaunchKernelGGL((k_eval2<NT, false, true, NB, false, true>), grid, block, lds, s, P);
+    } else {
+      if (jac) hipLaunchKernelGGL((k_eval2<NT, true, false, NB, false, true>), grid, block, lds, s, P);
+      else hipLaunchKernelGGL((k_eval2<NT, false, false, NB, false, true>), grid, block, lds, s, P);
+    }
+  } else if (strict) {
     if (jac) hipLaunchKernelGGL((k_eval2<NT, true, true, NB, DBG>), grid, block, lds, s, P);
     else hipLaunchKernelGGL((k_eval2<NT, false, true, NB, DBG>), grid, block, lds, s, P);
   } else {
@@ -230,6 +246,7 @@ void fill_common_params(nid_ctx *ctx, double delta, EvalParams *P) {
   P->huber_dsqr = (float)(delta * delta);  // RobustKernelHuber::setDelta, float dsqr (robust_kernel_impl.h:84)
   P->group_size = ctx->group_size;
   P->ctab = ctx->ctab_dev;
+  P->slots_ext = nullptr;  // launch_batch points it at a device array for more than kMaxBatch poses
   P->g = ctx->g;
   P->t = ctx->t;
   P->im1 = ctx->im1_dev;
@@ -284,7 +301,7 @@ int launch_slot(nid_ctx *ctx, int slot, const Pose &pose, int want_jac, double d
   double *target = S.external_target ? static_cast<double *>(reduced_target) : S.reduced_host_devptr;
   unsigned long long *host_seq =
       S.external_target ? nullptr : reinterpret_cast<unsigned long long *>(S.reduced_host_devptr + kReducedLen);
-  EvalParams P;
+  EvalParams P{};
   fill_eval_params(ctx, pose, S, delta, target, host_seq, &P);
   if (ctx->dbg_enabled) {
     const size_t N = (size_t)ctx->g.rows * ctx->g.cols;
@@ -314,26 +331,45 @@ int launch_batch(nid_ctx *ctx, int first_slot, int n, const Pose *poses, int wan
                  double *reduced_dev_base = nullptr, bool on_aux_stream = false) {
   int rc = check_ready(ctx);
   if (rc) return rc;
-  if (n < 1 || n > kMaxBatch || first_slot < 0 || first_slot + n > NID_SLOTS) return NID_ERR_INVALID_ARG;
+  if (n < 1 || n > kMaxBatchExt || first_slot < 0 || first_slot + n > NID_SLOTS) return NID_ERR_INVALID_ARG;
   if (ctx->dbg_enabled) return NID_ERR_STATE;  // the per-pixel dump describes one pose
-  EvalParams P;
+  EvalParams P{};
   fill_common_params(ctx, delta, &P);
+  hipStream_t st = (on_aux_stream && !ctx->external_stream) ? ctx->aux_stream : ctx->stream;
+  // up to kMaxBatch poses: the per-pose records are kernel arguments; beyond: a device array from the ring
+  int ring = -1;
+  SlotArgs *recs = P.slot;
+  if (n > kMaxBatch) {
+    ring = ctx->ext_next;
+    ctx->ext_next = (ctx->ext_next + 1) % nid_ctx::kExtRing;
+    if (ctx->ext_busy[ring]) {  // the launch that last used this entry must have consumed its records
+      NID_HIP(ctx, hipEventSynchronize(ctx->ext_done[ring]));
+      ctx->ext_busy[ring] = false;
+    }
+    recs = ctx->ext_host[ring];
+    P.slots_ext = ctx->ext_dev[ring];
+  }
   for (int k = 0; k < n; k++) {
     Slot &S = ctx->slots[first_slot + k];
     S.seq++;
     S.external_target = reduced_dev_base != nullptr;
     if (S.external_target)  // caller-owned device buffer: pose k's block at base + k*32 (multi-GPU all-reduce)
-      fill_slot_args(poses[k], S, reduced_dev_base + (size_t)k * kReducedLen, nullptr, &P.slot[k]);
+      fill_slot_args(poses[k], S, reduced_dev_base + (size_t)k * kReducedLen, nullptr, &recs[k]);
     else
       fill_slot_args(poses[k], S, S.reduced_host_devptr,
-                     reinterpret_cast<unsigned long long *>(S.reduced_host_devptr + kReducedLen), &P.slot[k]);
+                     reinterpret_cast<unsigned long long *>(S.reduced_host_devptr + kReducedLen), &recs[k]);
   }
+  if (ring >= 0)
+    NID_HIP(ctx, hipMemcpyAsync(ctx->ext_dev[ring], recs, (size_t)n * sizeof(SlotArgs), hipMemcpyHostToDevice, st));
   Slot &S0 = ctx->slots[first_slot];
   S0.timed = ctx->timing;
-  hipStream_t st = (on_aux_stream && !ctx->external_stream) ? ctx->aux_stream : ctx->stream;
   if (S0.timed) NID_HIP(ctx, hipEventRecord(S0.e0, st));
   rc = launch_eval(ctx, P, want_jac != 0, st, n);
   if (rc) return rc;
+  if (ring >= 0) {
+    NID_HIP(ctx, hipEventRecord(ctx->ext_done[ring], st));
+    ctx->ext_busy[ring] = true;
+  }
   if (S0.timed) NID_HIP(ctx, hipEventRecord(S0.e1, st));
   for (int k = 0; k < n; k++) {
     Slot &S = ctx->slots[first_slot + k];
@@ -349,7 +385,7 @@ int evaluate_common(nid_ctx *ctx, const Pose &pose, int want_jac, double *Ht, do
   int rc = check_ready(ctx);
   if (rc) return rc;
   Slot &S = ctx->slots[0];
-  EvalParams P;
+  EvalParams P{};
   fill_eval_params(ctx, pose, S, std::sqrt(0.95), S.reduced_dev, nullptr, &P);
   if (ctx->dbg_enabled) {
     const size_t N = (size_t)ctx->g.rows * ctx->g.cols;
@@ -551,6 +587,12 @@ int nid_create(const nid_config *cfg, nid_ctx **out) {
     if (hipEventCreate(&S.e0) != hipSuccess || hipEventCreate(&S.e1) != hipSuccess ||
         hipEventCreate(&S.e2) != hipSuccess) return fail(NID_ERR_HIP);
   }
+  for (int r = 0; r < nid_ctx::kExtRing; r++) {
+    if ((rc = dev_alloc(ctx, &ctx->ext_dev[r], (size_t)kMaxBatchExt))) return fail(rc);
+    if (hipHostMalloc(reinterpret_cast<void **>(&ctx->ext_host[r]), (size_t)kMaxBatchExt * sizeof(SlotArgs),
+                      hipHostMallocDefault) != hipSuccess) return fail(NID_ERR_NOMEM);
+    if (hipEventCreateWithFlags(&ctx->ext_done[r], hipEventDisableTiming) != hipSuccess) return fail(NID_ERR_HIP);
+  }
   *out = ctx;
   return NID_OK;
 }
@@ -576,6 +618,11 @@ int nid_destroy(nid_ctx *ctx) {
     if (S.e0) (void)hipEventDestroy(S.e0);
     if (S.e1) (void)hipEventDestroy(S.e1);
     if (S.e2) (void)hipEventDestroy(S.e2);
+  }
+  for (int r = 0; r < nid_ctx::kExtRing; r++) {
+    (void)hipFree(ctx->ext_dev[r]);
+    if (ctx->ext_host[r]) (void)hipHostFree(ctx->ext_host[r]);
+    if (ctx->ext_done[r]) (void)hipEventDestroy(ctx->ext_done[r]);
   }
   if (ctx->aux_stream) { (void)hipStreamSynchronize(ctx->aux_stream); (void)hipStreamDestroy(ctx->aux_stream); }
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
@@ -826,16 +873,16 @@ int nid_launch(nid_ctx *ctx, int slot, const double *pose7, int want_jac, double
 }
 
 int nid_launch_batch(nid_ctx *ctx, int first_slot, int n, const double *poses7, int want_jac, double delta) {
-  if (!ctx || !poses7 || n < 1 || n > kMaxBatch) return NID_ERR_INVALID_ARG;
-  Pose p[kMaxBatch];
+  if (!ctx || !poses7 || n < 1 || n > kMaxBatchExt) return NID_ERR_INVALID_ARG;
+  Pose p[kMaxBatchExt];
   for (int k = 0; k < n; k++) pose_from_pose7(poses7 + 7 * k, ctx->xform, &p[k]);
   return launch_batch(ctx, first_slot, n, p, want_jac, delta);
 }
 
 int nid_launch_batch_to(nid_ctx *ctx, int first_slot, int n, const double *poses7, int want_jac, double delta,
                         void *reduced_dev) {
-  if (!ctx || !poses7 || !reduced_dev || n < 1 || n > kMaxBatch) return NID_ERR_INVALID_ARG;
-  Pose p[kMaxBatch];
+  if (!ctx || !poses7 || !reduced_dev || n < 1 || n > kMaxBatchExt) return NID_ERR_INVALID_ARG;
+  Pose p[kMaxBatchExt];
   for (int k = 0; k < n; k++) pose_from_pose7(poses7 + 7 * k, ctx->xform, &p[k]);
   return launch_batch(ctx, first_slot, n, p, want_jac, delta, static_cast<double *>(reduced_dev));
 }
@@ -844,7 +891,7 @@ int nid_run_sequence(nid_ctx *ctx, const double *poses7, int n, int batch, int w
                      double *reduced_out) {
   // host-side pipeline: `batch` poses per launch, NID_SLOTS / batch launches in flight, every
   // pose's 32-double result block collected from pinned host memory in order
-  if (!ctx || !poses7 || n < 0 || batch < 1 || batch > kMaxBatch || NID_SLOTS % batch) return NID_ERR_INVALID_ARG;
+  if (!ctx || !poses7 || n < 0 || batch < 1 || batch > kMaxBatchExt || NID_SLOTS % batch) return NID_ERR_INVALID_ARG;
   NID_HIP(ctx, hipSetDevice(ctx->cfg.device));
   for (int s = 0; s < NID_SLOTS; s++) if (ctx->slots[s].pending) return NID_ERR_STATE;
   // Consecutive launches alternate between the context's two streams: the kernel is VALU-bound and
@@ -852,7 +899,7 @@ int nid_run_sequence(nid_ctx *ctx, const double *poses7, int n, int batch, int w
   // fill that tail (measured on MI355X, 8 poses per launch: 151k -> 197k evaluations/s).  Launches
   // are independent (own slots, own result blocks), so no cross-stream ordering is needed.
   static const bool one_stream = getenv("NID_ONE_STREAM") != nullptr;
-  Pose p[kMaxBatch];
+  Pose p[kMaxBatchExt];
   int launched = 0, collected = 0, launches = 0;
   auto collect = [&](int upto) -> int {
     for (; collected < upto; collected++) {
@@ -1007,10 +1054,10 @@ int nid_time_launches(nid_ctx *ctx, int n, const double *poses7, int want_jac, d
   // `repeats` identical n-pose launches back to back on the context's stream between two events: the
   // per-launch duration a kernel trace reports (event pairs around ONE launch add ~5 us of marker and
   // dispatch latency to a ~50 us kernel).  Same-stream launches are serialised, so reusing the slots is safe.
-  if (!ctx || !poses7 || !ms_per_launch || n < 1 || n > kMaxBatch || repeats < 1) return NID_ERR_INVALID_ARG;
+  if (!ctx || !poses7 || !ms_per_launch || n < 1 || n > kMaxBatchExt || repeats < 1) return NID_ERR_INVALID_ARG;
   NID_HIP(ctx, hipSetDevice(ctx->cfg.device));
   for (int s = 0; s < NID_SLOTS; s++) if (ctx->slots[s].pending) return NID_ERR_STATE;
-  Pose p[kMaxBatch];
+  Pose p[kMaxBatchExt];
   for (int k = 0; k < n; k++) pose_from_pose7(poses7 + 7 * k, ctx->xform, &p[k]);
   Slot &S0 = ctx->slots[0];
   NID_HIP(ctx, hipEventRecord(S0.e0, ctx->stream));

@@ -63,7 +63,8 @@ struct Tiles {
   uint8_t *I0;        // reference intensity
 };
 
-constexpr int kMaxBatch = 16;  // candidate poses evaluated by one launch (grid.y)
+constexpr int kMaxBatch = 16;     // candidate poses of one launch whose arguments ride in the kernel arguments
+constexpr int kMaxBatchExt = 64;  // ... or, beyond that, in a device-resident SlotArgs array (EvalParams::slots_ext)
 // FAST math mode: per span 4 basis functions x (4 value + 3 derivative) polynomial coefficients in
 // t = u - floor(u):  B_k = ((a3 t + a2) t + a1) t + a0,  B_k' = (d2 t + d1) t + d0
 constexpr int kCoefRow = 28;
@@ -94,7 +95,8 @@ struct EvalParams {
   int group_size;                  // cells per first-level group
   int batch;                       // poses in this launch (slot[0..batch-1])
   const double *ctab;              // FAST mode: per-span B-spline polynomial coefficients [S][kCoefRow]
-  SlotArgs slot[kMaxBatch];        // indexed by blockIdx.y
+  SlotArgs slot[kMaxBatch];        // per-pose arguments of launches of <= kMaxBatch poses (3.7 KB of kernel arguments)
+  const SlotArgs *slots_ext;       // larger launches: the same records in device memory (copied in-stream); else null
   // optional per-pixel dump (image order), null when disabled
   double *dbg_u, *dbg_v, *dbg_ic, *dbg_wc;
   int *dbg_jc;
@@ -823,7 +825,10 @@ __device__ __forceinline__ int pixel_sample(const PixelFront &f, int nb, int S, 
 #ifndef NID_FAST_WAVES
 #define NID_FAST_WAVES 5
 #endif
-template <int NT, bool JAC, bool STRICT, int NB, bool DBG>
+// EXT: the launch has more than kMaxBatch poses and their records live in P.slots_ext (device memory); the
+// workgroup's record is then pulled into scalar registers once, dword by dword, so that the pose matrix and
+// the pointers are SGPR operands exactly as when they come from the kernel arguments.
+template <int NT, bool JAC, bool STRICT, int NB, bool DBG, bool EXT = false>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(STRICT ? 4 : NID_FAST_WAVES))) void k_eval2(EvalParams P) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int NC = eval_hist_copies(NT);
@@ -849,7 +854,15 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(STRICT ? 4 :
   const int pose_idx = q % P.batch;
   const int cl = (q / P.batch) * 8 + (bid & 7);
   if (cl >= g.nloc) return;  // padding of the last group of 8 cells
-  const SlotArgs &SA = P.slot[pose_idx];
+  SlotArgs sa_ext;
+  if (EXT) {
+    static_assert(sizeof(SlotArgs) % 4 == 0, "SlotArgs is copied dword by dword");
+    const unsigned *src = reinterpret_cast<const unsigned *>(P.slots_ext + pose_idx);
+    unsigned *dst = reinterpret_cast<unsigned *>(&sa_ext);
+#pragma unroll
+    for (unsigned i = 0; i < sizeof(SlotArgs) / 4; i++) dst[i] = (unsigned)__builtin_amdgcn_readfirstlane((int)src[i]);
+  }
+  const SlotArgs &SA = EXT ? sa_ext : P.slot[pose_idx];
   const int n_c = P.Nc[cl];
   const double href = P.Href[cl];
   double *out = SA.cellout + (size_t)cl * kCellOut;

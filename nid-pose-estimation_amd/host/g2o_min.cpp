@@ -363,11 +363,12 @@ OptimizationAlgorithmLevenberg::SolverResult OptimizationAlgorithmLevenberg::sol
     // the reference's accept/reject scan over the results.  Same poses, same chi2 bits, same
     // decisions as the sequential loop below -- only the number of launches changes.
     const SE3Quat T0 = vm->estimate();
+    constexpr int kTrialBatch = 16;  // one launch whose per-pose records travel as kernel arguments
     while (qmax < _maxTrialsAfterFailure) {
-      const int nb = std::min((int)NID_MAX_BATCH, _maxTrialsAfterFailure - qmax);
-      double lam[NID_MAX_BATCH], nis[NID_MAX_BATCH], xs[NID_MAX_BATCH][6], poses[NID_MAX_BATCH * 7];
-      bool oks[NID_MAX_BATCH];
-      SE3Quat cand[NID_MAX_BATCH];
+      const int nb = std::min(kTrialBatch, _maxTrialsAfterFailure - qmax);
+      double lam[kTrialBatch], nis[kTrialBatch], xs[kTrialBatch][6], poses[kTrialBatch * 7];
+      bool oks[kTrialBatch];
+      SE3Quat cand[kTrialBatch];
       double l = _currentLambda, n_i = _ni;
       for (int k = 0; k < nb; k++) {
         lam[k] = l; nis[k] = n_i;
@@ -384,7 +385,7 @@ OptimizationAlgorithmLevenberg::SolverResult OptimizationAlgorithmLevenberg::sol
         l *= n_i; n_i *= 2;
       }
       if (nid_launch_batch(ctx, 0, nb, poses, 0, delta) != NID_OK) return Fail;
-      double chis[NID_MAX_BATCH];
+      double chis[kTrialBatch];
       for (int k = 0; k < nb; k++)
         if (nid_wait(ctx, k, nullptr, nullptr, &chis[k], &na) != NID_OK) return Fail;
       bool accepted = false;

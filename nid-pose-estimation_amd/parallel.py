@@ -120,7 +120,7 @@ class ShardedProblem:
                 lam, ni, n_bad = tau * max(abs(H[j, j]) for j in range(6)), 2.0, 0
             rho, q, accepted = 0.0, 0, False
             while q < max_trials:
-                nb = min(self.capi.NID_MAX_BATCH, max_trials - q)
+                nb = min(16, self.capi.NID_MAX_BATCH, max_trials - q)
                 lams, nis, xs, oks, cands = [], [], [], [], []
                 l, n_i = lam, ni
                 for k in range(nb):
