@@ -364,7 +364,7 @@ def main():
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": measured_traffic(args.config, args.bins, B) if world == 1 else None,
                 "poses_per_launch": B,
-                "kernel": "nid::k_eval2<128, JAC=true, FAST, NB, false>",
+                "kernel": "nid::k_eval2<128, JAC=true, FAST, NB=8|10|generic, DBG=false, EXT=(poses per launch > 16)>",
                 "kernel_ms": eval_ms,
                 "algorithmic_bytes_per_launch": contract,
                 "achieved_pipelined": (contract / B) * (K / elapsed) / 1e9,
