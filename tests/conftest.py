@@ -13,6 +13,13 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_sessionstart(session):
+    """The shared libraries are build artefacts (git-ignored): make sure they exist and are not older than
+    their sources before any test loads them (hipcc cross-compiles gfx950 without a GPU)."""
+    import __graft_entry__ as entry
+    entry.build()
+
+
 @pytest.fixture(scope="session")
 def synth():
     return importlib.import_module("nid-pose-estimation_amd.synth")
