@@ -744,12 +744,16 @@ int nid_set_target_u8(nid_ctx *ctx, const uint8_t *im1) {
 
 int nid_set_reference_image_f64(const double *im, int64_t n, uint8_t *out) {
   if (!im || !out || n < 0) return NID_ERR_INVALID_ARG;
+  // branch-free so that it vectorises (this conversion sits on the first call of every frame pair)
+  int bad = 0;
   for (int64_t i = 0; i < n; i++) {
     const double v = im[i];
-    if (!(v >= 0.0 && v <= 255.0) || v != std::floor(v)) return NID_ERR_UNSUPPORTED;
-    out[i] = (uint8_t)v;
+    const bool in = (v >= 0.0) & (v <= 255.0);  // false for NaN
+    const uint8_t u = (uint8_t)(int)(in ? v : 0.0);
+    bad |= (int)!in | (int)((double)u != v);
+    out[i] = u;
   }
-  return NID_OK;
+  return bad ? NID_ERR_UNSUPPORTED : NID_OK;
 }
 
 int nid_set_target_f64(nid_ctx *ctx, const double *im1) {
