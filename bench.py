@@ -311,7 +311,11 @@ def main():
         torch.cuda.synchronize(dev)
         ctx.wait(0)
         sync = ring[0, 0].cpu().numpy()
-        assert np.array_equal(piped, sync), "pipelined multi-rank result differs from the synchronous one"
+        # the per-rank partial blocks are bitwise reproducible; the collective may sum the ranks in a different
+        # order for a [G*B,32] tensor than for a [32] one (ring / tree by message size), so from 3 ranks on the
+        # comparison is to rounding
+        same = np.array_equal(piped, sync) if world <= 2 else np.allclose(piped, sync, rtol=1e-12, atol=1e-300)
+        assert same, "pipelined multi-rank result differs from the synchronous one"
         H, b, chi2, na = capi.unpack_reduced(sync)
     assert ablation or (np.isfinite(chi2) and np.all(np.isfinite(H)) and na > 0)
     if args.cost_only and rank == 0:
