@@ -7,10 +7,15 @@ delivered to host memory.  Workload at N=1 is
 BASELINE.json configs[1]: the 640x480 pair, 16x16 cells, 8-bin B-spline
 histogram (synthetic pair: the ETH-CVG data is not available offline).
 
+N = 1: the timed region is the library's own host pipeline (nid_run_sequence):
+64 poses per kernel launch, consecutive launches alternating between two
+streams, every pose's 6x6 system collected from pinned host memory.
+
 N > 1: one process per GPU (torch.distributed, backend nccl = RCCL), the cells
-of the SAME pair are partitioned over the ranks (strong scaling) and the
-per-rank partial [chi2, b(6), H upper (21), n_active] block (32 doubles) is
-all-reduced over xGMI every step.
+of the SAME pair are partitioned over the ranks (strong scaling); the per-rank
+partial [chi2, b(6), H upper (21), n_active] blocks (32 doubles per pose) of a
+group of launches are summed by one all-reduce over xGMI on a comm stream while
+the compute streams work on the next group.
 
 Prints ONE JSON line on rank 0.
 """
