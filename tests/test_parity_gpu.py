@@ -520,6 +520,28 @@ def test_full_batches(capi, synth, pair_S, n):
         ctx.launch_batch(0, [poses[0]] * 65, DELTA)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("math", MODES)
+@pytest.mark.parametrize("nt", [128, 256])
+@pytest.mark.parametrize("nb", [8, 10, 6])
+def test_large_batches_every_kernel_family(capi, synth, pair_S_edge, nb, nt, math):
+    """40 poses in one launch (device-resident records) for every kernel family -- bin specialisations and the
+    generic one, both workgroup shapes, both math modes, with and without the Jacobian phase -- against single
+    launches, bit for bit."""
+    ctx = capi.from_pair(pair_S_edge, nb, math=_mode(capi, math))
+    ctx.set_block_threads(nt)
+    ctx.compute_href(pair_S_edge.pose_init)
+    poses = [synth.perturb_pose7(pair_S_edge.pose_init, [1e-4 * k, 0, 0], [0, 1e-4 * k, 0]) for k in range(40)]
+    for jac in (True, False):
+        ctx.launch_batch(3, poses, DELTA, want_jac=jac)
+        got = [ctx.wait(3 + k) for k in range(40)]
+        for k in (0, 17, 39):
+            H, b, chi2, na = ctx.normal_equations(poses[k], DELTA, want_jac=jac)
+            assert chi2 == got[k][2] and na == got[k][3]
+            if jac:
+                assert np.array_equal(_bits(H), _bits(got[k][0])) and np.array_equal(_bits(b), _bits(got[k][1]))
+
+
 def _random_case(synth, seed):
     """A small random frame pair: geometry, bin count, image statistics, depth holes and poses all drawn from
     one seeded generator (reproducible)."""
