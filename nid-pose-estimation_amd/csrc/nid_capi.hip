@@ -742,17 +742,26 @@ int nid_set_target_u8(nid_ctx *ctx, const uint8_t *im1) {
   return NID_OK;
 }
 
+// branch-free so that it vectorises (this conversion sits on the first call of every frame pair: the
+// reference's operators take the images as double arrays); compiled twice, the AVX2 body is picked at run time
+#define NID_F64_TO_U8_BODY                                      \
+  int bad = 0;                                                  \
+  for (int64_t i = 0; i < n; i++) {                             \
+    const double v = im[i];                                     \
+    const bool in = (v >= 0.0) & (v <= 255.0); /* NaN: false */ \
+    const int iv = (int)(in ? v : 0.0);                         \
+    bad |= (int)!in | (int)((double)iv != v);                   \
+    out[i] = (uint8_t)iv;                                       \
+  }                                                             \
+  return bad;
+static int f64_to_u8_generic(const double *__restrict__ im, int64_t n, uint8_t *__restrict__ out) { NID_F64_TO_U8_BODY }
+__attribute__((target("avx2"))) static int f64_to_u8_avx2(const double *__restrict__ im, int64_t n,
+                                                          uint8_t *__restrict__ out) { NID_F64_TO_U8_BODY }
+#undef NID_F64_TO_U8_BODY
+
 int nid_set_reference_image_f64(const double *im, int64_t n, uint8_t *out) {
   if (!im || !out || n < 0) return NID_ERR_INVALID_ARG;
-  // branch-free so that it vectorises (this conversion sits on the first call of every frame pair)
-  int bad = 0;
-  for (int64_t i = 0; i < n; i++) {
-    const double v = im[i];
-    const bool in = (v >= 0.0) & (v <= 255.0);  // false for NaN
-    const uint8_t u = (uint8_t)(int)(in ? v : 0.0);
-    bad |= (int)!in | (int)((double)u != v);
-    out[i] = u;
-  }
+  const int bad = __builtin_cpu_supports("avx2") ? f64_to_u8_avx2(im, n, out) : f64_to_u8_generic(im, n, out);
   return bad ? NID_ERR_UNSUPPORTED : NID_OK;
 }
 
