@@ -616,3 +616,76 @@ def test_randomised_pairs(capi, oracle, synth, seed):
             _compare_cells(got, ref, cnt_o, loose=sat if math == "fast" else None)
             H, b, chi2, na = ctx.normal_equations(pose, DELTA)
             assert na == int(act.sum())
+
+
+@pytest.mark.gpu
+def test_context_lifecycle_and_interleaving(capi, oracle, synth, pair_S, pair_S_edge):
+    """Two contexts used alternately, state replaced in place (new target, new reference, recomputed href),
+    math mode switched between calls, a context destroyed with launches in flight."""
+    nb = 8
+    a = capi.from_pair(pair_S, nb)
+    b = capi.from_pair(pair_S_edge, nb)
+    oa, ob = oracle.from_pair(pair_S, nb), oracle.from_pair(pair_S_edge, nb)
+    ca, _ = a.compute_href(pair_S.pose_init)
+    cb, _ = b.compute_href(pair_S_edge.pose_init)
+    ca_o, _ = oa.compute_href(pair_S.pose_init)
+    cb_o, _ = ob.compute_href(pair_S_edge.pose_init)
+    for _ in range(3):                                   # interleaved use
+        _compare_cells(a.evaluate(pair_S.pose_true, True), oa.evaluate(pair_S.pose_true, True), ca_o)
+        _compare_cells(b.evaluate(pair_S_edge.pose_true, True), ob.evaluate(pair_S_edge.pose_true, True), cb_o,
+                       loose=_saturated_cells(ob, pair_S_edge))
+    # math mode switched on a live context
+    a.set_math_mode(capi.MATH_STRICT)
+    _compare_cells(a.evaluate(pair_S.pose_init, True), oa.evaluate(pair_S.pose_init, True), ca_o)
+    a.set_math_mode(capi.MATH_FAST)
+    # new target in place: results follow it
+    a.set_target(pair_S_edge.im1)
+    oa.set_target(pair_S_edge.im1)
+    _compare_cells(a.evaluate(pair_S.pose_init, True), oa.evaluate(pair_S.pose_init, True), ca_o,
+                   loose=np.ones(ca_o.size, dtype=bool))
+    # new reference: href state is invalidated until recomputed
+    a.set_reference_depth(pair_S_edge.depth_m, pair_S_edge.im0, synth.matrix_colmajor16(pair_S_edge.T_wc0))
+    with pytest.raises(capi.NidError):
+        a.evaluate(pair_S.pose_init, True)
+    a.compute_href(pair_S_edge.pose_init)
+    _compare_cells(a.evaluate(pair_S_edge.pose_true, True), ob.evaluate(pair_S_edge.pose_true, True), cb_o,
+                   loose=_saturated_cells(ob, pair_S_edge))
+    # href recomputed at another pose (Q1: the counts and weights follow the pose given to computeHref)
+    cnt2, href2 = a.compute_href(pair_S_edge.pose_true)
+    cnt2_o, href2_o = ob.compute_href(pair_S_edge.pose_true)
+    assert np.array_equal(cnt2, cnt2_o)
+    # destroy with launches in flight
+    poses = [synth.perturb_pose7(pair_S.pose_init, [1e-4 * k, 0, 0], [0, 0, 1e-4 * k]) for k in range(64)]
+    for rep in range(4):
+        b.launch_batch(0, poses, DELTA)
+        b.launch_batch(64, poses, DELTA)
+        if rep < 3:
+            for k in range(128):
+                b.wait(k)
+    b.close()
+    a.close()
+
+
+@pytest.mark.gpu
+def test_many_small_cells(capi, oracle, synth):
+    """40 x 40 = 1600 cells of 12 x 16 pixels: every cell is below the 300-pixel activity threshold, the
+    two-level reduction runs with 40 groups of 40 cells and must deliver an all-zero system; then 20 x 20 cells
+    of 24 x 32 pixels (400 cells, 20 groups), active."""
+    pair = synth.make_pair("S", rows=480, cols=640, cell=40)
+    ctx = capi.from_pair(pair, 8)
+    cnt, href = ctx.compute_href(pair.pose_init)
+    assert cnt.max() < 300 and np.isnan(href).all()
+    H, b, chi2, na = ctx.normal_equations(pair.pose_init, DELTA)
+    assert na == 0 and chi2 == 0.0 and not H.any()
+    pair = synth.make_pair("S", rows=480, cols=640, cell=20)
+    ctx = capi.from_pair(pair, 8)
+    o = oracle.from_pair(pair, 8)
+    cnt, _ = ctx.compute_href(pair.pose_init)
+    cnt_o, _ = o.compute_href(pair.pose_init)
+    assert np.array_equal(cnt, cnt_o) and (cnt_o >= 300).sum() > 300
+    got, ref = ctx.evaluate(pair.pose_true, True), o.evaluate(pair.pose_true, True)
+    _compare_cells(got, ref, cnt_o, loose=_saturated_cells(o, pair))
+    H, b, chi2, na = ctx.normal_equations(pair.pose_true, DELTA)
+    H_o, b_o, chi2_o, na_o = oracle.normal_equations(ref[2], ref[3], DELTA)
+    assert na == na_o and abs(chi2 - chi2_o) <= 1e-9 * chi2_o
+    np.testing.assert_allclose(H, H_o, rtol=0, atol=1e-7 * np.abs(H_o).max())
