@@ -52,6 +52,8 @@ def parse():
                     help="N>1: kernel launches per all-reduce (group of GROUP*BATCH poses)")
     ap.add_argument("--cost-only", action="store_true",
                     help="time cost-only evaluations (what LM trial poses need) instead of cost+Jacobian; not the metric")
+    ap.add_argument("--strict", action="store_true",
+                    help="NID_MATH_STRICT (every rounding of the reference path) instead of the default FAST math; not the metric")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -208,6 +210,8 @@ def main():
     ctx = capi.from_pair(pair, args.bins, device=local_rank, cell_begin=lo, cell_end=hi)
     if args.block_threads:
         ctx.set_block_threads(args.block_threads)
+    if args.strict:
+        ctx.set_math_mode(capi.MATH_STRICT)
     sides = None
     if world > 1:
         # Explicit streams (torch's default stream has the null handle, which nid_set_stream() reads as "use
