@@ -982,18 +982,23 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(STRICT ? 4 :
   // block_sum leaves the same value in every lane: keep the per-cell scalars in SGPRs
   const double Hc = wave_uniform(0.0 - ent[0]);
   const double Hj = wave_uniform(0.0 - ent[1]);
-  const double err = wave_uniform((2 * Hj - href - Hc) / Hj);  // types_six_dof_expmap.h:227
-  const double e2 = err * err;                                 // Huber, robust_kernel_impl.cpp:77-91 (float dsqr)
-  double rho0 = e2, rho1 = 1.0;
-  if (!(e2 <= P.huber_dsqr)) {
-    const double sqrte = sqrt(e2);
-    rho0 = 2 * sqrte * P.huber_delta - P.huber_dsqr;
-    rho1 = P.huber_delta / sqrte;
-  }
-  rho0 = wave_uniform(rho0);
-  rho1 = wave_uniform(rho1);
+  // residual and Huber weights: needed by the cell's tail only, i.e. by wave 0 after the other waves retired
+  double err, rho0, rho1;
+  auto residual_and_huber = [&]() {
+    err = wave_uniform((2 * Hj - href - Hc) / Hj);  // types_six_dof_expmap.h:227
+    const double e2 = err * err;                    // Huber, robust_kernel_impl.cpp:77-91 (float dsqr)
+    rho0 = e2; rho1 = 1.0;
+    if (!(e2 <= P.huber_dsqr)) {
+      const double sqrte = sqrt(e2);
+      rho0 = 2 * sqrte * P.huber_delta - P.huber_dsqr;
+      rho1 = P.huber_delta / sqrte;
+    }
+    rho0 = wave_uniform(rho0);
+    rho1 = wave_uniform(rho1);
+  };
   if (!JAC) {
     if (tid >= 64) return;  // the cell's tail is wave 0's business: the other waves free their slots now
+    residual_and_huber();
     if (tid == 0) { out[0] = Hc; out[1] = Hj; out[2] = err; out[kCellOut - 1] = (double)n_c; }
     if (tid < kQuad) store_sc1(quad + tid, tid == 0 ? rho0 : (tid == 28 ? 1.0 : 0.0));
     NID_STAMP(6);
@@ -1130,6 +1135,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(STRICT ? 4 :
     }
   }
   NID_STAMP(5, acc[0], acc[2], acc[3], acc[5]);
+  residual_and_huber();
   {
     const double kappa = (double)S / 255.0;  // d_mi_i (:393), 1/N_c (:488,494), 1/Hj^2 (:521)
     const double scale = (kappa / (double)n_c) * (1.0 / (Hj * Hj));
