@@ -89,6 +89,7 @@ class ShardedProblem:
         self.blocks = torch.zeros((capi.NID_MAX_BATCH, REDUCED_LEN), dtype=torch.float64, device=device)
         self.stream = torch.cuda.Stream(device=device)
         ctx.set_stream(self.stream.cuda_stream)
+        ctx.set_block_threads(256)   # blocking, small launches: the latency shape (see host/legacy_ops.cpp)
 
     def evaluate(self, poses7, want_jac):
         """[(H, b, chi2, n_active)] of the WHOLE image for up to NID_MAX_BATCH poses: one launch + one all-reduce."""
