@@ -276,7 +276,7 @@ class SparseOptimizer {
   VertexSE3Expmap *vertex(int id) const;
   bool initializeOptimization(int level = 0);
   int optimize(int iterations);                               // sparse_optimizer.cpp:356-450
-  void computeActiveErrors();                                 // :61-90
+  bool computeActiveErrors();                                 // :61-90; false: the NaN-skip walk overran (see .cpp)
   double activeRobustChi2() const;                            // :102-116
   void set_h_pointer(double *h_target, double *h_joint) { h_target_ = h_target; h_joint_ = h_joint; }  // :648-651
   void update(const double *upd);                             // :453-466

@@ -174,7 +174,11 @@ int nid_unpack_reduced(const double *reduced, double *H36, double *b6, double *c
 
 /* ---- introspection / tests ---------------------------------------------- */
 /* per-pixel intermediates of the most recent nid_evaluate* in image order
- * (NaN / -1 where a pixel was not visited); any pointer may be NULL */
+ * (NaN / -1 where a pixel was not visited); any pointer may be NULL.
+ * enable = 1: the cost phase -- u, v, ic, jc, wc4 as named;
+ * enable = 2: the Jacobian phase of a want_jac evaluation, for every sample that contributes -- in the same
+ *             arrays: u <- gx, v <- gy (central difference / 2), ic <- bin position, jc, wc4 <- the four
+ *             B-spline derivatives (all zero at bin position 0, Q5) */
 int nid_debug_enable_pixel_dump(nid_ctx *ctx, int enable);
 int nid_debug_get_pixel_dump(nid_ctx *ctx, double *u, double *v, double *ic, int32_t *jc,
                              double *wc4);

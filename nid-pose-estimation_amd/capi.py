@@ -306,7 +306,8 @@ class Context:
 
     # ---- debug ----------------------------------------------------------------
     def enable_pixel_dump(self, on=True):
-        self._check(self.lib.nid_debug_enable_pixel_dump(self.h, 1 if on else 0), "nid_debug_enable_pixel_dump")
+        """True / 1: cost-phase dump (u, v, ic, jc, wc); 2: Jacobian-phase dump (gx, gy, pc, jc, dw in the same arrays)."""
+        self._check(self.lib.nid_debug_enable_pixel_dump(self.h, int(on)), "nid_debug_enable_pixel_dump")
 
     def enable_stamps(self, on=True):
         self._check(self.lib.nid_debug_enable_stamps(self.h, 1 if on else 0), "nid_debug_enable_stamps")

@@ -63,6 +63,8 @@ struct nid_ctx {
   bool ext_busy[kExtRing] = {false, false, false, false};
   int ext_next = 0;
   uint8_t *im1_dev = nullptr, *im0_dev = nullptr;
+  int16_t *im1s_dev = nullptr;   // int16 copy with the extrapolated top / left margin the evaluation kernel samples (k_im1_margins)
+  int im1_stride = 0;
   double *depth_dev = nullptr, *points_dev = nullptr, *Twc_dev = nullptr;
   int *Nc_dev = nullptr;
   double *Href_dev = nullptr;
@@ -70,6 +72,7 @@ struct nid_ctx {
   int *dbg_jc = nullptr;
   long long *dbg_stamps = nullptr;
   bool dbg_enabled = false;
+  int dbg_jac = 0;
   bool timing = false;
   bool have_ref = false, have_target = false, have_href = false, ref_from_depth = false;
   double hist_scale = 0, hist_inv_scale = 0;            // k_href: whole-cell sums below 2^62
@@ -174,7 +177,7 @@ void build_coef_table(int S, std::vector<double> *out) {
 
 size_t eval_lds_bytes(const Geometry &g, int nt) {
   const int nbins = g.nb * g.nb + g.nb;
-  return (size_t)nbins * eval_hist_copies(nt) * 8 + (size_t)((nbins + 1) & ~1) * 8 +
+  return (size_t)nbins * (eval_hist_copies(nt) + kFineLevels) * 8 + (size_t)((nbins + 1) & ~1) * 8 +  // copies + the fine levels
          (size_t)g.S * kCoefRow * 8 + (size_t)kRedDoubles(nt) * 8;
 }
 
@@ -249,14 +252,22 @@ void fill_common_params(nid_ctx *ctx, double delta, EvalParams *P) {
   P->slots_ext = nullptr;  // launch_batch points it at a device array for more than kMaxBatch poses
   P->g = ctx->g;
   P->t = ctx->t;
-  P->im1 = ctx->im1_dev;
+  P->im1s = ctx->im1s_dev;
+  P->im1_stride = ctx->im1_stride;
   P->Nc = ctx->Nc_dev;
   P->Href = ctx->Href_dev;
   P->jac_cols = (ctx->jac_bound == NID_JACBOUND_CPU) ? ctx->g.cols - 1 : ctx->g.cols;
+  P->u_in = (double)ctx->g.cols - 3.0 - kBorderEps;
+  P->v_in = (double)ctx->g.rows - 3.0 - kBorderEps;
+  P->u_jin = (double)P->jac_cols - 3.0 - kBorderEps;
+  P->u_out = (double)ctx->g.cols - 3.0 + kBorderEps;
+  P->v_out = (double)ctx->g.rows - 3.0 + kBorderEps;
+  P->u_jout = (double)P->jac_cols - 3.0 + kBorderEps;
   P->hist_scale = P->hist_inv_scale = 0.0;  // set by launch_eval2 (depends on the workgroup shape)
   if (ctx->dbg_enabled) {
     P->dbg_u = ctx->dbg_u; P->dbg_v = ctx->dbg_v; P->dbg_ic = ctx->dbg_ic;
     P->dbg_wc = ctx->dbg_wc; P->dbg_jc = ctx->dbg_jc;
+    P->dbg_jac = ctx->dbg_jac;
   } else {
     P->dbg_u = P->dbg_v = P->dbg_ic = P->dbg_wc = nullptr;
     P->dbg_jc = nullptr;
@@ -296,6 +307,11 @@ int launch_slot(nid_ctx *ctx, int slot, const Pose &pose, int want_jac, double d
   if (rc) return rc;
   if (slot < 0 || slot >= NID_SLOTS) return NID_ERR_INVALID_ARG;
   Slot &S = ctx->slots[slot];
+  if (S.pending) {  // its result has not been collected: a second launch would silently replace it
+    ctx->last_error = "slot still pending: nid_wait() it first";
+    return NID_ERR_STATE;
+  }
+  NID_HIP(ctx, hipSetDevice(ctx->cfg.device));
   S.seq++;
   S.external_target = reduced_target != nullptr;
   double *target = S.external_target ? static_cast<double *>(reduced_target) : S.reduced_host_devptr;
@@ -328,11 +344,18 @@ int launch_slot(nid_ctx *ctx, int slot, const Pose &pose, int want_jac, double d
 // pinned result block), so the reduction tails and the launch cost overlap with other poses' work
 // and two workgroups share a CU.  Results are collected per slot with nid_wait().
 int launch_batch(nid_ctx *ctx, int first_slot, int n, const Pose *poses, int want_jac, double delta,
-                 double *reduced_dev_base = nullptr, bool on_aux_stream = false) {
+                 double *reduced_dev_base = nullptr, bool on_aux_stream = false, bool relaunch_ok = false) {
   int rc = check_ready(ctx);
   if (rc) return rc;
   if (n < 1 || n > kMaxBatchExt || first_slot < 0 || first_slot + n > NID_SLOTS) return NID_ERR_INVALID_ARG;
   if (ctx->dbg_enabled) return NID_ERR_STATE;  // the per-pixel dump describes one pose
+  if (!relaunch_ok)  // (nid_time_launches re-issues the same launch on one in-order stream on purpose)
+    for (int k = 0; k < n; k++)
+      if (ctx->slots[first_slot + k].pending) {
+        ctx->last_error = "slot still pending: nid_wait() it first";
+        return NID_ERR_STATE;
+      }
+  NID_HIP(ctx, hipSetDevice(ctx->cfg.device));
   EvalParams P{};
   fill_common_params(ctx, delta, &P);
   hipStream_t st = (on_aux_stream && !ctx->external_stream) ? ctx->aux_stream : ctx->stream;
@@ -385,6 +408,10 @@ int evaluate_common(nid_ctx *ctx, const Pose &pose, int want_jac, double *Ht, do
   int rc = check_ready(ctx);
   if (rc) return rc;
   Slot &S = ctx->slots[0];
+  if (S.pending) {  // the blocking calls use slot 0's buffers
+    ctx->last_error = "slot 0 has an uncollected launch: nid_wait(ctx, 0, ...) first";
+    return NID_ERR_STATE;
+  }
   EvalParams P{};
   fill_eval_params(ctx, pose, S, std::sqrt(0.95), S.reduced_dev, nullptr, &P);
   if (ctx->dbg_enabled) {
@@ -556,6 +583,14 @@ int nid_create(const nid_config *cfg, nid_ctx **out) {
   if ((rc = dev_alloc(ctx, &ctx->t.JR, plane))) return fail(rc);
   if ((rc = dev_alloc(ctx, &ctx->t.I0, plane))) return fail(rc);
   if ((rc = dev_alloc(ctx, &ctx->im1_dev, N + 64))) return fail(rc);
+  {
+    // int16 image with margins: (rows + 1) rows of `stride` elements, plus slack for the windows of lanes
+    // without a sample (origin (0,0): rows 0..3) on images of fewer than 4 rows
+    ctx->im1_stride = (g.cols + 1 + 3) & ~3;
+    const size_t n16 = (size_t)(g.rows + 5) * ctx->im1_stride + 64;
+    if ((rc = dev_alloc(ctx, &ctx->im1s_dev, n16))) return fail(rc);
+    if (hipMemset(ctx->im1s_dev, 0, n16 * sizeof(int16_t)) != hipSuccess) return fail(NID_ERR_HIP);
+  }
   if ((rc = dev_alloc(ctx, &ctx->im0_dev, N))) return fail(rc);
   if ((rc = dev_alloc(ctx, &ctx->depth_dev, N))) return fail(rc);
   if ((rc = dev_alloc(ctx, &ctx->Twc_dev, 16))) return fail(rc);
@@ -603,7 +638,7 @@ int nid_destroy(nid_ctx *ctx) {
   if (ctx->own_stream) (void)hipStreamSynchronize(ctx->own_stream);
   (void)hipFree(ctx->t.X); (void)hipFree(ctx->t.Y); (void)hipFree(ctx->t.Z); (void)hipFree(ctx->t.W);
   (void)hipFree(ctx->t.JR); (void)hipFree(ctx->t.I0);
-  (void)hipFree(ctx->im1_dev); (void)hipFree(ctx->im0_dev); (void)hipFree(ctx->depth_dev);
+  (void)hipFree(ctx->im1_dev); (void)hipFree(ctx->im1s_dev); (void)hipFree(ctx->im0_dev); (void)hipFree(ctx->depth_dev);
   (void)hipFree(ctx->points_dev); (void)hipFree(ctx->Twc_dev);
   (void)hipFree(ctx->Nc_dev); (void)hipFree(ctx->Href_dev); (void)hipFree(ctx->ctab_dev);
   (void)hipFree(ctx->dbg_u); (void)hipFree(ctx->dbg_v); (void)hipFree(ctx->dbg_ic);
@@ -737,6 +772,13 @@ int nid_set_target_u8(nid_ctx *ctx, const uint8_t *im1) {
   NID_HIP(ctx, hipSetDevice(ctx->cfg.device));
   const size_t N = (size_t)ctx->g.rows * ctx->g.cols;
   NID_HIP(ctx, hipMemcpyAsync(ctx->im1_dev, im1, N, hipMemcpyHostToDevice, ctx->stream));
+  {
+    const Geometry &g = ctx->g;
+    const long total = (long)(g.rows + 1) * (g.cols + 1);
+    hipLaunchKernelGGL(k_im1_margins, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, g.rows, g.cols,
+                       ctx->im1_stride, ctx->im1_dev, ctx->im1s_dev);
+    NID_HIP(ctx, hipGetLastError());
+  }
   NID_HIP(ctx, hipStreamSynchronize(ctx->stream));
   ctx->have_target = true;
   return NID_OK;
@@ -948,9 +990,12 @@ int nid_wait(nid_ctx *ctx, int slot, double *H36, double *b6, double *chi2, int3
   if (!ctx || slot < 0 || slot >= NID_SLOTS) return NID_ERR_INVALID_ARG;
   Slot &S = ctx->slots[slot];
   if (!S.pending) return NID_ERR_STATE;
-  S.pending = false;
+  // `pending` is cleared only once the result is known to have arrived: after an error the slot stays
+  // pending (a retry is possible, a relaunch is refused)
   if (S.external_target) {
+    NID_HIP(ctx, hipSetDevice(ctx->cfg.device));
     NID_HIP(ctx, hipEventSynchronize(S.done));
+    S.pending = false;
     return NID_OK;
   }
   // the last workgroup stores the 32 results, then the sequence word (system-scope release)
@@ -958,6 +1003,7 @@ int nid_wait(nid_ctx *ctx, int slot, double *H36, double *b6, double *chi2, int3
   unsigned long spins = 0;
   while (__atomic_load_n(seqw, __ATOMIC_ACQUIRE) != S.seq) {
     if (++spins > 20000000ul) {  // fall back to the runtime so that a device error surfaces
+      NID_HIP(ctx, hipSetDevice(ctx->cfg.device));
       NID_HIP(ctx, hipStreamSynchronize(ctx->stream));
       NID_HIP(ctx, hipStreamSynchronize(ctx->aux_stream));
       if (__atomic_load_n(seqw, __ATOMIC_ACQUIRE) != S.seq) {
@@ -967,6 +1013,7 @@ int nid_wait(nid_ctx *ctx, int slot, double *H36, double *b6, double *chi2, int3
       break;
     }
   }
+  S.pending = false;
   return nid_unpack_reduced(S.reduced_host, H36, b6, chi2, n_active);
 }
 
@@ -999,6 +1046,7 @@ int nid_debug_enable_pixel_dump(nid_ctx *ctx, int enable) {
     if ((rc = dev_alloc(ctx, &ctx->dbg_jc, N))) return rc;
   }
   ctx->dbg_enabled = enable != 0;
+  ctx->dbg_jac = enable == 2 ? 1 : 0;
   return NID_OK;
 }
 
@@ -1075,7 +1123,7 @@ int nid_time_launches(nid_ctx *ctx, int n, const double *poses7, int want_jac, d
   Slot &S0 = ctx->slots[0];
   NID_HIP(ctx, hipEventRecord(S0.e0, ctx->stream));
   for (int r = 0; r < repeats; r++) {
-    int rc = launch_batch(ctx, 0, n, p, want_jac, delta);
+    int rc = launch_batch(ctx, 0, n, p, want_jac, delta, nullptr, false, /*relaunch_ok=*/r > 0);
     if (rc) return rc;
   }
   NID_HIP(ctx, hipEventRecord(S0.e1, ctx->stream));

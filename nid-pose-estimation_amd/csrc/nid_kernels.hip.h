@@ -24,7 +24,10 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
+#include <stddef.h>
 #include <stdint.h>
+
+#include <type_traits>
 
 #include "nid_bspline.h"
 
@@ -55,6 +58,7 @@ struct Pose {
   double M[12];  // rows of the 3x4 [R|t]: M[4*r + c]
   int mode;      // NID_XFORM_*
 };
+constexpr unsigned kPoseQuatDwords = 14;  // q[7] leads the record
 
 struct Tiles {
   double *X, *Y, *Z;  // [nloc*pstride]; NaN where depth invalid / padding
@@ -84,10 +88,13 @@ struct SlotArgs {
 struct EvalParams {
   Geometry g;
   Tiles t;
-  const uint8_t *im1;
+  const int16_t *im1s;  // target image as int16, (rows+1) x im1_stride, element (r, c) at [(r+1)*stride + c+1]; see Win
+  int im1_stride;
   const int *Nc;        // [nloc]
   const double *Href;   // [nloc]
   int jac_cols;         // cols or cols-1
+  double u_in, v_in, u_jin;  // FAST border bounds, kBorderEps inside the reference's: cols-3-eps, rows-3-eps, jac_cols-3-eps
+  double u_out, v_out, u_jout;  // ... and kBorderEps outside: cols-3+eps, rows-3+eps, jac_cols-3+eps
   double hist_scale, hist_inv_scale;
   // fused Huber + 6x6 reduction
   double huber_delta;
@@ -100,6 +107,7 @@ struct EvalParams {
   // optional per-pixel dump (image order), null when disabled
   double *dbg_u, *dbg_v, *dbg_ic, *dbg_wc;
   int *dbg_jc;
+  int dbg_jac;  // 0: the dump describes the cost phase (u, v, ic, jc, wc[4]); 1: the Jacobian phase (gx, gy, pc, jc, dw[4])
   // optional phase stamps (s_memtime) of wave 0 of every workgroup: [nloc][10] (8 phase stamps + s_memrealtime at start/end); diagnostic runs only
   long long *dbg_stamps;
 };
@@ -158,35 +166,46 @@ __device__ __forceinline__ double bilinear_u8(const uint8_t *__restrict__ im, in
   return dxdy * i11 + (dy - dxdy) * i10 + (dx - dxdy) * i01 + (1 - dx - dy + dxdy) * i00;
 }
 
-// 4x4 target-image window around a warped pixel, one 32-bit word per row
-// (byte k of a row word = column wx + k).  Every tap of the five bilinear
-// samples a pixel needs -- (u,v), (u+-1,v), (u,v+-1) -- lies inside it, so the
-// image is read once per pixel (4 unaligned dword loads) and the Jacobian phase
-// touches no global memory.  wx = max((int)u - 1, 0), wy = max((int)v - 1, 0).
+// 4x4 target-image window around a warped pixel.  Every tap of the five bilinear samples a pixel needs --
+// (u,v), (u+-1,v), (u,v+-1) -- lies inside it, so the image is read once per pixel and phase (4 unaligned
+// 8-byte loads) and nothing else of the pixel touches global memory.
+// The kernels read the target image as int16 with a one-pixel margin on the top and on the left that holds the
+// LINEAR EXTRAPOLATION 2*I[0] - I[1] of the first two rows / columns (k_im1_margins).  Reason: the reference
+// samples bil(u - 1, v) for the gradient, and for u < 1 its (int) truncation toward zero turns that sample into
+// an extrapolation from columns 0 and 1 (types_six_dof_expmap.h:312-317, Q3); interpolating between the margin
+// and column 0 is the same number, so the fixed-tap gradient below holds for the first row / column too and
+// the window origin ((int)u - 1, (int)v - 1) needs no clamping.  A row is two dwords: taps 0,1 | taps 2,3.
+typedef uint2 WRow;
 struct Win {
-  unsigned r0, r1, r2, r3;
+  WRow r0, r1, r2, r3;
   int wx, wy;
 };
 
-__device__ __forceinline__ unsigned load_u32_unaligned(const uint8_t *p) {
-  unsigned v;
-  __builtin_memcpy(&v, p, 4);
+__device__ __forceinline__ WRow load_row_unaligned(const int16_t *p) {
+  WRow v;
+  __builtin_memcpy(&v, p, 8);
   return v;
 }
 
-__device__ __forceinline__ unsigned win_row(const Win &w, int k) {
-  const unsigned a = (k & 1) ? w.r1 : w.r0;
-  const unsigned b = (k & 1) ? w.r3 : w.r2;
-  return (k & 2) ? b : a;
+__device__ __forceinline__ WRow win_row(const Win &w, int k) {
+  WRow a, b;
+  a.x = (k & 1) ? w.r1.x : w.r0.x; a.y = (k & 1) ? w.r1.y : w.r0.y;
+  b.x = (k & 1) ? w.r3.x : w.r2.x; b.y = (k & 1) ? w.r3.y : w.r2.y;
+  WRow r;
+  r.x = (k & 2) ? b.x : a.x; r.y = (k & 2) ? b.y : a.y;
+  return r;
 }
 
-__device__ __forceinline__ double win_tap(unsigned row, int k) {
-  return (double)((row >> ((k & 3) * 8)) & 0xffu);
+// tap k (0..3, taken modulo 4) of a window row, sign-extended
+__device__ __forceinline__ int tap_i(WRow row, int k) {
+  const unsigned word = (k & 2) ? row.y : row.x;
+  return __builtin_amdgcn_sbfe((int)word, (unsigned)(k & 1) * 16u, 16u);
 }
+__device__ __forceinline__ double win_tap(WRow row, int k) { return (double)tap_i(row, k); }
 
 // the two window rows a sample at ordinate y interpolates between, and its dy
 struct RowPair {
-  unsigned ra, rb;
+  WRow ra, rb;
   double dy;
 };
 __device__ __forceinline__ RowPair win_rows(const Win &w, double y) {
@@ -226,7 +245,6 @@ __device__ __forceinline__ double bilinear_rows_fast(const RowPair &r, int wx, d
   return fma(r.dy, bot - top, top);
 }
 
-__device__ __forceinline__ int tap_i(unsigned row, int k) { return (int)((row >> (k * 8)) & 0xffu); }
 
 // TWICE the central-difference image gradient of the bilinear surface at (u, v) (the caller folds
 // the 1/2 into its constants):
@@ -235,47 +253,36 @@ __device__ __forceinline__ int tap_i(unsigned row, int k) { return (int)((row >>
 // shared taps with exact integer differences; the first row/column falls back to the generic form,
 // which also reproduces the (int)-truncation extrapolation of the reference there.
 // Centre sample only (cost phase): interior pixels read the four fixed taps.
-__device__ __forceinline__ double sample_fast(const Win &w, double u, double v) {
+__device__ __forceinline__ double sample_fast_interior(const Win &w, double u, double v) {
   const int ix = (int)u, iy = (int)v;
   const double dx = u - ix, dy = v - iy;
-  if (ix - w.wx == 1 && iy - w.wy == 1) {
-    const int a11 = tap_i(w.r1, 1), a12 = tap_i(w.r1, 2), a21 = tap_i(w.r2, 1), a22 = tap_i(w.r2, 2);
-    const double m1 = fma(dx, (double)(a12 - a11), (double)a11);
-    const double m2 = fma(dx, (double)(a22 - a21), (double)a21);
-    return fma(dy, m2 - m1, m1);
-  }
-  return bilinear_rows_fast(win_rows(w, v), w.wx, u);
+  const int a11 = tap_i(w.r1, 1), a12 = tap_i(w.r1, 2), a21 = tap_i(w.r2, 1), a22 = tap_i(w.r2, 2);
+  const double m1 = fma(dx, (double)(a12 - a11), (double)a11);
+  const double m2 = fma(dx, (double)(a22 - a21), (double)a21);
+  return fma(dy, m2 - m1, m1);
 }
-
-// `ic` receives the centre sample bil(u,v) (same arithmetic as sample_fast).
-__device__ __forceinline__ void gradient_fast(const Win &w, double u, double v, double &gx, double &gy, double &ic) {
+// Gradient by the 12 shared taps of the window at origin (ix-1, iy-1), exact integer differences; `ic` receives
+// the centre sample bil(u,v) (same arithmetic as sample_fast_interior).  Valid for every in-frame sample: the
+// first row / column of the image interpolates towards the extrapolated margin (see Win).
+__device__ __forceinline__ void gradient_fast_interior(const Win &w, double u, double v, double &gx, double &gy, double &ic) {
   const int ix = (int)u, iy = (int)v;
   const double dx = u - ix, dy = v - iy;
-  if (ix - w.wx == 1 && iy - w.wy == 1) {
-    // gx: rows iy (r1), iy+1 (r2); L(ix+1) - L(ix-1) = (a2 - a0) + dx*((a3 - a2) - (a1 - a0))
-    const int a10 = tap_i(w.r1, 0), a11 = tap_i(w.r1, 1), a12 = tap_i(w.r1, 2), a13 = tap_i(w.r1, 3);
-    const int a20 = tap_i(w.r2, 0), a21 = tap_i(w.r2, 1), a22 = tap_i(w.r2, 2), a23 = tap_i(w.r2, 3);
-    const double g1 = fma(dx, (double)((a13 - a12) - (a11 - a10)), (double)(a12 - a10));
-    const double g2 = fma(dx, (double)((a23 - a22) - (a21 - a20)), (double)(a22 - a20));
-    gx = fma(dy, g2 - g1, g1);
-    // gy: M(j) = a(j,1) + dx*(a(j,2) - a(j,1)) on rows iy-1 .. iy+2;
-    //     bil(v+1) - bil(v-1) = (M2 - M0) + dy*((M3 - M2) - (M1 - M0))
-    const int a01 = tap_i(w.r0, 1), a02 = tap_i(w.r0, 2), a31 = tap_i(w.r3, 1), a32 = tap_i(w.r3, 2);
-    const double m0 = fma(dx, (double)(a02 - a01), (double)a01);
-    const double m1 = fma(dx, (double)(a12 - a11), (double)a11);
-    const double m2 = fma(dx, (double)(a22 - a21), (double)a21);
-    const double m3 = fma(dx, (double)(a32 - a31), (double)a31);
-    gy = fma(dy, (m3 - m2) - (m1 - m0), m2 - m0);
-    ic = fma(dy, m2 - m1, m1);
-  } else {
-    const RowPair r0 = win_rows(w, v);
-    ic = bilinear_rows_fast(r0, w.wx, u);
-    gx = bilinear_rows_fast(r0, w.wx, u + 1) - bilinear_rows_fast(r0, w.wx, u - 1);
-    const RowPair rp = win_rows(w, v + 1), rm = win_rows(w, v - 1);
-    gy = bilinear_rows_fast(rp, w.wx, u) - bilinear_rows_fast(rm, w.wx, u);
-  }
+  // gx: rows iy (r1), iy+1 (r2); L(ix+1) - L(ix-1) = (a2 - a0) + dx*((a3 - a2) - (a1 - a0))
+  const int a10 = tap_i(w.r1, 0), a11 = tap_i(w.r1, 1), a12 = tap_i(w.r1, 2), a13 = tap_i(w.r1, 3);
+  const int a20 = tap_i(w.r2, 0), a21 = tap_i(w.r2, 1), a22 = tap_i(w.r2, 2), a23 = tap_i(w.r2, 3);
+  const double g1 = fma(dx, (double)((a13 - a12) - (a11 - a10)), (double)(a12 - a10));
+  const double g2 = fma(dx, (double)((a23 - a22) - (a21 - a20)), (double)(a22 - a20));
+  gx = fma(dy, g2 - g1, g1);
+  // gy: M(j) = a(j,1) + dx*(a(j,2) - a(j,1)) on rows iy-1 .. iy+2;
+  //     bil(v+1) - bil(v-1) = (M2 - M0) + dy*((M3 - M2) - (M1 - M0))
+  const int a01 = tap_i(w.r0, 1), a02 = tap_i(w.r0, 2), a31 = tap_i(w.r3, 1), a32 = tap_i(w.r3, 2);
+  const double m0 = fma(dx, (double)(a02 - a01), (double)a01);
+  const double m1 = fma(dx, (double)(a12 - a11), (double)a11);
+  const double m2 = fma(dx, (double)(a22 - a21), (double)a21);
+  const double m3 = fma(dx, (double)(a32 - a31), (double)a31);
+  gy = fma(dy, (m3 - m2) - (m1 - m0), m2 - m0);
+  ic = fma(dy, m2 - m1, m1);
 }
-
 // B-spline values/derivatives from the per-span polynomial table (kCoefRow doubles per span):
 // row layout [k][a0 a1 a2 a3 d0 d1 d2], k = 0..3.  t = u - jc in [0,1).  The reference's u == 0
 // quirk (derivative identically 0 at exactly 0, Q5) is kept by a select.
@@ -327,7 +334,7 @@ __device__ __forceinline__ double bilinear_w(const Win &w, double x, double y) {
   int kx = ix - w.wx, ky = iy - w.wy;
   kx = min(max(kx, 0), 3);
   ky = min(max(ky, 0), 3);
-  const unsigned ra = win_row(w, ky), rb = win_row(w, min(ky + 1, 3));
+  const WRow ra = win_row(w, ky), rb = win_row(w, min(ky + 1, 3));
   const double i00 = win_tap(ra, kx), i01 = win_tap(ra, kx + 1);
   const double i10 = win_tap(rb, kx), i11 = win_tap(rb, kx + 1);
   return dxdy * i11 + (dy - dxdy) * i10 + (dx - dxdy) * i01 + (1 - dx - dy + dxdy) * i00;
@@ -396,6 +403,34 @@ __device__ __forceinline__ unsigned long long fx_encode_raw(double w, double sca
 }
 constexpr unsigned kFxHiMask = 0x000FFFFFu;
 
+// Fine histogram levels for SMALL target weights.  The copies above resolve 2^-45..2^-46 per addend (hist_scale):
+// exact enough for every bin's entropy term, but not for the Jacobian's weight W = -(1 + log2 p) of a bin whose
+// whole mass is made of small addends -- the reference keeps such masses in f64, takes W ~ 50..100 of
+// p ~ 1e-15..1e-30 and multiplies it with that bin's derivative sums.  A sample within 2^-9 of a knot feeds its
+// outer bins with t^3/6-like weights; on the two END spans of the clamped knot vector the basis functions next
+// to the end are LINEAR / quadratic in t (weight 3t, derivative 3), so a weight of 1e-16 (a black or clamped
+// saturated sample, or any sample at an integer position of an identity-like pose) carries an O(1) derivative:
+// the bin mass must then be right to ~1e-9 RELATIVE.  Integer accumulation (order-independent, bitwise
+// reproducible) with that dynamic range = several fixed-point levels: a weight w < 2^-8 of such a sample goes to
+// level L = min(floor((-8 - e) / 24), 4), e = its binary exponent, scaled by 2^(59 + 24 L): at least 27 bits of
+// every addend survive, at most 2^51 per addend and 2^62 per bin.  Weights >= 2^-8 stay in the coarse copies
+// (error of the Jacobian term there <= quantum * |dw| / w = 2.8e-14 * 3 * 256 = 2e-11).  kTinyW: the smaller
+// outer weight of a sample is below it iff the sample sits within ~2.8e-3 of a knot.
+constexpr double kTinyW = 0x1p-28;
+constexpr double kFineW = 0x1p-8;
+constexpr int kFineLevels = 5;
+__device__ __forceinline__ int fine_level(double w) {
+  const int e = __builtin_amdgcn_frexp_exp(w);  // w = m * 2^e, m in [0.5, 1): e <= -8 for w < 2^-8
+  const int x = min(max(-8 - e, 0), 119);
+  return (x * 43) >> 10;                        // floor(x / 24) for 0 <= x < 120
+}
+__device__ __forceinline__ double fine_scale(int level) {  // 2^(59 + 24 level)
+  return __hiloint2double((1023 + 59 + 24 * level) << 20, 0);
+}
+__device__ __forceinline__ double fine_inv_scale(int level) {
+  return __hiloint2double((1023 - 59 - 24 * level) << 20, 0);
+}
+
 // ---------------------------------------------------------------------------
 // Setup: back-projection + tiling.  Calculate3DpointKernel (CudaPoints3d.cu:5-32)
 // == Get3dPointAndIntensity (NID_pose_estimation.cpp:401-432) folded into the
@@ -448,6 +483,22 @@ __global__ void k_tile(Geometry g, const double *__restrict__ depth,
   t.X[gid] = X; t.Y[gid] = Y; t.Z[gid] = Z;
   t.JR[gid] = (int8_t)jr;
   t.I0[gid] = i0;
+}
+
+// Target image for the evaluation kernel: int16 copy of the u8 image with the extrapolated top / left margin
+// (see Win).  dst is (rows + 1) x stride; one thread per destination element of the first `cols + 1` columns.
+__global__ void k_im1_margins(int rows, int cols, int stride, const uint8_t *__restrict__ src, int16_t *__restrict__ dst) {
+  const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= (long)(rows + 1) * (cols + 1)) return;
+  const int r = (int)(gid / (cols + 1)) - 1, c = (int)(gid % (cols + 1)) - 1;
+  auto at = [&](int rr, int cc) { return (int)src[(size_t)rr * cols + cc]; };
+  auto col_m1 = [&](int rr) { return cols > 1 ? 2 * at(rr, 0) - at(rr, 1) : at(rr, 0); };
+  int v;
+  if (r >= 0 && c >= 0) v = at(r, c);
+  else if (r >= 0) v = col_m1(r);
+  else if (c >= 0) v = rows > 1 ? 2 * at(0, c) - at(1, c) : at(0, c);
+  else v = rows > 1 ? 2 * col_m1(0) - col_m1(1) : col_m1(0);  // corner: never read with a non-zero weight
+  dst[(size_t)(r + 1) * stride + (c + 1)] = (int16_t)v;
 }
 
 // depth pixels that belong to no cell (rows/cols not divisible by cell_num, Q11)
@@ -714,8 +765,13 @@ __device__ __forceinline__ void finish_and_reduce_w0(const EvalParams &P, const 
 // reference's Q7 "Jacobian reuses the cost pass's intensities" holds by construction).  The
 // pixel loops are NOT unrolled: ~100 VGPRs instead of ~220, so 4-5 workgroups share a CU
 // and the scheduler hides the load / LDS latencies that one wave per SIMD exposes.
+// guard bands of the FAST-mode decision re-check (see exact_decisions)
+// clamp guard: ic within 1e-4 of 0 or of 255 (the clamp replaces ic >= 255 by 254.999), as ONE compare |ic - mid| > half
+constexpr double kGuardMid = 127.5, kGuardHalf = 127.4999;
+constexpr double kBorderEps = 0x1p-20;  // FAST u, v are within ~1e-12 of the reference's (|u| < 2^11): a wide margin
 struct PixelFront {
   bool in, jin;
+  bool redo;  // FAST: valid pixel outside the interior band -- decided by exact_decisions, not by FAST arithmetic
   int jr;
   double x, y, zq, u, v;  // zq = z (STRICT) or 1/z (FAST)
   Win w;
@@ -751,6 +807,69 @@ __device__ __forceinline__ void load_tile(const EvalParams &P, unsigned gi, unsi
   load_tile_w(P, gi, plane, t);
 }
 
+// the 4x4 window at origin (w.wx, w.wy) >= (-1, -1); the image buffer starts at pixel (-1, -1)
+__device__ __forceinline__ void load_window(const EvalParams &P, Win &w) {
+  const unsigned st = (unsigned)P.im1_stride;
+  const unsigned po = (unsigned)(w.wy + 1) * st + (unsigned)(w.wx + 1);
+  w.r0 = load_row_unaligned(P.im1s + po);
+  w.r1 = load_row_unaligned(P.im1s + (po + st));
+  w.r2 = load_row_unaligned(P.im1s + (po + 2u * st));
+  w.r3 = load_row_unaligned(P.im1s + (po + 3u * st));
+}
+
+// What the FAST main passes load instead of the whole window.  Cost phase: the 2x2 cell of the sample = taps 1, 2
+// of window rows 1 and 2 (two unaligned dwords).  Jacobian phase: rows 1 and 2 whole, of rows 0 and 3 taps 1, 2.
+struct WinC { unsigned c1, c2; };
+struct WinJ { WRow r1, r2; unsigned c0, c3; };
+__device__ __forceinline__ unsigned load_u32_unaligned(const int16_t *p) {
+  unsigned v;
+  __builtin_memcpy(&v, p, 4);
+  return v;
+}
+__device__ __forceinline__ void load_win_centre(const EvalParams &P, int wx, int wy, WinC &w) {
+  const unsigned st = (unsigned)P.im1_stride;
+  const unsigned po = (unsigned)(wy + 2) * st + (unsigned)(wx + 2);  // row 1, tap 1
+  w.c1 = load_u32_unaligned(P.im1s + po);
+  w.c2 = load_u32_unaligned(P.im1s + (po + st));
+}
+__device__ __forceinline__ void load_win_jac(const EvalParams &P, int wx, int wy, WinJ &w) {
+  const unsigned st = (unsigned)P.im1_stride;
+  const unsigned po = (unsigned)(wy + 1) * st + (unsigned)(wx + 1);
+  w.c0 = load_u32_unaligned(P.im1s + (po + 1u));
+  w.r1 = load_row_unaligned(P.im1s + (po + st));
+  w.r2 = load_row_unaligned(P.im1s + (po + 2u * st));
+  w.c3 = load_u32_unaligned(P.im1s + (po + 3u * st + 1u));
+}
+__device__ __forceinline__ int lo16(unsigned w) { return __builtin_amdgcn_sbfe((int)w, 0u, 16u); }
+__device__ __forceinline__ int hi16(unsigned w) { return __builtin_amdgcn_sbfe((int)w, 16u, 16u); }
+
+// FAST centre sample from the 2x2 cell (two lerps on exact integer tap differences)
+__device__ __forceinline__ double sample_fast_c(const WinC &w, double u, double v) {
+  const int ix = (int)u, iy = (int)v;
+  const double dx = u - ix, dy = v - iy;
+  const int a11 = lo16(w.c1), a12 = hi16(w.c1), a21 = lo16(w.c2), a22 = hi16(w.c2);
+  const double m1 = fma(dx, (double)(a12 - a11), (double)a11);
+  const double m2 = fma(dx, (double)(a22 - a21), (double)a21);
+  return fma(dy, m2 - m1, m1);
+}
+// FAST gradient (TWICE the central difference, see gradient_fast_interior) and centre sample from WinJ
+__device__ __forceinline__ void gradient_fast_j(const WinJ &w, double u, double v, double &gx, double &gy, double &ic) {
+  const int ix = (int)u, iy = (int)v;
+  const double dx = u - ix, dy = v - iy;
+  const int a10 = lo16(w.r1.x), a11 = hi16(w.r1.x), a12 = lo16(w.r1.y), a13 = hi16(w.r1.y);
+  const int a20 = lo16(w.r2.x), a21 = hi16(w.r2.x), a22 = lo16(w.r2.y), a23 = hi16(w.r2.y);
+  const double g1 = fma(dx, (double)((a13 - a12) - (a11 - a10)), (double)(a12 - a10));
+  const double g2 = fma(dx, (double)((a23 - a22) - (a21 - a20)), (double)(a22 - a20));
+  gx = fma(dy, g2 - g1, g1);
+  const int a01 = lo16(w.c0), a02 = hi16(w.c0), a31 = lo16(w.c3), a32 = hi16(w.c3);
+  const double m0 = fma(dx, (double)(a02 - a01), (double)a01);
+  const double m1 = fma(dx, (double)(a12 - a11), (double)a11);
+  const double m2 = fma(dx, (double)(a22 - a21), (double)a21);
+  const double m3 = fma(dx, (double)(a32 - a31), (double)a31);
+  gy = fma(dy, (m3 - m2) - (m1 - m0), m2 - m0);
+  ic = fma(dy, m2 - m1, m1);
+}
+
 template <bool STRICT>
 __device__ __forceinline__ void pixel_front(const EvalParams &P, const SlotArgs &SA, const TileIn &t, PixelFront &f) {
   const Geometry &g = P.g;
@@ -774,16 +893,108 @@ __device__ __forceinline__ void pixel_front(const EvalParams &P, const SlotArgs 
     v = fma(g.fy * qy, iz, g.cy);
     f.zq = iz;
   }
-  f.in = (f.jr >= 0) && (u >= 0 && u + 3 <= g.cols && v >= 0 && v + 3 <= g.rows);
-  f.jin = f.in && (u + 3 <= P.jac_cols);  // FAST; STRICT re-decides from fx*(x/z)+cx (Q6)
+  f.redo = false;
   f.x = qx; f.y = qy; f.u = u; f.v = v;
-  f.w.wx = f.in ? max((int)u - 1, 0) : 0;  // out-of-frame pixels load the window at (0,0); never used
-  f.w.wy = f.in ? max((int)v - 1, 0) : 0;
-  const unsigned po = (unsigned)f.w.wy * (unsigned)g.cols + (unsigned)f.w.wx;
-  f.w.r0 = load_u32_unaligned(P.im1 + po);
-  f.w.r1 = load_u32_unaligned(P.im1 + (po + (unsigned)g.cols));
-  f.w.r2 = load_u32_unaligned(P.im1 + (po + 2u * (unsigned)g.cols));
-  f.w.r3 = load_u32_unaligned(P.im1 + (po + 3u * (unsigned)g.cols));
+  if (STRICT) {
+    f.in = (f.jr >= 0) && (u >= 0 && u + 3 <= g.cols && v >= 0 && v + 3 <= g.rows);
+    f.jin = f.in;  // re-decided in the Jacobian phase from fx*(x/z)+cx (Q6)
+    f.w.wx = f.in ? (int)u - 1 : 0;  // out-of-frame pixels load the window at (0,0); never used
+    f.w.wy = f.in ? (int)v - 1 : 0;
+  } else {
+    // FAST u, v carry ~1e-12 of error, so FAST arithmetic decides a border test only when the value is at least
+    // kBorderEps away from equality (five compares against precomputed bounds); a pixel whose FAST tests
+    // leave any doubt is flagged (`redo`, classified in the rarely taken branch of the pixel loops: clearly out
+    // of frame, clearly outside the Jacobian's narrower bound, or within kBorderEps of a border -> exact_decisions).
+    // The window origin is NOT clamped: ((int)u - 1, (int)v - 1) may be -1 (the image buffer has zeroed
+    // margins), so the fixed-tap sample applies to every in-frame pixel.
+    const bool in = (f.jr >= 0) && (u >= kBorderEps && u <= P.u_in && v >= kBorderEps && v <= P.v_in);
+    f.in = in;
+    f.jin = in && (u <= P.u_jin);
+    f.redo = (f.jr >= 0) && !f.jin;
+#ifdef NID_EXP_NO_REDO
+    f.redo = false;
+#endif
+    f.w.wx = in ? (int)u - 1 : 0;
+    f.w.wy = in ? (int)v - 1 : 0;
+  }
+}
+
+// FAST: what `redo` means for a pixel, from FAST values that are at least kBorderEps away from every border they
+// are compared with.  Returns true when the pixel needs exact_decisions (a border within kBorderEps, or NaN).
+__device__ __forceinline__ bool classify_redo(const EvalParams &P, PixelFront &f) {
+  const double u = f.u, v = f.v;
+  if (u < -kBorderEps || v < -kBorderEps || u > P.u_out || v > P.v_out) {
+    f.in = false; f.jin = false;  // clearly out of frame
+    return false;
+  }
+  if (f.in && u > P.u_jout) {
+    f.jin = false;  // clearly in frame for the cost, clearly outside linearizeOplus' narrower bound (cols-1, :433)
+    return false;
+  }
+  return true;
+}
+
+// ---- FAST math: decisions that are discontinuous in the arithmetic -----------------------------------
+// FAST mode evaluates the SAME algorithm with cheaper arithmetic; every quantity it feeds into the
+// histograms is a continuous function of (u, v, ic), so a few ulp of difference stay a few ulp -- except
+// where the reference takes a DECISION on a value that sits within rounding of the decision threshold:
+//   * the frame-border tests u >= 0, u+3 <= cols (cost) / cols-1 (Jacobian), v >= 0, v+3 <= rows
+//     (types_six_dof_expmap.cpp:565, :433) -- an identity-like pose projects every pixel onto integer
+//     coordinates +- an ulp, so whole rows / columns of pixels sit ON the border;
+//   * the saturation clamp ic >= 255 -> 254.999 (:572-573): with all four taps at 255 the reference's
+//     four-term bilinear sum lands on either side of 255.0 by its last rounding, a 1e-3 intensity jump;
+//   * ic < 0 -> 0 (:574-575) and the u == 0 quirk of the B-spline derivative (Q5).
+// FAST arithmetic therefore decides only the pixels that are safe from all of that (the interior band of
+// pixel_front and |ic - 127.5| <= kGuardHalf); the others (PixelFront::redo, ic within 1e-4 of 0 or 255) are
+// decided here with the reference's own operation order -- xform_point in the configured mode, IEEE
+// divisions, fx*x/z + cx, the (int)-truncating four-term bilinear form on the register window,
+// fx*(x/z) + cx for the Jacobian's border test (Q6) -- so FAST takes bit for bit the decisions STRICT takes
+// and the clamp sees the reference's intensity.  Everything else about the pixel (weights, gradient,
+// d(u,v)/d(xi)) stays FAST.  Rare on natural images: the pixels that leave the frame or land within a
+// pixel of its border, and every pixel of a saturated (flash) or black region.
+// Returns with f.in / f.jin / f.u / f.v replaced and, for f.in, the whole window f.w loaded and ic valid.
+// EXT launches keep only the matrix of the pose in scalar registers (see k_eval2); the quaternion is fetched here,
+// where it is needed, from the launch's record array.
+template <bool EXT>
+__device__ __forceinline__ void exact_decisions(const EvalParams &P, const SlotArgs &SA, int pose_idx, unsigned gi,
+                                                PixelFront &f, double &ic) {
+  const Geometry &g = P.g;
+  const unsigned bo = gi << 3;
+  const double lx = ld_f64(P.t.X, bo), ly = ld_f64(P.t.Y, bo), lz = ld_f64(P.t.Z, bo);
+  double qx, qy, qz;
+  if (EXT && SA.pose.mode == 0) {
+    Pose pq;
+    const unsigned *src = reinterpret_cast<const unsigned *>(&P.slots_ext[pose_idx].pose);
+    unsigned *dst = reinterpret_cast<unsigned *>(&pq);
+#pragma unroll
+    for (unsigned i = 0; i < kPoseQuatDwords; i++) dst[i] = (unsigned)__builtin_amdgcn_readfirstlane((int)src[i]);
+    pq.mode = 0;
+    xform_point(pq, lx, ly, lz, qx, qy, qz);
+  } else {
+    xform_point(SA.pose, lx, ly, lz, qx, qy, qz);
+  }
+  const double u = g.fx * qx / qz + g.cx;  // types_six_dof_expmap.cpp:562-563
+  const double v = g.fy * qy / qz + g.cy;
+  const bool in = (f.jr >= 0) && (u >= 0 && u + 3 <= g.cols && v >= 0 && v + 3 <= g.rows);
+  bool jin = false;
+  if (in) {
+    // the whole window around the REFERENCE's (u, v) -- which may truncate to the pixel next to FAST's
+    f.w.wx = (int)u - 1; f.w.wy = (int)v - 1;
+    load_window(P, f.w);
+    ic = bilinear_rows(win_rows(f.w, v), f.w.wx, u);
+    if (ic < 0) ic = 0.0;                              // :574-575
+    const double uj = g.fx * (qx / qz) + g.cx;         // linearizeOplus' own projection (:407-422, Q6)
+    const double vj = g.fy * (qy / qz) + g.cy;
+    jin = (uj >= 0 && uj + 3 <= P.jac_cols && vj >= 0 && vj + 3 <= g.rows);
+  }
+  f.in = in; f.jin = jin; f.u = u; f.v = v;
+}
+
+// FAST: clamped centre sample -> bin position -> span; returns jc, pc
+__device__ __forceinline__ int fast_bin(double &ic, int S, double &pc) {
+  if (ic >= 255) ic = 254.999;
+  pc = ic * ((double)S / 255.0);
+  return (int)pc;
 }
 
 // centre sample -> clamped intensity -> bin position -> B-spline weights (and derivatives)
@@ -799,11 +1010,10 @@ __device__ __forceinline__ int pixel_sample(const PixelFront &f, int nb, int S, 
     const double pc = ic * ((double)nb - 3.0) / 255.0;
     jc = (int)floor(pc);
     bspline4_tab<WANT_DER>(pc, jc, S, rtab, wc, dw);
-  } else {
-    ic = sample_fast(f.w, f.u, f.v);  // a convex combination of u8 taps: never negative
-    if (ic >= 255) ic = 254.999;
-    const double pc = ic * ((double)S / 255.0);
-    jc = (int)pc;
+  } else {  // (the FAST loops of k_eval2 inline this with the exact_decisions guard in front)
+    ic = sample_fast_interior(f.w, f.u, f.v);
+    double pc;
+    jc = fast_bin(ic, S, pc);
     bspline4_poly<WANT_DER>(pc, jc, rtab, wc, dw);
   }
   return jc;
@@ -842,6 +1052,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(STRICT ? 4 :
   double *rtab = tab + ((nbins + 1) & ~1);
   double *red = rtab + S * kCoefRow;  // S rows of kCoefRow (FAST) or kRcpRow <= kCoefRow (STRICT) doubles
   unsigned long long *hist = reinterpret_cast<unsigned long long *>(red + kRedDoubles(NT));
+  unsigned long long *hist_lo = hist + nbins * NC;  // [kFineLevels][nbins], single copies (see kTinyW)
 
   // XCD-aware block -> (cell, pose) map: workgroups are dealt round-robin over the 8 XCDs, so
   // id % 8 fixes the XCD; all `batch` poses of a cell get the same id % 8 and consecutive slots
@@ -859,8 +1070,12 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(STRICT ? 4 :
     static_assert(sizeof(SlotArgs) % 4 == 0, "SlotArgs is copied dword by dword");
     const unsigned *src = reinterpret_cast<const unsigned *>(P.slots_ext + pose_idx);
     unsigned *dst = reinterpret_cast<unsigned *>(&sa_ext);
+    // FAST math transforms with the matrix; the quaternion (the first kPoseQuatDwords of the record) is only
+    // needed by exact_decisions, which fetches it itself: 14 scalar registers less across the pixel loops
+    static_assert(offsetof(SlotArgs, pose) == 0 && offsetof(Pose, q) == 0 && offsetof(Pose, M) == 4 * kPoseQuatDwords, "record layout");
 #pragma unroll
-    for (unsigned i = 0; i < sizeof(SlotArgs) / 4; i++) dst[i] = (unsigned)__builtin_amdgcn_readfirstlane((int)src[i]);
+    for (unsigned i = STRICT ? 0u : kPoseQuatDwords; i < sizeof(SlotArgs) / 4; i++)
+      dst[i] = (unsigned)__builtin_amdgcn_readfirstlane((int)src[i]);
   }
   const SlotArgs &SA = EXT ? sa_ext : P.slot[pose_idx];
   const int n_c = P.Nc[cl];
@@ -875,7 +1090,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(STRICT ? 4 :
     return;
   }
   NID_STAMP(0);
-  for (int i = tid; i < nbins * NC; i += NT) hist[i] = 0ull;
+  for (int i = tid; i < nbins * (NC + kFineLevels); i += NT) hist[i] = 0ull;  // the copies and the fine levels behind them
   if (STRICT) {
     if (tid < S * 6) {
       const int jj = tid / 6, e = tid % 6;
@@ -895,64 +1110,131 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(STRICT ? 4 :
   NID_STAMP(1);
 
   // ---- phase 1: cost ---------------------------------------------------------------
-  // Tile entry of the round being worked on.  PF = NID_PREFETCH_P1: 0 load at the top of the round;
-  // 1 the NEXT round's entry is requested during the current round (unconditionally -- the last round
-  // re-requests its own entry -- so that the vmcnt bookkeeping stays exact), fenced so that it is
-  // issued AFTER the window loads: vector memory returns in order, and the window is then waited for
-  // with the eight tile loads still outstanding; 2 as 1 for the point, the reference weights of the
-  // current round are requested behind the window (they are used last).
-  TileIn tin;
-#if NID_PREFETCH_P1 == 1
-  if (wave_base < g.pstride) load_tile(P, base + (unsigned)(wave_base + lane), plane, tin);
-#elif NID_PREFETCH_P1 == 2
-  if (wave_base < g.pstride) load_tile_xyz(P, base + (unsigned)(wave_base + lane), tin);
-#endif
-#pragma clang loop unroll(disable)
-  for (int sb = wave_base; sb < g.pstride; sb += NT) {
-    const int s = sb + lane;
-    PixelFront f;
-#if NID_PREFETCH_P1 == 0
-    load_tile(P, base + (unsigned)s, plane, tin);
-#endif
-    pixel_front<STRICT>(P, SA, tin, f);
-#if NID_PREFETCH_P1 == 1
-    asm volatile("" ::: "memory");
-    load_tile(P, base + (unsigned)(sb + NT < g.pstride ? s + NT : s), plane, tin);
-#elif NID_PREFETCH_P1 == 2
-    asm volatile("" ::: "memory");
-    load_tile_w(P, base + (unsigned)s, plane, tin);
+  // One round = 64 consecutive tile slots per wave.  The histogram update of one in-frame sample:
+  auto hist_add = [&](int jr, int jc, const double (&wr)[4], const double (&wc)[4]) {
+    // fixed-point encode: the scale is a power of two, so wcs = wc*scale is exact and
+    // fma(wr, wcs, 2^52) rounds wr*wc*scale once
+    double wcs[4];
 #pragma unroll
-    for (int k = 0; k < 4; k++) f.wr[k] = tin.wr[k];
-    load_tile_xyz(P, base + (unsigned)(sb + NT < g.pstride ? s + NT : s), tin);
-#endif
-    double ic = NAN, wc[4] = {NAN, NAN, NAN, NAN}, dw[4];
-    int jc = -1;
-    if (f.in) {
-      jc = pixel_sample<STRICT, false>(f, nb, S, rtab, ic, wc, dw);
-      // fixed-point encode: the scale is a power of two, so wcs = wc*scale is exact and
-      // fma(wr, wcs, 2^52) rounds wr*wc*scale once
-      double wcs[4];
+    for (int k = 0; k < 4; k++) wcs[k] = wc[k] * P.hist_scale;
+    const unsigned hrow = (unsigned)(__mul24(jr, nb) + jc);
+    unsigned long long *hc = hist + ((unsigned)jc * NC + (unsigned)copy);
+    unsigned long long *hj = hist + (((unsigned)nb + hrow) * NC + (unsigned)copy);
+#ifndef NID_EXP_NO_LO
+    if (fmin(wc[0], wc[3]) < kTinyW) {
+      // rare: the sample sits next to a knot (also: clamped saturated, black, integer-position samples): its
+      // small weights go to the fine levels, the others as usual
 #pragma unroll
-      for (int k = 0; k < 4; k++) wcs[k] = wc[k] * P.hist_scale;
-      const unsigned hrow = (unsigned)(__mul24(f.jr, nb) + jc);
-      unsigned long long *hc = hist + ((unsigned)jc * NC + (unsigned)copy);
+      for (int k = 0; k < 4; k++) {
+        if (wc[k] < kFineW) {
+          if (wc[k] != 0.0) {
+            const int lv = fine_level(fabs(wc[k]));
+            const double wl = wc[k] * fine_scale(lv);
+            unsigned long long *hl = hist_lo + lv * nbins;
+            atomicAdd(hl + (unsigned)(jc + k), fx_encode(wl, 1.0));
 #pragma unroll
-      for (int k = 0; k < 4; k++) atomicAdd(hc + k * NC, fx_encode_raw(wcs[k], 1.0));
-      unsigned long long *hj = hist + (((unsigned)nb + hrow) * NC + (unsigned)copy);
+            for (int m = 0; m < 4; m++) atomicAdd(hl + ((unsigned)nb + hrow + (unsigned)(m * nb + k)), fx_encode(wr[m], wl));
+          }
+        } else {
+          atomicAdd(hc + k * NC, fx_encode_raw(wcs[k], 1.0));
 #pragma unroll
-      for (int m = 0; m < 4; m++)
-#pragma unroll
-        for (int k = 0; k < 4; k++)
-          atomicAdd(hj + (m * nb + k) * NC, fx_encode_raw(f.wr[m], wcs[k]));
+          for (int m = 0; m < 4; m++) atomicAdd(hj + (m * nb + k) * NC, fx_encode_raw(wr[m], wcs[k]));
+        }
+      }
+      return;
     }
-    if (DBG && P.dbg_u && pose_idx == 0 && f.jr >= 0) {
-      const int c = g.cell_begin + cl;
-      const int r = (c / g.cell_num) * g.rb + s / g.cb;
-      const int col = (c % g.cell_num) * g.cb + s % g.cb;
-      const size_t id = (size_t)r * g.cols + col;
-      P.dbg_u[id] = f.u; P.dbg_v[id] = f.v; P.dbg_ic[id] = ic; P.dbg_jc[id] = jc;
+#endif
 #pragma unroll
-      for (int k = 0; k < 4; k++) P.dbg_wc[4 * id + k] = wc[k];
+    for (int k = 0; k < 4; k++) atomicAdd(hc + k * NC, fx_encode_raw(wcs[k], 1.0));
+#pragma unroll
+    for (int m = 0; m < 4; m++)
+#pragma unroll
+      for (int k = 0; k < 4; k++)
+        atomicAdd(hj + (m * nb + k) * NC, fx_encode_raw(wr[m], wcs[k]));
+  };
+  auto dump_pixel = [&](int s, const PixelFront &f, double ic, int jc, const double (&wc)[4]) {
+    const int c = g.cell_begin + cl;
+    const int r = (c / g.cell_num) * g.rb + s / g.cb;
+    const int col = (c % g.cell_num) * g.cb + s % g.cb;
+    const size_t id = (size_t)r * g.cols + col;
+    P.dbg_u[id] = f.u; P.dbg_v[id] = f.v; P.dbg_ic[id] = ic; P.dbg_jc[id] = jc;
+#pragma unroll
+    for (int k = 0; k < 4; k++) P.dbg_wc[4 * id + k] = wc[k];
+  };
+  // FAST math runs every pixel loop as TWO passes.  The main pass does the samples FAST arithmetic may decide
+  // (see exact_decisions) and records, per round, whether the wave met any other ("rare") sample; the second
+  // pass revisits only those rounds and only those samples, with the reference's arithmetic.  The code of the
+  // rare path thus sits outside the hot loop (its registers, its loads and its IEEE divisions cost the main
+  // pass nothing: ten compares and a ballot), the lane -> sample assignment is the same in both passes (so
+  // the sums stay run-to-run reproducible), and integer histogram adds do not care about the order.
+  // rounds: bit min(r, 63) of a wave-uniform mask; a cell of more than 64 rounds per wave shares the last bit.
+  unsigned long long rare_rounds = 0ull;
+  if constexpr (STRICT) {
+#pragma clang loop unroll(disable)
+    for (int sb = wave_base; sb < g.pstride; sb += NT) {
+      const int s = sb + lane;
+      TileIn tin;
+      PixelFront f;
+      load_tile(P, base + (unsigned)s, plane, tin);
+      pixel_front<true>(P, SA, tin, f);
+      load_window(P, f.w);
+      double ic = NAN, wc[4] = {NAN, NAN, NAN, NAN}, dw[4];
+      int jc = -1;
+      if (f.in) {
+        jc = pixel_sample<true, false>(f, nb, S, rtab, ic, wc, dw);
+        hist_add(f.jr, jc, f.wr, wc);
+      }
+      if (DBG && P.dbg_u && !P.dbg_jac && pose_idx == 0 && f.jr >= 0) dump_pixel(s, f, ic, jc, wc);
+    }
+  } else {
+    auto cost_round = [&](int sb, auto second_pass) -> bool {
+      constexpr bool SECOND = decltype(second_pass)::value;
+      const int s = sb + lane;
+      TileIn tin;
+      PixelFront f;
+      load_tile(P, base + (unsigned)s, plane, tin);
+      pixel_front<false>(P, SA, tin, f);
+      WinC wc2;
+      load_win_centre(P, f.w.wx, f.w.wy, wc2);
+      // fixed-tap sample (a convex combination of u8 taps: never negative), computed for every lane -- lanes
+      // without a sample hold a harmless window
+      double ic = sample_fast_c(wc2, f.u, f.v);
+#ifdef NID_EXP_NO_GUARD
+      bool rare = false;
+#else
+      bool rare = f.in && fabs(ic - kGuardMid) > kGuardHalf;
+#endif
+      if (f.redo && classify_redo(P, f)) rare = true;  // (waves that meet the frame border)
+      bool go = f.in && !rare;
+      if (SECOND) {
+        go = false;
+        if (rare) {
+          exact_decisions<EXT>(P, SA, pose_idx, base + (unsigned)s, f, ic);
+          go = f.in;
+        }
+      }
+      double wc[4] = {NAN, NAN, NAN, NAN}, dw[4];
+      int jc = -1;
+      if (go) {
+        double pc;
+        jc = fast_bin(ic, S, pc);
+        bspline4_poly<false>(pc, jc, rtab, wc, dw);
+        hist_add(f.jr, jc, f.wr, wc);
+      } else {
+        ic = NAN;
+      }
+      if (DBG && P.dbg_u && !P.dbg_jac && pose_idx == 0 && f.jr >= 0 && rare == SECOND) dump_pixel(s, f, ic, jc, wc);
+      return !SECOND && __builtin_amdgcn_ballot_w64(rare) != 0ull;
+    };
+    int r = 0;
+#pragma clang loop unroll(disable)
+    for (int sb = wave_base; sb < g.pstride; sb += NT, r++)
+      if (cost_round(sb, std::false_type{})) rare_rounds |= 1ull << min(r, 63);
+    if (rare_rounds != 0ull) {
+      r = 0;
+#pragma clang loop unroll(disable)
+      for (int sb = wave_base; sb < g.pstride; sb += NT, r++)
+        if ((rare_rounds >> min(r, 63)) & 1ull) cost_round(sb, std::true_type{});
     }
   }
   NID_STAMP(2);
@@ -968,7 +1250,13 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(STRICT ? 4 :
       const uint4 q = hv[(c + b) & (NC / 2 - 1)];
       acc += ((unsigned long long)(q.y & kFxHiMask) << 32 | q.x) + ((unsigned long long)(q.w & kFxHiMask) << 32 | q.z);
     }
-    const double p = ((double)(long long)acc * P.hist_inv_scale) / (double)n_c;  // Q1: N_c of the initial pose
+    double mass = (double)(long long)acc * P.hist_inv_scale;
+#pragma unroll
+    for (int lv = 0; lv < kFineLevels; lv++) {  // small target weights (kTinyW); all zero leaves `mass` bit for bit
+      const long long lo = (long long)hist_lo[lv * nbins + b];
+      if (lo != 0) mass += (double)lo * fine_inv_scale(lv);
+    }
+    const double p = mass / (double)n_c;  // Q1: N_c of the initial pose
     double w = 0.0;
     if (!(p < kSigma)) {
       const double l = STRICT ? log2(p) : log2_fast(p);
@@ -1015,100 +1303,152 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(STRICT ? 4 :
   // FAST-mode constants: the gradient helper returns twice the gradient, so 1/2 rides on fx, fy
   const double cAx = wave_uniform(cA * (0.5 * g.fx)), cBx = wave_uniform(cB * (0.5 * g.fx));
   const double cAy = wave_uniform(cA * (0.5 * g.fy)), cBy = wave_uniform(cB * (0.5 * g.fy));
-#if NID_PREFETCH_P2 == 1
-  if (wave_base < g.pstride) load_tile(P, base + (unsigned)(wave_base + lane), plane, tin);
-#elif NID_PREFETCH_P2 == 2
-  if (wave_base < g.pstride) load_tile_xyz(P, base + (unsigned)(wave_base + lane), tin);
-#endif
+  auto jac_accumulate = [&](const PixelFront &f, double invz, double gx, double gy, double pc, int jc, const double (&dw)[4]) {
+    const double *tj = tab + ((unsigned)nb + (unsigned)(__mul24(f.jr, nb) + jc));
+    double tt = 0.0, ss = 0.0;
+#pragma unroll
+    for (int m = 0; m < 4; m++) tt = fma(tab[jc + m], dw[m], tt);
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      double inner = 0.0;
+#pragma unroll
+      for (int m = 0; m < 4; m++) inner = fma(tj[k * nb + m], dw[m], inner);
+      ss = fma(f.wr[k], inner, ss);
+    }
+    if (!STRICT) {
+      // d(u,v)/d(xi) with a = x/z, b = y/z (types_six_dof_expmap.cpp:438-450 regrouped):
+      //   Ju = fx [-ab, 1+a^2, -b, 1/z, 0, -a/z],  Jv = fy [-(1+b^2), ab, a, 0, 1/z, -b/z]
+      // acc[0] and acc[5] accumulate the NEGATED sums (fixed after the loop).
+      double cP = fma(ss, cAx, -(tt * cBx)), cQ = fma(ss, cAy, -(tt * cBy));
+      if (pc == 0.0) { cP = 0.0; cQ = 0.0; }  // Q5: B-spline derivative identically 0 at u == 0
+      const double Pg = cP * gx, Qg = cQ * gy;
+      const double a = f.x * invz, b = f.y * invz;
+      const double Pa = Pg * a, Qb = Qg * b;
+      acc[0] = fma(Pa, b, fma(Qb, b, Qg + acc[0]));
+      acc[1] = fma(Pa, a, fma(Qb, a, Pg + acc[1]));
+      acc[2] = fma(Qg, a, fma(-Pg, b, acc[2]));
+      acc[3] = fma(Pg, invz, acc[3]);
+      acc[4] = fma(Qg, invz, acc[4]);
+      acc[5] = fma(Pa + Qb, invz, acc[5]);
+      return;
+    }
+    const double c = fma(ss, cA, -(tt * cB));
+    const double cgx = c * gx, cgy = c * gy;
+    const double x = f.x, y = f.y;
+    const double invz_2 = invz * invz;
+    // rows of d(u,v)/d(xi), types_six_dof_expmap.cpp:438-450 (omega first, then upsilon)
+    const double ju0 = -x * y * invz_2 * g.fx, ju1 = (1 + (x * x * invz_2)) * g.fx;
+    const double ju2 = -y * invz * g.fx, ju3 = invz * g.fx, ju5 = -x * invz_2 * g.fx;
+    const double jv0 = -(1 + y * y * invz_2) * g.fy, jv1 = x * y * invz_2 * g.fy;
+    const double jv2 = x * invz * g.fy, jv4 = invz * g.fy, jv5 = -y * invz_2 * g.fy;
+    acc[0] = fma(cgx, ju0, fma(cgy, jv0, acc[0]));
+    acc[1] = fma(cgx, ju1, fma(cgy, jv1, acc[1]));
+    acc[2] = fma(cgx, ju2, fma(cgy, jv2, acc[2]));
+    acc[3] = fma(cgx, ju3, acc[3]);
+    acc[4] = fma(cgy, jv4, acc[4]);
+    acc[5] = fma(cgx, ju5, fma(cgy, jv5, acc[5]));
+  };
+  // Jacobian-phase dump (dbg_jac): for every sample that contributes, the image gradient in the reference's
+  // convention (central difference / 2), the bin position, the span and the four B-spline derivatives
+  auto dump_jac = [&](int s, double gx, double gy, double pc, int jc, const double (&dw)[4]) {
+    const int c = g.cell_begin + cl;
+    const int r = (c / g.cell_num) * g.rb + s / g.cb;
+    const int col = (c % g.cell_num) * g.cb + s % g.cb;
+    const size_t id = (size_t)r * g.cols + col;
+    P.dbg_u[id] = gx; P.dbg_v[id] = gy; P.dbg_ic[id] = pc; P.dbg_jc[id] = jc;
+#pragma unroll
+    for (int k = 0; k < 4; k++) P.dbg_wc[4 * id + k] = dw[k];
+  };
+  if constexpr (STRICT) {
 #pragma clang loop unroll(disable)
-  for (int sb = wave_base; sb < g.pstride; sb += NT) {
-    const int s = sb + lane;
-    PixelFront f;
-#if NID_PREFETCH_P2 == 0
-    load_tile(P, base + (unsigned)s, plane, tin);
-#endif
-    pixel_front<STRICT>(P, SA, tin, f);
-#if NID_PREFETCH_P2 == 1
-    asm volatile("" ::: "memory");
-    load_tile(P, base + (unsigned)(sb + NT < g.pstride ? s + NT : s), plane, tin);
-#elif NID_PREFETCH_P2 == 2
-    asm volatile("" ::: "memory");
-    load_tile_w(P, base + (unsigned)s, plane, tin);
-#pragma unroll
-    for (int k = 0; k < 4; k++) f.wr[k] = tin.wr[k];
-    load_tile_xyz(P, base + (unsigned)(sb + NT < g.pstride ? s + NT : s), tin);
-#endif
-    if (f.in) {
-      double invz, u, v;
-      bool jin;
-      if (STRICT) {  // linearizeOplus: fx*(x/z)+cx (types_six_dof_expmap.cpp:407-422, Q6)
-        invz = 1.0 / f.zq;
-        u = g.fx * (f.x / f.zq) + g.cx;
-        v = g.fy * (f.y / f.zq) + g.cy;
-        jin = (u >= 0 && u + 3 <= P.jac_cols && v >= 0 && v + 3 <= g.rows);
-      } else {
-        invz = f.zq; u = f.u; v = f.v; jin = f.jin;
-      }
-      if (jin) {
-        double ic, wc[4], dw[4], gx, gy, pc = 1.0;
-        int jc;
-        if (STRICT) {
-          jc = pixel_sample<STRICT, true>(f, nb, S, rtab, ic, wc, dw);
+    for (int sb = wave_base; sb < g.pstride; sb += NT) {
+      const int s = sb + lane;
+      TileIn tin;
+      PixelFront f;
+      load_tile(P, base + (unsigned)s, plane, tin);
+      pixel_front<true>(P, SA, tin, f);
+      load_window(P, f.w);
+      if (f.in) {
+        // linearizeOplus: fx*(x/z)+cx (types_six_dof_expmap.cpp:407-422, Q6)
+        const double invz = 1.0 / f.zq;
+        const double u = g.fx * (f.x / f.zq) + g.cx;
+        const double v = g.fy * (f.y / f.zq) + g.cy;
+        if (u >= 0 && u + 3 <= P.jac_cols && v >= 0 && v + 3 <= g.rows) {
+          double ic, wc[4], dw[4];
+          const int jc = pixel_sample<true, true>(f, nb, S, rtab, ic, wc, dw);  // from the cost pass's (u, v): Q7
+          // The gradient is sampled around linearizeOplus' OWN (u, v) (Q6), which may truncate to the neighbouring
+          // pixel when the cost pass's sits within an ulp of an integer (identity-like poses): its taps then lie
+          // outside the window loaded around the cost pass's position -- load the one it needs.
+          if ((int)u - 1 != f.w.wx || (int)v - 1 != f.w.wy) {
+            f.w.wx = (int)u - 1; f.w.wy = (int)v - 1;
+            load_window(P, f.w);
+          }
           const RowPair r0 = win_rows(f.w, v);
-          gx = (bilinear_rows(r0, f.w.wx, u + 1) - bilinear_rows(r0, f.w.wx, u - 1)) / 2;
+          const double gx = (bilinear_rows(r0, f.w.wx, u + 1) - bilinear_rows(r0, f.w.wx, u - 1)) / 2;
           const RowPair rp = win_rows(f.w, v + 1), rm = win_rows(f.w, v - 1);
-          gy = (bilinear_rows(rp, f.w.wx, u) - bilinear_rows(rm, f.w.wx, u)) / 2;
-        } else {
-          gradient_fast(f.w, u, v, gx, gy, ic);  // centre sample shares the gradient's taps
-          if (ic >= 255) ic = 254.999;
-          pc = ic * ((double)S / 255.0);
-          jc = (int)pc;
-          bspline4_poly_der(pc, jc, rtab, dw);
+          const double gy = (bilinear_rows(rp, f.w.wx, u) - bilinear_rows(rm, f.w.wx, u)) / 2;
+          jac_accumulate(f, invz, gx, gy, 1.0, jc, dw);
+          if (DBG && P.dbg_u && P.dbg_jac && pose_idx == 0) dump_jac(s, gx, gy, ic * ((double)nb - 3.0) / 255.0, jc, dw);
         }
-        const double *tj = tab + ((unsigned)nb + (unsigned)(__mul24(f.jr, nb) + jc));
-        double tt = 0.0, ss = 0.0;
-#pragma unroll
-        for (int m = 0; m < 4; m++) tt = fma(tab[jc + m], dw[m], tt);
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-          double inner = 0.0;
-#pragma unroll
-          for (int m = 0; m < 4; m++) inner = fma(tj[k * nb + m], dw[m], inner);
-          ss = fma(f.wr[k], inner, ss);
-        }
-        if (!STRICT) {
-          // d(u,v)/d(xi) with a = x/z, b = y/z (types_six_dof_expmap.cpp:438-450 regrouped):
-          //   Ju = fx [-ab, 1+a^2, -b, 1/z, 0, -a/z],  Jv = fy [-(1+b^2), ab, a, 0, 1/z, -b/z]
-          // acc[0] and acc[5] accumulate the NEGATED sums (fixed after the loop).
-          double cP = fma(ss, cAx, -(tt * cBx)), cQ = fma(ss, cAy, -(tt * cBy));
-          if (pc == 0.0) { cP = 0.0; cQ = 0.0; }  // Q5: B-spline derivative identically 0 at u == 0
-          const double Pg = cP * gx, Qg = cQ * gy;
-          const double a = f.x * invz, b = f.y * invz;
-          const double Pa = Pg * a, Qb = Qg * b;
-          acc[0] = fma(Pa, b, fma(Qb, b, Qg + acc[0]));
-          acc[1] = fma(Pa, a, fma(Qb, a, Pg + acc[1]));
-          acc[2] = fma(Qg, a, fma(-Pg, b, acc[2]));
-          acc[3] = fma(Pg, invz, acc[3]);
-          acc[4] = fma(Qg, invz, acc[4]);
-          acc[5] = fma(Pa + Qb, invz, acc[5]);
-          continue;
-        }
-        const double c = fma(ss, cA, -(tt * cB));
-        const double cgx = c * gx, cgy = c * gy;
-        const double x = f.x, y = f.y;
-        const double invz_2 = invz * invz;
-        // rows of d(u,v)/d(xi), types_six_dof_expmap.cpp:438-450 (omega first, then upsilon)
-        const double ju0 = -x * y * invz_2 * g.fx, ju1 = (1 + (x * x * invz_2)) * g.fx;
-        const double ju2 = -y * invz * g.fx, ju3 = invz * g.fx, ju5 = -x * invz_2 * g.fx;
-        const double jv0 = -(1 + y * y * invz_2) * g.fy, jv1 = x * y * invz_2 * g.fy;
-        const double jv2 = x * invz * g.fy, jv4 = invz * g.fy, jv5 = -y * invz_2 * g.fy;
-        acc[0] = fma(cgx, ju0, fma(cgy, jv0, acc[0]));
-        acc[1] = fma(cgx, ju1, fma(cgy, jv1, acc[1]));
-        acc[2] = fma(cgx, ju2, fma(cgy, jv2, acc[2]));
-        acc[3] = fma(cgx, ju3, acc[3]);
-        acc[4] = fma(cgy, jv4, acc[4]);
-        acc[5] = fma(cgx, ju5, fma(cgy, jv5, acc[5]));
       }
+    }
+  } else {
+    // Two passes like the cost phase, with the same classification on the same values (gradient_fast_interior's
+    // centre sample IS sample_fast_interior's): both phases take the same decisions and use the same
+    // intensity (Q7).
+    auto jac_round = [&](int sb, auto second_pass) {
+      constexpr bool SECOND = decltype(second_pass)::value;
+      const int s = sb + lane;
+      TileIn tin;
+      PixelFront f;
+      load_tile(P, base + (unsigned)s, plane, tin);
+      pixel_front<false>(P, SA, tin, f);
+      WinJ wj;
+      load_win_jac(P, f.w.wx, f.w.wy, wj);
+      double ic, gx, gy;
+      gradient_fast_j(wj, f.u, f.v, gx, gy, ic);  // every lane, see the cost phase
+#ifdef NID_EXP_NO_GUARD
+      bool exact = false;
+#else
+      bool exact = f.in && fabs(ic - kGuardMid) > kGuardHalf;
+#endif
+      if (f.redo && classify_redo(P, f)) exact = true;
+      bool go = f.jin && !exact;
+      if (SECOND) {
+        go = false;
+        if (exact) {
+          exact_decisions<EXT>(P, SA, pose_idx, base + (unsigned)s, f, ic);
+          go = f.jin;
+          if (go) {  // the gradient again, on the window around the reference's (u, v)
+            double dummy;
+            gradient_fast_interior(f.w, f.u, f.v, gx, gy, dummy);
+          }
+        }
+      }
+      if (go) {
+        double pc, dw[4];
+        const int jc = fast_bin(ic, S, pc);
+        bspline4_poly_der(pc, jc, rtab, dw);
+        jac_accumulate(f, f.zq, gx, gy, pc, jc, dw);
+        if (DBG && P.dbg_u && P.dbg_jac && pose_idx == 0) {
+          double dq[4];
+#pragma unroll
+          for (int k = 0; k < 4; k++) dq[k] = (pc == 0.0) ? 0.0 : dw[k];  // Q5, applied inside jac_accumulate
+          dump_jac(s, 0.5 * gx, 0.5 * gy, pc, jc, dq);
+        }
+      }
+      return !SECOND && __builtin_amdgcn_ballot_w64(exact) != 0ull;
+    };
+    unsigned long long rare2 = 0ull;
+    int r = 0;
+#pragma clang loop unroll(disable)
+    for (int sb = wave_base; sb < g.pstride; sb += NT, r++)
+      if (jac_round(sb, std::false_type{})) rare2 |= 1ull << min(r, 63);
+    if (rare2 != 0ull) {
+      r = 0;
+#pragma clang loop unroll(disable)
+      for (int sb = wave_base; sb < g.pstride; sb += NT, r++)
+        if ((rare2 >> min(r, 63)) & 1ull) jac_round(sb, std::true_type{});
     }
   }
   if (!STRICT) { acc[0] = -acc[0]; acc[5] = -acc[5]; }

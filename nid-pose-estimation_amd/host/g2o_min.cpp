@@ -277,9 +277,17 @@ bool BlockSolver_6_X::buildSystem() {  // block_solver.hpp:503-570
   VertexSE3Expmap *v = _opt->_vertices[0];
   v->clearQuadraticForm();
   const std::vector<EdgeSE3ProjectIntensityOnlyPoseNID *> &edges = _opt->_activeEdges;
+  // The reference's walk (`while (isnan(der[6*m])) m++`, :535) assumes that exactly the level-1 cells are NaN
+  // and runs off the array otherwise (an ACTIVE cell can still be NaN: im0 and im1 both constant over it give
+  // Hj = 0, err = 0/0).  Same walk, bounded: an overrun fails the solve instead of reading past the array.
+  const int n_cells = _opt->cell_num_ * _opt->cell_num_;
   for (int k = 0, m = 0; k < (int)edges.size(); ++k, m++) {
     EdgeSE3ProjectIntensityOnlyPoseNID *e = edges[k];
-    while (std::isnan(der_[6 * m])) m++;  // NaN-skip walk, :535
+    while (m < n_cells && std::isnan(der_[6 * m])) m++;  // NaN-skip walk, :535
+    if (m >= n_cells) {
+      std::cerr << "BlockSolver::buildSystem: NaN Jacobian in an active cell (edge " << k << "): cell walk overran\n";
+      return false;
+    }
     e->set_j(der_[6 * m], der_[6 * m + 1], der_[6 * m + 2], der_[6 * m + 3], der_[6 * m + 4], der_[6 * m + 5]);
     e->linearizeOplus();
     e->constructQuadraticForm();
@@ -470,12 +478,12 @@ OptimizationAlgorithmLevenberg::SolverResult OptimizationAlgorithmLevenberg::sol
                M.data(), opt->camera_intrincis_, opt->bin_num_, opt->bs_degree_, opt->cell_num_, opt->rows_,
                opt->cols_, opt->Href_, nullptr, nullptr, Htarget.data(), Hjoint.data(), der.data());
   opt->set_h_pointer(Htarget.data(), Hjoint.data());
-  opt->computeActiveErrors();
+  if (!opt->computeActiveErrors()) return Fail;
   double currentChi = opt->activeRobustChi2();
   double tempChi = currentChi;
   const double iniChi = currentChi;
   _solver->set_j_bs(der.data());
-  _solver->buildSystem();
+  if (!_solver->buildSystem()) return Fail;
 
   if (iteration == 0) {
     _currentLambda = computeLambdaInit();
@@ -500,7 +508,7 @@ OptimizationAlgorithmLevenberg::SolverResult OptimizationAlgorithmLevenberg::sol
                  opt->bs_index_ref_, Mn.data(), opt->camera_intrincis_, opt->bin_num_, opt->bs_degree_,
                  opt->cell_num_, opt->rows_, opt->cols_, opt->Href_, nullptr, nullptr, Htarget.data(),
                  Hjoint.data(), der.data());
-    opt->computeActiveErrors();
+    if (!opt->computeActiveErrors()) return Fail;
     tempChi = opt->activeRobustChi2();
     if (!ok2) tempChi = std::numeric_limits<double>::max();
 
@@ -559,13 +567,19 @@ bool SparseOptimizer::initializeOptimization(int level) {
   return !_vertices.empty();
 }
 
-void SparseOptimizer::computeActiveErrors() {  // sparse_optimizer.cpp:61-90
+bool SparseOptimizer::computeActiveErrors() {  // sparse_optimizer.cpp:61-90
+  const int n_cells = cell_num_ * cell_num_;
   for (int k = 0, n = 0; k < (int)_activeEdges.size(); ++k, ++n) {
     EdgeSE3ProjectIntensityOnlyPoseNID *e = _activeEdges[k];
-    while (std::isnan(h_target_[n]) || std::isnan(h_joint_[n])) n++;
+    while (n < n_cells && (std::isnan(h_target_[n]) || std::isnan(h_joint_[n]))) n++;  // bounded, see buildSystem
+    if (n >= n_cells) {
+      std::cerr << "SparseOptimizer::computeActiveErrors: NaN entropy in an active cell (edge " << k << "): cell walk overran\n";
+      return false;
+    }
     e->set_h(h_target_[n], h_joint_[n]);
     e->computeError();
   }
+  return true;
 }
 
 double SparseOptimizer::activeRobustChi2() const {  // sparse_optimizer.cpp:102-116
@@ -648,8 +662,9 @@ int SparseOptimizer::optimize(int iterations) {  // sparse_optimizer.cpp:356-450
                    camera_intrincis_, bin_num_, bs_degree_, cell_num_, rows_, cols_, Href_, nullptr, nullptr,
                    Htarget.data(), Hjoint.data(), nullptr);
       set_h_pointer(Htarget.data(), Hjoint.data());
-      computeActiveErrors();
+      const bool walked = computeActiveErrors();
       set_h_pointer(nullptr, nullptr);
+      if (!walked) return 0;
       const double chi = activeRobustChi2();
       if (_log) {
         char buf[256];

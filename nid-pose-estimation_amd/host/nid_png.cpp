@@ -14,6 +14,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <new>
 #include <vector>
 
 #include "nid_pose_problem.h"
@@ -33,7 +34,14 @@ int paeth(int a, int b, int c) {
 }
 
 // 0 ok; -1 cannot open; -2 not a PNG / corrupt; -3 unsupported variant; -4 inflate failed
-int decode_png(const char *path, Png *out) {
+// Sizes come from the file: they are capped (kMaxPixels, and what the IDAT stream can possibly inflate to)
+// BEFORE anything is allocated, chunk CRCs are checked, and the extern "C" entry points catch allocation
+// failures -- nothing throws across the boundary.
+constexpr uint64_t kMaxPixels = 64ull << 20;  // 64 MPix: far beyond any camera frame this driver is fed
+
+uint32_t crc32_png(const uint8_t *p, size_t n) { return (uint32_t)crc32(crc32(0L, Z_NULL, 0), p, (uInt)n); }
+
+int decode_png_impl(const char *path, Png *out) {
   FILE *f = std::fopen(path, "rb");
   if (!f) return -1;
   std::vector<uint8_t> file;
@@ -51,6 +59,7 @@ int decode_png(const char *path, Png *out) {
     const uint32_t len = be32(&file[pos]);
     const uint8_t *type = &file[pos + 4], *data = &file[pos + 8];
     if (pos + 12 + (size_t)len > file.size()) return -2;
+    if (crc32_png(type, 4 + (size_t)len) != be32(data + len)) return -2;  // chunk CRC covers type + data
     if (!std::memcmp(type, "IHDR", 4)) {
       if (len != 13) return -2;
       out->cols = (int)be32(data); out->rows = (int)be32(data + 4);
@@ -67,6 +76,7 @@ int decode_png(const char *path, Png *out) {
     pos += 12 + (size_t)len;
   }
   if (!have_ihdr || idat.empty() || out->rows <= 0 || out->cols <= 0) return -2;
+  if ((uint64_t)out->rows * (uint64_t)out->cols > kMaxPixels) return -3;
   if (interlace != 0 || (out->depth != 8 && out->depth != 16)) return -3;
   int ch;
   switch (colour) {
@@ -78,6 +88,8 @@ int decode_png(const char *path, Png *out) {
     default: return -3;
   }
   const size_t bps = (size_t)out->depth / 8, bpp = bps * ch, stride = bpp * out->cols;
+  // deflate cannot expand by more than ~1032:1: a header that promises more than the IDAT stream can hold is corrupt
+  if ((uint64_t)out->rows * (stride + 1) > (uint64_t)idat.size() * 1032ull + 1024ull) return -2;
   std::vector<uint8_t> raw((size_t)out->rows * (stride + 1));
   uLongf rawlen = (uLongf)raw.size();
   if (uncompress(raw.data(), &rawlen, idat.data(), (uLong)idat.size()) != Z_OK || rawlen != raw.size()) return -4;
@@ -111,6 +123,16 @@ int decode_png(const char *path, Png *out) {
     out->px.swap(img);
   }
   return 0;
+}
+
+int decode_png(const char *path, Png *out) {
+  try {
+    return decode_png_impl(path, out);
+  } catch (const std::bad_alloc &) {
+    return -4;
+  } catch (...) {
+    return -2;
+  }
 }
 
 }  // namespace

@@ -250,10 +250,23 @@ def disturb_pose(R_cw, t_cw, r_offset=0.005, t_offset=0.02):
     return rot @ R_cw, t_cw + t_dist
 
 
+def flash_term(rows, cols, amplitude=300.0, sigma_frac=0.12):
+    """Radial "flash" of the second exposure (BASELINE configs[0] is the ETH-CVG
+    real_flash pair): a Gaussian hot spot slightly off the image centre, strong enough to drive a disc of
+    about 13 % of the pixels into saturation (255) after the illumination change."""
+    r = np.arange(rows, dtype=np.float64)[:, None]
+    c = np.arange(cols, dtype=np.float64)[None, :]
+    r0, c0 = 0.45 * rows, 0.55 * cols
+    sig = sigma_frac * cols
+    return amplitude * np.exp(-((r - r0) ** 2 + (c - c0) ** 2) / (2.0 * sig * sig))
+
+
 def make_pair(config="A", texture="blocky", edge_cases=False, rows=None, cols=None, cell=None,
-              r_offset=0.005, t_offset=0.02):
+              r_offset=0.005, t_offset=0.02, flash=False):
     """config 'A' = 640x480 / 16x16 cells, 'B' = 1280x960 / 32x32 cells (A upsampled 2x),
-    'S' = 160x120 / 4x4 cells (small parity case; cells stay 30x40 px)."""
+    'S' = 160x120 / 4x4 cells (small parity case; cells stay 30x40 px).  flash=True adds the saturating
+    hot spot of flash_term() to the second image; edge_cases=True adds 5 % zero-depth holes, saturated and
+    black patches and an inactive cell."""
     base = dict(fx=481.20, fy=-480.0, cx=319.5, cy=239.5)
     if config == "S":
         R_, C_, G_ = 120, 160, 4
@@ -292,6 +305,8 @@ def make_pair(config="A", texture="blocky", edge_cases=False, rows=None, cols=No
 
     im1_f = render_second_view(tex, depth_m, fx, fy, cx, cy, T_wc0, T_cw1)
     im1 = illumination_change(im1_f)
+    if flash:   # saturating hot spot on top of the global gain / gamma / offset change
+        im1 = np.clip(np.rint(np.minimum(im1.astype(np.float64) + flash_term(R_, C_), 255.0)), 0, 255).astype(np.uint8)
     if edge_cases:
         im1 = im1.copy()
         im1[R_ // 3: R_ // 3 + 20, C_ // 3: C_ // 3 + 30] = 255

@@ -36,6 +36,7 @@ struct nid_oracle {
   double *I0;           /* N  (_measurement) */
   double *wr;           /* 4N (bs_value_ref_), zero until computeHref */
   double *ic;           /* N  (intensity_current_), zero-initialised: .cpp:652 */
+  double *jgx, *jgy, *jpc, *jdw; int *jjc;  /* Jacobian-pass dump: gx, gy, bin position, 4 derivatives, span (NaN / -1: no contribution) */
   unsigned char *im1;   /* N  (image1_) */
   /* dump of the last evaluate */
   double *du, *dv, *dwc;
@@ -335,6 +336,9 @@ nid_oracle *nid_oracle_create(int rows, int cols, int cell, int bin_num,
   o->I0 = (double *)calloc(N, sizeof(double));
   o->wr = (double *)calloc(4 * N, sizeof(double));
   o->ic = (double *)calloc(N, sizeof(double));
+  o->jgx = (double *)calloc(N, sizeof(double)); o->jgy = (double *)calloc(N, sizeof(double));
+  o->jpc = (double *)calloc(N, sizeof(double)); o->jdw = (double *)calloc(4 * N, sizeof(double));
+  o->jjc = (int *)calloc(N, sizeof(int));
   o->im1 = (unsigned char *)calloc(N, 1);
   o->du = (double *)calloc(N, sizeof(double));
   o->dv = (double *)calloc(N, sizeof(double));
@@ -354,6 +358,7 @@ nid_oracle *nid_oracle_create(int rows, int cols, int cell, int bin_num,
 void nid_oracle_destroy(nid_oracle *o) {
   if (!o) return;
   free(o->pts); free(o->I0); free(o->wr); free(o->ic); free(o->im1);
+  free(o->jgx); free(o->jgy); free(o->jpc); free(o->jdw); free(o->jjc);
   free(o->du); free(o->dv); free(o->dwc); free(o->djc);
   free(o->Nc); free(o->active); free(o->Href); free(o->pc); free(o->pj);
   free(o->Hc); free(o->Hj);
@@ -555,6 +560,8 @@ static void cell_linearize(nid_oracle *o, const xform_t *xf, int ci, int cj, dou
   for (int r = o->rb * ci; r < o->rb * (ci + 1); r++)
     for (int cc = o->cb * cj; cc < o->cb * (cj + 1); cc++) {
       int id = r * o->cols + cc;
+      o->jgx[id] = NAN; o->jgy[id] = NAN; o->jpc[id] = NAN; o->jjc[id] = -1;
+      for (int k = 0; k < 4; k++) o->jdw[4 * (size_t)id + k] = NAN;
       if (!pixel_valid(o, id)) continue;
       double p_c[3];
       xform_apply(xf, o->pts + 3 * (size_t)id, p_c);
@@ -595,6 +602,8 @@ static void cell_linearize(nid_oracle *o, const xform_t *xf, int ci, int cj, dou
       for (int n = 0; n < 6; n++) d_i_pose[n] = gx * Ju[n] + gy * Jv[n];
       double d_bs_mi[4];
       for (int m = 0; m < 4; m++) d_bs_mi[m] = bspline_der(o->knots, jc + m, o->deg + 1, bin_pos_current);
+      o->jgx[id] = gx; o->jgy[id] = gy; o->jpc[id] = bin_pos_current; o->jjc[id] = jc;
+      for (int m = 0; m < 4; m++) o->jdw[4 * (size_t)id + m] = d_bs_mi[m];
       for (int m = 0; m < 4; m++)
         for (int n = 0; n < 6; n++) d_sum_bs_pose[jc + m][n] += d_bs_mi[m] * d_mi_i * d_i_pose[n];
       const double *wr = o->wr + 4 * (size_t)id;
@@ -670,6 +679,15 @@ void nid_oracle_dump_pixels(const nid_oracle *o, double *u, double *v, double *i
       if (obs >= 255) obs = 254.999;
       jr[i] = (int)floor(obs * (o->nb - o->deg) / 255.0);
     }
+}
+
+void nid_oracle_dump_jac(const nid_oracle *o, double *gx, double *gy, double *pc, int *jc, double *dw4) {
+  size_t N = (size_t)o->rows * o->cols;
+  if (gx) memcpy(gx, o->jgx, N * sizeof(double));
+  if (gy) memcpy(gy, o->jgy, N * sizeof(double));
+  if (pc) memcpy(pc, o->jpc, N * sizeof(double));
+  if (jc) memcpy(jc, o->jjc, N * sizeof(int));
+  if (dw4) memcpy(dw4, o->jdw, 4 * N * sizeof(double));
 }
 
 /* base_unary_edge.hpp:43-72, robust_kernel_impl.cpp:65-91 (float dsqr,

@@ -72,6 +72,10 @@ void nid_oracle_dump_pixels(const nid_oracle *o, double *u, double *v,
                             double *ic, int *jc, double *wc4, double *wr4,
                             int *jr);
 
+/* per-pixel dump of the Jacobian pass of the last evaluate(want_jac): image gradient (gx, gy), bin position,
+ * span and the four B-spline derivatives of every pixel that contributed (NaN / -1 elsewhere) */
+void nid_oracle_dump_jac(const nid_oracle *o, double *gx, double *gy, double *pc, int *jc, double *dw4);
+
 /* ---- B-spline (types_six_dof_expmap.cpp:738-800) ----------------------- */
 double nid_oracle_bspline(int bin_num, int index, int order, double u);
 double nid_oracle_bspline_der(int bin_num, int index, int order, double u);

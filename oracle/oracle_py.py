@@ -50,6 +50,7 @@ def load(path: str | None = None):
     lib.nid_oracle_evaluate.argtypes = [C.c_void_p, c_dp, C.c_int, c_dp, c_dp, c_dp, c_dp]
     lib.nid_oracle_normal_equations.argtypes = [c_dp, c_dp, C.c_int, C.c_double, c_dp, c_dp, c_dp, c_ip]
     lib.nid_oracle_dump_pixels.argtypes = [C.c_void_p, c_dp, c_dp, c_dp, c_ip, c_dp, c_dp, c_ip]
+    lib.nid_oracle_dump_jac.argtypes = [C.c_void_p, c_dp, c_dp, c_dp, c_ip, c_dp]
     lib.nid_oracle_bspline.restype = C.c_double
     lib.nid_oracle_bspline.argtypes = [C.c_int, C.c_int, C.c_int, C.c_double]
     lib.nid_oracle_bspline_der.restype = C.c_double
@@ -197,6 +198,14 @@ class Oracle:
         jr = np.zeros(N, dtype=np.int32)
         self.lib.nid_oracle_dump_pixels(self.h, _dp(u), _dp(v), _dp(ic), _ip(jc), _dp(wc), _dp(wr), _ip(jr))
         return dict(u=u, v=v, ic=ic, jc=jc, wc=wc, wr=wr, jr=jr)
+
+    def dump_jac(self):
+        """Jacobian pass of the last evaluate(want_jac=True): gx, gy, pc, jc, dw[4] per contributing pixel."""
+        N = self.rows * self.cols
+        gx = np.zeros(N); gy = np.zeros(N); pc = np.zeros(N)
+        jc = np.zeros(N, dtype=np.int32); dw = np.zeros((N, 4))
+        self.lib.nid_oracle_dump_jac(self.h, _dp(gx), _dp(gy), _dp(pc), _ip(jc), _dp(dw))
+        return dict(gx=gx, gy=gy, pc=pc, jc=jc, dw=dw)
 
     def lm(self, pose7, iterations=10, delta=np.sqrt(0.95)):
         p = _d(pose7).copy()

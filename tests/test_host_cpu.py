@@ -210,6 +210,22 @@ def test_png_reader_and_grey_conversion(hostlib, tmp_path):
     assert lib.nid_png_info(os.fsencode(str(tmp_path / "missing.png")), None, None, None, None) == -1
     with pytest.raises(RuntimeError):
         hostlib.png_read_u16(str(tmp_path / "rgb.png"))      # depth must be single-channel
+    # hostile headers: sizes that would need gigabytes are refused before anything is allocated; nothing throws
+    import struct
+    import zlib
+    good = _png_bytes(rgb, 8, 2, [0])
+
+    def with_ihdr(cols, rows):
+        ihdr = struct.pack(">IIBBBBB", cols, rows, 8, 2, 0, 0, 0)
+        return good[:16] + ihdr + struct.pack(">I", zlib.crc32(b"IHDR" + ihdr) & 0xffffffff) + good[33:]
+    bad.write_bytes(with_ihdr(1 << 20, 1 << 20))            # 2^40 pixels
+    assert lib.nid_png_info(os.fsencode(str(bad)), None, None, None, None) == -3
+    bad.write_bytes(with_ihdr(8000, 8000))                   # under the pixel cap, but far more than 60 bytes of IDAT inflate to
+    assert lib.nid_png_info(os.fsencode(str(bad)), None, None, None, None) == -2
+    corrupt = bytearray(good)
+    corrupt[-20] ^= 0x40                                      # a flipped bit in the IDAT payload: the chunk CRC catches it
+    bad.write_bytes(bytes(corrupt))
+    assert lib.nid_png_info(os.fsencode(str(bad)), None, None, None, None) == -2
 
 
 def test_driver_refuses_cpu_mode(tmp_path):

@@ -1,8 +1,12 @@
 """Parity of the HIP path (through the C-ABI) against the CPU oracle on the same
 seeded inputs.  Tolerances: per-cell Href/Hc/Hj/err
-1e-11 absolute; per-cell Jacobian 1e-9 relative to the cell array's largest
-component (summation order differs); in-bound counts, bin indices and every
-per-pixel intermediate (u, v, bilinear intensity, B-spline weights) bit-exact."""
+1e-11 absolute; per-cell Jacobian 1e-9 relative PER CELL (to the cell's own largest
+component; summation order differs); in-bound counts, bin indices and -- in STRICT
+math -- every per-pixel intermediate (u, v, bilinear intensity, B-spline weights)
+bit-exact.  Both math modes meet the same bounds on every input, saturated and
+border-aligned ones included: FAST re-decides the reference's discontinuous
+decisions (frame border, 255 clamp, zero clamp) with the reference's own arithmetic
+(exact_decisions in csrc/nid_kernels.hip.h), so there is no loose set."""
 import numpy as np
 import pytest
 
@@ -10,6 +14,11 @@ pytestmark = pytest.mark.gpu
 
 ATOL_H = 1e-11
 RTOL_J = 1e-9
+# Each cell's Jacobian is held to RTOL_J relative to ITS OWN largest component.  Cells whose whole
+# Jacobian is below J_FLOOR x the frame's largest component count as numerically zero (a constant image gives
+# exact zeros against 1e-32 residue) and are checked against RTOL_J x that floor.  Observed worst case on the
+# flash pair, where fully saturated cells keep |J| ~ 1e-7 of the frame's maximum: 3e-10 of the cell's own scale.
+J_FLOOR = 1e-6
 DELTA = float(np.sqrt(0.95))
 
 
@@ -23,48 +32,46 @@ def _poses(synth, pair):
     return {"init": pair.pose_init, "true": pair.pose_true, "near": near, "far": far}
 
 
+def _cell_ids(pair):
+    G, rb, cb = pair.cell, pair.rows // pair.cell, pair.cols // pair.cell
+    rr, cc = np.divmod(np.arange(pair.rows * pair.cols), pair.cols)
+    inc = (rr < G * rb) & (cc < G * cb)
+    return np.where(inc, (rr // max(rb, 1)) * G + cc // max(cb, 1), 0), inc
+
+
 def _saturated_cells(o, pair):
     """Cells that own an in-frame target sample at the saturation clamp (ic >= 255 -> 254.999,
     types_six_dof_expmap.cpp:572-573).  With all four taps at 255 the reference's bilinear sum lands
-    on either side of 255.0 by its last rounding, a 1e-3 intensity jump decided by noise: such cells
-    are reproducible only by bit-identical arithmetic (STRICT), FAST math always clamps there."""
+    on either side of 255.0 by its last rounding, a 1e-3 intensity jump decided by noise.  Used only to
+    assert that a test really exercises such cells -- they get no looser bound."""
     d = o.dump_pixels()
-    G, rb, cb = pair.cell, pair.rows // pair.cell, pair.cols // pair.cell
-    rr, cc = np.divmod(np.arange(pair.rows * pair.cols), pair.cols)
-    cell = (rr // rb) * G + cc // cb
-    sat = (d["jc"] >= 0) & (d["ic"] > 254.99)
-    out = np.zeros(G * G, dtype=bool)
+    cell, inc = _cell_ids(pair)
+    sat = (d["jc"] >= 0) & (d["ic"] > 254.99) & inc
+    out = np.zeros(pair.cell * pair.cell, dtype=bool)
     out[np.unique(cell[sat])] = True
     return out
 
 
-def _compare_cells(got, ref, cnt, loose=None):
-    """`loose`: cells compared at 1e-4 (FAST math on saturation-clamp cells, see _saturated_cells)."""
+def _compare_cells(got, ref, cnt):
     Hc, Hj, err, J = got
     Hc_o, Hj_o, err_o, J_o = ref
     act = cnt >= 300
     assert np.array_equal(np.isnan(err), ~act)
     assert np.array_equal(np.isnan(err_o), ~act)
-    tight = act if loose is None else act & ~loose
-    np.testing.assert_allclose(Hc[tight], Hc_o[tight], rtol=0, atol=ATOL_H)
-    np.testing.assert_allclose(Hj[tight], Hj_o[tight], rtol=0, atol=ATOL_H)
-    np.testing.assert_allclose(err[tight], err_o[tight], rtol=0, atol=ATOL_H)
-    if loose is not None and (act & loose).any():
-        m = act & loose
-        np.testing.assert_allclose(Hc[m], Hc_o[m], rtol=0, atol=1e-4)
-        np.testing.assert_allclose(Hj[m], Hj_o[m], rtol=0, atol=1e-4)
-        np.testing.assert_allclose(err[m], err_o[m], rtol=0, atol=1e-4)
+    np.testing.assert_allclose(Hc[act], Hc_o[act], rtol=0, atol=ATOL_H)
+    np.testing.assert_allclose(Hj[act], Hj_o[act], rtol=0, atol=ATOL_H)
+    np.testing.assert_allclose(err[act], err_o[act], rtol=0, atol=ATOL_H)
     if J is not None:
         # an active cell whose pixels all left the frame has Hj == 0: err = -inf, J = NaN on both sides
-        fin = np.isfinite(J_o[act])
-        assert np.array_equal(np.isfinite(J[act]), fin)
-        # Jacobians of real cells are O(0.01 .. 10); a constant image gives exact zeros against 1e-32 residue
-        scale = max(np.abs(J_o[act][fin]).max(), 1e-3) if fin.any() else 1.0
-        np.testing.assert_allclose(J[tight][np.isfinite(J_o[tight])], J_o[tight][np.isfinite(J_o[tight])], rtol=0,
-                                   atol=RTOL_J * scale)
-        if loose is not None and (act & loose).any():
-            m = act & loose
-            np.testing.assert_allclose(J[m][np.isfinite(J_o[m])], J_o[m][np.isfinite(J_o[m])], rtol=0, atol=5e-2 * scale)
+        fin = np.isfinite(J_o).all(axis=1)
+        assert np.array_equal(np.isfinite(J).all(axis=1)[act], fin[act])
+        m = act & fin
+        if m.any():
+            percell = np.abs(J_o[m]).max(axis=1)
+            # (a constant image gives exact zeros against 1e-32 residue: the frame scale is at least 1e-3)
+            scale = np.maximum(percell, J_FLOOR * max(percell.max(), 1e-3))
+            assert np.all(np.abs(J[m] - J_o[m]) <= RTOL_J * scale[:, None]), \
+                f"worst per-cell relative Jacobian error {np.max(np.abs(J[m] - J_o[m]) / scale[:, None]):.3e}"
         assert np.all(np.isnan(J[~act]))
 
 
@@ -99,7 +106,7 @@ def test_small_pair_all_stages(capi, oracle, synth, pair_S, pair_S_edge, nb, whi
     for name, pose in _poses(synth, pair).items():
         got = ctx.evaluate(pose, True)
         ref = o.evaluate(pose, True)
-        _compare_cells(got, ref, cnt_o, loose=_saturated_cells(o, pair) if math == "fast" else None)
+        _compare_cells(got, ref, cnt_o)
         got_c = ctx.evaluate(pose, False)
         assert np.array_equal(_bits(got_c[0][act]), _bits(got[0][act])), "cost-only and cost+Jacobian kernels disagree"
         assert np.array_equal(_bits(got_c[2][act]), _bits(got[2][act]))
@@ -146,33 +153,37 @@ def test_per_pixel_intermediates_bit_exact(capi, oracle, synth, pair_S_edge, nb)
 
 @pytest.mark.parametrize("nb", [8, 10])
 def test_per_pixel_intermediates_fast_mode(capi, oracle, synth, pair_S_edge, nb):
-    """FAST math: per-pixel values within a few ulp of the reference's, same bins (a bin index may
-    differ only where the intensity sits on a bin boundary to within rounding)."""
+    """FAST math: per-pixel values within a few ulp of the reference's; the in-frame decision of every pixel is
+    the reference's; samples inside the guard bands of the clamps (all-255 and all-0 patches of the edge-case
+    pair) carry the reference's intensity bit for bit; a bin index may differ only where the intensity sits on a
+    bin boundary to within rounding (the basis is continuous there)."""
     pair = pair_S_edge
     ctx = capi.from_pair(pair, nb, math=capi.MATH_FAST)
     o = oracle.from_pair(pair, nb)
     cnt, _ = ctx.compute_href(pair.pose_init)
     o.compute_href(pair.pose_init)
     ctx.enable_pixel_dump(True)
+    n_guard = 0
     for name, pose in _poses(synth, pair).items():
         ctx.evaluate(pose, True)
         o.evaluate(pose, True)
         g, d = ctx.pixel_dump(), o.dump_pixels()
-        G, rb, cb = pair.cell, pair.rows // pair.cell, pair.cols // pair.cell
-        rr, cc = np.divmod(np.arange(pair.rows * pair.cols), pair.cols)
-        cell = (rr // rb) * G + cc // cb
-        both = ~np.isnan(d["u"]) & (cnt[cell] >= 300) & (d["jc"] >= 0) & (g["jc"] >= 0)
-        both &= ~((d["ic"] > 254.99) | (g["ic"] > 254.99))   # saturation clamp: see _saturated_cells
+        cell, inc = _cell_ids(pair)
+        seen = ~np.isnan(d["u"]) & (cnt[cell] >= 300) & inc
+        assert np.array_equal((d["jc"] >= 0)[seen], (g["jc"] >= 0)[seen]), name
+        both = seen & (d["jc"] >= 0)
         assert both.sum() > 1000
-        assert ((d["jc"] >= 0) != (g["jc"] >= 0))[~np.isnan(d["u"]) & (cnt[cell] >= 300)].sum() <= 2
         np.testing.assert_allclose(g["u"][both], d["u"][both], rtol=0, atol=1e-10)
         np.testing.assert_allclose(g["v"][both], d["v"][both], rtol=0, atol=1e-10)
         np.testing.assert_allclose(g["ic"][both], d["ic"][both], rtol=0, atol=1e-10)
+        guard = both & ((d["ic"] > 254.9999) | (d["ic"] < 2.0 ** -20) | (d["ic"] == 254.999))
+        n_guard += int(guard.sum())
+        assert np.array_equal(_bits(g["ic"][guard]), _bits(d["ic"][guard])), name
         same = g["jc"][both] == d["jc"][both]
-        # a different bin index only where the intensity sits ON a bin boundary (weights are continuous there)
         pc = d["ic"][both][~same] * (nb - 3.0) / 255.0
         assert (~same).sum() <= 0.002 * both.sum() and np.all(np.abs(pc - np.rint(pc)) < 1e-12)
         np.testing.assert_allclose(g["wc"][both][same], d["wc"][both][same], rtol=0, atol=1e-12)
+    assert n_guard > 100, "the edge-case pair must exercise the clamp guard bands"
     ctx.enable_pixel_dump(False)
 
 
@@ -437,16 +448,14 @@ def test_edge_geometries(capi, oracle, synth, geom, math):
     for name, pose in _poses(synth, pair).items():
         got = ctx.evaluate(pose, True)
         ref = o.evaluate(pose, True)
-        _compare_cells(got, ref, cnt_o, loose=_saturated_cells(o, pair) if math == "fast" else None)
+        _compare_cells(got, ref, cnt_o)
         H, b, chi2, na = ctx.normal_equations(pose, DELTA)
         assert na == int(act.sum())
         H_o, b_o, chi2_o, na_o = oracle.normal_equations(ref[2], ref[3], DELTA)
         assert na_o == na
         if np.isfinite(chi2_o):
-            # FAST math on cells with saturation-clamp samples is only good to 1e-4 per cell (_saturated_cells)
-            sat = math == "fast" and (_saturated_cells(o, pair) & act).any()
-            assert abs(chi2 - chi2_o) <= (1e-3 if sat else 1e-9) * max(1.0, abs(chi2_o))
-            np.testing.assert_allclose(H, H_o, rtol=0, atol=(5e-2 if sat else 1e-7) * max(1.0, np.abs(H_o).max()))
+            assert abs(chi2 - chi2_o) <= 1e-9 * max(1.0, abs(chi2_o))
+            np.testing.assert_allclose(H, H_o, rtol=0, atol=1e-7 * max(1.0, np.abs(H_o).max()))
 
 
 @pytest.mark.gpu
@@ -463,8 +472,7 @@ def test_extreme_bin_counts(capi, oracle, synth, pair_S_edge, nb):
         act = cnt_o >= 300
         np.testing.assert_allclose(href[act], href_o[act], rtol=0, atol=ATOL_H)
         for pose in (pair.pose_init, pair.pose_true):
-            _compare_cells(ctx.evaluate(pose, True), o.evaluate(pose, True), cnt_o,
-                           loose=_saturated_cells(o, pair) if math == "fast" else None)
+            _compare_cells(ctx.evaluate(pose, True), o.evaluate(pose, True), cnt_o)
     with pytest.raises(capi.NidError):
         capi.Context(pair.rows, pair.cols, pair.cell, 17, pair.fx, pair.fy, pair.cx, pair.cy)
     with pytest.raises(capi.NidError):
@@ -600,20 +608,7 @@ def test_randomised_pairs(capi, oracle, synth, seed):
         for pose in poses:
             ref = o.evaluate(pose, True)
             got = ctx.evaluate(pose, True)
-            sat = _saturated_cells(o, pair)
-            if math == "fast":
-                # FAST may put a sample that sits EXACTLY on a bin boundary into the neighbouring span (the
-                # basis is continuous there, the histograms are not bit-for-bit): such cells get the loose bound
-                d = o.dump_pixels()
-                pc = d["ic"] * (nb - 3) / 255.0
-                onb = (d["jc"] >= 0) & (np.abs(pc - np.rint(pc)) < 1e-9)
-                G, rb, cb = pair.cell, pair.rows // pair.cell, pair.cols // pair.cell
-                rr, cc = np.divmod(np.arange(pair.rows * pair.cols), pair.cols)
-                inc = (rr < G * rb) & (cc < G * cb)
-                cellid = np.where(inc, (rr // max(rb, 1)) * G + cc // max(cb, 1), 0)
-                sat = sat.copy()
-                sat[np.unique(cellid[onb & inc])] = True
-            _compare_cells(got, ref, cnt_o, loose=sat if math == "fast" else None)
+            _compare_cells(got, ref, cnt_o)
             H, b, chi2, na = ctx.normal_equations(pose, DELTA)
             assert na == int(act.sum())
 
@@ -632,8 +627,7 @@ def test_context_lifecycle_and_interleaving(capi, oracle, synth, pair_S, pair_S_
     cb_o, _ = ob.compute_href(pair_S_edge.pose_init)
     for _ in range(3):                                   # interleaved use
         _compare_cells(a.evaluate(pair_S.pose_true, True), oa.evaluate(pair_S.pose_true, True), ca_o)
-        _compare_cells(b.evaluate(pair_S_edge.pose_true, True), ob.evaluate(pair_S_edge.pose_true, True), cb_o,
-                       loose=_saturated_cells(ob, pair_S_edge))
+        _compare_cells(b.evaluate(pair_S_edge.pose_true, True), ob.evaluate(pair_S_edge.pose_true, True), cb_o)
     # math mode switched on a live context
     a.set_math_mode(capi.MATH_STRICT)
     _compare_cells(a.evaluate(pair_S.pose_init, True), oa.evaluate(pair_S.pose_init, True), ca_o)
@@ -641,15 +635,13 @@ def test_context_lifecycle_and_interleaving(capi, oracle, synth, pair_S, pair_S_
     # new target in place: results follow it
     a.set_target(pair_S_edge.im1)
     oa.set_target(pair_S_edge.im1)
-    _compare_cells(a.evaluate(pair_S.pose_init, True), oa.evaluate(pair_S.pose_init, True), ca_o,
-                   loose=np.ones(ca_o.size, dtype=bool))
+    _compare_cells(a.evaluate(pair_S.pose_init, True), oa.evaluate(pair_S.pose_init, True), ca_o)
     # new reference: href state is invalidated until recomputed
     a.set_reference_depth(pair_S_edge.depth_m, pair_S_edge.im0, synth.matrix_colmajor16(pair_S_edge.T_wc0))
     with pytest.raises(capi.NidError):
         a.evaluate(pair_S.pose_init, True)
     a.compute_href(pair_S_edge.pose_init)
-    _compare_cells(a.evaluate(pair_S_edge.pose_true, True), ob.evaluate(pair_S_edge.pose_true, True), cb_o,
-                   loose=_saturated_cells(ob, pair_S_edge))
+    _compare_cells(a.evaluate(pair_S_edge.pose_true, True), ob.evaluate(pair_S_edge.pose_true, True), cb_o)
     # href recomputed at another pose (Q1: the counts and weights follow the pose given to computeHref)
     cnt2, href2 = a.compute_href(pair_S_edge.pose_true)
     cnt2_o, href2_o = ob.compute_href(pair_S_edge.pose_true)
@@ -684,8 +676,119 @@ def test_many_small_cells(capi, oracle, synth):
     cnt_o, _ = o.compute_href(pair.pose_init)
     assert np.array_equal(cnt, cnt_o) and (cnt_o >= 300).sum() > 300
     got, ref = ctx.evaluate(pair.pose_true, True), o.evaluate(pair.pose_true, True)
-    _compare_cells(got, ref, cnt_o, loose=_saturated_cells(o, pair))
+    _compare_cells(got, ref, cnt_o)
     H, b, chi2, na = ctx.normal_equations(pair.pose_true, DELTA)
     H_o, b_o, chi2_o, na_o = oracle.normal_equations(ref[2], ref[3], DELTA)
     assert na == na_o and abs(chi2 - chi2_o) <= 1e-9 * chi2_o
     np.testing.assert_allclose(H, H_o, rtol=0, atol=1e-7 * np.abs(H_o).max())
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# The decisions FAST math must take exactly like the reference (exact_decisions in csrc/nid_kernels.hip.h)
+@pytest.mark.gpu
+@pytest.mark.parametrize("math", MODES)
+@pytest.mark.parametrize("nb", [8, 10])
+def test_flash_pair_cells(capi, oracle, synth, nb, math):
+    """640x480 'flash' variant of pair A (BASELINE configs[0] is the ETH-CVG real_flash pair): a saturating hot
+    spot covers ~13 % of the second image, plus black / saturated patches and 5 % depth holes.  Every cell,
+    saturated ones included, at the stated bounds in both math modes."""
+    pair = synth.make_pair("A", flash=True, edge_cases=True)
+    assert (pair.im1 == 255).mean() > 0.10
+    ctx = capi.from_pair(pair, nb, math=_mode(capi, math))
+    o = oracle.from_pair(pair, nb)
+    cnt, href = ctx.compute_href(pair.pose_init)
+    cnt_o, href_o = o.compute_href(pair.pose_init)
+    assert np.array_equal(cnt, cnt_o)
+    act = cnt_o >= 300
+    np.testing.assert_allclose(href[act], href_o[act], rtol=0, atol=ATOL_H)
+    for name, pose in _poses(synth, pair).items():
+        ref = o.evaluate(pose, True)
+        sat = _saturated_cells(o, pair) & act
+        assert sat.sum() >= 20, "the flash pair must put many active cells on the saturation clamp"
+        _compare_cells(ctx.evaluate(pose, True), ref, cnt_o)
+        H, b, chi2, na = ctx.normal_equations(pose, DELTA)
+        H_o, b_o, chi2_o, na_o = oracle.normal_equations(ref[2], ref[3], DELTA)
+        assert na == na_o
+        np.testing.assert_allclose(chi2, chi2_o, rtol=1e-12)
+        np.testing.assert_allclose(H, H_o, rtol=0, atol=1e-9 * np.abs(H_o).max())
+        np.testing.assert_allclose(b, b_o, rtol=0, atol=1e-9 * np.abs(b_o).max())
+
+
+def _identity_pose(synth, pair):
+    R = pair.T_wc0[:3, :3].T
+    return synth.pose7_from_Rt(R, -R @ pair.T_wc0[:3, 3])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("math", MODES)
+@pytest.mark.parametrize("cfg", ["S", "A"])
+def test_identity_like_pose_border_ties(capi, oracle, synth, cfg, math):
+    """The constant-position start of a tracker: T_cw1 = inverse(T_wc0) projects every reference pixel onto its
+    own integer coordinates +- an ulp, so the reference's border tests u >= 0, u + 3 <= cols (cols - 1 in
+    linearizeOplus), v >= 0, v + 3 <= rows are decided by ROUNDING for whole rows / columns of pixels (up to 3 % of a
+    border cell).  Both math modes must take the reference's decisions: in-frame counts and per-pixel in-frame
+    flags equal, entropies at the stated bound in every cell, Jacobians in every cell the reference defines:
+    where linearizeOplus' u (or v) is EXACTLY 0.0 the reference samples bil(u - 1, v) at column (int)(-1.0) = -1,
+    i.e. it reads before the image row (before the buffer in row 0: undefined behaviour, the oracle run under
+    AddressSanitizer reports it, and its result changes from one oracle instance to the next).  That happens
+    only to samples landing on row 0 / column 0 of the target, which at this pose belong to the first row /
+    column of cells: their Jacobians are not compared."""
+    pair = synth.make_pair(cfg, edge_cases=(cfg == "S"))
+    ident = _identity_pose(synth, pair)
+    nb = 8
+    ctx = capi.from_pair(pair, nb, math=_mode(capi, math))
+    o = oracle.from_pair(pair, nb)
+    cnt, href = ctx.compute_href(ident)          # reference stage AT the identity-like pose (strict arithmetic)
+    cnt_o, href_o = o.compute_href(ident)
+    assert np.array_equal(cnt, cnt_o)
+    act = cnt_o >= 300
+    np.testing.assert_allclose(href[act], href_o[act], rtol=0, atol=ATOL_H)
+    ref = o.evaluate(ident, True)
+    d = o.dump_pixels()
+    near_int = np.abs(d["u"] - np.rint(d["u"])) < 1e-9
+    assert near_int[~np.isnan(d["u"])].mean() > 0.9, "the pose must project onto integer coordinates"
+    G = pair.cell
+    defined = (np.arange(G * G) // G > 0) & (np.arange(G * G) % G > 0)
+    got = ctx.evaluate(ident, True)
+    Jg, Jo = got[3].copy(), ref[3].copy()
+    Jg[~defined & act] = 0.0
+    Jo[~defined & act] = 0.0
+    _compare_cells((got[0], got[1], got[2], Jg), (ref[0], ref[1], ref[2], Jo), cnt_o)
+    ctx.enable_pixel_dump(True)
+    ctx.evaluate(ident, True)
+    g = ctx.pixel_dump()
+    ctx.enable_pixel_dump(False)
+    cell, inc = _cell_ids(pair)
+    seen = ~np.isnan(d["u"]) & (cnt_o[cell] >= 300) & inc
+    assert np.array_equal((d["jc"] >= 0)[seen], (g["jc"] >= 0)[seen])
+    border = seen & ((np.abs(d["u"]) < 1e-9) | (np.abs(d["v"]) < 1e-9) | (np.abs(d["u"] + 3 - pair.cols) < 1e-9)
+                     | (np.abs(d["v"] + 3 - pair.rows) < 1e-9))
+    assert border.sum() > 100 and 0 < (d["jc"] >= 0)[border].sum() < border.sum(), "ties must fall on both sides"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("math", MODES)
+@pytest.mark.parametrize("shift", [3e-10, -3e-10])
+def test_border_guard_band(capi, oracle, synth, shift, math):
+    """Samples a hair inside / outside the frame border (3e-10 px: inside FAST math's guard band of 2^-20 px, far
+    above rounding, so the reference's decisions are well defined and no sample sits exactly on 0.0): every border
+    row / column goes through exact_decisions, and every cell -- first row / column of cells included -- is at
+    the stated bounds."""
+    pair = synth.make_pair("S", edge_cases=True)
+    # a small camera translation moves every sample by f * t / z: depth dependent (z = 1.5 .. 2.8 m here) but of one
+    # sign, so no sample is left exactly on an integer
+    ident = _identity_pose(synth, pair)
+    pose = synth.perturb_pose7(ident, [0.0, 0.0, 0.0], [2.0 * shift / pair.fx, 2.0 * shift / pair.fy, 0.0])
+    nb = 8
+    ctx = capi.from_pair(pair, nb, math=_mode(capi, math))
+    o = oracle.from_pair(pair, nb)
+    cnt, _ = ctx.compute_href(pose)
+    cnt_o, _ = o.compute_href(pose)
+    assert np.array_equal(cnt, cnt_o)
+    ref = o.evaluate(pose, True)
+    d = o.dump_pixels()
+    cell, inc = _cell_ids(pair)
+    vis = ~np.isnan(d["u"]) & inc & (cnt_o[cell] >= 300)
+    frac = np.abs(d["u"][vis] - np.rint(d["u"][vis]))
+    assert np.median(frac) < 1e-6 and frac.min() > 1e-13, "samples must sit near, not on, integer coordinates"
+    _compare_cells(ctx.evaluate(pose, True), ref, cnt_o)

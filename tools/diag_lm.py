@@ -1,0 +1,24 @@
+#!/usr/bin/env python3
+"""tools/diag_lm.py: host-stack LM (legacy operator flow and fused) against the oracle's LM on variants of pair A."""
+import importlib, os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+hostlib = importlib.import_module("nid-pose-estimation_amd.hostlib")
+synth = importlib.import_module("nid-pose-estimation_amd.synth")
+from oracle import oracle_py as O
+mv = synth.pose7_minimal
+for label, kw in (("plain", {}), ("flash", dict(flash=True)), ("edge", dict(edge_cases=True)), ("flash+edge", dict(flash=True, edge_cases=True))):
+    pair = synth.make_pair("A", **kw)
+    for nb in (8,):
+        o = O.from_pair(pair, nb, jac_bound="cpu", xform="matrix")
+        o.compute_href(pair.pose_init)
+        pose_o, recs_o = o.lm(pair.pose_init, 10)
+        for strict in (False, True):
+            for fused in (0, 2):
+                pose, recs, log = hostlib.run_lm(pair, nb, pair.pose_init, 10, strict=strict, fused=fused)
+                same = [r["lm_trials"] for r in recs] == [r["lm_trials"] for r in recs_o]
+                n = min(len(recs), len(recs_o))
+                dchi = max(abs(recs[i]["chi2"] - recs_o[i]["chi2"]) / recs_o[i]["chi2"] for i in range(n))
+                print(f"{label:10s} nb={nb} {'STRICT' if strict else 'FAST  '} fused={fused}: trace equal {same}  max rel dchi2 {dchi:.2e}  "
+                      f"max|dpose| {np.abs(mv(pose) - mv(pose_o)).max():.2e}  first chi2 {recs[0]['chi2']:.10f} / {recs_o[0]['chi2']:.10f}")
