@@ -1,20 +1,23 @@
 #!/usr/bin/env python3
 """bench.py -- NID Gauss-Newton iterations/sec on MI355X (BASELINE.json metric).
 
-One "step" = one NID cost + Jacobian evaluation of every active cell at one
-SE(3) candidate plus the Huber-weighted reduction to the 6x6 normal equations,
-delivered to host memory.  Workload at N=1 is
-BASELINE.json configs[1]: the 640x480 pair, 16x16 cells, 8-bin B-spline
-histogram (synthetic pair: the ETH-CVG data is not available offline).
+One "step" = one NID cost + Jacobian evaluation of every active cell at one SE(3) candidate plus the
+Huber-weighted reduction to the 6x6 normal equations, delivered to host memory.
+Workload at N=1 is BASELINE.json configs[1]: the 640x480 pair, 16x16 cells, 8-bin B-spline histogram
+(synthetic pair: the ETH-CVG data is not available offline).
 
-N = 1: the timed region is the library's own host pipeline (nid_run_sequence):
-64 poses per kernel launch, consecutive launches alternating between two
-streams, every pose's 6x6 system collected from pinned host memory.
+`value` is PIPELINED EVALUATION THROUGHPUT: the K steps are K independent candidate poses pushed through the
+library's own host pipeline (nid_run_sequence: 64 poses per kernel launch, launches alternating between two
+streams, every pose's 6x6 system collected from pinned host memory).  A Gauss-Newton / LM loop is sequentially
+dependent; its rates are reported next to it (roofline.sequential: one blocking evaluation per launch;
+pose_error_vs_ref.lm_outer_iterations_per_s: the reference's LM schedule), as are the kernel-alone, cold and
+>= 1 s sustained numbers, so that a short driver invocation (--steps 20: one launch) still carries them.
 
-N > 1: one process per GPU (torch.distributed, backend nccl = RCCL), the cells
-of the SAME pair are partitioned over the ranks (strong scaling); the per-rank
-partial [chi2, b(6), H upper (21), n_active] blocks (32 doubles per pose) of a
-group of launches are summed by one all-reduce over xGMI on a comm stream while
+N > 1: one process per GPU (launched by torch.distributed.run; torch.distributed is only the control plane:
+rendezvous, the exchange of the RCCL id, barriers).  The cells of the SAME pair are partitioned over the ranks
+(strong scaling) by the library's multi-GPU layer in C++ (include/nid/nid_multi.h): every rank evaluates its
+cells for the same poses, the per-rank partial [chi2, b(6), H upper (21), n_active] blocks (32 doubles per pose)
+of a group of launches are summed by ONE ncclAllReduce over xGMI on a comm stream -- issued from C++ -- while
 the compute streams work on the next group.
 
 Prints ONE JSON line on rank 0.
@@ -26,6 +29,7 @@ import importlib
 import json
 import os
 import sys
+import threading
 import time
 
 import numpy as np
@@ -34,7 +38,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec ...
+HBM_MEASURED_PEAK_GBS = 6290.0  # ... 6.29 TB/s measured float4 copy (same guide, line 36)
+SIMD_ISSUE_PEAK = 1024 * 2.4e9 / 2.0  # wave-instructions/s: 1024 SIMDs, one instruction per 2 cycles per SIMD with
+#                                       >= 4 waves resident (profiles/r01_valu_rates.txt), 2.4 GHz
 
 
 def parse():
@@ -45,20 +52,27 @@ def parse():
     ap.add_argument("--config", default="A", choices=["A", "B", "S"])
     ap.add_argument("--bins", type=int, default=8)
     ap.add_argument("--block-threads", type=int, default=0)
-    ap.add_argument("--batch", type=int, default=64,
-                    help="candidate poses per kernel launch at N=1 (1 = one launch per step)")
-    ap.add_argument("--compute-streams", type=int, default=0, help="N>1: 1, 2 or 4 (0 = 2 for N<=2, else 4)")
-    ap.add_argument("--group", type=int, default=4,
-                    help="N>1: kernel launches per all-reduce (group of GROUP*BATCH poses)")
+    ap.add_argument("--batch", type=int, default=64, help="candidate poses per kernel launch")
+    ap.add_argument("--group", type=int, default=0,
+                    help="N>1 / --shards: kernel launches per exchange (0 = 4 launches of min(batch, 16) poses)")
+    ap.add_argument("--shards", type=int, default=1,
+                    help="N=1 only: shard the cells over SHARDS contexts on the one GPU through the multi-GPU layer "
+                         "(host sum); exercises the N>1 code path on a one-GPU box, not the metric")
+    ap.add_argument("--rccl-one-rank", action="store_true",
+                    help="N=1 only: run through the multi-GPU layer with an RCCL communicator of ONE rank (ncclCommInitRank, "
+                         "ncclAllReduce from C++ in-stream), i.e. the N>1 data path on a one-GPU box; not the metric")
     ap.add_argument("--cost-only", action="store_true",
                     help="time cost-only evaluations (what LM trial poses need) instead of cost+Jacobian; not the metric")
     ap.add_argument("--strict", action="store_true",
                     help="NID_MATH_STRICT (every rounding of the reference path) instead of the default FAST math; not the metric")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0)
-    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
-                    help="nccl (= RCCL over xGMI) is the product path; gloo lets the multi-rank code path be "
-                         "exercised on a box with fewer GPUs than ranks (ranks then share devices)")
+    ap.add_argument("--quick", action="store_true", help="skip the sustained / cold / sequential / STRICT side measurements")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0)
+    ap.add_argument("--sustained-seconds", type=float, default=1.5)
+    ap.add_argument("--backend", default="rccl", choices=["rccl", "nccl", "gloo"],
+                    help="rccl (= nccl): ncclAllReduce from C++ is the product path; gloo: the exchange goes through "
+                         "torch.distributed on the host (nid_multi_set_exchange_hook) so that the multi-rank code path "
+                         "runs on a box with fewer GPUs than ranks (ranks then share devices)")
     return ap.parse_args()
 
 
@@ -72,9 +86,9 @@ def pose_trajectory(synth, pair, n):
 
 
 def cpu_baseline(pair, bins, seconds):
-    """The oracle (CPU restatement of the reference's CPU edge) timed on this
-    host, single thread like the reference (OpenMP off, g2o/CMakeLists.txt:58).
-    Rebuilt with -march=native here (g2o/CMakeLists.txt:67); bounded sample."""
+    """The oracle (CPU restatement of the reference's CPU edge) timed on this host: single thread like the reference
+    (OpenMP off, g2o/CMakeLists.txt:58), then one instance per hardware thread (poses are independent: the fair
+    multi-core bound).  Rebuilt with -march=native here (g2o/CMakeLists.txt:67); bounded samples."""
     from oracle import oracle_py
     lib = None
     try:
@@ -84,25 +98,47 @@ def cpu_baseline(pair, bins, seconds):
     except Exception:
         lib = oracle_py.load()
     synth = importlib.import_module("nid-pose-estimation_amd.synth")
-    o = oracle_py.Oracle(pair.rows, pair.cols, pair.cell, bins, pair.fx, pair.fy, pair.cx, pair.cy, lib=lib)
     pts = oracle_py.backproject(pair.depth_m, synth.matrix_colmajor16(pair.T_wc0), pair.fx, pair.fy, pair.cx, pair.cy)
-    o.set_reference(pts, pair.im0)
-    o.set_target(pair.im1)
-    o.compute_href(pair.pose_init)
     poses = pose_trajectory(synth, pair, 64)
     delta = float(np.sqrt(0.95))
-    n = 0
+
+    def make():
+        o = oracle_py.Oracle(pair.rows, pair.cols, pair.cell, bins, pair.fx, pair.fy, pair.cx, pair.cy, lib=lib)
+        o.set_reference(pts, pair.im0)
+        o.set_target(pair.im1)
+        o.compute_href(pair.pose_init)
+        return o
+
+    def loop(o, budget, counter, k0):
+        n, t0 = 0, time.perf_counter()
+        while True:
+            _, _, err, J = o.evaluate(poses[(k0 + n) % len(poses)], True)
+            oracle_py.normal_equations(err, J, delta)
+            n += 1
+            if time.perf_counter() - t0 >= budget or n >= 400:
+                break
+        counter.append((n, time.perf_counter() - t0))
+
+    res = []
+    loop(make(), seconds * 0.6, res, 0)
+    n1, el1 = res[0]
+    nproc = os.cpu_count() or 1
+    oracles = [make() for _ in range(nproc)]
+    res = []
+    th = [threading.Thread(target=loop, args=(oracles[i], seconds * 0.4, res, 7 * i)) for i in range(nproc)]
     t0 = time.perf_counter()
-    while True:
-        _, _, err, J = o.evaluate(poses[n % len(poses)], True)
-        oracle_py.normal_equations(err, J, delta)
-        n += 1
-        el = time.perf_counter() - t0
-        if el >= seconds or n >= 400:
-            break
-    return {"value": n / el, "unit": "iterations/s", "cores": 1, "kind": "port",
-            "sample": f"{n} cost+Jacobian evaluations + 6x6 reduction of the same {pair.cols}x{pair.rows} pair, "
-                      f"{el:.1f} s on 1 host core (oracle rebuilt -O3 -march=native -ffp-contract=off)"}
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    el_all = time.perf_counter() - t0
+    n_all = sum(n for n, _ in res)
+    return {"value": n1 / el1, "unit": "iterations/s", "cores": 1, "kind": "port",
+            "sample": f"{n1} cost+Jacobian evaluations + 6x6 reduction of the same {pair.cols}x{pair.rows} pair, "
+                      f"{el1:.1f} s on 1 host core (oracle rebuilt -O3 -march=native -ffp-contract=off)",
+            "all_cores": {"value": n_all / el_all, "unit": "iterations/s", "nproc": nproc, "threads": nproc,
+                          "sample": f"{n_all} evaluations in {el_all:.1f} s, one oracle instance per hardware thread "
+                                    f"(independent poses)"}}
 
 
 def pose_error_vs_ref(pair, bins):
@@ -112,18 +148,12 @@ def pose_error_vs_ref(pair, bins):
     from oracle import oracle_py
     hostlib = importlib.import_module("nid-pose-estimation_amd.hostlib")
     synth = importlib.import_module("nid-pose-estimation_amd.synth")
-    t0 = time.perf_counter()
-    pose_gpu, recs, _ = hostlib.run_lm(pair, bins, pair.pose_init, 10)
-    t_gpu = time.perf_counter() - t0
-    o_gpu = hostlib.last_optimize_seconds()
-    t0 = time.perf_counter()
-    pose_fused, recs_f, _ = hostlib.run_lm(pair, bins, pair.pose_init, 10, fused=1)
-    t_fused = time.perf_counter() - t0
-    o_fused = hostlib.last_optimize_seconds()
-    t0 = time.perf_counter()
-    pose_spec, recs_s, _ = hostlib.run_lm(pair, bins, pair.pose_init, 10, fused=2)
-    t_spec = time.perf_counter() - t0
-    o_spec = hostlib.last_optimize_seconds()
+    runs = {}
+    for name, fused in (("hip_reference_flow", 0), ("hip_fused", 1), ("hip_fused_batched_trials", 2)):
+        hostlib.run_lm(pair, bins, pair.pose_init, 10, fused=fused)     # warm (library, clocks)
+        t0 = time.perf_counter()
+        pose, recs, _ = hostlib.run_lm(pair, bins, pair.pose_init, 10, fused=fused)
+        runs[name] = dict(pose=pose, recs=recs, wall=time.perf_counter() - t0, opt=hostlib.last_optimize_seconds())
     o = oracle_py.from_pair(pair, bins, jac_bound="cpu", xform="matrix")
     o.compute_href(pair.pose_init)
     t0 = time.perf_counter()
@@ -145,34 +175,49 @@ def pose_error_vs_ref(pair, bins):
         "error_vs_truth_end": float(np.linalg.norm(mv(pair.pose_true) - mv(pose_pyr))),
         "wall_s": {"hip_fused_batched_trials": t_pyr, "cpu_oracle_1core": t_pyr_o},
     }
+    ref = runs["hip_reference_flow"]
+    spec = runs["hip_fused_batched_trials"]
+    n_outer = len(spec["recs"])
+    n_eval = sum(1 + r["lm_trials"] for r in ref["recs"])
     return {
         "pyramid_3_levels": pyramid,
-        "max_abs_minimal_vector_diff": float(np.abs(mv(pose_gpu) - mv(pose_cpu)).max()),
-        "fused_path_diff": float(np.abs(mv(pose_fused) - mv(pose_cpu)).max()),
+        "max_abs_minimal_vector_diff": float(np.abs(mv(ref["pose"]) - mv(pose_cpu)).max()),
+        "fused_path_diff": float(np.abs(mv(runs["hip_fused"]["pose"]) - mv(pose_cpu)).max()),
+        "speculative_path_diff": float(np.abs(mv(spec["pose"]) - mv(pose_cpu)).max()),
         "tolerance": 1e-6,
-        "same_lm_trace": [r["lm_trials"] for r in recs] == [r["lm_trials"] for r in recs_o],
-        "lm_outer_iterations": len(recs),
+        "same_lm_trace": [r["lm_trials"] for r in ref["recs"]] == [r["lm_trials"] for r in recs_o],
+        "lm_outer_iterations": len(ref["recs"]),
         "error_vs_truth_start": float(np.linalg.norm(mv(pair.pose_true) - mv(pair.pose_init))),
-        "error_vs_truth_end": float(np.linalg.norm(mv(pair.pose_true) - mv(pose_gpu))),
-        "speculative_path_diff": float(np.abs(mv(pose_spec) - mv(pose_cpu)).max()),
-        "lm_wall_s": {"hip_reference_flow": t_gpu, "hip_fused": t_fused, "hip_fused_batched_trials": t_spec,
-                      "cpu_oracle_1core": t_cpu},
-        "optimize_only_s": {"hip_reference_flow": o_gpu, "hip_fused": o_fused, "hip_fused_batched_trials": o_spec},
+        "error_vs_truth_end": float(np.linalg.norm(mv(pair.pose_true) - mv(ref["pose"]))),
+        "lm_wall_s": {k: v["wall"] for k, v in runs.items()} | {"cpu_oracle_1core": t_cpu},
+        "optimize_only_s": {k: v["opt"] for k, v in runs.items()},
+        # the DEPENDENT rates: what a real optimisation gets out of the path
+        "lm_outer_iterations_per_s": n_outer / spec["opt"],
+        "lm_evaluations_per_s_reference_flow": n_eval / ref["opt"],
         "note": "lm_wall_s includes the per-pair setup (upload, back-projection, reference weights); "
-                "reference schedule = 1 Jacobian + k cost-only + 1 verbose evaluation per outer iteration",
+                "reference schedule = 1 Jacobian + k cost-only + 1 verbose evaluation per outer iteration; "
+                "lm_outer_iterations_per_s = outer iterations / optimize() time of the fused + batched-trials path",
     }
 
 
-def measured_traffic(config, bins, poses_per_launch):
-    """HBM bytes per launch of the evaluation kernel from the committed rocprofv3 PMC passes
-    (profiles/traffic.json, written from tools/summarize_profile.py output); None if that
-    configuration / launch shape was not profiled.  bench.py cannot run the profiler on itself."""
+def profile_numbers(config, bins, poses_per_launch):
+    """HBM bytes per launch and instruction mix per wave of the evaluation kernel from the committed rocprofv3 PMC
+    passes (profiles/traffic.json, profiles/issue_model.json, written by tools/); None where that configuration /
+    launch shape was not profiled.  bench.py cannot run the profiler on itself."""
+    traffic = issue = None
     try:
         with open(os.path.join(ROOT, "profiles", "traffic.json")) as fh:
             e = json.load(fh)[f"{config}:{bins}"]
-        return float(e["hbm_bytes_per_launch"]) if int(e["poses_per_launch"]) == poses_per_launch else None
+        if int(e["poses_per_launch"]) == poses_per_launch:
+            traffic = float(e["hbm_bytes_per_launch"])
     except Exception:
-        return None
+        pass
+    try:
+        with open(os.path.join(ROOT, "profiles", "issue_model.json")) as fh:
+            issue = json.load(fh)[f"{config}:{bins}"]
+    except Exception:
+        pass
+    return traffic, issue
 
 
 def main():
@@ -184,164 +229,208 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world > 1 and args.shards != 1:
+        raise SystemExit("--shards is a single-process option")
+    rccl = args.backend in ("rccl", "nccl")
     dist = None
     if world > 1:
         import torch.distributed as dist_
         dist = dist_
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.backend == "nccl":
-            dist.init_process_group(backend="nccl", rank=rank, world_size=world,
-                                    device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        # control plane only (rendezvous, RCCL id, barrier, max of the timings): gloo.  The data plane is the
+        # library's own RCCL communicator (C++), or -- --backend gloo -- an exchange hook over this group.
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback of the product path)")
-    if args.backend == "gloo":
+    if not rccl:
         local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
     capi = importlib.import_module("nid-pose-estimation_amd.capi")
     synth = importlib.import_module("nid-pose-estimation_amd.synth")
-    parallel = importlib.import_module("nid-pose-estimation_amd.parallel")
     pair = synth.make_pair(args.config)
     ncell = pair.cell * pair.cell
-    lo, hi = parallel.cell_range(rank, world, ncell)
-    ctx = capi.from_pair(pair, args.bins, device=local_rank, cell_begin=lo, cell_end=hi)
-    if args.block_threads:
-        ctx.set_block_threads(args.block_threads)
-    if args.strict:
-        ctx.set_math_mode(capi.MATH_STRICT)
-    sides = None
-    if world > 1:
-        # Explicit streams (torch's default stream has the null handle, which nid_set_stream() reads as "use
-        # the context's own stream"): consecutive kernel launches rotate over 2 (N <= 2) or 4 COMPUTE
-        # streams, so that many launches are resident at once (at N = 8 a shard of 32 cells x 16 poses is
-        # only 2 workgroups per CU, and the kernel wants 5); a COMM stream waits for a group's launches,
-        # runs its RCCL all-reduce and the D2H copy, while the compute streams already work on the next group.
-        ncomp = args.compute_streams if args.compute_streams in (1, 2, 4) else (2 if world <= 2 else 4)
-        ncomp = max(1, min(ncomp, capi.NID_SLOTS // max(1, min(args.batch, capi.NID_MAX_BATCH))))
-        sides = [torch.cuda.Stream(device=dev) for _ in range(ncomp)]
-        comm = torch.cuda.Stream(device=dev)
-        ctx.set_stream(sides[0].cuda_stream)
-    # world == 1: the library's own in-order stream; torch.cuda.synchronize() below fences the whole device
-    cnt, href = ctx.compute_href(pair.pose_init)
+    math_mode = capi.MATH_STRICT if args.strict else capi.MATH_FAST
+    B = max(1, min(args.batch, capi.NID_MAX_BATCH))
+    multi = world > 1 or args.shards > 1 or args.rccl_one_rank
+    rccl_ranks_seen = None
+    if multi:
+        if world > 1:
+            m = capi.multi_from_pair(pair, args.bins, devices=[local_rank], rank=rank, world=world, math=math_mode)
+            if rccl:
+                ids = [capi.rccl_unique_id() if rank == 0 else None]
+                dist.broadcast_object_list(ids, src=0)
+                m.comm_init(ids[0])
+                rccl_ranks_seen = m.comm_ranks()
+            else:
+                def gloo_sum(a):
+                    t = torch.from_numpy(a)
+                    dist.all_reduce(t)
+                m.set_exchange_hook(gloo_sum)
+        elif args.rccl_one_rank:
+            m = capi.multi_from_pair(pair, args.bins, devices=[local_rank], rank=0, world=1, math=math_mode)
+            m.comm_init(capi.rccl_unique_id())
+            rccl_ranks_seen = m.comm_ranks()
+        else:
+            m = capi.multi_from_pair(pair, args.bins, devices=[local_rank] * args.shards, math=math_mode)
+        if args.block_threads:
+            m.set_block_threads(args.block_threads)
+        ctx = None
+        cnt, href = m.compute_href(pair.pose_init)
+        # latency-bound exchange: fewer, larger ones -- a group = G launches of Bm poses, one exchange per group
+        Bm = min(B, 16) if args.group == 0 else B
+        G = 4 if args.group == 0 else max(1, args.group)
+    else:
+        ctx = capi.from_pair(pair, args.bins, device=local_rank)
+        if args.block_threads:
+            ctx.set_block_threads(args.block_threads)
+        ctx.set_math_mode(math_mode)
+        cnt, href = ctx.compute_href(pair.pose_init)
+        m = None
     delta = float(np.sqrt(0.95))
     K, W = args.steps, args.warmup
     poses = pose_trajectory(synth, pair, 256)
-
-    # device-side result ring (world > 1): a group = G launches of B poses on one stream, summed by ONE
-    # all-reduce of [G*B, 32] doubles (the collective is latency-bound: fewer, larger ones)
-    B = max(1, min(args.batch, capi.NID_MAX_BATCH))
-    assert capi.NID_SLOTS % B == 0
-    G = max(1, args.group)
-    ngroups = 2
-    ring = torch.zeros((ngroups, G * B, capi.NID_REDUCED_LEN), dtype=torch.float64, device=dev)
-    host_ring = torch.zeros((ngroups, G * B, capi.NID_REDUCED_LEN), dtype=torch.float64).pin_memory()
-    done = [torch.cuda.Event() for _ in range(ngroups)] if world > 1 else None
     pose_arr = np.stack(poses)
+    want_jac = not args.cost_only
 
-    def launch_group(j, n):
-        """world > 1: poses j*G*B .. +n-1 as up to G kernel launches per rank, alternating between the two
-        compute streams (each with its own B result slots, reused launch after launch: a stream runs its
-        launches in order); then, on the comm stream, the RCCL sum of the [G*B, 32] partial blocks over xGMI
-        and the copy to pinned host memory."""
-        gidx = j % ngroups
-        if j >= ngroups:
-            done[gidx].synchronize()             # the group that last used this ring entry has been delivered
-        nl = (n + B - 1) // B
-        for l in range(nl):
-            m = min(B, n - l * B)
-            idx = [(j * G * B + l * B + k) % len(poses) for k in range(m)]
-            st = sides[l % len(sides)]
-            ctx.set_stream(st.cuda_stream)
-            with torch.cuda.stream(st):
-                ctx.launch_batch((l % len(sides)) * B, pose_arr[idx], delta, True,
-                                 reduced_dev=ring[gidx, l * B].data_ptr())
-        for st in sides[:min(nl, len(sides))]:
-            comm.wait_stream(st)
-        with torch.cuda.stream(comm):
-            dist.all_reduce(ring[gidx])
-            host_ring[gidx].copy_(ring[gidx], non_blocking=True)
-            done[gidx].record(comm)
-
-    def run(n):
-        if world == 1:
-            # the C host loop of the library drives the pipeline (B poses per launch, 16/B launches in
-            # flight); every pose's 6x6 system is collected from pinned host memory
-            seq = pose_arr[np.arange(n) % len(poses)]
-            return ctx.run_sequence(seq, delta, batch=B, want_jac=not args.cost_only)
-        ngr = (n + G * B - 1) // (G * B)
-        for j in range(ngr):
-            launch_group(j, min(G * B, n - j * G * B))
-        for j in range(max(0, ngr - ngroups), ngr):
-            done[j % ngroups].synchronize()
-        for k in range(capi.NID_SLOTS):
-            try:
-                ctx.wait(k)                      # clear the slots' pending marks (their kernels are long done)
-            except capi.NidError:
-                pass
-        return None
+    def run(n, collect=True):
+        seq = pose_arr[np.arange(n) % len(poses)]
+        if multi:
+            return m.run_sequence(seq, delta, batch=Bm, group=G, want_jac=want_jac, collect=collect)
+        return ctx.run_sequence(seq, delta, batch=B, want_jac=want_jac, collect=collect)
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    run(W)
+    run(W, collect=False)
     barrier()
     t0 = time.perf_counter()
     results = run(K)
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # sanity: the last result is finite and every rank agrees after the all-reduce
+    # sanity: every result is finite, and the pipelined result of the last step equals a synchronous evaluation of
+    # the same pose (every rank holds the same sums after the exchange)
     ablation = bool(os.environ.get("NID_HIP_LIB"))  # kernel-ablation builds (exp/) produce meaningless numbers
-    if world == 1:
-        assert ablation or (results.shape == (K, capi.NID_REDUCED_LEN) and np.all(np.isfinite(results)))
-        ctx.launch(0, poses[(K - 1) % len(poses)], delta, not args.cost_only)
-        H, b, chi2, na = ctx.wait(0)
-        assert ablation or (np.array_equal(capi.unpack_reduced(results[K - 1])[0], H)
-                            and capi.unpack_reduced(results[K - 1])[2] == chi2), \
-            "pipelined result differs from a single launch"
-    else:
-        # the pipelined result of the last step must equal a synchronous evaluation of the same pose
-        jl, kl = (K - 1) // (G * B), (K - 1) % (G * B)
-        piped = host_ring[jl % ngroups, kl].clone().numpy()
-        torch.cuda.synchronize(dev)
-        ctx.set_stream(sides[0].cuda_stream)
-        with torch.cuda.stream(sides[0]):
-            ctx.launch(0, poses[(K - 1) % len(poses)], delta, True, reduced_dev=ring[0, 0].data_ptr())
-            dist.all_reduce(ring[0, 0])
-        torch.cuda.synchronize(dev)
-        ctx.wait(0)
-        sync = ring[0, 0].cpu().numpy()
-        # the per-rank partial blocks are bitwise reproducible; the collective may sum the ranks in a different
-        # order for a [G*B,32] tensor than for a [32] one (ring / tree by message size), so from 3 ranks on the
-        # comparison is to rounding
-        same = np.array_equal(piped, sync) if world <= 2 else np.allclose(piped, sync, rtol=1e-12, atol=1e-300)
-        assert same, "pipelined multi-rank result differs from the synchronous one"
-        H, b, chi2, na = capi.unpack_reduced(sync)
+    assert ablation or (results.shape == (K, capi.NID_REDUCED_LEN) and np.all(np.isfinite(results)))
+    last = poses[(K - 1) % len(poses)]
+    H, b, chi2, na = (m if multi else ctx).normal_equations(last, delta, want_jac=want_jac)
+    Hp, bp, chi2p, nap = capi.unpack_reduced(results[K - 1])
+    exact = world <= 2   # a collective may add >= 3 ranks in another order for another message size
+    same = (np.array_equal(Hp, H) and chi2p == chi2) if exact else (np.allclose(Hp, H, rtol=1e-12, atol=1e-300) and abs(chi2p - chi2) <= 1e-12 * abs(chi2))
+    assert ablation or same, "pipelined result differs from the synchronous evaluation"
     assert ablation or (np.isfinite(chi2) and np.all(np.isfinite(H)) and na > 0)
     if args.cost_only and rank == 0:
         print("[bench] --cost-only: cost evaluations without the Jacobian phase; not the BASELINE metric", file=sys.stderr)
 
-    # dominant-kernel duration: groups of 10 identical launches (B poses each, this rank's cells) back to
-    # back on the launch stream between ONE pair of HIP events -- the per-launch duration a kernel trace
-    # reports; launches of a stream are serialised, so nothing else overlaps them
+    # ---- side measurements on this rank's shard (rank 0 reports) -----------------------------------------------
+    kctx = ctx if ctx is not None else capi.Context.borrow(m, 0)
+    Bk = B if not multi else Bm
+    # dominant-kernel duration: groups of 10 identical launches (Bk poses each, this rank's cells) back to back on
+    # the launch stream between ONE pair of HIP events -- the per-launch duration a kernel trace reports; the
+    # timed region above has just run, so the clocks are up; >= 20 samples, median
     ev_ms = []
-    for i in range(min(max(K // (10 * B), 5), 40)):
-        idx = [(i * B + k) % len(poses) for k in range(B)]
-        ev_ms.append(ctx.time_launches(pose_arr[idx], delta, repeats=10, want_jac=not args.cost_only))
+    for i in range(24):
+        idx = [(i * Bk + k) % len(poses) for k in range(Bk)]
+        ev_ms.append(kctx.time_launches(pose_arr[idx], delta, repeats=10, want_jac=want_jac))
+    eval_ms = float(np.median(ev_ms[4:]))
 
+    out = None
     if rank == 0:
-        eval_ms = float(np.median(ev_ms))
-        contract = ctx.contract_bytes() * B  # this rank's cells x poses per launch
+        contract = kctx.contract_bytes() * Bk  # this rank's cells x poses per launch
         achieved = contract / (eval_ms * 1e-3) / 1e9
+        N = pair.rows * pair.cols
+        compact_bytes = N * 4 + 64 * ncell      # u16 depth + u8 im0 + u8 im1 per pixel, everything else recomputed
+        traffic, issue = profile_numbers(args.config, args.bins, Bk) if world == 1 and not multi else (None, None)
+        roof = {
+            "bound": "hbm",
+            "achieved": achieved,
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS,
+            "frac_vs_measured_peak": achieved / HBM_MEASURED_PEAK_GBS,
+            "traffic": traffic,
+            "poses_per_launch": Bk,
+            "kernel": "nid::k_eval2<128, JAC=true, FAST, NB=8|10|generic, DBG=false, EXT=(poses per launch > 16)>",
+            "kernel_ms": eval_ms,
+            "kernel_ms_samples": len(ev_ms) - 4,
+            "algorithmic_bytes_per_launch": contract,
+            "compact_bytes_per_evaluation": compact_bytes,
+            "achieved_pipelined": (contract / Bk) * (K / elapsed) / 1e9,
+            # what actually limits the kernel: the tile is L2/MALL resident after the first launch (measured HBM
+            # traffic is ~2 % of the contract bytes), the waves are bound by instruction issue + exposed latency
+            "limiter": "valu_issue",
+            "note": "achieved = contract bytes (68 B/px + 64 B/cell, SURVEY 8d) / median per-launch duration of "
+                    "evaluation launches running one at a time (10 back to back per HIP event pair; what "
+                    "rocprofv3 reports per kernel); achieved_pipelined = the same bytes / (timed region / launches); "
+                    "the contract's HBM roof is notional for this kernel (see limiter, issue_bound, traffic)",
+        }
+        if issue:
+            per_wave = sum(issue[k] for k in ("valu", "salu", "lds", "vmem", "smem", "branch") if k in issue)
+            waves = issue["waves_per_pose"] * Bk
+            roof["issue_bound"] = {"wave_instructions_per_launch": per_wave * waves,
+                                   "achieved_per_s": per_wave * waves / (eval_ms * 1e-3), "peak_per_s": SIMD_ISSUE_PEAK,
+                                   "frac": per_wave * waves / (eval_ms * 1e-3) / SIMD_ISSUE_PEAK,
+                                   "source": issue.get("source", "profiles/issue_model.json")}
+        if not args.quick and not multi:
+            # sustained: the same pipeline for >= sustained_seconds whatever --steps was
+            rate = K / elapsed
+            n_s = int(max(rate * args.sustained_seconds, 64 * 200))
+            n_s = (n_s + B - 1) // B * B
+            t0 = time.perf_counter()
+            run(n_s, collect=False)
+            torch.cuda.synchronize(dev)
+            el = time.perf_counter() - t0
+            if el < args.sustained_seconds * 0.7:      # the first estimate came from a latency-bound short run
+                n_s = int(n_s * args.sustained_seconds / el) // B * B
+                t0 = time.perf_counter()
+                run(n_s, collect=False)
+                torch.cuda.synchronize(dev)
+                el = time.perf_counter() - t0
+            roof["sustained"] = {"it_per_s": n_s / el, "ms_per_step": el / n_s * 1e3, "steps": n_s, "seconds": el,
+                                 "frac": (contract / Bk) * (n_s / el) / 1e9 / HBM_PEAK_GBS}
+            # cold: ONE launch right after the L2 / Infinity Cache have been flushed by a 1 GiB fill
+            cold = []
+            junk = torch.empty(1 << 28, dtype=torch.float32, device=dev)
+            for i in range(5):
+                junk.fill_(float(i))
+                torch.cuda.synchronize(dev)
+                idx = [(i * Bk + k) % len(poses) for k in range(Bk)]
+                cold.append(kctx.time_launches(pose_arr[idx], delta, repeats=1, want_jac=want_jac))
+            del junk
+            cold_ms = float(np.median(cold))
+            roof["cold"] = {"kernel_ms": cold_ms, "achieved": contract / (cold_ms * 1e-3) / 1e9,
+                            "frac": contract / (cold_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                            "note": "one launch after a 1 GiB device fill (tile and image come from HBM)"}
+            # sequential: a dependent chain -- one pose per launch, the next launch waits for the result on the host
+            nseq = 2000
+            chain = pose_arr[np.arange(nseq) % len(poses)]
+            ctx.run_chain(chain[:200], delta, want_jac=want_jac, collect=False)
+            _, el = ctx.run_chain(chain, delta, want_jac=want_jac, collect=False)
+            one = float(np.median([kctx.time_launches(pose_arr[[i]], delta, repeats=10, want_jac=want_jac) for i in range(8)]))
+            per_pose = kctx.contract_bytes()
+            roof["sequential"] = {"it_per_s": nseq / el, "us_per_evaluation": el / nseq * 1e6, "kernel_us_one_pose": one * 1e3,
+                                  "frac": per_pose / (el / nseq) / 1e9 / HBM_PEAK_GBS,
+                                  "note": "nid_run_chain: one pose per launch, the host waits for each 6x6 system before it launches the next "
+                                          "(launch + kernel + result in host memory)"}
+            # the other math mode in the same run
+            other = capi.MATH_FAST if args.strict else capi.MATH_STRICT
+            ctx.set_math_mode(other)
+            n_o = max(B * 40, int(0.4 * rate) // B * B)
+            run(B * 8, collect=False)
+            t0 = time.perf_counter()
+            run(n_o, collect=False)
+            torch.cuda.synchronize(dev)
+            el = time.perf_counter() - t0
+            ctx.set_math_mode(math_mode)
+            roof["other_math_mode"] = {"mode": "FAST" if args.strict else "STRICT", "it_per_s": n_o / el, "steps": n_o}
         out = {
             "metric": "NID GN iterations/sec (640x480 dense pair)" if args.config == "A" else
                       f"NID GN iterations/sec ({pair.cols}x{pair.rows} dense pair)",
@@ -352,45 +441,35 @@ def main():
             "warmup": W,
             "ms_per_step": elapsed / K * 1e3,
             "higher_is_better": True,
-            "scaling": "strong",
+            "scaling": "strong" if world > 1 else None,
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
+            "value_is": "pipelined evaluation throughput over independent candidate poses; dependent-chain rates: "
+                        "roofline.sequential, pose_error_vs_ref.lm_outer_iterations_per_s",
+            "math": {"mode": "STRICT" if args.strict else "FAST",
+                     "exceptions": "none: FAST re-decides the reference's border / clamp decisions with the reference's "
+                                   "arithmetic (same tolerances as STRICT on every input, tests/test_parity_gpu.py)"},
             "config": {
                 "workload": f"{pair.cols}x{pair.rows} synthetic RGB-D pair, {pair.cell}x{pair.cell} cells of "
                             f"{pair.rows // pair.cell}x{pair.cols // pair.cell} px, {args.bins}-bin cubic B-spline "
                             f"histograms, cost+Jacobian+Huber 6x6 reduction per step, "
-                            f"{int((cnt[lo:hi] >= 300).sum())} active cells on rank 0",
+                            f"{int((cnt >= 300).sum())} active cells",
                 "cells": ncell, "bins": args.bins,
-                "parallelism": f"cells/{world}" + ("" if world == 1 else
-                                                   f" + {'RCCL' if args.backend == 'nccl' else 'gloo'} all-reduce([{G * B},32] f64)"),
-                "pipelining": f"{B} candidate poses per kernel launch, 2 launches in flight on 2 streams, "
-                              + ("each pose's 6x6 system lands in pinned host memory" if world == 1 else
-                                 f"launches rotate over {len(sides) if sides else 2} compute streams; one all-reduce of [{G * B},32] f64 per "
-                                 f"{G} launches + D2H to pinned memory on a comm stream, 2 groups in flight"),
+                "parallelism": (f"cells/{world}" if world > 1 else (f"cells/{args.shards} shards on one GPU" if multi else "cells/1"))
+                               + ("" if not multi else (f" + {'RCCL ncclAllReduce from C++' if ((world > 1 and rccl) or args.rccl_one_rank) else ('gloo exchange hook' if world > 1 else 'host sum')}"
+                                                        f" of [{G * Bm},32] f64 per {G} launches")),
+                "pipelining": (f"{B} candidate poses per kernel launch, 2 launches in flight on 2 streams, each pose's 6x6 "
+                               f"system lands in pinned host memory") if not multi else
+                              (f"{Bm} poses per launch, launches alternate between 2 compute streams per shard, one exchange per "
+                               f"{G} launches + D2H to pinned memory on a comm stream, 2 groups in flight (nid_multi_run_sequence)"),
             },
-            "roofline": {
-                "bound": "hbm",
-                "achieved": achieved,
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS,
-                "traffic": measured_traffic(args.config, args.bins, B) if world == 1 else None,
-                "poses_per_launch": B,
-                "kernel": "nid::k_eval2<128, JAC=true, FAST, NB=8|10|generic, DBG=false, EXT=(poses per launch > 16)>",
-                "kernel_ms": eval_ms,
-                "algorithmic_bytes_per_launch": contract,
-                "achieved_pipelined": (contract / B) * (K / elapsed) / 1e9,
-                "note": "achieved = contract bytes (68 B/px + 64 B/cell, SURVEY 8d) / median per-launch duration of "
-                        "evaluation launches running one at a time (10 back to back per HIP event pair; what "
-                        "rocprofv3 reports per kernel); "
-                        "achieved_pipelined = the same bytes / (timed region / launches): the timed pipeline keeps "
-                        "launches on two streams in flight, so the next launch fills the tail of the previous one; "
-                        "the tile is L2/MALL-resident after the first launch",
-            },
+            "roofline": roof,
         }
+        if rccl_ranks_seen is not None:
+            out["rccl_ranks_seen"] = rccl_ranks_seen
         out["check"] = {"chi2": chi2, "n_active": int(na), "H00": float(H[0, 0]), "b0": float(b[0])}
-        if not args.no_cpu_baseline and world == 1:   # CPU legs: rank 0 at N=1 only
+        if not args.no_cpu_baseline and not multi:   # CPU legs: rank 0 at N=1 only
             out["cpu_baseline"] = cpu_baseline(pair, args.bins, args.cpu_seconds)
             out["pose_error_vs_ref"] = pose_error_vs_ref(pair, args.bins)
         print(json.dumps(out))

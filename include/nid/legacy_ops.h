@@ -29,6 +29,8 @@
 #ifndef NID_LEGACY_OPS_H
 #define NID_LEGACY_OPS_H
 
+#include <stdint.h>
+
 void Calculate3Dpoint(double *depth, double *pose_c2w, double *points_3d, double *camera_intrincis,
                       int rows, int cols);
 
@@ -45,16 +47,25 @@ void CudaComputeH(bool calculate_der, double *im0, double *im1, double *points3d
 
 extern "C" {
 struct nid_ctx;
+struct nid_multi;
 // 0 = CPU-edge bound (default), 1 = CUDA-kernel bound
 void nid_legacy_set_jacobian_bound(int mode);
 // 0 = FAST arithmetic (default), 1 = STRICT: every rounding of the reference reproduced (nid_c.h)
 void nid_legacy_set_math_mode(int mode);
 void nid_legacy_set_device(int device);
+// Multi-GPU (include/nid/nid_multi.h): the operators shard the cells of the frame pair over `n` devices of THIS
+// process (entries may repeat); reduce_rccl != 0 sums the fused 6x6 blocks with RCCL instead of on the host ...
+void nid_legacy_set_devices(const int32_t *devices, int n, int reduce_rccl);
+// ... or this process is rank `rank` of `world` (one process per GPU); rccl_id128 = the ncclUniqueId of the job
+// (nid_multi_comm_unique_id on rank 0, handed to every rank).  The communicator is created on first use and kept
+// until the device set changes.
+void nid_legacy_set_rank(int device, int rank, int world, const uint8_t *rccl_id128);
 // drop every cached context (e.g. before the caller frees its buffers)
 void nid_legacy_reset(void);
 // the context the legacy calls are currently using (NULL before the first call); lets a host
 // mix the legacy operators with the fused C-ABI entry points on the same device state
-nid_ctx *nid_legacy_context(void);
+nid_ctx *nid_legacy_context(void);   // shard 0
+nid_multi *nid_legacy_multi(void);
 // number of host->device uploads of frame-pair data done so far (tests: must not grow per call)
 long nid_legacy_upload_count(void);
 }

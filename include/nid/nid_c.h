@@ -160,6 +160,11 @@ int nid_launch_batch_to(nid_ctx *ctx, int first_slot, int n, const double *poses
  * may be NULL) receives every pose's [chi2, b, H upper, n_active] block.  Blocking. */
 int nid_run_sequence(nid_ctx *ctx, const double *poses7, int n, int batch, int want_jac,
                      double huber_delta, double *reduced_out);
+/* A DEPENDENT chain of n evaluations, the way a Gauss-Newton / LM loop issues them: one pose per launch, the host
+ * waits for each result before it launches the next (slot 0).  reduced_out (n x NID_REDUCED_LEN) may be NULL;
+ * *seconds (may be NULL) receives the wall time of the chain.  Blocking. */
+int nid_run_chain(nid_ctx *ctx, const double *poses7, int n, int want_jac, double huber_delta, double *reduced_out,
+                  double *seconds);
 /* device address of slot's reduced block (NID_REDUCED_LEN doubles) and of its
  * per-cell block (cells_local x NID_CELL_OUT doubles: Hc,Hj,err,J[6], pad) so
  * that a caller can run a collective on them (RCCL all-reduce / all-gather) */

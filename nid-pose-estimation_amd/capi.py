@@ -43,7 +43,7 @@ SYMBOLS = [
     "nid_set_reference_depth", "nid_set_reference_points", "nid_backproject", "nid_get_points3d", "nid_set_target_u8",
     "nid_set_target_f64", "nid_set_reference_image_f64", "nid_compute_href",
     "nid_compute_href_matrix", "nid_set_href_state", "nid_plain_nid", "nid_evaluate", "nid_evaluate_matrix",
-    "nid_normal_equations", "nid_launch", "nid_launch_batch", "nid_launch_batch_to", "nid_run_sequence", "nid_wait", "nid_slot_buffers", "nid_launch_to",
+    "nid_normal_equations", "nid_launch", "nid_launch_batch", "nid_launch_batch_to", "nid_run_sequence", "nid_run_chain", "nid_wait", "nid_slot_buffers", "nid_launch_to",
     "nid_unpack_reduced", "nid_debug_enable_pixel_dump", "nid_debug_get_pixel_dump",
     "nid_debug_enable_stamps", "nid_debug_get_stamps", "nid_bspline4_host", "nid_bspline4_poly_host", "nid_log2_fast_host", "nid_div_small_host", "nid_last_kernel_ms", "nid_enable_timing", "nid_time_launches",
     "nid_contract_bytes",
@@ -95,6 +95,7 @@ def load():
     lib.nid_launch_batch_to.argtypes = [vp, C.c_int, C.c_int, c_dp, C.c_int, C.c_double, vp]
     lib.nid_run_sequence.argtypes = [vp, c_dp, C.c_int, C.c_int, C.c_int, C.c_double, c_dp]
     lib.nid_launch_to.argtypes = [vp, C.c_int, c_dp, C.c_int, C.c_double, vp]
+    lib.nid_run_chain.argtypes = [vp, c_dp, C.c_int, C.c_int, C.c_double, c_dp, c_dp]
     lib.nid_wait.argtypes = [vp, C.c_int, c_dp, c_dp, c_dp, c_ip]
     lib.nid_slot_buffers.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(vp)]
     lib.nid_unpack_reduced.argtypes = [c_dp, c_dp, c_dp, c_dp, c_ip]
@@ -151,6 +152,20 @@ class Context:
         self.cell_end = cell_end if cell_end else self.ncell
         self._check(self.lib.nid_set_options(self.h, jac_bound, xform), "nid_set_options")
 
+    @classmethod
+    def borrow(cls, multi, k):
+        """Shard k of a Multi as a Context (not owned: closing it does nothing)."""
+        self = cls.__new__(cls)
+        self.lib = load()
+        self.h = C.c_void_p(multi.lib.nid_multi_shard(multi.h, int(k)))
+        if not self.h:
+            raise NidError(f"nid_multi_shard({k}): no such shard")
+        self._borrowed = True
+        self.rows, self.cols, self.cell_num, self.bin_num = multi.rows, multi.cols, multi.cell_num, multi.bin_num
+        self.ncell = multi.ncell
+        self.cell_begin, self.cell_end = 0, self.ncell
+        return self
+
     def _check(self, rc, what):
         if rc != NID_OK:
             msg = self.lib.nid_last_error(self.h).decode() if self.h else ""
@@ -158,7 +173,8 @@ class Context:
 
     def close(self):
         if getattr(self, "h", None):
-            self.lib.nid_destroy(self.h)
+            if not getattr(self, "_borrowed", False):
+                self.lib.nid_destroy(self.h)
             self.h = None
 
     def __del__(self):
@@ -268,6 +284,16 @@ class Context:
                                               float(delta), _dp(out)), "nid_run_sequence")
         return out
 
+    def run_chain(self, poses7, delta, want_jac=True, collect=True):
+        """A dependent chain: one pose per launch, each result awaited on the host before the next launch.
+        Returns (reduced blocks or None, seconds)."""
+        p = _d(np.asarray(poses7).reshape(-1, 7))
+        out = np.zeros((p.shape[0], NID_REDUCED_LEN)) if collect else None
+        sec = C.c_double(0)
+        self._check(self.lib.nid_run_chain(self.h, _dp(p), p.shape[0], 1 if want_jac else 0, float(delta), _dp(out),
+                                           C.byref(sec)), "nid_run_chain")
+        return out, float(sec.value)
+
     def wait(self, slot):
         H = np.zeros(36)
         b = np.zeros(6)
@@ -371,3 +397,222 @@ def from_pair(pair, bin_num, device=0, cell_begin=0, cell_end=0, jac_bound=JACBO
     ctx.set_reference_depth(pair.depth_m, pair.im0, synth.matrix_colmajor16(pair.T_wc0))
     ctx.set_target(pair.im1)
     return ctx
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# include/nid/nid_multi.h: cell shards over several GPUs (one process, or one process per GPU), in C++
+REDUCE_HOST, REDUCE_RCCL, REDUCE_HOOK = 0, 1, 2
+EXCHANGE_FN = C.CFUNCTYPE(C.c_int, c_dp, C.c_int64, C.c_void_p)
+RCCL_ID_BYTES = 128
+MULTI_SYMBOLS = [
+    "nid_multi_cell_range", "nid_multi_create", "nid_multi_create_rank", "nid_multi_destroy", "nid_multi_last_error",
+    "nid_multi_shards", "nid_multi_shard", "nid_multi_world", "nid_multi_comm_unique_id", "nid_comm_create_rank",
+    "nid_comm_create_local", "nid_comm_destroy", "nid_comm_ranks", "nid_multi_attach_comm", "nid_multi_comm_init",
+    "nid_multi_comm_init_local", "nid_multi_comm_ranks", "nid_multi_set_exchange_hook", "nid_multi_set_reduce_mode",
+    "nid_multi_set_options",
+    "nid_multi_set_math_mode", "nid_multi_set_block_threads", "nid_multi_set_reference_depth",
+    "nid_multi_set_reference_points", "nid_multi_set_target_u8", "nid_multi_compute_href",
+    "nid_multi_compute_href_matrix", "nid_multi_set_href_state", "nid_multi_evaluate", "nid_multi_evaluate_matrix",
+    "nid_multi_normal_equations", "nid_multi_launch_batch", "nid_multi_wait", "nid_multi_run_sequence",
+    "nid_multi_contract_bytes",
+]
+
+
+def _load_multi():
+    lib = load()
+    if getattr(lib, "_multi_ready", False):
+        return lib
+    vp = C.c_void_p
+    lib.nid_multi_cell_range.argtypes = [C.c_int32] * 3 + [c_ip, c_ip]
+    lib.nid_multi_create.argtypes = [C.POINTER(NidConfig), c_ip, C.c_int32, C.POINTER(vp)]
+    lib.nid_multi_create_rank.argtypes = [C.POINTER(NidConfig), C.c_int32, C.c_int32, C.c_int32, C.POINTER(vp)]
+    lib.nid_multi_destroy.argtypes = [vp]
+    lib.nid_multi_last_error.restype = C.c_char_p
+    lib.nid_multi_last_error.argtypes = [vp]
+    lib.nid_multi_shards.argtypes = [vp]
+    lib.nid_multi_shard.restype = vp
+    lib.nid_multi_shard.argtypes = [vp, C.c_int32]
+    lib.nid_multi_comm_unique_id.argtypes = [c_u8p]
+    lib.nid_multi_comm_init.argtypes = [vp, c_u8p]
+    lib.nid_multi_comm_init_local.argtypes = [vp]
+    lib.nid_multi_comm_ranks.argtypes = [vp, c_ip]
+    lib.nid_multi_set_reduce_mode.argtypes = [vp, C.c_int]
+    lib.nid_multi_set_exchange_hook.argtypes = [vp, EXCHANGE_FN, vp]
+    lib.nid_multi_set_options.argtypes = [vp, C.c_int, C.c_int]
+    lib.nid_multi_set_math_mode.argtypes = [vp, C.c_int]
+    lib.nid_multi_set_block_threads.argtypes = [vp, C.c_int]
+    lib.nid_multi_set_reference_depth.argtypes = [vp, c_dp, c_u8p, c_dp]
+    lib.nid_multi_set_target_u8.argtypes = [vp, c_u8p]
+    lib.nid_multi_compute_href.argtypes = [vp, c_dp, c_ip, c_dp, c_dp, c_ip]
+    lib.nid_multi_evaluate.argtypes = [vp, c_dp, C.c_int, c_dp, c_dp, c_dp, c_dp]
+    lib.nid_multi_normal_equations.argtypes = [vp, c_dp, C.c_int, C.c_double, c_dp, c_dp, c_dp, c_ip]
+    lib.nid_multi_launch_batch.argtypes = [vp, C.c_int, C.c_int, c_dp, C.c_int, C.c_double]
+    lib.nid_multi_wait.argtypes = [vp, C.c_int, c_dp, c_dp, c_dp, c_ip]
+    lib.nid_multi_run_sequence.argtypes = [vp, c_dp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, c_dp]
+    lib.nid_multi_contract_bytes.restype = C.c_int64
+    lib.nid_multi_contract_bytes.argtypes = [vp]
+    lib._multi_ready = True
+    return lib
+
+
+def cell_range(k, n, ncell):
+    lib = _load_multi()
+    lo, hi = C.c_int32(0), C.c_int32(0)
+    rc = lib.nid_multi_cell_range(k, n, ncell, C.byref(lo), C.byref(hi))
+    if rc != NID_OK:
+        raise NidError(f"nid_multi_cell_range({k}, {n}, {ncell}): {lib.nid_status_string(rc).decode()}")
+    return lo.value, hi.value
+
+
+def rccl_unique_id():
+    """ncclGetUniqueId through the library (rank 0 of a multi-process job; 128 bytes)."""
+    lib = _load_multi()
+    buf = (C.c_uint8 * RCCL_ID_BYTES)()
+    rc = lib.nid_multi_comm_unique_id(buf)
+    if rc != NID_OK:
+        raise NidError(f"nid_multi_comm_unique_id: {lib.nid_status_string(rc).decode()} ({rc})")
+    return bytes(buf)
+
+
+class Multi:
+    """One frame pair on the cell shards of several GPUs: `devices` = one shard per entry in this process, or
+    rank/world = this process's shard of a one-process-per-GPU job (then comm_init(id) before evaluating)."""
+
+    def __init__(self, rows, cols, cell_num, bin_num, fx, fy, cx, cy, devices=(0,), rank=None, world=None,
+                 jac_bound=JACBOUND_CPU, xform=XFORM_QUAT):
+        self.lib = _load_multi()
+        cfg = NidConfig(rows, cols, cell_num, bin_num, 3, 0, 0, 0, fx, fy, cx, cy)
+        h = C.c_void_p()
+        if world is not None:
+            rc = self.lib.nid_multi_create_rank(C.byref(cfg), int(devices[0]), int(rank), int(world), C.byref(h))
+        else:
+            dv = np.ascontiguousarray(devices, dtype=np.int32)
+            rc = self.lib.nid_multi_create(C.byref(cfg), _ip(dv), dv.size, C.byref(h))
+        if rc != NID_OK:
+            raise NidError(f"nid_multi_create: {self.lib.nid_status_string(rc).decode()} ({rc})")
+        self.h = h
+        self.rows, self.cols, self.cell_num, self.bin_num = rows, cols, cell_num, bin_num
+        self.ncell = cell_num * cell_num
+        self._check(self.lib.nid_multi_set_options(self.h, jac_bound, xform), "nid_multi_set_options")
+
+    def _check(self, rc, what):
+        if rc != NID_OK:
+            msg = self.lib.nid_multi_last_error(self.h).decode() if self.h else ""
+            raise NidError(f"{what}: {self.lib.nid_status_string(rc).decode()} ({rc}) {msg}")
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.nid_multi_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def shards(self):
+        return int(self.lib.nid_multi_shards(self.h))
+
+    def comm_init(self, id_bytes):
+        buf = (C.c_uint8 * RCCL_ID_BYTES).from_buffer_copy(id_bytes)
+        self._check(self.lib.nid_multi_comm_init(self.h, buf), "nid_multi_comm_init")
+
+    def comm_init_local(self):
+        self._check(self.lib.nid_multi_comm_init_local(self.h), "nid_multi_comm_init_local")
+
+    def comm_ranks(self):
+        n = C.c_int32(0)
+        self._check(self.lib.nid_multi_comm_ranks(self.h, C.byref(n)), "nid_multi_comm_ranks")
+        return n.value
+
+    def set_exchange_hook(self, fn):
+        """fn(array) must replace the float64 array by its sum over all processes, in place (e.g. a gloo all_reduce)."""
+        def _cb(ptr, count, _user):
+            try:
+                fn(np.ctypeslib.as_array(ptr, shape=(count,)))
+                return 0
+            except Exception:
+                return 1
+        self._hook = EXCHANGE_FN(_cb)       # keep the trampoline alive
+        self._check(self.lib.nid_multi_set_exchange_hook(self.h, self._hook, None), "nid_multi_set_exchange_hook")
+
+    def set_reduce_mode(self, mode):
+        self._check(self.lib.nid_multi_set_reduce_mode(self.h, int(mode)), "nid_multi_set_reduce_mode")
+
+    def set_math_mode(self, mode):
+        self._check(self.lib.nid_multi_set_math_mode(self.h, int(mode)), "nid_multi_set_math_mode")
+
+    def set_block_threads(self, n):
+        self._check(self.lib.nid_multi_set_block_threads(self.h, int(n)), "nid_multi_set_block_threads")
+
+    def set_reference_depth(self, depth_m, im0, T_wc0_colmajor16):
+        d, im, T = _d(depth_m).reshape(-1), _u8(im0).reshape(-1), _d(T_wc0_colmajor16)
+        self._check(self.lib.nid_multi_set_reference_depth(self.h, _dp(d), im.ctypes.data_as(c_u8p), _dp(T)),
+                    "nid_multi_set_reference_depth")
+
+    def set_target(self, im1):
+        im = _u8(im1).reshape(-1)
+        self._check(self.lib.nid_multi_set_target_u8(self.h, im.ctypes.data_as(c_u8p)), "nid_multi_set_target_u8")
+
+    def compute_href(self, pose7):
+        cnt = np.zeros(self.ncell, dtype=np.int32)
+        href = np.full(self.ncell, np.nan)
+        self._check(self.lib.nid_multi_compute_href(self.h, _dp(_d(pose7)), _ip(cnt), _dp(href), None, None),
+                    "nid_multi_compute_href")
+        return cnt, href
+
+    def evaluate(self, pose7, want_jac=True):
+        Hc = np.full(self.ncell, np.nan)
+        Hj = np.full(self.ncell, np.nan)
+        err = np.full(self.ncell, np.nan)
+        J = np.full((self.ncell, 6), np.nan) if want_jac else None
+        self._check(self.lib.nid_multi_evaluate(self.h, _dp(_d(pose7)), 1 if want_jac else 0, _dp(Hc), _dp(Hj),
+                                                _dp(err), _dp(J)), "nid_multi_evaluate")
+        return Hc, Hj, err, J
+
+    def normal_equations(self, pose7, delta, want_jac=True):
+        H = np.zeros(36)
+        b = np.zeros(6)
+        chi2 = C.c_double(0)
+        na = C.c_int32(0)
+        self._check(self.lib.nid_multi_normal_equations(self.h, _dp(_d(pose7)), 1 if want_jac else 0, float(delta),
+                                                        _dp(H), _dp(b), C.byref(chi2), C.byref(na)),
+                    "nid_multi_normal_equations")
+        return H.reshape(6, 6), b, chi2.value, na.value
+
+    def launch_batch(self, first_slot, poses7, delta, want_jac=True):
+        p = _d(np.asarray(poses7).reshape(-1, 7))
+        self._check(self.lib.nid_multi_launch_batch(self.h, first_slot, p.shape[0], _dp(p), 1 if want_jac else 0,
+                                                    float(delta)), "nid_multi_launch_batch")
+
+    def wait(self, slot):
+        H = np.zeros(36)
+        b = np.zeros(6)
+        chi2 = C.c_double(0)
+        na = C.c_int32(0)
+        self._check(self.lib.nid_multi_wait(self.h, slot, _dp(H), _dp(b), C.byref(chi2), C.byref(na)), "nid_multi_wait")
+        return H.reshape(6, 6), b, chi2.value, na.value
+
+    def run_sequence(self, poses7, delta, batch=64, group=1, want_jac=True, collect=True):
+        p = _d(np.asarray(poses7).reshape(-1, 7))
+        out = np.zeros((p.shape[0], NID_REDUCED_LEN)) if collect else None
+        self._check(self.lib.nid_multi_run_sequence(self.h, _dp(p), p.shape[0], int(batch), int(group),
+                                                    1 if want_jac else 0, float(delta), _dp(out)),
+                    "nid_multi_run_sequence")
+        return out
+
+    def contract_bytes(self):
+        return int(self.lib.nid_multi_contract_bytes(self.h))
+
+
+def multi_from_pair(pair, bin_num, devices=(0,), rank=None, world=None, jac_bound=JACBOUND_CPU, xform=XFORM_QUAT,
+                    math=MATH_FAST):
+    import importlib
+    synth = importlib.import_module("nid-pose-estimation_amd.synth")
+    m = Multi(pair.rows, pair.cols, pair.cell, bin_num, pair.fx, pair.fy, pair.cx, pair.cy, devices=devices,
+              rank=rank, world=world, jac_bound=jac_bound, xform=xform)
+    m.set_math_mode(math)
+    m.set_reference_depth(pair.depth_m, pair.im0, synth.matrix_colmajor16(pair.T_wc0))
+    m.set_target(pair.im1)
+    return m

@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -980,6 +981,21 @@ int nid_run_sequence(nid_ctx *ctx, const double *poses7, int n, int batch, int w
   return collect(n);
 }
 
+int nid_run_chain(nid_ctx *ctx, const double *poses7, int n, int want_jac, double delta, double *reduced_out, double *seconds) {
+  if (!ctx || !poses7 || n < 0) return NID_ERR_INVALID_ARG;
+  NID_HIP(ctx, hipSetDevice(ctx->cfg.device));
+  const auto t0 = std::chrono::steady_clock::now();
+  for (int i = 0; i < n; i++) {
+    int rc = nid_launch(ctx, 0, poses7 + 7 * (size_t)i, want_jac, delta);
+    if (rc) return rc;
+    rc = nid_wait(ctx, 0, nullptr, nullptr, nullptr, nullptr);
+    if (rc) return rc;
+    if (reduced_out) std::memcpy(reduced_out + (size_t)i * kReducedLen, ctx->slots[0].reduced_host, kReducedLen * sizeof(double));
+  }
+  if (seconds) *seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  return NID_OK;
+}
+
 int nid_launch_to(nid_ctx *ctx, int slot, const double *pose7, int want_jac, double delta, void *reduced_dev) {
   if (!ctx || !pose7 || !reduced_dev) return NID_ERR_INVALID_ARG;
   Pose p; pose_from_pose7(pose7, ctx->xform, &p);
@@ -1144,3 +1160,6 @@ int64_t nid_contract_bytes(const nid_ctx *ctx) {
 }
 
 }  // extern "C"
+
+// multi-GPU layer (include/nid/nid_multi.h): same translation unit, it drives the shard contexts' internals
+#include "nid_multi.inc"

@@ -11,6 +11,7 @@
 
 #include "nid/legacy_ops.h"
 #include "nid/nid_c.h"
+#include "nid/nid_multi.h"
 
 namespace g2o {
 
@@ -337,7 +338,9 @@ double OptimizationAlgorithmLevenberg::computeScale() const {
 OptimizationAlgorithmLevenberg::SolverResult OptimizationAlgorithmLevenberg::solveFused(int iteration) {
   SparseOptimizer *opt = _optimizer;
   VertexSE3Expmap *vm = opt->_vertices[0];
-  nid_ctx *ctx = nid_legacy_context();
+  // the shards the legacy operators run on (one context on one GPU, or the cells of the pair spread over several:
+  // include/nid/nid_multi.h): H, b and chi2 arrive already summed over the whole image
+  nid_multi *ctx = nid_legacy_multi();
   if (!ctx || iteration == 0) {  // first use: let the legacy operator upload the frame-pair state
     const int n2 = opt->cell_num_ * opt->cell_num_;
     std::vector<double> ht(n2, 0.0), hj(n2, 0.0);
@@ -345,7 +348,7 @@ OptimizationAlgorithmLevenberg::SolverResult OptimizationAlgorithmLevenberg::sol
     CudaComputeH(false, opt->im0_, opt->im1_, opt->points3d_, opt->bs_counter_, opt->bs_value_ref_,
                  opt->bs_index_ref_, M0.data(), opt->camera_intrincis_, opt->bin_num_, opt->bs_degree_,
                  opt->cell_num_, opt->rows_, opt->cols_, opt->Href_, nullptr, nullptr, ht.data(), hj.data(), nullptr);
-    ctx = nid_legacy_context();
+    ctx = nid_legacy_multi();
     if (!ctx) return Fail;
   }
   double delta = 1e300;
@@ -354,7 +357,7 @@ OptimizationAlgorithmLevenberg::SolverResult OptimizationAlgorithmLevenberg::sol
   double p7[7], H[36], b[6], currentChi = 0;
   int32_t na = 0;
   vm->estimate().toPose7(p7);
-  if (nid_normal_equations(ctx, p7, 1, delta, H, b, &currentChi, &na) != NID_OK) return Fail;
+  if (nid_multi_normal_equations(ctx, p7, 1, delta, H, b, &currentChi, &na) != NID_OK) return Fail;
   std::memcpy(vm->H, H, sizeof(H));
   std::memcpy(vm->b, b, sizeof(b));
   _solver->setSystem(H, b);
@@ -392,10 +395,10 @@ OptimizationAlgorithmLevenberg::SolverResult OptimizationAlgorithmLevenberg::sol
         cand[k].toPose7(poses + 7 * k);
         l *= n_i; n_i *= 2;
       }
-      if (nid_launch_batch(ctx, 0, nb, poses, 0, delta) != NID_OK) return Fail;
+      if (nid_multi_launch_batch(ctx, 0, nb, poses, 0, delta) != NID_OK) return Fail;
       double chis[kTrialBatch];
       for (int k = 0; k < nb; k++)
-        if (nid_wait(ctx, k, nullptr, nullptr, &chis[k], &na) != NID_OK) return Fail;
+        if (nid_multi_wait(ctx, k, nullptr, nullptr, &chis[k], &na) != NID_OK) return Fail;
       bool accepted = false;
       for (int k = 0; k < nb; k++) {
         tempChi = oks[k] ? chis[k] : std::numeric_limits<double>::max();
@@ -436,7 +439,7 @@ OptimizationAlgorithmLevenberg::SolverResult OptimizationAlgorithmLevenberg::sol
     opt->update(_solver->x());
     _solver->restoreDiagonal();
     opt->_vertices[0]->estimate().toPose7(p7);
-    if (nid_normal_equations(ctx, p7, 0, delta, nullptr, nullptr, &tempChi, &na) != NID_OK) return Fail;
+    if (nid_multi_normal_equations(ctx, p7, 0, delta, nullptr, nullptr, &tempChi, &na) != NID_OK) return Fail;
     if (!ok2) tempChi = std::numeric_limits<double>::max();
     rho = (currentChi - tempChi);
     double scale = computeScale();

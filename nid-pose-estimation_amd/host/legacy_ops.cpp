@@ -1,5 +1,16 @@
 // legacy_ops.cpp -- Calculate3Dpoint / CudaComputeHref / g2o::CudaComputeH on top
-// of the C-ABI (include/nid/nid_c.h).  See include/nid/legacy_ops.h.
+// of the C-ABI (include/nid/nid_c.h, include/nid/nid_multi.h).  See include/nid/legacy_ops.h.
+//
+// The three operators keep the reference's signatures and its ownership rules (the caller owns every buffer
+// and hands ALL of them over on every call, computeH.cu:373-502), but not its per-call cost (>= 10 mallocs,
+// 52-367 MB of memsets, 11 MB of uploads): the frame-pair state stays resident on the device(s) between calls.
+// What is resident is identified by CONTENT, not by pointer: a caller that frees and re-mallocs its buffers per
+// pair (NID_pose_estimation.cpp:229-251, 385-392) usually gets the same addresses back.
+//   * CudaComputeHref is called once per pair: it always uploads the reference (im0, points3d) afresh;
+//   * CudaComputeH compares a fingerprint of im0 / im1 / points3d / bs_ref / bs_counter / Href -- 64 samples
+//     spread over each array plus its length -- with the fingerprint of what is resident, and uploads what
+//     changed.  A new frame pair differs in essentially every sample; a caller that changes single pixels in
+//     place between calls can force the upload with NID_LEGACY_ALWAYS_UPLOAD=1 or nid_legacy_reset().
 #include "nid/legacy_ops.h"
 
 #include <cmath>
@@ -9,23 +20,28 @@
 #include <vector>
 
 #include "nid/nid_c.h"
+#include "nid/nid_multi.h"
 
 namespace {
 
 struct LegacyState {
-  nid_ctx *ctx = nullptr;
+  nid_multi *m = nullptr;
   int rows = 0, cols = 0, cell = 0, bins = 0;
   double intr[4] = {0, 0, 0, 0};
-  // identity of what is resident on the device
-  const double *im0 = nullptr, *im1 = nullptr, *points = nullptr, *bs_ref = nullptr, *href = nullptr;
-  const int *bs_counter = nullptr;
+  // fingerprints of what is resident on the device(s)
+  uint64_t fp_im0 = 0, fp_points = 0, fp_im1 = 0, fp_bs_ref = 0, fp_counter = 0, fp_href = 0;
   bool have_ref = false, have_target = false, have_href = false;
 };
 
 LegacyState g_state;
-int g_device = 0;
+std::vector<int32_t> g_devices = {0};
+int g_rank = 0, g_world = 1;
+bool g_have_id = false;
+uint8_t g_id[NID_RCCL_ID_BYTES];
 int g_jac_bound = NID_JACBOUND_CPU;
 int g_math_mode = NID_MATH_FAST;
+int g_reduce_rccl = 0;
+nid_comm *g_comm = nullptr;  // lives across nid_legacy_reset(): one communicator per process, however many pairs / levels
 long g_uploads = 0;
 
 bool always_upload() {
@@ -33,37 +49,64 @@ bool always_upload() {
   return v;
 }
 
-void report(const char *where, int rc, nid_ctx *ctx) {
-  // the reference prints CUDA errors and carries on (computeH.cu:454-473)
-  std::fprintf(stderr, "[nid legacy] %s failed: %s (%d) %s\n", where, nid_status_string(rc), rc,
-               ctx ? nid_last_error(ctx) : "");
+// 64 samples spread over the array + its length, FNV-1a over their bytes (never 0)
+template <typename T>
+uint64_t fingerprint(const T *a, size_t n) {
+  if (!a) return 1;
+  uint64_t h = 1469598103934665603ull;
+  auto mix = [&](const void *p, size_t bytes) {
+    const unsigned char *b = static_cast<const unsigned char *>(p);
+    for (size_t i = 0; i < bytes; i++) { h ^= b[i]; h *= 1099511628211ull; }
+  };
+  mix(&n, sizeof(n));
+  const size_t samples = n < 64 ? n : 64;
+  for (size_t k = 0; k < samples; k++) {
+    const size_t i = samples > 1 ? (size_t)((unsigned __int128)k * (n - 1) / (samples - 1)) : 0;
+    mix(&a[i], sizeof(T));
+  }
+  return h ? h : 2;
 }
 
-nid_ctx *get_ctx(int rows, int cols, int cell, int bins, int deg, const double *intr) {
+void report(const char *where, int rc, nid_multi *m) {
+  // the reference prints CUDA errors and carries on (computeH.cu:454-473)
+  std::fprintf(stderr, "[nid legacy] %s failed: %s (%d) %s\n", where, nid_status_string(rc), rc,
+               m ? nid_multi_last_error(m) : "");
+}
+
+nid_multi *get_multi(int rows, int cols, int cell, int bins, int deg, const double *intr) {
   LegacyState &S = g_state;
-  const bool same = S.ctx && S.rows == rows && S.cols == cols && S.cell == cell && S.bins == bins &&
+  const bool same = S.m && S.rows == rows && S.cols == cols && S.cell == cell && S.bins == bins &&
                     S.intr[0] == intr[0] && S.intr[1] == intr[1] && S.intr[2] == intr[2] && S.intr[3] == intr[3];
-  if (same) return S.ctx;
-  if (S.ctx) nid_destroy(S.ctx);
+  if (same) return S.m;
+  if (S.m) nid_multi_destroy(S.m);
   S = LegacyState();
   nid_config cfg;
   std::memset(&cfg, 0, sizeof(cfg));
   cfg.rows = rows; cfg.cols = cols; cfg.cell_num = cell; cfg.bin_num = bins; cfg.bs_degree = deg;
-  cfg.device = g_device; cfg.cell_begin = 0; cfg.cell_end = 0;
   cfg.fx = intr[0]; cfg.fy = intr[1]; cfg.cx = intr[2]; cfg.cy = intr[3];
-  nid_ctx *ctx = nullptr;
-  int rc = nid_create(&cfg, &ctx);
-  if (rc != NID_OK) { report("nid_create", rc, nullptr); return nullptr; }
+  nid_multi *m = nullptr;
+  int rc = g_world > 1 ? nid_multi_create_rank(&cfg, g_devices[0], g_rank, g_world, &m)
+                       : nid_multi_create(&cfg, g_devices.data(), (int32_t)g_devices.size(), &m);
+  if (rc != NID_OK) { report("nid_multi_create", rc, nullptr); return nullptr; }
+  if (g_world > 1 || g_reduce_rccl) {
+    if (!g_comm) {
+      if (g_world > 1 && !g_have_id) { report("nid_legacy_set_rank: no RCCL id", NID_ERR_STATE, m); nid_multi_destroy(m); return nullptr; }
+      rc = g_world > 1 ? nid_comm_create_rank(g_id, g_rank, g_world, g_devices[0], &g_comm)
+                       : nid_comm_create_local(g_devices.data(), (int32_t)g_devices.size(), &g_comm);
+      if (rc != NID_OK) { report("RCCL communicator", rc, m); nid_multi_destroy(m); return nullptr; }
+    }
+    rc = nid_multi_attach_comm(m, g_comm);
+    if (rc != NID_OK) { report("nid_multi_attach_comm", rc, m); nid_multi_destroy(m); return nullptr; }
+  }
   // the operator signatures carry a 4x4 matrix: computeH.cu:152-154 semantics for the transform
-  nid_set_options(ctx, g_jac_bound, NID_XFORM_MATRIX);
-  nid_set_math_mode(ctx, g_math_mode);
+  nid_multi_set_options(m, g_jac_bound, NID_XFORM_MATRIX);
+  nid_multi_set_math_mode(m, g_math_mode);
   // the operators are blocking, one pose (or one LM rejection chain) at a time: latency matters, not the
-  // pipelined throughput the 128-thread default is tuned for.  256-thread workgroups: single-pose
-  // cost+Jacobian 29.6 -> 18.6 us, cost-only 17.7 -> 14.1 us, a 10-pose cost-only chain 30.7 -> 27.8 us.
-  nid_set_block_threads(ctx, 256);
-  S.ctx = ctx; S.rows = rows; S.cols = cols; S.cell = cell; S.bins = bins;
+  // pipelined throughput the 128-thread default is tuned for
+  nid_multi_set_block_threads(m, 256);
+  S.m = m; S.rows = rows; S.cols = cols; S.cell = cell; S.bins = bins;
   std::memcpy(S.intr, intr, sizeof(S.intr));
-  return ctx;
+  return m;
 }
 
 bool to_u8(const double *im, size_t n, std::vector<uint8_t> *out) {
@@ -71,16 +114,22 @@ bool to_u8(const double *im, size_t n, std::vector<uint8_t> *out) {
   return nid_set_reference_image_f64(im, (int64_t)n, out->data()) == NID_OK;
 }
 
-int ensure_reference(LegacyState &S, const double *im0, const double *points3d) {
-  if (S.have_ref && !always_upload() && S.im0 == im0 && S.points == points3d) return NID_OK;
+int upload_reference(LegacyState &S, const double *im0, const double *points3d) {
   const size_t N = (size_t)S.rows * S.cols;
   std::vector<uint8_t> im;
   if (!to_u8(im0, N, &im)) return NID_ERR_UNSUPPORTED;
-  int rc = nid_set_reference_points(S.ctx, points3d, im.data());
+  int rc = nid_multi_set_reference_points(S.m, points3d, im.data());
   if (rc != NID_OK) return rc;
-  S.im0 = im0; S.points = points3d; S.have_ref = true; S.have_href = false;
+  S.fp_im0 = fingerprint(im0, N); S.fp_points = fingerprint(points3d, 3 * N);
+  S.have_ref = true; S.have_href = false;
   g_uploads++;
   return NID_OK;
+}
+
+int ensure_reference(LegacyState &S, const double *im0, const double *points3d) {
+  const size_t N = (size_t)S.rows * S.cols;
+  if (S.have_ref && !always_upload() && S.fp_im0 == fingerprint(im0, N) && S.fp_points == fingerprint(points3d, 3 * N)) return NID_OK;
+  return upload_reference(S, im0, points3d);
 }
 
 }  // namespace
@@ -88,24 +137,26 @@ int ensure_reference(LegacyState &S, const double *im0, const double *points3d) 
 void Calculate3Dpoint(double *depth, double *pose_c2w, double *points_3d, double *camera_intrincis, int rows,
                       int cols) {
   int rc = nid_backproject(depth, pose_c2w, camera_intrincis[0], camera_intrincis[1], camera_intrincis[2],
-                           camera_intrincis[3], rows, cols, g_device, points_3d);
+                           camera_intrincis[3], rows, cols, g_devices[0], points_3d);
   if (rc != NID_OK) report("Calculate3Dpoint", rc, nullptr);
 }
 
 void CudaComputeHref(double *im0, double *points3d, double *pose, double *camera_intrincis, int bin_num,
                      int bs_degree, int cell_num, int rows, int cols, double *bs_value, int *bs_index,
                      int *bs_counter, double *Href) {
-  nid_ctx *ctx = get_ctx(rows, cols, cell_num, bin_num, bs_degree, camera_intrincis);
-  if (!ctx) return;
+  nid_multi *m = get_multi(rows, cols, cell_num, bin_num, bs_degree, camera_intrincis);
+  if (!m) return;
   LegacyState &S = g_state;
-  int rc = ensure_reference(S, im0, points3d);
-  if (rc != NID_OK) { report("CudaComputeHref(reference upload)", rc, ctx); return; }
+  int rc = upload_reference(S, im0, points3d);  // once per frame pair: always fresh
+  if (rc != NID_OK) { report("CudaComputeHref(reference upload)", rc, m); return; }
+  S.have_target = false;                        // a new pair: the next CudaComputeH re-checks its target
   const size_t N = (size_t)rows * cols;
   const int ncell = cell_num * cell_num;
   std::vector<int32_t> cnt(ncell), idx(bs_index ? N : 0);
   std::vector<double> href(ncell);
-  rc = nid_compute_href_matrix(ctx, pose, cnt.data(), href.data(), bs_value, bs_index ? idx.data() : nullptr);
-  if (rc != NID_OK) { report("CudaComputeHref", rc, ctx); return; }
+  if (bs_value) std::memset(bs_value, 0, 4 * N * sizeof(double));  // a process that owns some of the cells fills those
+  rc = nid_multi_compute_href_matrix(m, pose, cnt.data(), href.data(), bs_value, bs_index ? idx.data() : nullptr);
+  if (rc != NID_OK) { report("CudaComputeHref", rc, m); return; }
   for (int c = 0; c < ncell; c++) {
     bs_counter[c] = cnt[c];
     // CudaComputeHref.cu:205-220: NaN when inactive, otherwise subtract onto the caller's value
@@ -120,8 +171,11 @@ void CudaComputeHref(double *im0, double *points3d, double *pose, double *camera
     }
   }
   if (bs_index) for (size_t i = 0; i < N; i++) bs_index[i] = idx[i];
-  S.have_href = true;  // the device already holds these weights (CPU-edge convention: 0 instead of NaN)
-  S.bs_ref = bs_value; S.bs_counter = bs_counter; S.href = Href;
+  // the device already holds these weights (CPU-edge convention: 0 instead of NaN)
+  S.have_href = true;
+  S.fp_bs_ref = fingerprint(bs_value, bs_value ? 4 * N : 0);
+  S.fp_counter = fingerprint(bs_counter, (size_t)ncell);
+  S.fp_href = fingerprint(Href, (size_t)ncell);
 }
 
 namespace g2o {
@@ -131,35 +185,37 @@ void CudaComputeH(bool calculate_der, double *im0, double *im1, double *points3d
                   int cell_num, int rows, int cols, double *Href, double *pro_target, double *pro_joint,
                   double *Htarget, double *Hjoint, double *der) {
   (void)pro_target; (void)pro_joint;  // accepted, never read or written (computeH.cu:373-502)
-  nid_ctx *ctx = get_ctx(rows, cols, cell_num, bin_num, bs_degree, camera_intrincis);
-  if (!ctx) return;
+  nid_multi *m = get_multi(rows, cols, cell_num, bin_num, bs_degree, camera_intrincis);
+  if (!m) return;
   LegacyState &S = g_state;
   const size_t N = (size_t)rows * cols;
   const int ncell = cell_num * cell_num;
   int rc = ensure_reference(S, im0, points3d);
-  if (rc != NID_OK) { report("CudaComputeH(reference upload)", rc, ctx); return; }
-  if (!S.have_target || always_upload() || S.im1 != im1) {
+  if (rc != NID_OK) { report("CudaComputeH(reference upload)", rc, m); return; }
+  const uint64_t fp1 = fingerprint(im1, N);
+  if (!S.have_target || always_upload() || S.fp_im1 != fp1) {
     std::vector<uint8_t> im;
-    if (!to_u8(im1, N, &im)) { report("CudaComputeH(im1 is not u8-valued)", NID_ERR_UNSUPPORTED, ctx); return; }
-    rc = nid_set_target_u8(ctx, im.data());
-    if (rc != NID_OK) { report("CudaComputeH(target upload)", rc, ctx); return; }
-    S.im1 = im1; S.have_target = true;
+    if (!to_u8(im1, N, &im)) { report("CudaComputeH(im1 is not u8-valued)", NID_ERR_UNSUPPORTED, m); return; }
+    rc = nid_multi_set_target_u8(m, im.data());
+    if (rc != NID_OK) { report("CudaComputeH(target upload)", rc, m); return; }
+    S.fp_im1 = fp1; S.have_target = true;
     g_uploads++;
   }
-  if (!S.have_href || always_upload() || S.bs_ref != bs_ref || S.bs_counter != bs_counter) {
-    // Href is only handed over with calculate_der (computeH.cu:428-429); the kernels also need it to
-    // know which cells are active, so the first call must carry it
+  // Href is only READ by the reference with calculate_der (computeH.cu:428-429); the kernels also need it to know
+  // which cells are active.  A NULL Href gives zeros (cost-only outputs do not depend on it) and the first call
+  // that brings one replaces them: Href is part of the key.
+  const uint64_t fpb = fingerprint(bs_ref, 4 * N), fpc = fingerprint(bs_counter, (size_t)ncell), fph = fingerprint(Href, (size_t)ncell);
+  if (!S.have_href || always_upload() || S.fp_bs_ref != fpb || S.fp_counter != fpc || (Href && S.fp_href != fph)) {
     std::vector<double> href(ncell, 0.0);
     if (Href) for (int c = 0; c < ncell; c++) href[c] = Href[c];
-    rc = nid_set_href_state(ctx, bs_counter, href.data(), bs_ref, bs_index_ref);
-    if (rc != NID_OK) { report("CudaComputeH(href state upload)", rc, ctx); return; }
-    S.bs_ref = bs_ref; S.bs_counter = bs_counter; S.href = Href; S.have_href = true;
+    rc = nid_multi_set_href_state(m, bs_counter, href.data(), bs_ref, bs_index_ref);
+    if (rc != NID_OK) { report("CudaComputeH(href state upload)", rc, m); return; }
+    S.fp_bs_ref = fpb; S.fp_counter = fpc; S.fp_href = Href ? fph : 1; S.have_href = true;
     g_uploads++;
   }
   std::vector<double> ht(ncell), hj(ncell);
-  rc = nid_evaluate_matrix(ctx, pose, calculate_der ? 1 : 0, ht.data(), hj.data(), nullptr,
-                           calculate_der ? der : nullptr);
-  if (rc != NID_OK) { report("CudaComputeH", rc, ctx); return; }
+  rc = nid_multi_evaluate_matrix(m, pose, calculate_der ? 1 : 0, ht.data(), hj.data(), nullptr, calculate_der ? der : nullptr);
+  if (rc != NID_OK) { report("CudaComputeH", rc, m); return; }
   for (int c = 0; c < ncell; c++) {
     // CalculateHKernel: NaN for bs_counter < 300, else `-=` onto the caller's (zeroed) value
     Htarget[c] = std::isnan(ht[c]) ? NAN : Htarget[c] + ht[c];
@@ -173,25 +229,50 @@ extern "C" {
 
 void nid_legacy_set_jacobian_bound(int mode) {
   g_jac_bound = mode ? NID_JACBOUND_CUDA : NID_JACBOUND_CPU;
-  if (g_state.ctx) nid_set_options(g_state.ctx, g_jac_bound, NID_XFORM_MATRIX);
+  if (g_state.m) nid_multi_set_options(g_state.m, g_jac_bound, NID_XFORM_MATRIX);
 }
 
 void nid_legacy_set_math_mode(int mode) {
   g_math_mode = mode ? NID_MATH_STRICT : NID_MATH_FAST;
-  if (g_state.ctx) nid_set_math_mode(g_state.ctx, g_math_mode);
+  if (g_state.m) nid_multi_set_math_mode(g_state.m, g_math_mode);
 }
 
 void nid_legacy_set_device(int device) {
-  if (device != g_device) nid_legacy_reset();
-  g_device = device;
+  const int32_t d = device;
+  nid_legacy_set_devices(&d, 1, 0);
+}
+
+static void drop_comm() {
+  if (g_comm) { nid_comm_destroy(g_comm); g_comm = nullptr; }
+}
+
+void nid_legacy_set_devices(const int32_t *devices, int n, int reduce_rccl) {
+  if (!devices || n < 1 || n > NID_MAX_SHARDS) return;
+  nid_legacy_reset();
+  drop_comm();
+  g_devices.assign(devices, devices + n);
+  g_rank = 0; g_world = 1; g_have_id = false;
+  g_reduce_rccl = reduce_rccl ? 1 : 0;
+}
+
+void nid_legacy_set_rank(int device, int rank, int world, const uint8_t *rccl_id128) {
+  nid_legacy_reset();
+  drop_comm();
+  g_devices.assign(1, device);
+  g_rank = rank; g_world = world < 1 ? 1 : world;
+  g_have_id = rccl_id128 != nullptr;
+  if (rccl_id128) std::memcpy(g_id, rccl_id128, sizeof(g_id));
+  g_reduce_rccl = g_world > 1 ? 1 : 0;
 }
 
 void nid_legacy_reset(void) {
-  if (g_state.ctx) nid_destroy(g_state.ctx);
+  if (g_state.m) nid_multi_destroy(g_state.m);
   g_state = LegacyState();
 }
 
-nid_ctx *nid_legacy_context(void) { return g_state.ctx; }
+nid_multi *nid_legacy_multi(void) { return g_state.m; }
+
+nid_ctx *nid_legacy_context(void) { return g_state.m ? nid_multi_shard(g_state.m, 0) : nullptr; }
 
 long nid_legacy_upload_count(void) { return g_uploads; }
 

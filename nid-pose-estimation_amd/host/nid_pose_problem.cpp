@@ -16,6 +16,9 @@
 static double g_last_optimize_s = 0.0;
 double nid_host_last_optimize_seconds(void) { return g_last_optimize_s; }
 
+void nid_host_set_devices(const int32_t *devices, int n, int reduce_rccl) { nid_legacy_set_devices(devices, n, reduce_rccl); }
+void nid_host_set_rank(int device, int rank, int world, const uint8_t *rccl_id128) { nid_legacy_set_rank(device, rank, world, rccl_id128); }
+
 int nid_host_run_lm(const nid_pose_problem *pb, double *pose7_inout, nid_host_lm_record *trace,
                     int max_trace, char *log_buf, int log_cap) {
   if (!pb || !pose7_inout) return -1;
@@ -58,6 +61,11 @@ int nid_host_run_lm(const nid_pose_problem *pb, double *pose7_inout, nid_host_lm
   CudaComputeHref(im0_data.data(), points_3d_all.data(), M0.data(), intrinscis.data(), bin_num, bs_degree, cell,
                   rows, cols, bs_value.data(), bin_index.data(), bs_counter.data(), Href.data());
 
+  if (!nid_legacy_multi()) {  // the operators print and carry on like the reference's (computeH.cu:454-473); a run must not
+    if (log_buf && log_cap > 0) std::snprintf(log_buf, (size_t)log_cap, "the NID operators could not set up their device state (see stderr)");
+    nid_legacy_reset();
+    return -3;
+  }
   // :264-276
   optimizer.im0_ = im0_data.data(); optimizer.im1_ = im1_data.data(); optimizer.points3d_ = points_3d_all.data();
   optimizer.rows_ = rows; optimizer.cols_ = cols; optimizer.camera_intrincis_ = intrinscis.data();

@@ -55,6 +55,14 @@ int nid_host_run_pyramid_lm(const nid_pose_problem *pb, int levels, double *pose
 void nid_pyr_down_u8(const uint8_t *src, int rows, int cols, uint8_t *dst);
 void nid_pyr_down_depth_u16(const uint16_t *src, int rows, int cols, double depth_factor, uint16_t *dst);
 
+/* Multi-GPU (include/nid/nid_multi.h, include/nid/legacy_ops.h): every later nid_host_run_lm /
+ * nid_host_run_pyramid_lm shards the cells of each frame pair (each pyramid level) over these devices of this
+ * process (entries may repeat; reduce_rccl: sum the 6x6 blocks with RCCL instead of on the host) ... */
+void nid_host_set_devices(const int32_t *devices, int n, int reduce_rccl);
+/* ... or runs as rank `rank` of `world` processes, one per GPU, summing with RCCL (id: nid_multi_comm_unique_id
+ * of rank 0).  Every rank runs the same optimisation and takes the same decisions. */
+void nid_host_set_rank(int device, int rank, int world, const uint8_t *rccl_id128);
+
 /* wall time of the optimize() call of the last nid_host_run_lm (setup excluded) */
 double nid_host_last_optimize_seconds(void);
 

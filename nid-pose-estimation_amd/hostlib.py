@@ -57,6 +57,10 @@ def load():
     lib.nid_legacy_set_jacobian_bound.argtypes = [C.c_int]
     lib.nid_legacy_upload_count.restype = C.c_long
     lib.nid_legacy_set_math_mode.argtypes = [C.c_int]
+    lib.nid_host_set_devices.restype = None
+    lib.nid_host_set_devices.argtypes = [C.POINTER(C.c_int32), C.c_int, C.c_int]
+    lib.nid_host_set_rank.restype = None
+    lib.nid_host_set_rank.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_uint8)]
     _lib = lib
     return lib
 
@@ -220,6 +224,18 @@ def png_read_u16(path):
     if rc:
         raise RuntimeError(f"nid_png_read_u16({path}) -> {rc}")
     return out
+
+
+def set_devices(devices=(0,), reduce_rccl=False):
+    """Every later run_lm / run_pyramid_lm shards the cells of each pair over these devices of this process."""
+    dv = np.ascontiguousarray(devices, dtype=np.int32)
+    load().nid_host_set_devices(dv.ctypes.data_as(C.POINTER(C.c_int32)), dv.size, 1 if reduce_rccl else 0)
+
+
+def set_rank(device, rank, world, rccl_id):
+    """This process is rank `rank` of `world` (one per GPU); rccl_id = capi.rccl_unique_id() of rank 0."""
+    buf = (C.c_uint8 * 128).from_buffer_copy(rccl_id) if rccl_id is not None else None
+    load().nid_host_set_rank(int(device), int(rank), int(world), buf)
 
 
 def last_optimize_seconds():

@@ -54,6 +54,19 @@ struct nid_oracle {
 /* ------------------------------------------------------------------------ */
 /* B-spline: types_six_dof_expmap.cpp:738-764 (value), :766-800 (derivative) */
 /* knot vector: types_six_dof_expmap.h:283-296, computeH.cu:99-112           */
+/* Pixel order inside a cell.  The reference walks a cell's pixels row-major (NID_pose_estimation.cpp:411-427 builds
+ * the edge's point set in that order; types_six_dof_expmap.cpp:549,397 loop over it).  Built with
+ * -DNID_ORACLE_REVERSE_PIXELS (oracle/libnid_oracle_rev.so) the same arithmetic runs over the pixels in the
+ * opposite order: every f64 sum gets a different rounding, nothing else changes.  Tests use the pair to MEASURE how
+ * far the reference's own optimisation is reproducible on given data (tests/test_oracle_known_answers.py). */
+#ifdef NID_ORACLE_REVERSE_PIXELS
+#define NID_FOR_PIXEL_ROWS(r, lo, hi) for (int r = (hi) - 1; r >= (lo); r--)
+#define NID_FOR_PIXEL_COLS(c, lo, hi) for (int c = (hi) - 1; c >= (lo); c--)
+#else
+#define NID_FOR_PIXEL_ROWS(r, lo, hi) for (int r = (lo); r < (hi); r++)
+#define NID_FOR_PIXEL_COLS(c, lo, hi) for (int c = (lo); c < (hi); c++)
+#endif
+
 static void make_knots(int nb, double *knots) {
   int S = nb - 3;
   for (int i = 0; i < nb + 4; i++) {
@@ -437,8 +450,8 @@ void nid_oracle_compute_href(nid_oracle *o, const double *pose7, int *bs_counter
       int c = cj + o->cell * ci;
       double pro_ref[NID_MAX_BINS] = {0};
       int n = 0, ob = 0;
-      for (int r = o->rb * ci; r < o->rb * (ci + 1); r++)
-        for (int cc = o->cb * cj; cc < o->cb * (cj + 1); cc++) {
+      NID_FOR_PIXEL_ROWS(r, o->rb * ci, o->rb * (ci + 1))
+        NID_FOR_PIXEL_COLS(cc, o->cb * cj, o->cb * (cj + 1)) {
           int id = r * o->cols + cc;
           if (!pixel_valid(o, id)) continue;
           n++;
@@ -490,8 +503,8 @@ static void cell_compute_h(nid_oracle *o, const xform_t *xf, int ci, int cj) {
   memset(pro_current, 0, nb * sizeof(double));
   memset(pro_joint, 0, (size_t)nb * nb * sizeof(double));
   double H_current = 0.0, H_joint = 0.0;
-  for (int r = o->rb * ci; r < o->rb * (ci + 1); r++)
-    for (int cc = o->cb * cj; cc < o->cb * (cj + 1); cc++) {
+  NID_FOR_PIXEL_ROWS(r, o->rb * ci, o->rb * (ci + 1))
+    NID_FOR_PIXEL_COLS(cc, o->cb * cj, o->cb * (cj + 1)) {
       int id = r * o->cols + cc;
       o->du[id] = NAN; o->dv[id] = NAN; o->djc[id] = -1;
       if (!pixel_valid(o, id)) continue;
@@ -557,8 +570,8 @@ static void cell_linearize(nid_oracle *o, const xform_t *xf, int ci, int cj, dou
   double d_mi_i = (nb - o->deg) / 255.0;
   const double fx = o->fx, fy = o->fy;
   const int jcols = (o->jac_bound_mode == NID_ORACLE_JACBOUND_CPU) ? o->cols - 1 : o->cols;
-  for (int r = o->rb * ci; r < o->rb * (ci + 1); r++)
-    for (int cc = o->cb * cj; cc < o->cb * (cj + 1); cc++) {
+  NID_FOR_PIXEL_ROWS(r, o->rb * ci, o->rb * (ci + 1))
+    NID_FOR_PIXEL_COLS(cc, o->cb * cj, o->cb * (cj + 1)) {
       int id = r * o->cols + cc;
       o->jgx[id] = NAN; o->jgy[id] = NAN; o->jpc[id] = NAN; o->jjc[id] = -1;
       for (int k = 0; k < 4; k++) o->jdw[4 * (size_t)id + k] = NAN;

@@ -80,3 +80,41 @@ def test_f64_image_conversion(capi):
     assert list(out) == [0, 1, 254, 255]
     src = np.array([0.5])
     assert lib.nid_set_reference_image_f64(src.ctypes.data_as(capi.c_dp), 1, out.ctypes.data_as(capi.c_u8p)) == -4
+
+
+def _declared_in(header):
+    txt = open(os.path.join(ROOT, "include", "nid", header)).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(nid_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_multi_header_symbols_are_exported(capi):
+    """include/nid/nid_multi.h: the multi-GPU layer is part of the same library, every symbol exported; the RCCL
+    library itself is NOT a load-time dependency (dlopen on first use: a single-GPU process never pays for it)."""
+    lib = capi._load_multi()
+    declared = _declared_in("nid_multi.h")
+    assert len(declared) >= 30 and sorted(capi.MULTI_SYMBOLS) == declared
+    nm = subprocess.run(["nm", "-D", "--defined-only", capi.LIB_PATH], capture_output=True, text=True).stdout
+    exported = set(re.findall(r" T (nid_[a-z0-9_]+)", nm))
+    assert set(declared) <= exported
+    needed = subprocess.run(["readelf", "-d", capi.LIB_PATH], capture_output=True, text=True).stdout
+    assert "rccl" not in needed.lower()
+
+
+def test_multi_cell_ranges_and_argument_checks(capi):
+    parallel = __import__("importlib").import_module("nid-pose-estimation_amd.parallel")
+    for ncell in (16, 64, 256, 1024, 250):
+        for n in (1, 2, 3, 4, 8):
+            rs = [capi.cell_range(k, n, ncell) for k in range(n)]
+            assert rs == parallel.all_ranges(n, ncell)
+    with pytest.raises(capi.NidError):
+        capi.cell_range(0, 17, 16)          # more shards than cells
+    lib = capi._load_multi()
+    h = C.c_void_p()
+    cfg = capi.NidConfig(480, 640, 16, 10, 3, 0, 0, 0, 481.2, -480.0, 319.5, 239.5)
+    dv = np.zeros(2, dtype=np.int32)
+    assert lib.nid_multi_create(C.byref(cfg), dv.ctypes.data_as(capi.c_ip), 0, C.byref(h)) == -1
+    assert lib.nid_multi_create(C.byref(cfg), None, 2, C.byref(h)) == -1
+    assert lib.nid_multi_create_rank(C.byref(cfg), 0, 3, 2, C.byref(h)) == -1   # rank >= world
+    if lib.nid_device_count() == 0:
+        assert lib.nid_multi_create(C.byref(cfg), dv.ctypes.data_as(capi.c_ip), 2, C.byref(h)) == -2   # no CPU fallback

@@ -85,12 +85,26 @@ def ident_pose(pair):
 
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "lmflash":
+        nb = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+        its = [int(x) for x in sys.argv[3].split(",")] if len(sys.argv) > 3 else [0, 1]
         flash = synth.make_pair("A", flash=True, edge_cases=True)
-        o = O.from_pair(flash, 8, jac_bound="cpu", xform="matrix")
+        o = O.from_pair(flash, nb, jac_bound="cpu", xform="matrix")
         o.compute_href(flash.pose_init)
         pose_o, recs_o = o.lm(flash.pose_init, 10)
-        for r in recs_o[:2]:
-            run(flash, 8, r["pose7"], f"flashA/matrix LM pose of iteration {r['iteration']}", "matrix")
+        print("oracle trace", [(r["lm_trials"], round(r["chi2"], 6), float("%.3g" % r["rho"])) for r in recs_o])
+        delta = float(np.sqrt(0.95))
+        for i in its:
+            r = recs_o[i]
+            run(flash, nb, r["pose7"], f"flashA/matrix LM pose of iteration {r['iteration']}", "matrix")
+            # the 6x6 system at that pose, both sides
+            o2 = O.from_pair(flash, nb, jac_bound="cpu", xform="matrix"); o2.compute_href(flash.pose_init)
+            ref = o2.evaluate(r["pose7"], True)
+            Ho, bo, co, no = O.normal_equations(ref[2], ref[3], delta)
+            ctx = capi.from_pair(flash, nb, xform=capi.XFORM_MATRIX); ctx.compute_href(flash.pose_init)
+            H, b, c, n = ctx.normal_equations(r["pose7"], delta)
+            print(f"    6x6 at iteration {i}: chi2 {c:.12f} / {co:.12f}  n {n}/{no}  max|dH|/max|H| {np.abs(H - Ho).max() / np.abs(Ho).max():.3e}  "
+                  f"max|db|/max|b| {np.abs(b - bo).max() / np.abs(bo).max():.3e}  cond(H) {np.linalg.cond(Ho):.3e}  "
+                  f"nonfinite cells oracle {int((~np.isfinite(ref[3]).all(axis=1) & (np.isfinite(ref[2]))).sum())}")
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "ident":
         S = synth.make_pair("S", edge_cases=True)
