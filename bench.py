@@ -222,6 +222,12 @@ def profile_numbers(config, bins, poses_per_launch):
 
 def main():
     args = parse()
+    # stdout carries ONE line, the result.  Libraries loaded below write there too (RCCL prints its "Librccl path"
+    # banner with printf, flushed only at exit, i.e. AFTER the result): keep a private handle on the real stdout
+    # for the JSON line and point fd 1 at stderr for everything else.
+    sys.stdout.flush()
+    result_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     import torch
 
     rank = int(os.environ.get("RANK", "0"))
@@ -472,7 +478,7 @@ def main():
         if not args.no_cpu_baseline and not multi:   # CPU legs: rank 0 at N=1 only
             out["cpu_baseline"] = cpu_baseline(pair, args.bins, args.cpu_seconds)
             out["pose_error_vs_ref"] = pose_error_vs_ref(pair, args.bins)
-        print(json.dumps(out))
+        print(json.dumps(out), file=result_out, flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -232,6 +232,9 @@ class OptimizationAlgorithmLevenberg {
   // with the fused path: evaluate the whole rejection chain of an outer iteration (up to 8
   // candidate poses) in one batched launch; decisions identical to the sequential trials
   void setSpeculativeTrials(bool on) { _speculative = on; }
+  // with speculative trials: evaluate the first (short) slice of the chain with its Jacobian, so that the accepted
+  // trial already carries the next iteration's H and b -- one launch per outer iteration
+  void setSpeculativeJacobian(bool on) { _speculativeJacobian = on; }
   bool fused() const { return _fused; }
   double fusedChi() const { return _fusedChi; }
  private:
@@ -244,7 +247,11 @@ class OptimizationAlgorithmLevenberg {
   int _maxTrialsAfterFailure, _levenbergIterations, _nBad;
   bool _fused;
   bool _speculative = false;
+  int _speculativeFirst = 3;   // trial poses of the first slice of an outer iteration's rejection chain (see solveFused)
+  int _lastTrials = 10;        // trials the previous outer iteration needed (the first iteration of a pair: all of them)
   double _fusedChi = 0.0;
+  bool _speculativeJacobian = false, _haveNext = false;
+  double _nextPose[7], _nextH[36], _nextB[6], _nextChi = 0.0;
 };
 
 // the fields of batch_stats.h:39-78 that exist for a one-vertex dense problem (no Schur complement, no

@@ -53,6 +53,8 @@ void nid_legacy_set_jacobian_bound(int mode);
 // 0 = FAST arithmetic (default), 1 = STRICT: every rounding of the reference reproduced (nid_c.h)
 void nid_legacy_set_math_mode(int mode);
 void nid_legacy_set_device(int device);
+// threads per workgroup of the operators' launches (nid_set_launch_shape in nid_c.h)
+void nid_legacy_set_launch_shape(int jac_threads, int cost_threads);
 // Multi-GPU (include/nid/nid_multi.h): the operators shard the cells of the frame pair over `n` devices of THIS
 // process (entries may repeat); reduce_rccl != 0 sums the fused 6x6 blocks with RCCL instead of on the host ...
 void nid_legacy_set_devices(const int32_t *devices, int n, int reduce_rccl);
@@ -66,6 +68,12 @@ void nid_legacy_reset(void);
 // mix the legacy operators with the fused C-ABI entry points on the same device state
 nid_ctx *nid_legacy_context(void);   // shard 0
 nid_multi *nid_legacy_multi(void);
+// What CudaComputeH does before its kernels, without the evaluation: the frame-pair state (images, points, Href
+// state) on the device(s), uploaded only where its content changed.  Returns the shards (NULL on error, reported on
+// stderr) for callers that continue on the nid_multi_* interface (g2o_min's fused LM).
+nid_multi *nid_legacy_prepare(double *im0, double *im1, double *points3d, int *bs_counter, double *bs_ref,
+                              int *bs_index_ref, double *camera_intrincis, int bin_num, int bs_degree, int cell_num,
+                              int rows, int cols, double *Href);
 // number of host->device uploads of frame-pair data done so far (tests: must not grow per call)
 long nid_legacy_upload_count(void);
 }

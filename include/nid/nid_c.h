@@ -87,7 +87,14 @@ int nid_set_math_mode(nid_ctx *ctx, int mode);
 /* run every kernel of this context on a caller-owned hipStream_t (e.g. the
  * current torch stream) instead of the context's own stream; NULL restores it */
 int nid_set_stream(nid_ctx *ctx, void *hip_stream);
-/* tuning knob: threads per workgroup of the evaluation kernel: 128 or 256 (0 = default = 128) */
+/* Threads per workgroup of the evaluation kernel (one workgroup per cell and pose): 128, 256, 512 or 1024.
+ * jac_threads: cost + Jacobian launches; 0 = 128, the throughput shape.  The six Jacobian sums depend on the
+ * shape in their last bits, so every launch of a context uses the same one.  A blocking caller that evaluates
+ * one pose at a time (an LM loop) wants 1024: a cell's pixels in two rounds instead of ten.
+ * cost_threads: cost-only launches; 0 = chosen per launch by its size (their results are the same bits in every
+ * shape).  NID_ERR_UNSUPPORTED for any other value. */
+int nid_set_launch_shape(nid_ctx *ctx, int jac_threads, int cost_threads);
+/* both at once (0 = the defaults above) */
 int nid_set_block_threads(nid_ctx *ctx, int threads);
 
 /* ---- once per frame pair ------------------------------------------------ */
@@ -150,6 +157,11 @@ int nid_wait(nid_ctx *ctx, int slot, double *H36, double *b6, double *chi2, int3
  * or consecutive candidates of a sampling optimiser); collect each with nid_wait() */
 int nid_launch_batch(nid_ctx *ctx, int first_slot, int n, const double *poses7, int want_jac,
                      double huber_delta);
+/* The rejection chain of a Levenberg-Marquardt iteration in ONE call: poses 0 .. n_jac-1 are evaluated WITH the
+ * Jacobian phase (the likely accepted trials: their H and b are the next iteration's linear system), the rest cost
+ * only, as two concurrent launches on the context's two streams (with a caller's stream: back to back).  Slot by slot
+ * the results are the bits nid_launch_batch gives for the same pose and want_jac.  0 <= n_jac <= n. */
+int nid_launch_chain(nid_ctx *ctx, int first_slot, int n, const double *poses7, int n_jac, double huber_delta);
 /* same, with the n result blocks written to a caller-owned DEVICE buffer (n x NID_REDUCED_LEN doubles,
  * pose k at offset k*NID_REDUCED_LEN) so that ONE collective can sum the partial blocks of all n poses
  * across the cell shards of several GPUs; nid_wait(slot) then only waits for the launch */

@@ -88,6 +88,7 @@ int nid_multi_set_reduce_mode(nid_multi *m, int mode);
 int nid_multi_set_options(nid_multi *m, int jac_bound_mode, int xform_mode);
 int nid_multi_set_math_mode(nid_multi *m, int mode);
 int nid_multi_set_block_threads(nid_multi *m, int threads);
+int nid_multi_set_launch_shape(nid_multi *m, int jac_threads, int cost_threads);
 int nid_multi_set_reference_depth(nid_multi *m, const double *depth_m, const uint8_t *im0, const double *T_wc0_colmajor16);
 int nid_multi_set_reference_points(nid_multi *m, const double *points3d, const uint8_t *im0);
 int nid_multi_set_target_u8(nid_multi *m, const uint8_t *im1);
@@ -109,6 +110,8 @@ int nid_multi_normal_equations(nid_multi *m, const double *pose7, int want_jac, 
                                double *b6, double *chi2, int32_t *n_active);
 /* n <= NID_MAX_BATCH candidate poses in one launch per shard + one exchange; collect each with nid_multi_wait */
 int nid_multi_launch_batch(nid_multi *m, int first_slot, int n, const double *poses7, int want_jac, double huber_delta);
+/* nid_launch_chain on every shard: the first n_jac poses with the Jacobian phase, the rest cost only; one exchange */
+int nid_multi_launch_chain(nid_multi *m, int first_slot, int n, const double *poses7, int n_jac, double huber_delta);
 int nid_multi_wait(nid_multi *m, int slot, double *H36, double *b6, double *chi2, int32_t *n_active);
 /* pipelined throughput loop (the bench's timed region): `batch` poses per launch, launches alternating between
  * each shard's two streams, one exchange per `group` launches, two groups in flight; reduced_out (n x

@@ -39,11 +39,11 @@ class NidConfig(C.Structure):
 # every symbol include/nid/nid_c.h declares (tests/test_abi.py checks the export table)
 SYMBOLS = [
     "nid_abi_version", "nid_status_string", "nid_last_error", "nid_device_count", "nid_create",
-    "nid_destroy", "nid_set_options", "nid_set_math_mode", "nid_set_stream", "nid_set_block_threads",
+    "nid_destroy", "nid_set_options", "nid_set_math_mode", "nid_set_stream", "nid_set_block_threads", "nid_set_launch_shape",
     "nid_set_reference_depth", "nid_set_reference_points", "nid_backproject", "nid_get_points3d", "nid_set_target_u8",
     "nid_set_target_f64", "nid_set_reference_image_f64", "nid_compute_href",
     "nid_compute_href_matrix", "nid_set_href_state", "nid_plain_nid", "nid_evaluate", "nid_evaluate_matrix",
-    "nid_normal_equations", "nid_launch", "nid_launch_batch", "nid_launch_batch_to", "nid_run_sequence", "nid_run_chain", "nid_wait", "nid_slot_buffers", "nid_launch_to",
+    "nid_normal_equations", "nid_launch", "nid_launch_batch", "nid_launch_chain", "nid_launch_batch_to", "nid_run_sequence", "nid_run_chain", "nid_wait", "nid_slot_buffers", "nid_launch_to",
     "nid_unpack_reduced", "nid_debug_enable_pixel_dump", "nid_debug_get_pixel_dump",
     "nid_debug_enable_stamps", "nid_debug_get_stamps", "nid_bspline4_host", "nid_bspline4_poly_host", "nid_log2_fast_host", "nid_div_small_host", "nid_last_kernel_ms", "nid_enable_timing", "nid_time_launches",
     "nid_contract_bytes",
@@ -77,6 +77,7 @@ def load():
     lib.nid_set_math_mode.argtypes = [vp, C.c_int]
     lib.nid_set_stream.argtypes = [vp, vp]
     lib.nid_set_block_threads.argtypes = [vp, C.c_int]
+    lib.nid_set_launch_shape.argtypes = [vp, C.c_int, C.c_int]
     lib.nid_set_reference_depth.argtypes = [vp, c_dp, c_u8p, c_dp]
     lib.nid_set_reference_points.argtypes = [vp, c_dp, c_u8p]
     lib.nid_get_points3d.argtypes = [vp, c_dp]
@@ -93,6 +94,7 @@ def load():
     lib.nid_launch.argtypes = [vp, C.c_int, c_dp, C.c_int, C.c_double]
     lib.nid_launch_batch.argtypes = [vp, C.c_int, C.c_int, c_dp, C.c_int, C.c_double]
     lib.nid_launch_batch_to.argtypes = [vp, C.c_int, C.c_int, c_dp, C.c_int, C.c_double, vp]
+    lib.nid_launch_chain.argtypes = [vp, C.c_int, C.c_int, c_dp, C.c_int, C.c_double]
     lib.nid_run_sequence.argtypes = [vp, c_dp, C.c_int, C.c_int, C.c_int, C.c_double, c_dp]
     lib.nid_launch_to.argtypes = [vp, C.c_int, c_dp, C.c_int, C.c_double, vp]
     lib.nid_run_chain.argtypes = [vp, c_dp, C.c_int, C.c_int, C.c_double, c_dp, c_dp]
@@ -277,6 +279,12 @@ class Context:
                                               float(delta), C.c_void_p(reduced_dev))
         self._check(rc, "nid_launch_batch")
 
+    def launch_chain(self, first_slot, poses7, n_jac, delta):
+        """an LM rejection chain: the first n_jac poses with the Jacobian phase, the rest cost only, concurrently"""
+        p = _d(np.asarray(poses7).reshape(-1, 7))
+        self._check(self.lib.nid_launch_chain(self.h, first_slot, p.shape[0], _dp(p), int(n_jac), float(delta)),
+                    "nid_launch_chain")
+
     def run_sequence(self, poses7, delta, batch=8, want_jac=True, collect=True):
         p = _d(np.asarray(poses7).reshape(-1, 7))
         out = np.zeros((p.shape[0], NID_REDUCED_LEN)) if collect else None
@@ -310,6 +318,9 @@ class Context:
 
     def set_block_threads(self, n):
         self._check(self.lib.nid_set_block_threads(self.h, int(n)), "nid_set_block_threads")
+
+    def set_launch_shape(self, jac_threads=0, cost_threads=0):
+        self._check(self.lib.nid_set_launch_shape(self.h, int(jac_threads), int(cost_threads)), "nid_set_launch_shape")
 
     def enable_timing(self, on=True):
         self._check(self.lib.nid_enable_timing(self.h, 1 if on else 0), "nid_enable_timing")
@@ -410,10 +421,10 @@ MULTI_SYMBOLS = [
     "nid_comm_create_local", "nid_comm_destroy", "nid_comm_ranks", "nid_multi_attach_comm", "nid_multi_comm_init",
     "nid_multi_comm_init_local", "nid_multi_comm_ranks", "nid_multi_set_exchange_hook", "nid_multi_set_reduce_mode",
     "nid_multi_set_options",
-    "nid_multi_set_math_mode", "nid_multi_set_block_threads", "nid_multi_set_reference_depth",
+    "nid_multi_set_math_mode", "nid_multi_set_block_threads", "nid_multi_set_launch_shape", "nid_multi_set_reference_depth",
     "nid_multi_set_reference_points", "nid_multi_set_target_u8", "nid_multi_compute_href",
     "nid_multi_compute_href_matrix", "nid_multi_set_href_state", "nid_multi_evaluate", "nid_multi_evaluate_matrix",
-    "nid_multi_normal_equations", "nid_multi_launch_batch", "nid_multi_wait", "nid_multi_run_sequence",
+    "nid_multi_normal_equations", "nid_multi_launch_batch", "nid_multi_launch_chain", "nid_multi_wait", "nid_multi_run_sequence",
     "nid_multi_contract_bytes",
 ]
 
@@ -447,6 +458,7 @@ def _load_multi():
     lib.nid_multi_evaluate.argtypes = [vp, c_dp, C.c_int, c_dp, c_dp, c_dp, c_dp]
     lib.nid_multi_normal_equations.argtypes = [vp, c_dp, C.c_int, C.c_double, c_dp, c_dp, c_dp, c_ip]
     lib.nid_multi_launch_batch.argtypes = [vp, C.c_int, C.c_int, c_dp, C.c_int, C.c_double]
+    lib.nid_multi_launch_chain.argtypes = [vp, C.c_int, C.c_int, c_dp, C.c_int, C.c_double]
     lib.nid_multi_wait.argtypes = [vp, C.c_int, c_dp, c_dp, c_dp, c_ip]
     lib.nid_multi_run_sequence.argtypes = [vp, c_dp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, c_dp]
     lib.nid_multi_contract_bytes.restype = C.c_int64
@@ -580,6 +592,11 @@ class Multi:
                                                         _dp(H), _dp(b), C.byref(chi2), C.byref(na)),
                     "nid_multi_normal_equations")
         return H.reshape(6, 6), b, chi2.value, na.value
+
+    def launch_chain(self, first_slot, poses7, n_jac, delta):
+        p = _d(np.asarray(poses7).reshape(-1, 7))
+        self._check(self.lib.nid_multi_launch_chain(self.h, first_slot, p.shape[0], _dp(p), int(n_jac), float(delta)),
+                    "nid_multi_launch_chain")
 
     def launch_batch(self, first_slot, poses7, delta, want_jac=True):
         p = _d(np.asarray(poses7).reshape(-1, 7))

@@ -31,7 +31,8 @@ struct Slot {
   double *quad_dev = nullptr;      // per-cell quadratic forms
   unsigned *ticket_dev = nullptr;  // [0] top, [1+g] groups
   double *gpart_dev = nullptr;     // group sums
-  double *cellout_host = nullptr;  // pinned
+  double *cellout_host = nullptr;  // pinned, mapped: the blocking per-cell calls let the kernel write here directly
+  double *cellout_host_devptr = nullptr;
   double *reduced_host = nullptr;  // pinned, mapped: [32 doubles][u64 sequence word]
   double *reduced_host_devptr = nullptr;
   unsigned long long seq = 0;      // sequence number of the last launch into this slot
@@ -48,7 +49,7 @@ struct nid_ctx {
   Geometry g{};
   int jac_bound = NID_JACBOUND_CPU;
   int xform = NID_XFORM_QUAT;
-  int block_threads = 0;
+  int jac_threads = 0, cost_threads = 0;  // nid_set_launch_shape: 0 = default (128) / automatic (pick_threads)
   // own_stream: setup + blocking calls; aux_stream: odd slots of the pipelined path, so that
   // launch N+1 overlaps the reduction tail and the launch gap of launch N (separate
   // per-slot buffers make that safe).  An external stream (nid_set_stream) disables it.
@@ -178,23 +179,28 @@ void build_coef_table(int S, std::vector<double> *out) {
 
 size_t eval_lds_bytes(const Geometry &g, int nt) {
   const int nbins = g.nb * g.nb + g.nb;
-  return (size_t)nbins * (eval_hist_copies(nt) + kFineLevels) * 8 + (size_t)((nbins + 1) & ~1) * 8 +  // copies + the fine levels
+  return (size_t)nbins * (eval_hist_copies(nt) + kFineLevels) * 8 + 2 * (size_t)((nbins + 1) & ~1) * 8 +  // copies + fine levels; tab + term
          (size_t)g.S * kCoefRow * 8 + (size_t)kRedDoubles(nt) * 8;
 }
 
-// k_eval2 (occupancy-organised, runtime pixel loop): one workgroup shape for every cell size
-template <int NT, int NB, bool DBG>
+// k_eval2 (occupancy-organised, runtime pixel loop): one workgroup shape for every cell size.
+// EXTOK: instantiate the variants for launches of more than kMaxBatch poses too (throughput shapes only).
+template <int NT, int NB, bool DBG, bool EXTOK = true>
 void launch_eval2_v(const EvalParams &P, bool jac, bool strict, size_t lds, hipStream_t s, int batch) {
   const dim3 grid((unsigned)(((P.g.nloc + 7) / 8) * 8 * batch)), block(NT);
-  if (P.slots_ext && !DBG) {  // more than kMaxBatch poses: per-pose records in device memory
-    if (strict) {
-      if (jac) hipLaunchKernelGGL((k_eval2<NT, true, true, NB, false, true>), grid, block, lds, s, P);
-      else hipLaunchKernelGGL((k_eval2<NT, false, true, NB, false, true>), grid, block, lds, s, P);
-    } else {
-      if (jac) hipLaunchKernelGGL((k_eval2<NT, true, false, NB, false, true>), grid, block, lds, s, P);
-      else hipLaunchKernelGGL((k_eval2<NT, false, false, NB, false, true>), grid, block, lds, s, P);
+  if constexpr (EXTOK && !DBG) {
+    if (P.slots_ext) {  // more than kMaxBatch poses: per-pose records in device memory
+      if (strict) {
+        if (jac) hipLaunchKernelGGL((k_eval2<NT, true, true, NB, false, true>), grid, block, lds, s, P);
+        else hipLaunchKernelGGL((k_eval2<NT, false, true, NB, false, true>), grid, block, lds, s, P);
+      } else {
+        if (jac) hipLaunchKernelGGL((k_eval2<NT, true, false, NB, false, true>), grid, block, lds, s, P);
+        else hipLaunchKernelGGL((k_eval2<NT, false, false, NB, false, true>), grid, block, lds, s, P);
+      }
+      return;
     }
-  } else if (strict) {
+  }
+  if (strict) {
     if (jac) hipLaunchKernelGGL((k_eval2<NT, true, true, NB, DBG>), grid, block, lds, s, P);
     else hipLaunchKernelGGL((k_eval2<NT, false, true, NB, DBG>), grid, block, lds, s, P);
   } else {
@@ -203,13 +209,42 @@ void launch_eval2_v(const EvalParams &P, bool jac, bool strict, size_t lds, hipS
   }
 }
 
+template <int NT, bool EXTOK>
+void launch_eval2_nb(const EvalParams &P, bool jac, bool strict, size_t lds, hipStream_t s, int batch) {
+  if (P.g.nb == 8) launch_eval2_v<NT, 8, false, EXTOK>(P, jac, strict, lds, s, batch);
+  else if (P.g.nb == 10) launch_eval2_v<NT, 10, false, EXTOK>(P, jac, strict, lds, s, batch);
+  else launch_eval2_v<NT, 0, false, EXTOK>(P, jac, strict, lds, s, batch);
+}
+
+// Threads per workgroup (one workgroup per cell and pose) of a launch.
+//  * Cost + Jacobian launches use the context's shape (nid_set_launch_shape; default 128): the six Jacobian sums
+//    depend on the shape in their last bits, and a pose must give the same bits alone and in a batch.
+//  * Cost-only launches (the trial poses of an LM iteration) give the same bits in every shape -- integer
+//    histograms, entropy sums in a fixed order --, so unless the context pins their shape they take the one that
+//    fills the chip: ~8 waves per SIMD at most, i.e. 1024 threads for a single pose of 256 cells (a cell's
+//    1200 pixels in two rounds instead of ten), 128 from 16 poses on.  Measured: tools/latency_sweep.py.
+int pick_threads(const nid_ctx *ctx, bool jac, int batch) {
+  int nt = jac ? ctx->jac_threads : ctx->cost_threads;
+  if (nt == 0) {
+    if (jac) return 128;
+    const long wg = (long)ctx->g.nloc * batch;
+    nt = 1024;
+    while (nt > 128 && wg * (nt / 64) > 8L * 1024) nt >>= 1;  // 1024 SIMDs
+  }
+  if (batch > kMaxBatch && nt > 256) nt = 256;  // the latency shapes exist for launches of <= kMaxBatch poses
+  return nt;
+}
+
 int launch_eval2(nid_ctx *ctx, EvalParams &P, bool jac, hipStream_t stream, int batch) {
   P.batch = batch;
-  // Workgroup shape: 128 threads by default.  Measured on MI355X (16 poses per launch, two launches in flight):
-  // 640x480 / 8 bins 237k (256 threads) -> 260k (128) evaluations/s, 1280x960 63.8k -> 70.5k; one-wave
-  // workgroups with 8 histogram copies measured 248k / 66.5k and were dropped.  Two waves per workgroup halve the wave-time lost at the workgroup's barriers and in its serial
-  // phases (fold, block sums, tail), and ten workgroups still fit a CU (LDS 14 KB, 96 VGPRs).
-  const int nt = ctx->block_threads == 256 ? 256 : 128;
+  // Workgroup shape of the throughput path: 128 threads.  Measured on MI355X (16 poses per launch, two launches in
+  // flight): 640x480 / 8 bins 237k (256 threads) -> 260k (128) evaluations/s, 1280x960 63.8k -> 70.5k; one-wave
+  // workgroups with 8 histogram copies measured 248k / 66.5k and were dropped.  Two waves per workgroup halve the
+  // wave-time lost at the workgroup's barriers and in its serial phases (fold, block sums, tail), and ten workgroups
+  // still fit a CU (LDS 16 KB, 96 VGPRs).  Launches of few poses are latency bound: see pick_threads.
+  const bool dbg = ctx->dbg_enabled || ctx->dbg_stamps != nullptr;
+  int nt = pick_threads(ctx, jac, batch);
+  if (dbg && nt > 256) nt = 256;  // the diagnostic instantiations exist for 128 and 256 threads
   size_t lds = eval_lds_bytes(P.g, nt);
   {
     // k_eval2 accumulates raw 2^52-magic bit patterns and masks the top 12 bits per copy in the fold, so no
@@ -223,19 +258,18 @@ int launch_eval2(nid_ctx *ctx, EvalParams &P, bool jac, hipStream_t stream, int 
   if (lds > 160 * 1024) return NID_ERR_UNSUPPORTED;
   static const char *pad_env = getenv("NID_EXP_LDS_PAD");  // occupancy experiments: pad the LDS request
   if (pad_env) lds = std::min<size_t>(160 * 1024, lds + (size_t)atoi(pad_env));
-  const bool dbg = ctx->dbg_enabled || ctx->dbg_stamps != nullptr;
   const bool strict = ctx->math_mode == NID_MATH_STRICT;
   if (dbg) {  // diagnostics keep the workgroup shape: the Jacobian sums depend on it in their last bits
     if (nt == 128) launch_eval2_v<128, 0, true>(P, jac, strict, lds, stream, batch);
     else launch_eval2_v<256, 0, true>(P, jac, strict, lds, stream, batch);
   } else if (nt == 128) {
-    if (P.g.nb == 8) launch_eval2_v<128, 8, false>(P, jac, strict, lds, stream, batch);
-    else if (P.g.nb == 10) launch_eval2_v<128, 10, false>(P, jac, strict, lds, stream, batch);
-    else launch_eval2_v<128, 0, false>(P, jac, strict, lds, stream, batch);
+    launch_eval2_nb<128, true>(P, jac, strict, lds, stream, batch);
+  } else if (nt == 256) {
+    launch_eval2_nb<256, true>(P, jac, strict, lds, stream, batch);
+  } else if (nt == 512) {
+    launch_eval2_nb<512, false>(P, jac, strict, lds, stream, batch);
   } else {
-    if (P.g.nb == 8) launch_eval2_v<256, 8, false>(P, jac, strict, lds, stream, batch);
-    else if (P.g.nb == 10) launch_eval2_v<256, 10, false>(P, jac, strict, lds, stream, batch);
-    else launch_eval2_v<256, 0, false>(P, jac, strict, lds, stream, batch);
+    launch_eval2_nb<1024, false>(P, jac, strict, lds, stream, batch);
   }
   NID_HIP(ctx, hipGetLastError());
   return NID_OK;
@@ -285,6 +319,8 @@ void fill_slot_args(const Pose &pose, Slot &S, double *out_reduced, unsigned lon
   A->out_reduced = out_reduced;
   A->host_seq = host_seq;
   A->launch_seq = S.seq;
+  A->cellout_host = 0;
+  A->pad_ = 0;
 }
 
 void fill_eval_params(nid_ctx *ctx, const Pose &pose, Slot &S, double delta, double *out_reduced,
@@ -404,6 +440,25 @@ int launch_batch(nid_ctx *ctx, int first_slot, int n, const Pose *poses, int wan
   return NID_OK;
 }
 
+// spin on the sequence word the last workgroup of slot S's launch writes behind its results (system-scope release)
+int wait_host_seq(nid_ctx *ctx, Slot &S) {
+  volatile unsigned long long *seqw = reinterpret_cast<volatile unsigned long long *>(S.reduced_host + kReducedLen);
+  unsigned long spins = 0;
+  while (__atomic_load_n(seqw, __ATOMIC_ACQUIRE) != S.seq) {
+    if (++spins > 20000000ul) {  // fall back to the runtime so that a device error surfaces
+      NID_HIP(ctx, hipSetDevice(ctx->cfg.device));
+      NID_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      NID_HIP(ctx, hipStreamSynchronize(ctx->aux_stream));
+      if (__atomic_load_n(seqw, __ATOMIC_ACQUIRE) != S.seq) {
+        ctx->last_error = "result sequence word never arrived";
+        return NID_ERR_HIP;
+      }
+      break;
+    }
+  }
+  return NID_OK;
+}
+
 int evaluate_common(nid_ctx *ctx, const Pose &pose, int want_jac, double *Ht, double *Hj,
                     double *err, double *der) {
   int rc = check_ready(ctx);
@@ -413,8 +468,16 @@ int evaluate_common(nid_ctx *ctx, const Pose &pose, int want_jac, double *Ht, do
     ctx->last_error = "slot 0 has an uncollected launch: nid_wait(ctx, 0, ...) first";
     return NID_ERR_STATE;
   }
+  // The kernel writes the per-cell outputs straight into mapped pinned host memory and the last workgroup posts the
+  // slot's sequence word behind them (as for the fused 6x6 path): no copy, no stream synchronisation -- the call
+  // returns ~6 us after the kernel ends instead of ~18.
+  S.seq++;
+  S.external_target = false;
   EvalParams P{};
-  fill_eval_params(ctx, pose, S, std::sqrt(0.95), S.reduced_dev, nullptr, &P);
+  fill_eval_params(ctx, pose, S, std::sqrt(0.95), S.reduced_host_devptr,
+                   reinterpret_cast<unsigned long long *>(S.reduced_host_devptr + kReducedLen), &P);
+  P.slot[0].cellout = S.cellout_host_devptr;
+  P.slot[0].cellout_host = 1;
   if (ctx->dbg_enabled) {
     const size_t N = (size_t)ctx->g.rows * ctx->g.cols;
     NID_HIP(ctx, hipMemsetAsync(ctx->dbg_u, 0xFF, N * 8, ctx->stream));
@@ -425,9 +488,9 @@ int evaluate_common(nid_ctx *ctx, const Pose &pose, int want_jac, double *Ht, do
   }
   rc = launch_eval(ctx, P, want_jac != 0, ctx->stream);
   if (rc) return rc;
-  const size_t bytes = (size_t)ctx->g.nloc * kCellOut * sizeof(double);
-  NID_HIP(ctx, hipMemcpyAsync(S.cellout_host, S.cellout_dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
-  NID_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  rc = wait_host_seq(ctx, S);
+  if (rc) return rc;
+  if (ctx->dbg_enabled) NID_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the dump is read back by the runtime
   for (int cl = 0; cl < ctx->g.nloc; cl++) {
     const double *o = S.cellout_host + (size_t)cl * kCellOut;
     const int c = ctx->g.cell_begin + cl;
@@ -562,9 +625,9 @@ int nid_create(const nid_config *cfg, nid_ctx **out) {
   ctx->hist_scale = std::ldexp(1.0, hs);
   ctx->hist_inv_scale = std::ldexp(1.0, -hs);
   if ((size_t)g.nloc * (size_t)g.pstride >= ((size_t)1 << 29)) { delete ctx; return NID_ERR_UNSUPPORTED; }
-  if (const char *bt = getenv("NID_BLOCK_THREADS")) {  // tuning
+  if (const char *bt = getenv("NID_BLOCK_THREADS")) {  // tuning: both kinds of launches
     const int v = atoi(bt);
-    ctx->block_threads = (v == 256) ? 256 : 128;
+    if (v == 128 || v == 256 || v == 512 || v == 1024) ctx->jac_threads = ctx->cost_threads = v;
   }
   auto fail = [&](int rc) { nid_destroy(ctx); return rc; };
   if (hipSetDevice(cfg->device) != hipSuccess) return fail(NID_ERR_NO_DEVICE);
@@ -613,7 +676,9 @@ int nid_create(const nid_config *cfg, nid_ctx **out) {
     if (hipMemset(S.ticket_dev, 0, ((size_t)ctx->ngroups + 4) * sizeof(unsigned)) != hipSuccess) return fail(NID_ERR_HIP);
     if ((rc = dev_alloc(ctx, &S.gpart_dev, (size_t)ctx->ngroups * kQuad))) return fail(rc);
     if (hipHostMalloc(reinterpret_cast<void **>(&S.cellout_host), (size_t)g.nloc * kCellOut * sizeof(double),
-                      hipHostMallocDefault) != hipSuccess) return fail(NID_ERR_NOMEM);
+                      hipHostMallocMapped) != hipSuccess) return fail(NID_ERR_NOMEM);
+    if (hipHostGetDevicePointer(reinterpret_cast<void **>(&S.cellout_host_devptr), S.cellout_host, 0) != hipSuccess)
+      return fail(NID_ERR_HIP);
     if (hipHostMalloc(reinterpret_cast<void **>(&S.reduced_host), (kReducedLen + 2) * sizeof(double),
                       hipHostMallocMapped) != hipSuccess) return fail(NID_ERR_NOMEM);
     std::memset(S.reduced_host, 0, (kReducedLen + 2) * sizeof(double));
@@ -704,12 +769,19 @@ int nid_set_stream(nid_ctx *ctx, void *hip_stream) {
   return NID_OK;
 }
 
-int nid_set_block_threads(nid_ctx *ctx, int threads) {
-  // the evaluation kernel has one workgroup shape (256 threads, runtime pixel loop)
-  if (!ctx || threads < 0) return NID_ERR_INVALID_ARG;
-  if (threads != 0 && threads != 256 && threads != 128) return NID_ERR_UNSUPPORTED;
-  ctx->block_threads = threads;
+static bool valid_threads(int t) { return t == 0 || t == 128 || t == 256 || t == 512 || t == 1024; }
+
+int nid_set_launch_shape(nid_ctx *ctx, int jac_threads, int cost_threads) {
+  if (!ctx) return NID_ERR_INVALID_ARG;
+  if (!valid_threads(jac_threads) || !valid_threads(cost_threads)) return NID_ERR_UNSUPPORTED;
+  ctx->jac_threads = jac_threads;
+  ctx->cost_threads = cost_threads;
   return NID_OK;
+}
+
+int nid_set_block_threads(nid_ctx *ctx, int threads) {  // one shape for both kinds of launches (0 = defaults)
+  if (!ctx || threads < 0) return NID_ERR_INVALID_ARG;
+  return nid_set_launch_shape(ctx, threads, threads);
 }
 
 int nid_set_reference_depth(nid_ctx *ctx, const double *depth_m, const uint8_t *im0, const double *Twc) {
@@ -935,6 +1007,19 @@ int nid_launch_batch(nid_ctx *ctx, int first_slot, int n, const double *poses7, 
   return launch_batch(ctx, first_slot, n, p, want_jac, delta);
 }
 
+int nid_launch_chain(nid_ctx *ctx, int first_slot, int n, const double *poses7, int n_jac, double delta) {
+  if (!ctx || !poses7 || n < 1 || n > kMaxBatchExt || n_jac < 0 || n_jac > n) return NID_ERR_INVALID_ARG;
+  if (first_slot < 0 || first_slot + n > NID_SLOTS) return NID_ERR_INVALID_ARG;
+  for (int k = 0; k < n; k++)  // all or nothing: no half-launched chain
+    if (ctx->slots[first_slot + k].pending) { ctx->last_error = "slot still pending: nid_wait() it first"; return NID_ERR_STATE; }
+  Pose p[kMaxBatchExt];
+  for (int k = 0; k < n; k++) pose_from_pose7(poses7 + 7 * k, ctx->xform, &p[k]);
+  int rc = NID_OK;
+  if (n_jac > 0) rc = launch_batch(ctx, first_slot, n_jac, p, 1, delta);
+  if (rc == NID_OK && n_jac < n) rc = launch_batch(ctx, first_slot + n_jac, n - n_jac, p + n_jac, 0, delta, nullptr, true);
+  return rc;
+}
+
 int nid_launch_batch_to(nid_ctx *ctx, int first_slot, int n, const double *poses7, int want_jac, double delta,
                         void *reduced_dev) {
   if (!ctx || !poses7 || !reduced_dev || n < 1 || n > kMaxBatchExt) return NID_ERR_INVALID_ARG;
@@ -1015,19 +1100,9 @@ int nid_wait(nid_ctx *ctx, int slot, double *H36, double *b6, double *chi2, int3
     return NID_OK;
   }
   // the last workgroup stores the 32 results, then the sequence word (system-scope release)
-  volatile unsigned long long *seqw = reinterpret_cast<volatile unsigned long long *>(S.reduced_host + kReducedLen);
-  unsigned long spins = 0;
-  while (__atomic_load_n(seqw, __ATOMIC_ACQUIRE) != S.seq) {
-    if (++spins > 20000000ul) {  // fall back to the runtime so that a device error surfaces
-      NID_HIP(ctx, hipSetDevice(ctx->cfg.device));
-      NID_HIP(ctx, hipStreamSynchronize(ctx->stream));
-      NID_HIP(ctx, hipStreamSynchronize(ctx->aux_stream));
-      if (__atomic_load_n(seqw, __ATOMIC_ACQUIRE) != S.seq) {
-        ctx->last_error = "result sequence word never arrived";
-        return NID_ERR_HIP;
-      }
-      break;
-    }
+  {
+    int rc = wait_host_seq(ctx, S);
+    if (rc) return rc;
   }
   S.pending = false;
   return nid_unpack_reduced(S.reduced_host, H36, b6, chi2, n_active);

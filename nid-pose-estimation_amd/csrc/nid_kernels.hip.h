@@ -83,6 +83,8 @@ struct SlotArgs {
   double *out_reduced;             // 32 doubles: device memory or pinned host memory
   unsigned long long *host_seq;    // pinned host word that receives launch_seq (or null)
   unsigned long long launch_seq;
+  int cellout_host;                // cellout is mapped pinned host memory (the blocking per-cell calls): publish it at system scope
+  int pad_;
 };
 
 struct EvalParams {
@@ -363,6 +365,13 @@ __device__ __forceinline__ double wave_sum_to_lane63(double v) {
 __device__ __forceinline__ double wave_uniform(double x) {
   const int lo = __builtin_amdgcn_readfirstlane(__double2loint(x));
   const int hi = __builtin_amdgcn_readfirstlane(__double2hiint(x));
+  return __hiloint2double(hi, lo);
+}
+
+// the value lane 63 holds, in scalar registers
+__device__ __forceinline__ double wave_lane63(double x) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(x), 63);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(x), 63);
   return __hiloint2double(hi, lo);
 }
 
@@ -674,7 +683,7 @@ __device__ __forceinline__ double load_sc1(const double *p) {
       reinterpret_cast<const unsigned long long *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
 }
 
-constexpr int kRedDoubles(int nt) { return ((6 * (nt / 64) > nt + 2 ? 6 * (nt / 64) : nt + 2) + 1) & ~1; }
+constexpr int kRedDoubles(int nt) { return (6 * (nt / 64) + 1) & ~1; }  // the six Jacobian sums of every wave
 constexpr int kQuad = 32;  // per-cell block: rho0 | b[6] | H upper[21] | 1.0 | 0 0 0
 
 // which (a,b) of the upper triangle a quad slot 7..27 holds
@@ -712,7 +721,10 @@ __device__ __forceinline__ void finish_and_reduce_w0(const EvalParams &P, const 
   const int gq = cl / gs;
   const int ngroups = (P.g.nloc + gs - 1) / gs;
   const int gcount = min(gs, P.g.nloc - gq * gs);
-  // level 0: drain the block's stores, take a group ticket
+  // level 0: drain the block's stores, take a group ticket.  Per-cell outputs that go straight to host memory
+  // (cellout_host) are made visible at system scope first: the host reads them as soon as the LAST workgroup's
+  // sequence word arrives, and that workgroup can only vouch for its own stores.
+  if (SA.cellout_host) __threadfence_system();
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   unsigned last = 0u;
   if (lane == 0) {
@@ -1049,7 +1061,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(STRICT ? 4 :
   // LDS: [weight table | B-spline table | reduction scratch | histogram copies].  The two tables come
   // first so that their reads sit inside the 2040-byte immediate range of ds_read2_b64.
   double *tab = reinterpret_cast<double *>(smem);
-  double *rtab = tab + ((nbins + 1) & ~1);
+  double *term = tab + ((nbins + 1) & ~1);  // p log2 p of every bin (entropy sums in a workgroup-shape independent order)
+  double *rtab = term + ((nbins + 1) & ~1);
   double *red = rtab + S * kCoefRow;  // S rows of kCoefRow (FAST) or kRcpRow <= kCoefRow (STRICT) doubles
   unsigned long long *hist = reinterpret_cast<unsigned long long *>(red + kRedDoubles(NT));
   unsigned long long *hist_lo = hist + nbins * NC;  // [kFineLevels][nbins], single copies (see kTinyW)
@@ -1257,15 +1270,26 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(STRICT ? 4 :
       if (lo != 0) mass += (double)lo * fine_inv_scale(lv);
     }
     const double p = mass / (double)n_c;  // Q1: N_c of the initial pose
-    double w = 0.0;
+    double w = 0.0, pl = 0.0;
     if (!(p < kSigma)) {
       const double l = STRICT ? log2(p) : log2_fast(p);
       w = -(1.0 + l);  // Q9
-      if (b < nb) ent[0] += p * l; else ent[1] += p * l;
+      pl = p * l;
     }
     tab[b] = w;
+    term[b] = pl;
   }
-  block_sum<NT, 2>(ent, red, tid);
+  __syncthreads();
+  // Entropies: every wave sums the bins' terms itself, in ONE order whatever the workgroup shape is (lane l takes
+  // the joint bins l, l + 64, ...; then the DPP tree), so that Hc, Hj, err and chi2 of a pose are the same bits
+  // for 128-, 256-, 512- and 1024-thread workgroups: cost-only launches may pick their shape by batch size.
+  {
+    const int lane_ = tid & 63;
+    double e0 = (lane_ < nb) ? term[lane_] : 0.0, e1 = 0.0;
+    for (int j = lane_; j < nb * nb; j += 64) e1 += term[nb + j];
+    ent[0] = wave_lane63(wave_sum_to_lane63(e0));
+    ent[1] = wave_lane63(wave_sum_to_lane63(e1));
+  }
   NID_STAMP(3, ent[0], ent[1]);
   // block_sum leaves the same value in every lane: keep the per-cell scalars in SGPRs
   const double Hc = wave_uniform(0.0 - ent[0]);

@@ -340,16 +340,14 @@ OptimizationAlgorithmLevenberg::SolverResult OptimizationAlgorithmLevenberg::sol
   VertexSE3Expmap *vm = opt->_vertices[0];
   // the shards the legacy operators run on (one context on one GPU, or the cells of the pair spread over several:
   // include/nid/nid_multi.h): H, b and chi2 arrive already summed over the whole image
+  const auto t_start = std::chrono::steady_clock::now();
   nid_multi *ctx = nid_legacy_multi();
-  if (!ctx || iteration == 0) {  // first use: let the legacy operator upload the frame-pair state
-    const int n2 = opt->cell_num_ * opt->cell_num_;
-    std::vector<double> ht(n2, 0.0), hj(n2, 0.0);
-    Matrix4d M0 = vm->estimate().to_homogeneous_matrix();
-    CudaComputeH(false, opt->im0_, opt->im1_, opt->points3d_, opt->bs_counter_, opt->bs_value_ref_,
-                 opt->bs_index_ref_, M0.data(), opt->camera_intrincis_, opt->bin_num_, opt->bs_degree_,
-                 opt->cell_num_, opt->rows_, opt->cols_, opt->Href_, nullptr, nullptr, ht.data(), hj.data(), nullptr);
-    ctx = nid_legacy_multi();
+  if (!ctx || iteration == 0) {  // first use: the legacy operator's own upload of the frame-pair state
+    ctx = nid_legacy_prepare(opt->im0_, opt->im1_, opt->points3d_, opt->bs_counter_, opt->bs_value_ref_,
+                             opt->bs_index_ref_, opt->camera_intrincis_, opt->bin_num_, opt->bs_degree_, opt->cell_num_,
+                             opt->rows_, opt->cols_, opt->Href_);
     if (!ctx) return Fail;
+    _haveNext = false;
   }
   double delta = 1e300;
   if (!opt->_activeEdges.empty() && opt->_activeEdges[0]->robustKernel())
@@ -357,7 +355,23 @@ OptimizationAlgorithmLevenberg::SolverResult OptimizationAlgorithmLevenberg::sol
   double p7[7], H[36], b[6], currentChi = 0;
   int32_t na = 0;
   vm->estimate().toPose7(p7);
-  if (nid_multi_normal_equations(ctx, p7, 1, delta, H, b, &currentChi, &na) != NID_OK) return Fail;
+  const double t_setup = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_start).count();
+  // NID_LM_TRACE=1: wall-clock of the stages of every outer iteration on stderr (tools/latency_sweep.py)
+  static const bool lm_trace = std::getenv("NID_LM_TRACE") != nullptr;
+  auto us_since = [&](std::chrono::steady_clock::time_point t0) {
+    return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+  };
+  if (_haveNext && std::memcmp(p7, _nextPose, sizeof(p7)) == 0) {
+    // the accepted trial of the previous outer iteration was evaluated WITH its Jacobian (see below): same pose bits,
+    // same launch shape, hence the bits a launch now would give
+    std::memcpy(H, _nextH, sizeof(H));
+    std::memcpy(b, _nextB, sizeof(b));
+    currentChi = _nextChi;
+  } else if (nid_multi_normal_equations(ctx, p7, 1, delta, H, b, &currentChi, &na) != NID_OK) {
+    return Fail;
+  }
+  _haveNext = false;
+  const double t_jac = us_since(t_start);
   std::memcpy(vm->H, H, sizeof(H));
   std::memcpy(vm->b, b, sizeof(b));
   _solver->setSystem(H, b);
@@ -375,19 +389,31 @@ OptimizationAlgorithmLevenberg::SolverResult OptimizationAlgorithmLevenberg::sol
     // decisions as the sequential loop below -- only the number of launches changes.
     const SE3Quat T0 = vm->estimate();
     constexpr int kTrialBatch = 16;  // one launch whose per-pose records travel as kernel arguments
+    double xprev[6], xlast[6] = {0, 0, 0, 0, 0, 0};
+    bool first_slice = true, first_of_chain = true;
+    // How many of them to evaluate at once: a steady iteration accepts its first or second trial, the first
+    // iteration of a pair needs up to seven (lambda_0 = 1e-5 max diag is far too small for this cost).  A launch of
+    // 3 trial poses costs ~15 us, one of 10 ~35 us (tools/latency_sweep.py), so the chain is evaluated in slices:
+    // as many trials as the PREVIOUS outer iteration needed (at least _speculativeFirst), then the rest.
+    // The first iteration's own count says nothing about the next one (lambda has been tuned by then).
+    int slice = iteration == 0 ? _maxTrialsAfterFailure
+                               : std::max(_speculativeFirst, std::min(_lastTrials, _maxTrialsAfterFailure));
     while (qmax < _maxTrialsAfterFailure) {
-      const int nb = std::min(kTrialBatch, _maxTrialsAfterFailure - qmax);
+      const int nb = std::min(std::min(kTrialBatch, slice), _maxTrialsAfterFailure - qmax);
+      slice = kTrialBatch;  // a second slice takes everything that is left
       double lam[kTrialBatch], nis[kTrialBatch], xs[kTrialBatch][6], poses[kTrialBatch * 7];
       bool oks[kTrialBatch];
       SE3Quat cand[kTrialBatch];
       double l = _currentLambda, n_i = _ni;
+      for (int j = 0; j < 6; j++) xprev[j] = first_slice ? _solver->x()[j] : xlast[j];
+      first_slice = false;
       for (int k = 0; k < nb; k++) {
         lam[k] = l; nis[k] = n_i;
         double Hl[36];
         std::memcpy(Hl, H, sizeof(Hl));
         for (int j = 0; j < 6; j++) Hl[j * 6 + j] += l;
         LinearSolverDense ls;
-        for (int j = 0; j < 6; j++) xs[k][j] = (k ? xs[k - 1][j] : _solver->x()[j]);  // failed solve leaves x untouched
+        for (int j = 0; j < 6; j++) xs[k][j] = (k ? xs[k - 1][j] : xprev[j]);  // failed solve leaves x untouched
         oks[k] = ls.solve(Hl, xs[k], b);
         Vector6d u;
         for (int j = 0; j < 6; j++) u[j] = xs[k][j];
@@ -395,10 +421,21 @@ OptimizationAlgorithmLevenberg::SolverResult OptimizationAlgorithmLevenberg::sol
         cand[k].toPose7(poses + 7 * k);
         l *= n_i; n_i *= 2;
       }
-      if (nid_multi_launch_batch(ctx, 0, nb, poses, 0, delta) != NID_OK) return Fail;
-      double chis[kTrialBatch];
+      const auto t_slice = std::chrono::steady_clock::now();
+      const double t_prep = us_since(t_start);
+      // The FIRST trial of the chain -- the one a steady iteration accepts -- is evaluated WITH the Jacobian phase,
+      // concurrently with the cost-only launch of the others (nid_launch_chain): if it is accepted, the next outer
+      // iteration's H and b are already on the host -- one round trip per outer iteration instead of two (the chi2
+      // of a pose is the same bits with and without the Jacobian phase).
+      const int n_jac = (_speculativeJacobian && first_of_chain) ? 1 : 0;
+      first_of_chain = false;
+      if (nid_multi_launch_chain(ctx, 0, nb, poses, n_jac, delta) != NID_OK) return Fail;
+      double chis[kTrialBatch], H0[36], b0[6];
       for (int k = 0; k < nb; k++)
-        if (nid_multi_wait(ctx, k, nullptr, nullptr, &chis[k], &na) != NID_OK) return Fail;
+        if (nid_multi_wait(ctx, k, k < n_jac ? H0 : nullptr, k < n_jac ? b0 : nullptr, &chis[k], &na) != NID_OK) return Fail;
+      if (lm_trace)
+        std::fprintf(stderr, "[lm] it %d: setup until %.1f us, J until %.1f us, host solves until %.1f us, %d trial poses%s %.1f us\n", iteration,
+                     t_setup, t_jac, t_prep, nb, n_jac ? " (first with J)" : "", us_since(t_slice));
       bool accepted = false;
       for (int k = 0; k < nb; k++) {
         tempChi = oks[k] ? chis[k] : std::numeric_limits<double>::max();
@@ -417,16 +454,25 @@ OptimizationAlgorithmLevenberg::SolverResult OptimizationAlgorithmLevenberg::sol
           currentChi = tempChi;
           vm->setEstimate(cand[k]);
           accepted = true;
+          if (k < n_jac) {
+            _haveNext = true;
+            std::memcpy(_nextPose, poses + 7 * k, sizeof(_nextPose));
+            std::memcpy(_nextH, H0, sizeof(_nextH));
+            std::memcpy(_nextB, b0, sizeof(_nextB));
+            _nextChi = chis[k];
+          }
           break;
         }
         _currentLambda = lam[k] * nis[k];
         _ni = nis[k] * 2;
         if (!(rho < 0)) break;  // rho == 0 (or NaN): the reference's do/while stops here
       }
+      for (int j = 0; j < 6; j++) xlast[j] = xs[nb - 1][j];
       if (accepted || !(rho < 0)) break;
     }
     _lastRho = rho;
     _fusedChi = currentChi;
+    _lastTrials = iteration == 0 ? 0 : qmax;
     if (qmax == _maxTrialsAfterFailure || rho == 0) return Terminate;
     if ((iniChi - currentChi) * 1e3 < iniChi) _nBad++; else _nBad = 0;
     if (_nBad >= 3) return Terminate;

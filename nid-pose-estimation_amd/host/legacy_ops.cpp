@@ -41,6 +41,9 @@ uint8_t g_id[NID_RCCL_ID_BYTES];
 int g_jac_bound = NID_JACBOUND_CPU;
 int g_math_mode = NID_MATH_FAST;
 int g_reduce_rccl = 0;
+// Blocking single-pose calls are latency bound: 512-thread workgroups for the Jacobian launch (18.3 us vs 28.5 us
+// at 128 on 640x480 / 8 bins), cost-only launches shaped per launch (profiles/r02_launch_cost_A.txt).
+int g_jac_threads = 512, g_cost_threads = 0;  // nid_legacy_set_launch_shape
 nid_comm *g_comm = nullptr;  // lives across nid_legacy_reset(): one communicator per process, however many pairs / levels
 long g_uploads = 0;
 
@@ -102,8 +105,8 @@ nid_multi *get_multi(int rows, int cols, int cell, int bins, int deg, const doub
   nid_multi_set_options(m, g_jac_bound, NID_XFORM_MATRIX);
   nid_multi_set_math_mode(m, g_math_mode);
   // the operators are blocking, one pose (or one LM rejection chain) at a time: latency matters, not the
-  // pipelined throughput the 128-thread default is tuned for
-  nid_multi_set_block_threads(m, 256);
+  // pipelined throughput the 128-thread default is tuned for (nid_set_launch_shape, tools/latency_sweep.py)
+  nid_multi_set_launch_shape(m, g_jac_threads, g_cost_threads);
   S.m = m; S.rows = rows; S.cols = cols; S.cell = cell; S.bins = bins;
   std::memcpy(S.intr, intr, sizeof(S.intr));
   return m;
@@ -178,6 +181,12 @@ void CudaComputeHref(double *im0, double *points3d, double *pose, double *camera
   S.fp_href = fingerprint(Href, (size_t)ncell);
 }
 
+namespace {
+nid_multi *ensure_state(double *im0, double *im1, double *points3d, int *bs_counter, double *bs_ref, int *bs_index_ref,
+                        double *camera_intrincis, int bin_num, int bs_degree, int cell_num, int rows, int cols,
+                        double *Href);
+}
+
 namespace g2o {
 
 void CudaComputeH(bool calculate_der, double *im0, double *im1, double *points3d, int *bs_counter, double *bs_ref,
@@ -185,19 +194,41 @@ void CudaComputeH(bool calculate_der, double *im0, double *im1, double *points3d
                   int cell_num, int rows, int cols, double *Href, double *pro_target, double *pro_joint,
                   double *Htarget, double *Hjoint, double *der) {
   (void)pro_target; (void)pro_joint;  // accepted, never read or written (computeH.cu:373-502)
-  nid_multi *m = get_multi(rows, cols, cell_num, bin_num, bs_degree, camera_intrincis);
+  nid_multi *m = ensure_state(im0, im1, points3d, bs_counter, bs_ref, bs_index_ref, camera_intrincis, bin_num, bs_degree,
+                              cell_num, rows, cols, Href);
   if (!m) return;
+  const int ncell = cell_num * cell_num;
+  std::vector<double> ht(ncell), hj(ncell);
+  int rc = nid_multi_evaluate_matrix(m, pose, calculate_der ? 1 : 0, ht.data(), hj.data(), nullptr, calculate_der ? der : nullptr);
+  if (rc != NID_OK) { report("CudaComputeH", rc, m); return; }
+  for (int c = 0; c < ncell; c++) {
+    // CalculateHKernel: NaN for bs_counter < 300, else `-=` onto the caller's (zeroed) value
+    Htarget[c] = std::isnan(ht[c]) ? NAN : Htarget[c] + ht[c];
+    Hjoint[c] = std::isnan(hj[c]) ? NAN : Hjoint[c] + hj[c];
+  }
+}
+
+}  // namespace g2o
+
+namespace {
+
+// Everything CudaComputeH does before its kernels: the frame-pair state on the device(s), keyed on content.
+nid_multi *ensure_state(double *im0, double *im1, double *points3d, int *bs_counter, double *bs_ref, int *bs_index_ref,
+                        double *camera_intrincis, int bin_num, int bs_degree, int cell_num, int rows, int cols,
+                        double *Href) {
+  nid_multi *m = get_multi(rows, cols, cell_num, bin_num, bs_degree, camera_intrincis);
+  if (!m) return nullptr;
   LegacyState &S = g_state;
   const size_t N = (size_t)rows * cols;
   const int ncell = cell_num * cell_num;
   int rc = ensure_reference(S, im0, points3d);
-  if (rc != NID_OK) { report("CudaComputeH(reference upload)", rc, m); return; }
+  if (rc != NID_OK) { report("CudaComputeH(reference upload)", rc, m); return nullptr; }
   const uint64_t fp1 = fingerprint(im1, N);
   if (!S.have_target || always_upload() || S.fp_im1 != fp1) {
     std::vector<uint8_t> im;
-    if (!to_u8(im1, N, &im)) { report("CudaComputeH(im1 is not u8-valued)", NID_ERR_UNSUPPORTED, m); return; }
+    if (!to_u8(im1, N, &im)) { report("CudaComputeH(im1 is not u8-valued)", NID_ERR_UNSUPPORTED, m); return nullptr; }
     rc = nid_multi_set_target_u8(m, im.data());
-    if (rc != NID_OK) { report("CudaComputeH(target upload)", rc, m); return; }
+    if (rc != NID_OK) { report("CudaComputeH(target upload)", rc, m); return nullptr; }
     S.fp_im1 = fp1; S.have_target = true;
     g_uploads++;
   }
@@ -209,21 +240,14 @@ void CudaComputeH(bool calculate_der, double *im0, double *im1, double *points3d
     std::vector<double> href(ncell, 0.0);
     if (Href) for (int c = 0; c < ncell; c++) href[c] = Href[c];
     rc = nid_multi_set_href_state(m, bs_counter, href.data(), bs_ref, bs_index_ref);
-    if (rc != NID_OK) { report("CudaComputeH(href state upload)", rc, m); return; }
+    if (rc != NID_OK) { report("CudaComputeH(href state upload)", rc, m); return nullptr; }
     S.fp_bs_ref = fpb; S.fp_counter = fpc; S.fp_href = Href ? fph : 1; S.have_href = true;
     g_uploads++;
   }
-  std::vector<double> ht(ncell), hj(ncell);
-  rc = nid_multi_evaluate_matrix(m, pose, calculate_der ? 1 : 0, ht.data(), hj.data(), nullptr, calculate_der ? der : nullptr);
-  if (rc != NID_OK) { report("CudaComputeH", rc, m); return; }
-  for (int c = 0; c < ncell; c++) {
-    // CalculateHKernel: NaN for bs_counter < 300, else `-=` onto the caller's (zeroed) value
-    Htarget[c] = std::isnan(ht[c]) ? NAN : Htarget[c] + ht[c];
-    Hjoint[c] = std::isnan(hj[c]) ? NAN : Hjoint[c] + hj[c];
-  }
+  return m;
 }
 
-}  // namespace g2o
+}  // namespace
 
 extern "C" {
 
@@ -235,6 +259,11 @@ void nid_legacy_set_jacobian_bound(int mode) {
 void nid_legacy_set_math_mode(int mode) {
   g_math_mode = mode ? NID_MATH_STRICT : NID_MATH_FAST;
   if (g_state.m) nid_multi_set_math_mode(g_state.m, g_math_mode);
+}
+
+void nid_legacy_set_launch_shape(int jac_threads, int cost_threads) {
+  g_jac_threads = jac_threads; g_cost_threads = cost_threads;
+  if (g_state.m) nid_multi_set_launch_shape(g_state.m, jac_threads, cost_threads);
 }
 
 void nid_legacy_set_device(int device) {
@@ -268,6 +297,13 @@ void nid_legacy_set_rank(int device, int rank, int world, const uint8_t *rccl_id
 void nid_legacy_reset(void) {
   if (g_state.m) nid_multi_destroy(g_state.m);
   g_state = LegacyState();
+}
+
+nid_multi *nid_legacy_prepare(double *im0, double *im1, double *points3d, int *bs_counter, double *bs_ref,
+                              int *bs_index_ref, double *camera_intrincis, int bin_num, int bs_degree, int cell_num,
+                              int rows, int cols, double *Href) {
+  return ensure_state(im0, im1, points3d, bs_counter, bs_ref, bs_index_ref, camera_intrincis, bin_num, bs_degree, cell_num,
+                      rows, cols, Href);
 }
 
 nid_multi *nid_legacy_multi(void) { return g_state.m; }

@@ -42,7 +42,8 @@ int nid_host_run_lm(const nid_pose_problem *pb, double *pose7_inout, nid_host_lm
   g2o::BlockSolver_6_X *solver_ptr = new g2o::BlockSolver_6_X(linearSolver);
   g2o::OptimizationAlgorithmLevenberg *solver = new g2o::OptimizationAlgorithmLevenberg(solver_ptr);
   solver->setFusedNormalEquations(pb->fused != 0);
-  solver->setSpeculativeTrials(pb->fused == 2);
+  solver->setSpeculativeTrials(pb->fused >= 2);
+  solver->setSpeculativeJacobian(pb->fused == 3);
   optimizer.setAlgorithm(solver);
   optimizer.setVerbose(true);
   optimizer.setComputeBatchStatistics(true);

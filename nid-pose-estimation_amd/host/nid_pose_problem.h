@@ -13,7 +13,8 @@ typedef struct {
   int32_t rows, cols, cell_num, bin_num, iterations;
   int32_t jac_bound_cuda;   /* 0 = CPU-edge bound (parity target), 1 = CUDA-kernel bound */
   int32_t fused;            /* 0 = per-edge walk like the reference, 1 = fused device normal equations,
-                               2 = fused + the LM rejection chain evaluated in one batched launch */
+                               2 = fused + the LM rejection chain evaluated in one batched launch,
+                               3 = 2 + the first trials evaluated with their Jacobian (one launch per outer iteration) */
   int32_t strict_math;      /* 1 = NID_MATH_STRICT, 0 = NID_MATH_FAST */
   int32_t pad_;
   double fx, fy, cx, cy, depth_factor, huber_delta;

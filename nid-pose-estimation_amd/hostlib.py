@@ -57,6 +57,8 @@ def load():
     lib.nid_legacy_set_jacobian_bound.argtypes = [C.c_int]
     lib.nid_legacy_upload_count.restype = C.c_long
     lib.nid_legacy_set_math_mode.argtypes = [C.c_int]
+    lib.nid_legacy_set_launch_shape.restype = None
+    lib.nid_legacy_set_launch_shape.argtypes = [C.c_int, C.c_int]
     lib.nid_host_set_devices.restype = None
     lib.nid_host_set_devices.argtypes = [C.POINTER(C.c_int32), C.c_int, C.c_int]
     lib.nid_host_set_rank.restype = None
@@ -224,6 +226,11 @@ def png_read_u16(path):
     if rc:
         raise RuntimeError(f"nid_png_read_u16({path}) -> {rc}")
     return out
+
+
+def set_launch_shape(jac_threads, cost_threads):
+    """Threads per workgroup of the legacy operators' / the host LM's launches (nid_set_launch_shape)."""
+    load().nid_legacy_set_launch_shape(int(jac_threads), int(cost_threads))
 
 
 def set_devices(devices=(0,), reduce_rccl=False):

@@ -242,6 +242,12 @@ def test_lm_fused_path_equals_per_edge_path(hostlib, synth, pair_A):
     assert [r["lm_trials"] for r in recs_c] == [r["lm_trials"] for r in recs_b]
     assert [r["chi2"] for r in recs_c] == [r["chi2"] for r in recs_b]
     assert np.array_equal(pose_c, pose_b)
+    # ... and with the first trials evaluated WITH their Jacobian (one launch per outer iteration): the accepted trial's
+    # H, b and chi2 are the bits a fresh launch at that pose gives, so nothing changes
+    pose_d, recs_d, _ = hostlib.run_lm(pair, nb, pair.pose_init, 10, fused=3)
+    assert [r["lm_trials"] for r in recs_d] == [r["lm_trials"] for r in recs_b]
+    assert [r["chi2"] for r in recs_d] == [r["chi2"] for r in recs_b]
+    assert np.array_equal(pose_d, pose_b)
 
 
 def test_pyramid_lm_pose_parity(hostlib, oracle, synth, pair_A):
@@ -351,6 +357,7 @@ def test_bench_multi_rank_code_path_on_one_gpu(tmp_path):
     rc = subprocess.run([sys.executable, bench, "--steps", "300", "--warmup", "70", "--no-cpu-baseline", "--rccl-one-rank"],
                         capture_output=True, text=True, env=env, timeout=600)
     assert rc.returncode == 0, rc.stderr[-2000:]
+    assert len(rc.stdout.strip().splitlines()) == 1, rc.stdout     # RCCL's own banner must not land on stdout
     rj = json.loads(rc.stdout.strip().splitlines()[-1])
     assert rj["rccl_ranks_seen"] == 1 and "RCCL" in rj["config"]["parallelism"]
     for port, world, extra in ((29517, 2, ["--steps", "20", "--warmup", "5"]),

@@ -59,6 +59,12 @@ def test_shards_equal_single_context(capi, synth, pair_A, nshards):
         assert chi2k == chi2s and nak == int(act.sum())
     with pytest.raises(capi.NidError):
         m.wait(4)                                   # nothing pending any more
+    # nid_multi_launch_chain: the rejection chain of an LM iteration, first trial(s) with the Jacobian phase
+    m.launch_chain(0, poses, 1, DELTA)
+    for k, pose in enumerate(poses):
+        Hk, bk, chi2k, _ = m.wait(k)
+        Hs, bs, chi2s, _ = m.normal_equations(pose, DELTA, want_jac=(k == 0))
+        assert chi2k == chi2s and np.array_equal(_bits(Hk), _bits(Hs)) and np.array_equal(_bits(bk), _bits(bs))
     with pytest.raises(capi.NidError):
         capi.multi_from_pair(synth.make_pair("S"), nb, devices=[0] * 17)   # more shards than cells
 
@@ -83,6 +89,14 @@ def test_rccl_one_rank_communicator(capi, synth, pair_A):
     for k in range(20):
         a, b = host.wait(10 + k), m.wait(10 + k)
         assert np.array_equal(_bits(a[0]), _bits(b[0])) and a[2] == b[2]
+    # an LM rejection chain (first pose with the Jacobian phase, the rest cost only) through the all-reduce
+    for n_jac in (0, 1, 3):
+        m.launch_chain(40, poses[:7], n_jac, DELTA)
+        host.launch_chain(40, poses[:7], n_jac, DELTA)
+        for k in range(7):
+            a, b = host.wait(40 + k), m.wait(40 + k)
+            assert np.array_equal(_bits(a[0]), _bits(b[0])) and np.array_equal(_bits(a[1]), _bits(b[1])) and a[2:] == b[2:]
+            assert (np.abs(a[0]).max() > 0) == (k < n_jac)
     seq = np.stack([poses[i % len(poses)] for i in range(300)])
     ra = host.run_sequence(seq, DELTA, batch=16, group=4)
     rb = m.run_sequence(seq, DELTA, batch=16, group=4)

@@ -376,6 +376,58 @@ def test_error_paths(capi, pair_S):
     with pytest.raises(capi.NidError):
         ctx.set_block_threads(384)                  # shape the kernel is not built for
     ctx.set_block_threads(256)
+    for bad in [(384, 0), (128, 96), (2048, 128), (-128, 128)]:
+        with pytest.raises(capi.NidError):
+            ctx.set_launch_shape(*bad)
+    ctx.set_launch_shape(512, 0)
+    ctx.set_launch_shape(0, 0)
+
+
+@pytest.mark.parametrize("math", MODES)
+@pytest.mark.parametrize("cfg,nb", [("S", 10), ("A", 8), ("A", 16)])
+def test_launch_shapes(capi, oracle, synth, cfg, nb, math):
+    """nid_set_launch_shape: the latency shapes (512 / 1024 threads per cell) and the throughput shapes (128 / 256)
+    evaluate the same sums.  Cost-only results -- chi2, active count, per-cell Hc / Hj / err -- are the SAME BITS in
+    every shape (fixed-point histograms; the entropy sums are taken in one fixed order whatever the wave count);
+    the Jacobian and the 6x6 system depend on the shape in their last bits and are held to the parity tolerances
+    against the oracle in every shape."""
+    pair = synth.make_pair(cfg)
+    o = oracle.from_pair(pair, nb)
+    cnt, _ = o.compute_href(pair.pose_init)
+    pose = _poses(synth, pair)["near"]
+    ref = o.evaluate(pose, True)
+    H_o, b_o, chi_o, na_o = oracle.normal_equations(ref[2], ref[3], DELTA)
+    base = None
+    for nt in (128, 256, 512, 1024):
+        ctx = capi.from_pair(pair, nb, math=_mode(capi, math))
+        ctx.set_launch_shape(nt, nt)
+        ctx.compute_href(pair.pose_init)
+        got = ctx.evaluate(pose, True)
+        _compare_cells(got, ref, cnt)
+        cost_only = ctx.evaluate(pose, False)
+        H, b, chi2, na = ctx.normal_equations(pose, DELTA)
+        _, _, chi2_c, na_c = ctx.normal_equations(pose, DELTA, want_jac=False)
+        assert chi2_c == chi2 and na_c == na == na_o
+        for x, y in zip(cost_only[:3], got[:3]):
+            assert np.array_equal(_bits(x), _bits(y))
+        if base is None:
+            base = (got, chi2, H, b)
+        else:
+            for x, y in zip(base[0][:3], got[:3]):
+                assert np.array_equal(_bits(x), _bits(y)), f"cost bits differ at {nt} threads"
+            assert chi2 == base[1]
+            scale = max(np.abs(base[2]).max(), 1e-300)
+            assert np.abs(H - base[2]).max() <= 1e-12 * scale and np.abs(b - base[3]).max() <= 1e-12 * max(np.abs(base[3]).max(), 1e-300)
+        np.testing.assert_allclose(chi2, chi_o, rtol=1e-13)
+        np.testing.assert_allclose(b, b_o, rtol=0, atol=1e-9 * np.abs(b_o).max())
+        np.testing.assert_allclose(H, H_o, rtol=0, atol=1e-9 * np.abs(H_o).max())
+        # cost-only launches shaped automatically from the launch size give the same bits again
+        ctx.set_launch_shape(nt, 0)
+        poses = [pose] * 3
+        ctx.launch_batch(1, poses, DELTA, want_jac=False)
+        for k in range(3):
+            _, _, c, n = ctx.wait(1 + k)
+            assert c == chi2 and n == na
 
 
 def test_batched_launch_equals_single_launches(capi, synth, pair_A):
@@ -553,6 +605,40 @@ def test_large_batches_every_kernel_family(capi, synth, pair_S_edge, nb, nt, mat
             assert chi2 == got[k][2] and na == got[k][3]
             if jac:
                 assert np.array_equal(_bits(H), _bits(got[k][0])) and np.array_equal(_bits(b), _bits(got[k][1]))
+
+
+@pytest.mark.parametrize("math", MODES)
+def test_launch_chain(capi, synth, pair_A, math):
+    """nid_launch_chain: the rejection chain of one LM iteration -- the first n_jac trial poses with the Jacobian
+    phase on one stream, the others cost only on the second, concurrently.  Slot by slot the bits of single launches;
+    the chi2 of a pose is the same bits with and without the Jacobian phase (the LM's decisions do not depend on
+    which launch evaluated a trial)."""
+    pair, nb = pair_A, 8
+    ctx = capi.from_pair(pair, nb, math=_mode(capi, math))
+    ctx.set_launch_shape(512, 0)            # the legacy operators' shapes
+    ctx.compute_href(pair.pose_init)
+    poses = [synth.perturb_pose7(pair.pose_init, [1e-3 * k, 0, 0], [0, 2e-3 * k, 1e-3]) for k in range(10)]
+    single = [ctx.normal_equations(p, DELTA) for p in poses]
+    single_c = [ctx.normal_equations(p, DELTA, want_jac=False) for p in poses]
+    for n_jac in (0, 1, 2, 10):
+        for rep in range(3):
+            ctx.launch_chain(7, poses, n_jac, DELTA)
+            for k in range(10):
+                H, b, chi2, na = ctx.wait(7 + k)
+                assert chi2 == single[k][2] == single_c[k][2] and na == single[k][3]
+                if k < n_jac:
+                    assert np.array_equal(_bits(H), _bits(single[k][0])) and np.array_equal(_bits(b), _bits(single[k][1]))
+                else:
+                    assert not H.any() and not b.any()
+    ctx.launch_chain(0, poses[:3], 1, DELTA)
+    with pytest.raises(capi.NidError):
+        ctx.launch_chain(2, poses[:2], 1, DELTA)       # slot 2 is pending: nothing is launched
+    with pytest.raises(capi.NidError):
+        ctx.launch_chain(20, poses[:2], 3, DELTA)      # n_jac > n
+    for k in range(3):
+        ctx.wait(k)
+    with pytest.raises(capi.NidError):
+        ctx.wait(3)
 
 
 def _random_case(synth, seed):

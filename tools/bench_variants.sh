@@ -4,7 +4,7 @@
 out=$1; shift
 mkdir -p $out
 for v in "$@"; do
-  NID_HIP_LIB=exp/libnid_$v.so python bench.py --no-cpu-baseline --steps 200000 --warmup 20000 > $out/bench_$v.json 2> $out/bench_$v.err
+  NID_HIP_LIB=exp/libnid_$v.so python bench.py --no-cpu-baseline --quick --steps 200000 --warmup 20000 > $out/bench_$v.json 2> $out/bench_$v.err
   python - "$v" "$out/bench_$v.json" <<'PY'
 import json, sys
 try:

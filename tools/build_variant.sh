@@ -6,7 +6,7 @@ name=$1; shift
 root=$(cd "$(dirname "$0")/.." && pwd)
 mkdir -p $root/exp /tmp/nidv_$name
 cd /tmp/nidv_$name
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -ffp-contract=off "$@" -I$root/include -I$root/nid-pose-estimation_amd/csrc \
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -ffp-contract=off -ldl "$@" -I$root/include -I$root/nid-pose-estimation_amd/csrc \
   -o /tmp/nidv_$name/libnid_$name.so $root/nid-pose-estimation_amd/csrc/nid_capi.hip --save-temps=obj 2>&1 | grep -E "error" -A5 || true
 python3 - "$name" <<'PY'
 import re, glob, sys
