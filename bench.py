@@ -415,17 +415,24 @@ def main():
             roof["cold"] = {"kernel_ms": cold_ms, "achieved": contract / (cold_ms * 1e-3) / 1e9,
                             "frac": contract / (cold_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                             "note": "one launch after a 1 GiB device fill (tile and image come from HBM)"}
-            # sequential: a dependent chain -- one pose per launch, the next launch waits for the result on the host
+            # sequential: a dependent chain -- one pose per launch, the next launch waits for the result on the host.
+            # A blocking caller picks the latency launch shape (512-thread workgroups; what the legacy operators and the
+            # LM host stack use, nid_set_launch_shape); the throughput shape (128) is reported beside it.
             nseq = 2000
             chain = pose_arr[np.arange(nseq) % len(poses)]
-            ctx.run_chain(chain[:200], delta, want_jac=want_jac, collect=False)
-            _, el = ctx.run_chain(chain, delta, want_jac=want_jac, collect=False)
-            one = float(np.median([kctx.time_launches(pose_arr[[i]], delta, repeats=10, want_jac=want_jac) for i in range(8)]))
             per_pose = kctx.contract_bytes()
-            roof["sequential"] = {"it_per_s": nseq / el, "us_per_evaluation": el / nseq * 1e6, "kernel_us_one_pose": one * 1e3,
-                                  "frac": per_pose / (el / nseq) / 1e9 / HBM_PEAK_GBS,
-                                  "note": "nid_run_chain: one pose per launch, the host waits for each 6x6 system before it launches the next "
-                                          "(launch + kernel + result in host memory)"}
+            seq = {}
+            for name, nt in (("throughput_shape_128", 128), ("latency_shape_512", 512)):
+                ctx.set_launch_shape(nt, nt)
+                ctx.run_chain(chain[:200], delta, want_jac=want_jac, collect=False)
+                _, el = ctx.run_chain(chain, delta, want_jac=want_jac, collect=False)
+                one = float(np.median([kctx.time_launches(pose_arr[[i]], delta, repeats=10, want_jac=want_jac) for i in range(8)]))
+                seq[name] = {"it_per_s": nseq / el, "us_per_evaluation": el / nseq * 1e6, "kernel_us_one_pose": one * 1e3,
+                             "frac": per_pose / (el / nseq) / 1e9 / HBM_PEAK_GBS}
+            ctx.set_launch_shape(args.block_threads, args.block_threads)
+            roof["sequential"] = dict(seq["latency_shape_512"], threads_per_cell=512, throughput_shape_128=seq["throughput_shape_128"],
+                                      note="nid_run_chain: one pose per launch, the host waits for each 6x6 system before it launches "
+                                           "the next (launch + kernel + result in host memory)")
             # the other math mode in the same run
             other = capi.MATH_FAST if args.strict else capi.MATH_STRICT
             ctx.set_math_mode(other)

@@ -209,6 +209,24 @@ void launch_eval2_v(const EvalParams &P, bool jac, bool strict, size_t lds, hipS
   }
 }
 
+// The latency form of the FAST pixel loops (k_eval2's LAT parameter): 512- / 1024-thread workgroups whose LAT rounds
+// cover the cell.  Register budget 128 per lane = the residency the loop form has at these shapes (2 / 1 workgroups
+// per CU), so it is used whenever it applies.
+template <int NT, int NB>
+void launch_eval2_lat(const EvalParams &P, bool jac, size_t lds, hipStream_t s, int batch) {
+  constexpr int LAT = NT == 512 ? 3 : 2;
+  const dim3 grid((unsigned)(((P.g.nloc + 7) / 8) * 8 * batch)), block(NT);
+  if (jac) hipLaunchKernelGGL((k_eval2<NT, true, false, NB, false, false, LAT>), grid, block, lds, s, P);
+  else hipLaunchKernelGGL((k_eval2<NT, false, false, NB, false, false, LAT>), grid, block, lds, s, P);
+}
+template <int NT>
+void launch_eval2_lat_nb(const EvalParams &P, bool jac, size_t lds, hipStream_t s, int batch) {
+  if (P.g.nb == 8) launch_eval2_lat<NT, 8>(P, jac, lds, s, batch);
+  else if (P.g.nb == 10) launch_eval2_lat<NT, 10>(P, jac, lds, s, batch);
+  else launch_eval2_lat<NT, 0>(P, jac, lds, s, batch);
+}
+constexpr int lat_rounds(int nt) { return nt == 512 ? 3 : (nt == 1024 ? 2 : 0); }
+
 template <int NT, bool EXTOK>
 void launch_eval2_nb(const EvalParams &P, bool jac, bool strict, size_t lds, hipStream_t s, int batch) {
   if (P.g.nb == 8) launch_eval2_v<NT, 8, false, EXTOK>(P, jac, strict, lds, s, batch);
@@ -266,10 +284,16 @@ int launch_eval2(nid_ctx *ctx, EvalParams &P, bool jac, hipStream_t stream, int 
     launch_eval2_nb<128, true>(P, jac, strict, lds, stream, batch);
   } else if (nt == 256) {
     launch_eval2_nb<256, true>(P, jac, strict, lds, stream, batch);
-  } else if (nt == 512) {
-    launch_eval2_nb<512, false>(P, jac, strict, lds, stream, batch);
   } else {
-    launch_eval2_nb<1024, false>(P, jac, strict, lds, stream, batch);
+    static const bool no_lat = getenv("NID_NO_LAT") != nullptr;  // experiments: the loop form at the latency shapes
+    const bool lat = !strict && !no_lat && P.g.pstride <= lat_rounds(nt) * nt;
+    if (nt == 512) {
+      if (lat) launch_eval2_lat_nb<512>(P, jac, lds, stream, batch);
+      else launch_eval2_nb<512, false>(P, jac, strict, lds, stream, batch);
+    } else {
+      if (lat) launch_eval2_lat_nb<1024>(P, jac, lds, stream, batch);
+      else launch_eval2_nb<1024, false>(P, jac, strict, lds, stream, batch);
+    }
   }
   NID_HIP(ctx, hipGetLastError());
   return NID_OK;

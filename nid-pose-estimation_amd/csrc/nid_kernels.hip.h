@@ -1038,6 +1038,14 @@ __device__ __forceinline__ int pixel_sample(const PixelFront &f, int nb, int S, 
 // the default 128-thread workgroups (ten per CU) the latency is hidden anyway: 0/0 258.8 k it/s at 1 272 W,
 // 2/2 256.4 k at 1 335 W, 1/1 250.8 k -- so the default is 0/0.  NID_FAST_WAVES: occupancy target of the
 // FAST kernels (5 waves/SIMD = 96 VGPRs; 6 spills inside the loops: 216.8 k).
+// LAT kernels: what the Jacobian phase needs of a pixel the cost phase has already worked out
+struct LatPix {
+  double x, y, iz, gx, gy, pc;
+  double wr[4];
+  int jr, jc;
+  bool go;  // contributes to the Jacobian in the main pass: inside linearizeOplus' frame and decided by FAST arithmetic
+};
+
 #ifndef NID_PREFETCH_P1
 #define NID_PREFETCH_P1 0
 #endif
@@ -1050,8 +1058,17 @@ __device__ __forceinline__ int pixel_sample(const PixelFront &f, int nb, int S, 
 // EXT: the launch has more than kMaxBatch poses and their records live in P.slots_ext (device memory); the
 // workgroup's record is then pulled into scalar registers once, dword by dword, so that the pose matrix and
 // the pointers are SGPR operands exactly as when they come from the kernel arguments.
-template <int NT, bool JAC, bool STRICT, int NB, bool DBG, bool EXT = false>
-__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(STRICT ? 4 : NID_FAST_WAVES))) void k_eval2(EvalParams P) {
+// LAT > 0 (FAST math, launches of few poses: one workgroup per CU or less): the latency form of the pixel loops.
+// A launch that cannot fill the chip is bound by the DEPENDENT memory round trips of one wave -- tile entry ->
+// projection -> target window -> sample -- once per round and phase.  With NT >= 512 a cell is LAT <= 3 rounds,
+// so the rounds are unrolled and staged: every round's tile loads are issued first, then every round's window
+// loads, then the arithmetic; and what the Jacobian phase needs of a pixel (its point over z, the image gradient,
+// the bin position, the reference weights: LatPix) stays in registers across the fold, so the Jacobian phase of
+// the main pass touches no global memory at all.  One workgroup per CU leaves 128+ VGPRs per lane for that.
+// Same operations on the same values in the same per-lane order as the loop form: bit-identical results (tested).
+template <int NT, bool JAC, bool STRICT, int NB, bool DBG, bool EXT = false, int LAT = 0>
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(STRICT ? 4 : (LAT ? 4 : NID_FAST_WAVES)))) void k_eval2(EvalParams P) {
+  static_assert(LAT == 0 || (!STRICT && !DBG && !EXT), "the latency form exists for FAST math launches of <= kMaxBatch poses");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int NC = eval_hist_copies(NT);
   const Geometry &g = P.g;
@@ -1182,6 +1199,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(STRICT ? 4 :
   // the sums stay run-to-run reproducible), and integer histogram adds do not care about the order.
   // rounds: bit min(r, 63) of a wave-uniform mask; a cell of more than 64 rounds per wave shares the last bit.
   unsigned long long rare_rounds = 0ull;
+  LatPix lat[LAT > 0 ? LAT : 1];  // LAT + JAC: the cost phase's hand-over to the Jacobian phase
+  (void)lat;
   if constexpr (STRICT) {
 #pragma clang loop unroll(disable)
     for (int sb = wave_base; sb < g.pstride; sb += NT) {
@@ -1240,9 +1259,55 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(STRICT ? 4 :
       return !SECOND && __builtin_amdgcn_ballot_w64(rare) != 0ull;
     };
     int r = 0;
+    if constexpr (LAT > 0) {
+      // staged main pass (see the template comment); the host launches this form only if LAT rounds cover the cell
+      TileIn tin[LAT];
+      PixelFront fr[LAT];
+      WinC wcn[LAT];
+      WinJ wjn[LAT];
+#pragma unroll
+      for (int q = 0; q < LAT; q++)
+        if (wave_base + q * NT < g.pstride) load_tile(P, base + (unsigned)(wave_base + q * NT + lane), plane, tin[q]);
+#pragma unroll
+      for (int q = 0; q < LAT; q++)
+        if (wave_base + q * NT < g.pstride) {
+          pixel_front<false>(P, SA, tin[q], fr[q]);
+          if (JAC) load_win_jac(P, fr[q].w.wx, fr[q].w.wy, wjn[q]);
+          else load_win_centre(P, fr[q].w.wx, fr[q].w.wy, wcn[q]);
+        }
+#pragma unroll
+      for (int q = 0; q < LAT; q++) {
+        lat[q].go = false;
+        if (wave_base + q * NT < g.pstride) {
+          PixelFront &f = fr[q];
+          double ic, gx = 0.0, gy = 0.0;
+          if (JAC) gradient_fast_j(wjn[q], f.u, f.v, gx, gy, ic);  // its centre sample IS sample_fast_c's
+          else ic = sample_fast_c(wcn[q], f.u, f.v);
+          bool rare = f.in && fabs(ic - kGuardMid) > kGuardHalf;
+          if (f.redo && classify_redo(P, f)) rare = true;
+          double wc[4], dw[4], pc = 0.0;
+          int jc = -1;
+          if (f.in && !rare) {
+            jc = fast_bin(ic, S, pc);
+            bspline4_poly<false>(pc, jc, rtab, wc, dw);
+            hist_add(f.jr, jc, f.wr, wc);
+          }
+          if (__builtin_amdgcn_ballot_w64(rare) != 0ull) rare_rounds |= 1ull << q;
+          if (JAC) {
+            LatPix &l = lat[q];
+            l.x = f.x; l.y = f.y; l.iz = f.zq; l.gx = gx; l.gy = gy; l.pc = pc;
+#pragma unroll
+            for (int k = 0; k < 4; k++) l.wr[k] = f.wr[k];
+            l.jr = f.jr; l.jc = jc;
+            l.go = f.jin && !rare;
+          }
+        }
+      }
+    } else {
 #pragma clang loop unroll(disable)
-    for (int sb = wave_base; sb < g.pstride; sb += NT, r++)
-      if (cost_round(sb, std::false_type{})) rare_rounds |= 1ull << min(r, 63);
+      for (int sb = wave_base; sb < g.pstride; sb += NT, r++)
+        if (cost_round(sb, std::false_type{})) rare_rounds |= 1ull << min(r, 63);
+    }
     if (rare_rounds != 0ull) {
       r = 0;
 #pragma clang loop unroll(disable)
@@ -1327,7 +1392,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(STRICT ? 4 :
   // FAST-mode constants: the gradient helper returns twice the gradient, so 1/2 rides on fx, fy
   const double cAx = wave_uniform(cA * (0.5 * g.fx)), cBx = wave_uniform(cB * (0.5 * g.fx));
   const double cAy = wave_uniform(cA * (0.5 * g.fy)), cBy = wave_uniform(cB * (0.5 * g.fy));
-  auto jac_accumulate = [&](const PixelFront &f, double invz, double gx, double gy, double pc, int jc, const double (&dw)[4]) {
+  auto jac_accumulate = [&](const auto &f, double invz, double gx, double gy, double pc, int jc, const double (&dw)[4]) {
     const double *tj = tab + ((unsigned)nb + (unsigned)(__mul24(f.jr, nb) + jc));
     double tt = 0.0, ss = 0.0;
 #pragma unroll
@@ -1465,9 +1530,22 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(STRICT ? 4 :
     };
     unsigned long long rare2 = 0ull;
     int r = 0;
+    if constexpr (LAT > 0) {
+      // main pass from the registers the cost phase left (same values, same per-lane order as the loop form);
+      // the rare samples are the cost phase's rare samples (same classification on the same values)
+#pragma unroll
+      for (int q = 0; q < LAT; q++)
+        if (lat[q].go) {
+          double dw[4];
+          bspline4_poly_der(lat[q].pc, lat[q].jc, rtab, dw);
+          jac_accumulate(lat[q], lat[q].iz, lat[q].gx, lat[q].gy, lat[q].pc, lat[q].jc, dw);
+        }
+      rare2 = rare_rounds;
+    } else {
 #pragma clang loop unroll(disable)
-    for (int sb = wave_base; sb < g.pstride; sb += NT, r++)
-      if (jac_round(sb, std::false_type{})) rare2 |= 1ull << min(r, 63);
+      for (int sb = wave_base; sb < g.pstride; sb += NT, r++)
+        if (jac_round(sb, std::false_type{})) rare2 |= 1ull << min(r, 63);
+    }
     if (rare2 != 0ull) {
       r = 0;
 #pragma clang loop unroll(disable)
