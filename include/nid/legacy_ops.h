@@ -53,7 +53,8 @@ void nid_legacy_set_jacobian_bound(int mode);
 // 0 = FAST arithmetic (default), 1 = STRICT: every rounding of the reference reproduced (nid_c.h)
 void nid_legacy_set_math_mode(int mode);
 void nid_legacy_set_device(int device);
-// threads per workgroup of the operators' launches (nid_set_launch_shape in nid_c.h)
+// threads per workgroup of the operators' launches (nid_set_launch_shape in nid_c.h); jac_threads -1 (default): 512 with
+// up to 256 cells per shard, 256 beyond
 void nid_legacy_set_launch_shape(int jac_threads, int cost_threads);
 // Multi-GPU (include/nid/nid_multi.h): the operators shard the cells of the frame pair over `n` devices of THIS
 // process (entries may repeat); reduce_rccl != 0 sums the fused 6x6 blocks with RCCL instead of on the host ...

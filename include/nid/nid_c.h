@@ -94,6 +94,10 @@ int nid_set_stream(nid_ctx *ctx, void *hip_stream);
  * cost_threads: cost-only launches; 0 = chosen per launch by its size (their results are the same bits in every
  * shape).  NID_ERR_UNSUPPORTED for any other value. */
 int nid_set_launch_shape(nid_ctx *ctx, int jac_threads, int cost_threads);
+/* Diagnostics: FAST launches of the 512 / 1024 shapes run the latency form of the pixel loops (rounds unrolled and
+ * staged, the Jacobian phase fed from registers) whenever its rounds cover a cell; on != 0 forces the loop form the
+ * other shapes use.  Same bits either way (tests/test_parity_gpu.py::test_latency_form_equals_loop_form). */
+int nid_set_loop_form(nid_ctx *ctx, int on);
 /* both at once (0 = the defaults above) */
 int nid_set_block_threads(nid_ctx *ctx, int threads);
 

@@ -50,6 +50,7 @@ struct nid_ctx {
   int jac_bound = NID_JACBOUND_CPU;
   int xform = NID_XFORM_QUAT;
   int jac_threads = 0, cost_threads = 0;  // nid_set_launch_shape: 0 = default (128) / automatic (pick_threads)
+  bool loop_form = false;                  // nid_set_loop_form (diagnostics)
   // own_stream: setup + blocking calls; aux_stream: odd slots of the pipelined path, so that
   // launch N+1 overlaps the reduction tail and the launch gap of launch N (separate
   // per-slot buffers make that safe).  An external stream (nid_set_stream) disables it.
@@ -262,7 +263,10 @@ int launch_eval2(nid_ctx *ctx, EvalParams &P, bool jac, hipStream_t stream, int 
   // still fit a CU (LDS 16 KB, 96 VGPRs).  Launches of few poses are latency bound: see pick_threads.
   const bool dbg = ctx->dbg_enabled || ctx->dbg_stamps != nullptr;
   int nt = pick_threads(ctx, jac, batch);
-  if (dbg && nt > 256) nt = 256;  // the diagnostic instantiations exist for 128 and 256 threads
+  // the diagnostic instantiations exist for 128 and 256 threads; phase stamps alone also for the latency form
+  const bool stamps_lat = dbg && !ctx->dbg_enabled && !ctx->loop_form && ctx->math_mode != NID_MATH_STRICT && nt >= 512 &&
+                          P.g.pstride <= lat_rounds(nt) * nt && batch <= kMaxBatch;
+  if (dbg && nt > 256 && !stamps_lat) nt = 256;
   size_t lds = eval_lds_bytes(P.g, nt);
   {
     // k_eval2 accumulates raw 2^52-magic bit patterns and masks the top 12 bits per copy in the fold, so no
@@ -277,7 +281,16 @@ int launch_eval2(nid_ctx *ctx, EvalParams &P, bool jac, hipStream_t stream, int 
   static const char *pad_env = getenv("NID_EXP_LDS_PAD");  // occupancy experiments: pad the LDS request
   if (pad_env) lds = std::min<size_t>(160 * 1024, lds + (size_t)atoi(pad_env));
   const bool strict = ctx->math_mode == NID_MATH_STRICT;
-  if (dbg) {  // diagnostics keep the workgroup shape: the Jacobian sums depend on it in their last bits
+  if (stamps_lat) {
+    const dim3 grid((unsigned)(((P.g.nloc + 7) / 8) * 8 * batch));
+    if (nt == 512) {
+      if (jac) hipLaunchKernelGGL((k_eval2<512, true, false, 0, true, false, 3>), grid, dim3(512), lds, stream, P);
+      else hipLaunchKernelGGL((k_eval2<512, false, false, 0, true, false, 3>), grid, dim3(512), lds, stream, P);
+    } else {
+      if (jac) hipLaunchKernelGGL((k_eval2<1024, true, false, 0, true, false, 2>), grid, dim3(1024), lds, stream, P);
+      else hipLaunchKernelGGL((k_eval2<1024, false, false, 0, true, false, 2>), grid, dim3(1024), lds, stream, P);
+    }
+  } else if (dbg) {  // diagnostics keep the workgroup shape: the Jacobian sums depend on it in their last bits
     if (nt == 128) launch_eval2_v<128, 0, true>(P, jac, strict, lds, stream, batch);
     else launch_eval2_v<256, 0, true>(P, jac, strict, lds, stream, batch);
   } else if (nt == 128) {
@@ -286,7 +299,7 @@ int launch_eval2(nid_ctx *ctx, EvalParams &P, bool jac, hipStream_t stream, int 
     launch_eval2_nb<256, true>(P, jac, strict, lds, stream, batch);
   } else {
     static const bool no_lat = getenv("NID_NO_LAT") != nullptr;  // experiments: the loop form at the latency shapes
-    const bool lat = !strict && !no_lat && P.g.pstride <= lat_rounds(nt) * nt;
+    const bool lat = !strict && !no_lat && !ctx->loop_form && P.g.pstride <= lat_rounds(nt) * nt;
     if (nt == 512) {
       if (lat) launch_eval2_lat_nb<512>(P, jac, lds, stream, batch);
       else launch_eval2_nb<512, false>(P, jac, strict, lds, stream, batch);
@@ -1208,6 +1221,12 @@ void nid_bspline4_host(double u, int bin_num, double *B4, double *D4) {
 }
 
 double nid_div_small_host(double x, double d) { return nid::div_small(x, d); }
+
+int nid_set_loop_form(nid_ctx *ctx, int on) {
+  if (!ctx) return NID_ERR_INVALID_ARG;
+  ctx->loop_form = on != 0;
+  return NID_OK;
+}
 
 int nid_enable_timing(nid_ctx *ctx, int enable) {
   if (!ctx) return NID_ERR_INVALID_ARG;

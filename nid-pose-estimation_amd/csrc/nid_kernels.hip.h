@@ -375,6 +375,14 @@ __device__ __forceinline__ double wave_lane63(double x) {
   return __hiloint2double(hi, lo);
 }
 
+// the value lane `l` (a constant) holds, in scalar registers
+template <int L>
+__device__ __forceinline__ double wave_lane(double x) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(x), L);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(x), L);
+  return __hiloint2double(hi, lo);
+}
+
 // Deterministic block sum of NV values; result broadcast to every thread.
 // `red` holds NV * (NT/64) doubles and must not be in use.
 template <int NT, int NV>
@@ -1067,8 +1075,8 @@ struct LatPix {
 // the main pass touches no global memory at all.  One workgroup per CU leaves 128+ VGPRs per lane for that.
 // Same operations on the same values in the same per-lane order as the loop form: bit-identical results (tested).
 template <int NT, bool JAC, bool STRICT, int NB, bool DBG, bool EXT = false, int LAT = 0>
-__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(STRICT ? 4 : (LAT ? 4 : NID_FAST_WAVES)))) void k_eval2(EvalParams P) {
-  static_assert(LAT == 0 || (!STRICT && !DBG && !EXT), "the latency form exists for FAST math launches of <= kMaxBatch poses");
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(STRICT ? 4 : ((LAT || NT >= 512) ? 4 : NID_FAST_WAVES)))) void k_eval2(EvalParams P) {
+  static_assert(LAT == 0 || (!STRICT && !EXT), "the latency form exists for FAST math launches of <= kMaxBatch poses (DBG: phase stamps only)");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int NC = eval_hist_copies(NT);
   const Geometry &g = P.g;
@@ -1569,11 +1577,22 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(STRICT ? 4 :
     }
     __syncthreads();
     if (tid >= 64) return;
+    if constexpr (NW <= 4) {
 #pragma unroll
-    for (int k = 0; k < 6; k++) {
-      double sum = red[k];
-      for (int w = 1; w < NW; w++) sum += red[w * 6 + k];
-      acc[k] = sum;
+      for (int k = 0; k < 6; k++) {
+        double sum = red[k];
+        for (int w = 1; w < NW; w++) sum += red[w * 6 + k];
+        acc[k] = sum;
+      }
+    } else {
+      // 8 / 16 waves: lane k < 6 sums column k (the same order, w ascending: the same bits), NW loads in flight
+      // per lane instead of 6 NW; the six sums come back as scalars
+      const int kk = tid < 6 ? tid : 0;
+      double sum = red[kk];
+#pragma unroll
+      for (int w = 1; w < NW; w++) sum += red[w * 6 + kk];
+      acc[0] = wave_lane<0>(sum); acc[1] = wave_lane<1>(sum); acc[2] = wave_lane<2>(sum);
+      acc[3] = wave_lane<3>(sum); acc[4] = wave_lane<4>(sum); acc[5] = wave_lane<5>(sum);
     }
   }
   NID_STAMP(5, acc[0], acc[2], acc[3], acc[5]);

@@ -41,9 +41,14 @@ uint8_t g_id[NID_RCCL_ID_BYTES];
 int g_jac_bound = NID_JACBOUND_CPU;
 int g_math_mode = NID_MATH_FAST;
 int g_reduce_rccl = 0;
-// Blocking single-pose calls are latency bound: 512-thread workgroups for the Jacobian launch (18.3 us vs 28.5 us
-// at 128 on 640x480 / 8 bins), cost-only launches shaped per launch (profiles/r02_launch_cost_A.txt).
-int g_jac_threads = 512, g_cost_threads = 0;  // nid_legacy_set_launch_shape
+// Blocking single-pose calls are latency bound: with up to 256 cells per shard (one workgroup per CU) 512-thread
+// workgroups for the Jacobian launch, 256 beyond; cost-only launches shaped per launch (profiles/r02_launch_cost_*.txt).
+int g_jac_threads = -1, g_cost_threads = 0;  // nid_legacy_set_launch_shape; -1 = by shard size
+
+int jac_threads_for(int cells, int shards) {
+  if (g_jac_threads >= 0) return g_jac_threads;
+  return (cells + shards - 1) / shards <= 256 ? 512 : 256;
+}
 nid_comm *g_comm = nullptr;  // lives across nid_legacy_reset(): one communicator per process, however many pairs / levels
 long g_uploads = 0;
 
@@ -106,7 +111,7 @@ nid_multi *get_multi(int rows, int cols, int cell, int bins, int deg, const doub
   nid_multi_set_math_mode(m, g_math_mode);
   // the operators are blocking, one pose (or one LM rejection chain) at a time: latency matters, not the
   // pipelined throughput the 128-thread default is tuned for (nid_set_launch_shape, tools/latency_sweep.py)
-  nid_multi_set_launch_shape(m, g_jac_threads, g_cost_threads);
+  nid_multi_set_launch_shape(m, jac_threads_for(cell * cell, g_world > 1 ? g_world : (int)g_devices.size()), g_cost_threads);
   S.m = m; S.rows = rows; S.cols = cols; S.cell = cell; S.bins = bins;
   std::memcpy(S.intr, intr, sizeof(S.intr));
   return m;
@@ -263,7 +268,9 @@ void nid_legacy_set_math_mode(int mode) {
 
 void nid_legacy_set_launch_shape(int jac_threads, int cost_threads) {
   g_jac_threads = jac_threads; g_cost_threads = cost_threads;
-  if (g_state.m) nid_multi_set_launch_shape(g_state.m, jac_threads, cost_threads);
+  if (g_state.m)
+    nid_multi_set_launch_shape(g_state.m, jac_threads_for(g_state.cell * g_state.cell, g_world > 1 ? g_world : (int)g_devices.size()),
+                               cost_threads);
 }
 
 void nid_legacy_set_device(int device) {

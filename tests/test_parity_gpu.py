@@ -607,6 +607,35 @@ def test_large_batches_every_kernel_family(capi, synth, pair_S_edge, nb, nt, mat
                 assert np.array_equal(_bits(H), _bits(got[k][0])) and np.array_equal(_bits(b), _bits(got[k][1]))
 
 
+@pytest.mark.parametrize("nb", [8, 10, 6])
+@pytest.mark.parametrize("nt", [512, 1024])
+def test_latency_form_equals_loop_form(capi, synth, nb, nt):
+    """The latency form of the FAST pixel loops (512 / 1024 threads per cell: rounds unrolled and staged, the
+    Jacobian phase fed from the registers the cost phase left) does the same operations on the same values in the
+    same per-lane order as the loop form: every output is the same bits -- on a pair with saturated and black
+    regions and border-aligned pixels too (the rare samples take the second pass in both forms)."""
+    for pair in (synth.make_pair("A"), synth.make_pair("A", flash=True), synth.make_pair("S")):
+        ctx = capi.from_pair(pair, nb)
+        ctx.set_launch_shape(nt, nt)
+        ctx.compute_href(pair.pose_init)
+        poses = list(_poses(synth, pair).values()) + [_identity_pose(synth, pair)]
+        got = {}
+        for loop in (False, True):
+            ctx.set_loop_form(loop)
+            got[loop] = [(ctx.evaluate(p, True), ctx.normal_equations(p, DELTA), ctx.normal_equations(p, DELTA, want_jac=False))
+                         for p in poses]
+            ctx.launch_batch(0, poses, DELTA)
+            got[loop].append([ctx.wait(k) for k in range(len(poses))])
+        for a, b in zip(got[False][:-1], got[True][:-1]):
+            for x, y in zip(a[0], b[0]):
+                assert np.array_equal(_bits(x), _bits(y))
+            for k in (1, 2):
+                assert np.array_equal(_bits(a[k][0]), _bits(b[k][0])) and np.array_equal(_bits(a[k][1]), _bits(b[k][1]))
+                assert a[k][2:] == b[k][2:]
+        for a, b in zip(got[False][-1], got[True][-1]):
+            assert np.array_equal(_bits(a[0]), _bits(b[0])) and np.array_equal(_bits(a[1]), _bits(b[1])) and a[2:] == b[2:]
+
+
 @pytest.mark.parametrize("math", MODES)
 def test_launch_chain(capi, synth, pair_A, math):
     """nid_launch_chain: the rejection chain of one LM iteration -- the first n_jac trial poses with the Jacobian
