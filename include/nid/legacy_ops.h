@@ -20,8 +20,8 @@
 //
 // Differences, all deliberate: no per-call allocation / memset / re-upload (the
 // frame-pair state is cached per (rows, cols, cell_num, bin_num) and re-uploaded
-// only when a caller buffer's address changes, or always with
-// NID_LEGACY_ALWAYS_UPLOAD=1); out-of-frame reference weights are NaN in the
+// only when the CONTENT of a caller buffer changes -- a fingerprint of its length
+// and 64 samples, not its address --, or always with NID_LEGACY_ALWAYS_UPLOAD=1); out-of-frame reference weights are NaN in the
 // arrays handed back (as CudaComputeHref.cu:126-130 writes them) but are treated
 // as 0 inside, the CPU edge's convention; the Jacobian in-frame
 // test defaults to the CPU edge's `cols-1` (the parity target),

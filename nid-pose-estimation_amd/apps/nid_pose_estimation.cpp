@@ -194,6 +194,16 @@ int main(int argc, char **argv) {
   pb.im0 = im0.data(); pb.im1 = im1.data(); pb.depth_u16 = d0.data(); pb.T_wc0_colmajor = T_wc0.data();
   pb.fused = fc.count("fused") ? std::atoi(fc["fused"].c_str()) : 0;
   pb.strict_math = fc.count("strict_math") ? std::atoi(fc["strict_math"].c_str()) : 0;
+  if (fc.count("devices")) {
+    // not in the reference: the cells of the pair sharded over several GPUs of this node (include/nid/nid_multi.h),
+    // e.g. "devices: 0,1,2,3"; "reduce_rccl: 1" sums the 6x6 blocks with RCCL instead of on the host
+    std::vector<int32_t> devs;
+    std::stringstream ss(fc["devices"]);
+    for (std::string tok; std::getline(ss, tok, ',');)
+      if (!tok.empty()) devs.push_back(std::atoi(tok.c_str()));
+    if (devs.empty()) { std::cerr << "devices: expected a comma-separated list of GPU ids" << std::endl; return 1; }
+    nid_host_set_devices(devs.data(), (int)devs.size(), fc.count("reduce_rccl") ? std::atoi(fc["reduce_rccl"].c_str()) : 0);
+  }
 
   if (fc.count("mode") && fc["mode"] == "standard_property") {
     // the reference's second program (NID_standard_property.cpp): plain-histogram NID of every cell at the

@@ -296,6 +296,24 @@ def test_driver_end_to_end(hostlib, synth, pair_S, tmp_path):
     np.testing.assert_allclose(err, want, rtol=0, atol=1e-5)
 
 
+def test_driver_on_shards(hostlib, synth, pair_S, tmp_path):
+    """The driver's `devices:` key (cells sharded over a device list, here two shards on GPU 0) with the one-launch-
+    per-iteration LM (`fused: 3`): the same nid_error.csv row as the single-context run to 1e-9."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "nid-pose-estimation_amd", "nid_pose_estimation")
+    rows_out = []
+    for extra in ("fused: 2\n", "fused: 3\ndevices: 0,0\n"):
+        d = tmp_path / ("a" if not rows_out else "b")
+        d.mkdir()
+        subprocess.check_call(["python", os.path.join(root, "tools", "make_dataset.py"), str(d), "S", "10"])
+        with open(d / "config.yaml", "a") as f:
+            f.write(extra)
+        r = subprocess.run([exe, str(d / "config.yaml")], capture_output=True, text=True, cwd=d, timeout=300)
+        assert r.returncode == 0, r.stderr
+        rows_out.append(np.array([float(x) for x in open(d / "nid_error.csv").read().strip().split(",")[:6]]))
+    np.testing.assert_allclose(rows_out[0], rows_out[1], rtol=0, atol=1e-9)
+
+
 def test_driver_reads_png_dataset(hostlib, synth, pair_S, tmp_path):
     """The driver on the ETH-CVG layout with PNG files (rgb/<id>.png, depth/<id>.png 16 bit): same result as
     with the PGM copies of the same pair."""
