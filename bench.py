@@ -54,7 +54,7 @@ def parse():
     ap.add_argument("--block-threads", type=int, default=0)
     ap.add_argument("--batch", type=int, default=64, help="candidate poses per kernel launch")
     ap.add_argument("--group", type=int, default=0,
-                    help="N>1 / --shards: kernel launches per exchange (0 = 4 launches of min(batch, 16) poses)")
+                    help="N>1 / --shards: kernel launches per exchange (0 = 2 launches of --batch poses)")
     ap.add_argument("--shards", type=int, default=1,
                     help="N=1 only: shard the cells over SHARDS contexts on the one GPU through the multi-GPU layer "
                          "(host sum); exercises the N>1 code path on a one-GPU box, not the metric")
@@ -284,9 +284,12 @@ def main():
             m.set_block_threads(args.block_threads)
         ctx = None
         cnt, href = m.compute_href(pair.pose_init)
-        # latency-bound exchange: fewer, larger ones -- a group = G launches of Bm poses, one exchange per group
-        Bm = min(B, 16) if args.group == 0 else B
-        G = 4 if args.group == 0 else max(1, args.group)
+        # A rank owns 1/N of the cells, so its launches are small: 64 poses per launch keep its chip filled (32 cells x
+        # 64 poses = 2048 workgroups; measured per-rank rate on 32 cells: 0.50 M/s with 16 poses per launch, 1.09 M/s
+        # with 64: tools/shard_rate.py).  The exchange is latency-bound: one per group of G launches (128 poses,
+        # 32 KB), two groups in flight.
+        Bm = B
+        G = 2 if args.group == 0 else max(1, args.group)
     else:
         ctx = capi.from_pair(pair, args.bins, device=local_rank)
         if args.block_threads:
@@ -335,6 +338,24 @@ def main():
     assert ablation or (np.isfinite(chi2) and np.all(np.isfinite(H)) and na > 0)
     if args.cost_only and rank == 0:
         print("[bench] --cost-only: cost evaluations without the Jacobian phase; not the BASELINE metric", file=sys.stderr)
+
+    # N > 1: the same pipeline for >= sustained_seconds whatever --steps was (every rank takes part; `elapsed` is the
+    # max over ranks, so every rank derives the same step count)
+    sustained_multi = None
+    if world > 1 and not args.quick:
+        n_s = max(int(K / elapsed * args.sustained_seconds), Bm * G * 16) // (Bm * G) * (Bm * G)
+        for attempt in range(2):
+            barrier()
+            t0 = time.perf_counter()
+            run(n_s, collect=False)
+            barrier()
+            t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+            if el >= args.sustained_seconds * 0.7:
+                break
+            n_s = int(n_s * args.sustained_seconds / el) // (Bm * G) * (Bm * G)   # the first estimate was latency-bound
+        sustained_multi = {"it_per_s": n_s / el, "ms_per_step": el / n_s * 1e3, "steps": n_s, "seconds": el}
 
     # ---- side measurements on this rank's shard (rank 0 reports) -----------------------------------------------
     kctx = ctx if ctx is not None else capi.Context.borrow(m, 0)
@@ -385,6 +406,8 @@ def main():
                                    "achieved_per_s": per_wave * waves / (eval_ms * 1e-3), "peak_per_s": SIMD_ISSUE_PEAK,
                                    "frac": per_wave * waves / (eval_ms * 1e-3) / SIMD_ISSUE_PEAK,
                                    "source": issue.get("source", "profiles/issue_model.json")}
+        if sustained_multi is not None:
+            roof["sustained"] = sustained_multi
         if not args.quick and not multi:
             # sustained: the same pipeline for >= sustained_seconds whatever --steps was
             rate = K / elapsed
