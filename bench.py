@@ -7,7 +7,7 @@ Workload at N=1 is BASELINE.json configs[1]: the 640x480 pair, 16x16 cells, 8-bi
 (synthetic pair: the ETH-CVG data is not available offline).
 
 `value` is PIPELINED EVALUATION THROUGHPUT: the K steps are K independent candidate poses pushed through the
-library's own host pipeline (nid_run_sequence: 64 poses per kernel launch, launches alternating between two
+library's own host pipeline (nid_run_sequence: 256 poses per kernel launch, launches alternating between two
 streams, every pose's 6x6 system collected from pinned host memory).  A Gauss-Newton / LM loop is sequentially
 dependent; its rates are reported next to it (roofline.sequential: one blocking evaluation per launch;
 pose_error_vs_ref.lm_outer_iterations_per_s: the reference's LM schedule), as are the kernel-alone, cold and
@@ -52,7 +52,10 @@ def parse():
     ap.add_argument("--config", default="A", choices=["A", "B", "S"])
     ap.add_argument("--bins", type=int, default=8)
     ap.add_argument("--block-threads", type=int, default=0)
-    ap.add_argument("--batch", type=int, default=64, help="candidate poses per kernel launch")
+    ap.add_argument("--batch", type=int, default=256, help="candidate poses per kernel launch (<= NID_MAX_BATCH = 256)")
+    ap.add_argument("--preheat-seconds", type=float, default=0.25,
+                    help="setup, before the W warmup steps: the timed region's own launch geometry for this long, so that the "
+                         "clocks are up and the kernel instantiation it uses is in the instruction caches (0 = off)")
     ap.add_argument("--group", type=int, default=0,
                     help="N>1 / --shards: kernel launches per exchange (0 = 2 launches of --batch poses)")
     ap.add_argument("--shards", type=int, default=1,
@@ -284,10 +287,10 @@ def main():
             m.set_block_threads(args.block_threads)
         ctx = None
         cnt, href = m.compute_href(pair.pose_init)
-        # A rank owns 1/N of the cells, so its launches are small: 64 poses per launch keep its chip filled (32 cells x
+        # A rank owns 1/N of the cells, so its launches are small: many poses per launch keep its chip filled (32 cells x
         # 64 poses = 2048 workgroups; measured per-rank rate on 32 cells: 0.50 M/s with 16 poses per launch, 1.09 M/s
-        # with 64: tools/shard_rate.py).  The exchange is latency-bound: one per group of G launches (128 poses,
-        # 32 KB), two groups in flight.
+        # with 64: tools/shard_rate.py).  The exchange is latency-bound: one per group of G launches (2 x 256 poses =
+        # 128 KB), two groups in flight.
         Bm = B
         G = 2 if args.group == 0 else max(1, args.group)
     else:
@@ -314,6 +317,20 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    # Setup, not warmup steps: the driver's W may be smaller than one launch and then exercises another kernel
+    # instantiation (<= 16 poses: records as kernel arguments) than the timed region (device-resident records); a
+    # cold instantiation costs its first launches ~10 us each in instruction-cache misses, idle clocks more.  Same
+    # step count on every rank (the launches are collective for N > 1).
+    if args.preheat_seconds > 0:
+        n_pre = min(K, Bm * G if multi else B)
+        t_pre = time.perf_counter()
+        for _ in range(1000):
+            run(n_pre, collect=False)
+            go_on = torch.tensor([1.0 if time.perf_counter() - t_pre < args.preheat_seconds else 0.0], dtype=torch.float64)
+            if dist is not None:
+                dist.all_reduce(go_on, op=dist.ReduceOp.MIN)
+            if go_on.item() == 0.0:
+                break
     run(W, collect=False)
     barrier()
     t0 = time.perf_counter()
@@ -475,6 +492,7 @@ def main():
             "n_gpus": world,
             "steps": K,
             "warmup": W,
+            "preheat_seconds": args.preheat_seconds,   # setup before the warmup steps: clocks + instruction caches (see --help)
             "ms_per_step": elapsed / K * 1e3,
             "higher_is_better": True,
             "scaling": "strong" if world > 1 else None,

@@ -36,7 +36,7 @@ struct Slot {
   double *reduced_host = nullptr;  // pinned, mapped: [32 doubles][u64 sequence word]
   double *reduced_host_devptr = nullptr;
   unsigned long long seq = 0;      // sequence number of the last launch into this slot
-  hipEvent_t done = nullptr, e0 = nullptr, e1 = nullptr, e2 = nullptr;
+  hipEvent_t done = nullptr, e0 = nullptr, e1 = nullptr;  // e0 / e1: timing events, created on first use
   bool pending = false;
   bool timed = false;
   bool external_target = false;
@@ -83,6 +83,9 @@ struct nid_ctx {
   int math_mode = NID_MATH_FAST;
   double *ctab_dev = nullptr;
   Slot slots[NID_SLOTS];
+  // what the slots' buffers are carved from (one allocation per kind)
+  double *slab_cellout = nullptr, *slab_reduced = nullptr, *slab_quad = nullptr, *slab_gpart = nullptr, *slab_reduced_host = nullptr;
+  unsigned *slab_ticket = nullptr;
   std::string last_error;
 };
 
@@ -375,6 +378,13 @@ int check_ready(nid_ctx *ctx) {
   return NID_OK;
 }
 
+// timing events of a slot (nid_enable_timing, nid_time_launches): created when first needed
+int timing_events(nid_ctx *ctx, Slot &S) {
+  if (!S.e0) NID_HIP(ctx, hipEventCreate(&S.e0));
+  if (!S.e1) NID_HIP(ctx, hipEventCreate(&S.e1));
+  return NID_OK;
+}
+
 int launch_slot(nid_ctx *ctx, int slot, const Pose &pose, int want_jac, double delta,
                 void *reduced_target) {
   int rc = check_ready(ctx);
@@ -405,6 +415,7 @@ int launch_slot(nid_ctx *ctx, int slot, const Pose &pose, int want_jac, double d
   // 2.2x slower); the batched pipeline of nid_run_sequence is the one that alternates
   hipStream_t st = ctx->stream;
   S.timed = ctx->timing;
+  if (S.timed) { rc = timing_events(ctx, S); if (rc) return rc; }
   if (S.timed) NID_HIP(ctx, hipEventRecord(S.e0, st));
   rc = launch_eval(ctx, P, want_jac != 0, st);
   if (rc) return rc;
@@ -460,6 +471,7 @@ int launch_batch(nid_ctx *ctx, int first_slot, int n, const Pose *poses, int wan
     NID_HIP(ctx, hipMemcpyAsync(ctx->ext_dev[ring], recs, (size_t)n * sizeof(SlotArgs), hipMemcpyHostToDevice, st));
   Slot &S0 = ctx->slots[first_slot];
   S0.timed = ctx->timing;
+  if (S0.timed) { rc = timing_events(ctx, S0); if (rc) return rc; }
   if (S0.timed) NID_HIP(ctx, hipEventRecord(S0.e0, st));
   rc = launch_eval(ctx, P, want_jac != 0, st, n);
   if (rc) return rc;
@@ -704,26 +716,40 @@ int nid_create(const nid_config *cfg, nid_ctx **out) {
     if (hipMemcpy(ctx->ctab_dev, coef.data(), coef.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess)
       return fail(NID_ERR_HIP);
   }
-  for (int s = 0; s < NID_SLOTS; s++) {
-    Slot &S = ctx->slots[s];
-    if ((rc = dev_alloc(ctx, &S.cellout_dev, (size_t)g.nloc * kCellOut))) return fail(rc);
-    if ((rc = dev_alloc(ctx, &S.reduced_dev, kReducedLen))) return fail(rc);
-    if ((rc = dev_alloc(ctx, &S.quad_dev, (size_t)g.nloc * kQuad))) return fail(rc);
-    if ((rc = dev_alloc(ctx, &S.ticket_dev, (size_t)ctx->ngroups + 4))) return fail(rc);
-    if (hipMemset(S.ticket_dev, 0, ((size_t)ctx->ngroups + 4) * sizeof(unsigned)) != hipSuccess) return fail(NID_ERR_HIP);
-    if ((rc = dev_alloc(ctx, &S.gpart_dev, (size_t)ctx->ngroups * kQuad))) return fail(rc);
-    if (hipHostMalloc(reinterpret_cast<void **>(&S.cellout_host), (size_t)g.nloc * kCellOut * sizeof(double),
+  {
+    // Per-slot buffers come out of ONE allocation per kind (NID_SLOTS x 5 hipMalloc + 2 hipHostMalloc calls used to be
+    // most of the context's creation time); the slots hold pointers into the slabs.
+    const size_t n_cellout = (size_t)g.nloc * kCellOut, n_quad = (size_t)g.nloc * kQuad;
+    const size_t n_ticket = ((size_t)ctx->ngroups + 4 + 3) & ~(size_t)3, n_gpart = (size_t)ctx->ngroups * kQuad;
+    const size_t n_rhost = kReducedLen + 2;  // [32 doubles][u64 sequence word][pad]
+    if ((rc = dev_alloc(ctx, &ctx->slab_cellout, n_cellout * NID_SLOTS))) return fail(rc);
+    if ((rc = dev_alloc(ctx, &ctx->slab_reduced, (size_t)kReducedLen * NID_SLOTS))) return fail(rc);
+    if ((rc = dev_alloc(ctx, &ctx->slab_quad, n_quad * NID_SLOTS))) return fail(rc);
+    if ((rc = dev_alloc(ctx, &ctx->slab_ticket, n_ticket * NID_SLOTS))) return fail(rc);
+    if (hipMemset(ctx->slab_ticket, 0, n_ticket * NID_SLOTS * sizeof(unsigned)) != hipSuccess) return fail(NID_ERR_HIP);
+    if ((rc = dev_alloc(ctx, &ctx->slab_gpart, n_gpart * NID_SLOTS))) return fail(rc);
+    if (hipHostMalloc(reinterpret_cast<void **>(&ctx->slab_reduced_host), n_rhost * NID_SLOTS * sizeof(double),
                       hipHostMallocMapped) != hipSuccess) return fail(NID_ERR_NOMEM);
-    if (hipHostGetDevicePointer(reinterpret_cast<void **>(&S.cellout_host_devptr), S.cellout_host, 0) != hipSuccess)
+    std::memset(ctx->slab_reduced_host, 0, n_rhost * NID_SLOTS * sizeof(double));
+    double *rhost_dev = nullptr;
+    if (hipHostGetDevicePointer(reinterpret_cast<void **>(&rhost_dev), ctx->slab_reduced_host, 0) != hipSuccess) return fail(NID_ERR_HIP);
+    for (int s = 0; s < NID_SLOTS; s++) {
+      Slot &S = ctx->slots[s];
+      S.cellout_dev = ctx->slab_cellout + n_cellout * s;
+      S.reduced_dev = ctx->slab_reduced + (size_t)kReducedLen * s;
+      S.quad_dev = ctx->slab_quad + n_quad * s;
+      S.ticket_dev = ctx->slab_ticket + n_ticket * s;
+      S.gpart_dev = ctx->slab_gpart + n_gpart * s;
+      S.reduced_host = ctx->slab_reduced_host + n_rhost * s;
+      S.reduced_host_devptr = rhost_dev + n_rhost * s;
+      if (hipEventCreateWithFlags(&S.done, hipEventDisableTiming) != hipSuccess) return fail(NID_ERR_HIP);
+    }
+    // the blocking per-cell calls use slot 0 only: its per-cell outputs can go straight to mapped pinned memory
+    Slot &S0 = ctx->slots[0];
+    if (hipHostMalloc(reinterpret_cast<void **>(&S0.cellout_host), n_cellout * sizeof(double), hipHostMallocMapped) != hipSuccess)
+      return fail(NID_ERR_NOMEM);
+    if (hipHostGetDevicePointer(reinterpret_cast<void **>(&S0.cellout_host_devptr), S0.cellout_host, 0) != hipSuccess)
       return fail(NID_ERR_HIP);
-    if (hipHostMalloc(reinterpret_cast<void **>(&S.reduced_host), (kReducedLen + 2) * sizeof(double),
-                      hipHostMallocMapped) != hipSuccess) return fail(NID_ERR_NOMEM);
-    std::memset(S.reduced_host, 0, (kReducedLen + 2) * sizeof(double));
-    if (hipHostGetDevicePointer(reinterpret_cast<void **>(&S.reduced_host_devptr), S.reduced_host, 0) != hipSuccess)
-      return fail(NID_ERR_HIP);
-    if (hipEventCreateWithFlags(&S.done, hipEventDisableTiming) != hipSuccess) return fail(NID_ERR_HIP);
-    if (hipEventCreate(&S.e0) != hipSuccess || hipEventCreate(&S.e1) != hipSuccess ||
-        hipEventCreate(&S.e2) != hipSuccess) return fail(NID_ERR_HIP);
   }
   for (int r = 0; r < nid_ctx::kExtRing; r++) {
     if ((rc = dev_alloc(ctx, &ctx->ext_dev[r], (size_t)kMaxBatchExt))) return fail(rc);
@@ -746,16 +772,15 @@ int nid_destroy(nid_ctx *ctx) {
   (void)hipFree(ctx->Nc_dev); (void)hipFree(ctx->Href_dev); (void)hipFree(ctx->ctab_dev);
   (void)hipFree(ctx->dbg_u); (void)hipFree(ctx->dbg_v); (void)hipFree(ctx->dbg_ic);
   (void)hipFree(ctx->dbg_wc); (void)hipFree(ctx->dbg_jc); (void)hipFree(ctx->dbg_stamps);
+  (void)hipFree(ctx->slab_cellout); (void)hipFree(ctx->slab_reduced); (void)hipFree(ctx->slab_quad);
+  (void)hipFree(ctx->slab_ticket); (void)hipFree(ctx->slab_gpart);
+  if (ctx->slab_reduced_host) (void)hipHostFree(ctx->slab_reduced_host);
   for (int s = 0; s < NID_SLOTS; s++) {
     Slot &S = ctx->slots[s];
-    (void)hipFree(S.cellout_dev); (void)hipFree(S.reduced_dev);
-    (void)hipFree(S.quad_dev); (void)hipFree(S.ticket_dev); (void)hipFree(S.gpart_dev);
     if (S.cellout_host) (void)hipHostFree(S.cellout_host);
-    if (S.reduced_host) (void)hipHostFree(S.reduced_host);
     if (S.done) (void)hipEventDestroy(S.done);
     if (S.e0) (void)hipEventDestroy(S.e0);
     if (S.e1) (void)hipEventDestroy(S.e1);
-    if (S.e2) (void)hipEventDestroy(S.e2);
   }
   for (int r = 0; r < nid_ctx::kExtRing; r++) {
     (void)hipFree(ctx->ext_dev[r]);
@@ -1255,6 +1280,7 @@ int nid_time_launches(nid_ctx *ctx, int n, const double *poses7, int want_jac, d
   Pose p[kMaxBatchExt];
   for (int k = 0; k < n; k++) pose_from_pose7(poses7 + 7 * k, ctx->xform, &p[k]);
   Slot &S0 = ctx->slots[0];
+  { int rc = timing_events(ctx, S0); if (rc) return rc; }
   NID_HIP(ctx, hipEventRecord(S0.e0, ctx->stream));
   for (int r = 0; r < repeats; r++) {
     int rc = launch_batch(ctx, 0, n, p, want_jac, delta, nullptr, false, /*relaunch_ok=*/r > 0);

@@ -68,7 +68,7 @@ struct Tiles {
 };
 
 constexpr int kMaxBatch = 16;     // candidate poses of one launch whose arguments ride in the kernel arguments
-constexpr int kMaxBatchExt = 64;  // ... or, beyond that, in a device-resident SlotArgs array (EvalParams::slots_ext)
+constexpr int kMaxBatchExt = 256;  // ... or, beyond that, in a device-resident SlotArgs array (EvalParams::slots_ext)
 // FAST math mode: per span 4 basis functions x (4 value + 3 derivative) polynomial coefficients in
 // t = u - floor(u):  B_k = ((a3 t + a2) t + a1) t + a0,  B_k' = (d2 t + d1) t + d0
 constexpr int kCoefRow = 28;

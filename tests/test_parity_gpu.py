@@ -566,13 +566,13 @@ def test_degenerate_inputs(capi, oracle, synth, pair_S):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n", [16, 17, 64])
+@pytest.mark.parametrize("n", [16, 17, 64, 256])
 def test_full_batches(capi, synth, pair_S, n):
-    """16 poses = the most whose per-pose records travel as kernel arguments (3.7 KB); 17 and NID_MAX_BATCH = 64
+    """16 poses = the most whose per-pose records travel as kernel arguments (3.7 KB); 17, 64 and NID_MAX_BATCH = 256
     go through the device-resident record array.  Either way == the single launches, bit for bit."""
     ctx = capi.from_pair(pair_S, 8)
     ctx.compute_href(pair_S.pose_init)
-    assert capi.NID_MAX_BATCH == 64
+    assert capi.NID_MAX_BATCH == 256
     poses = [synth.perturb_pose7(pair_S.pose_init, [1e-4 * k, -5e-5 * k, 0], [0, 1e-4 * k, 1e-3]) for k in range(n)]
     for rep in range(6):                     # more launches than ring entries: records are recycled
         ctx.launch_batch(32, poses, DELTA)
@@ -582,7 +582,7 @@ def test_full_batches(capi, synth, pair_S, n):
         assert np.array_equal(_bits(H), _bits(got[k][0])) and np.array_equal(_bits(b), _bits(got[k][1]))
         assert chi2 == got[k][2] and na == got[k][3]
     with pytest.raises(capi.NidError):
-        ctx.launch_batch(0, [poses[0]] * 65, DELTA)
+        ctx.launch_batch(0, [poses[0]] * 257, DELTA)
 
 
 @pytest.mark.gpu

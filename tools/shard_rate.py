@@ -13,16 +13,16 @@ ncell = pair.cell ** 2
 delta = float(np.sqrt(0.95))
 poses = np.stack([synth.perturb_pose7(pair.pose_init, [1e-4 * k, 0, 0], [0, 1e-4 * k, 0]) for k in range(256)])
 print(f"config {cfg}: {ncell} cells; evaluations/s of rank 0 of N on its cell range (nid_run_sequence, two streams)")
-print("   N | cells | batch 16 | batch 32 | batch 64 | speed-up of the evaluation rate over N = 1 (best batch)")
+print("   N | cells | batch 16 | batch 64 | batch 256 | speed-up of the evaluation rate over N = 1 (best batch)")
 base = None
 for n in (1, 2, 4, 8, 16, 32):
     lo, hi = capi.cell_range(0, n, ncell)
     ctx = capi.from_pair(pair, 8, cell_begin=lo, cell_end=hi)
     ctx.compute_href(pair.pose_init)
     row = []
-    for b in (16, 32, 64):
-        seq = poses[np.arange(64 * 200) % 256]
-        ctx.run_sequence(seq[:64 * 20], delta, batch=b, collect=False)
+    for b in (16, 64, 256):
+        seq = poses[np.arange(256 * 60) % 256]
+        ctx.run_sequence(seq[:256 * 8], delta, batch=b, collect=False)
         t0 = time.perf_counter()
         ctx.run_sequence(seq, delta, batch=b, collect=False)
         row.append(len(seq) / (time.perf_counter() - t0))
