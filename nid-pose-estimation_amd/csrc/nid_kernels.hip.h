@@ -1075,7 +1075,7 @@ struct LatPix {
 // the main pass touches no global memory at all.  One workgroup per CU leaves 128+ VGPRs per lane for that.
 // Same operations on the same values in the same per-lane order as the loop form: bit-identical results (tested).
 template <int NT, bool JAC, bool STRICT, int NB, bool DBG, bool EXT = false, int LAT = 0>
-__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(STRICT ? 4 : ((LAT || NT >= 512) ? 4 : NID_FAST_WAVES)))) void k_eval2(EvalParams P) {
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu((STRICT || DBG || LAT || NT >= 512) ? 4 : NID_FAST_WAVES))) void k_eval2(EvalParams P) {
   static_assert(LAT == 0 || (!STRICT && !EXT), "the latency form exists for FAST math launches of <= kMaxBatch poses (DBG: phase stamps only)");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int NC = eval_hist_copies(NT);
@@ -1227,15 +1227,28 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(STRICT ? 4 :
       if (DBG && P.dbg_u && !P.dbg_jac && pose_idx == 0 && f.jr >= 0) dump_pixel(s, f, ic, jc, wc);
     }
   } else {
+    // Main pass of the loop form: the NEXT round's point and bin index (7 registers) are fetched while this round is
+    // worked on, and this round's reference weights are fetched behind its window loads: a round then exposes ONE
+    // memory round trip (the window) instead of two.  Both phases; the Jacobian phase ends at 95 of its 96 VGPRs.
+    // Measured: 1030 -> 1008 us per 256-pose launch (profiles/r02_ablations_A.txt).
+    TileIn pre;
     auto cost_round = [&](int sb, auto second_pass) -> bool {
       constexpr bool SECOND = decltype(second_pass)::value;
       const int s = sb + lane;
       TileIn tin;
       PixelFront f;
-      load_tile(P, base + (unsigned)s, plane, tin);
+      if (!SECOND) {
+        tin = pre;
+        if (sb + NT < g.pstride) load_tile_xyz(P, base + (unsigned)(s + NT), pre);
+#pragma unroll
+        for (int k = 0; k < 4; k++) tin.wr[k] = 0.0;
+      } else {
+        load_tile(P, base + (unsigned)s, plane, tin);
+      }
       pixel_front<false>(P, SA, tin, f);
       WinC wc2;
       load_win_centre(P, f.w.wx, f.w.wy, wc2);
+      if (!SECOND) load_tile_w(P, base + (unsigned)s, plane, tin);
       // fixed-tap sample (a convex combination of u8 taps: never negative), computed for every lane -- lanes
       // without a sample hold a harmless window
       double ic = sample_fast_c(wc2, f.u, f.v);
@@ -1259,7 +1272,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(STRICT ? 4 :
         double pc;
         jc = fast_bin(ic, S, pc);
         bspline4_poly<false>(pc, jc, rtab, wc, dw);
-        hist_add(f.jr, jc, f.wr, wc);
+        hist_add(f.jr, jc, SECOND ? f.wr : tin.wr, wc);
       } else {
         ic = NAN;
       }
@@ -1312,6 +1325,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(STRICT ? 4 :
         }
       }
     } else {
+      if (wave_base < g.pstride) load_tile_xyz(P, base + (unsigned)(wave_base + lane), pre);
 #pragma clang loop unroll(disable)
       for (int sb = wave_base; sb < g.pstride; sb += NT, r++)
         if (cost_round(sb, std::false_type{})) rare_rounds |= 1ull << min(r, 63);
@@ -1493,15 +1507,28 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(STRICT ? 4 :
     // Two passes like the cost phase, with the same classification on the same values (gradient_fast_interior's
     // centre sample IS sample_fast_interior's): both phases take the same decisions and use the same
     // intensity (Q7).
+    TileIn prej;  // next round's point and bin index, as in the cost phase
     auto jac_round = [&](int sb, auto second_pass) {
       constexpr bool SECOND = decltype(second_pass)::value;
       const int s = sb + lane;
       TileIn tin;
       PixelFront f;
-      load_tile(P, base + (unsigned)s, plane, tin);
+      if (!SECOND) {
+        tin = prej;
+        if (sb + NT < g.pstride) load_tile_xyz(P, base + (unsigned)(s + NT), prej);
+#pragma unroll
+        for (int k = 0; k < 4; k++) tin.wr[k] = 0.0;
+      } else {
+        load_tile(P, base + (unsigned)s, plane, tin);
+      }
       pixel_front<false>(P, SA, tin, f);
       WinJ wj;
       load_win_jac(P, f.w.wx, f.w.wy, wj);
+      if (!SECOND) {
+        load_tile_w(P, base + (unsigned)s, plane, tin);
+#pragma unroll
+        for (int k = 0; k < 4; k++) f.wr[k] = tin.wr[k];
+      }
       double ic, gx, gy;
       gradient_fast_j(wj, f.u, f.v, gx, gy, ic);  // every lane, see the cost phase
 #ifdef NID_EXP_NO_GUARD
@@ -1550,6 +1577,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(STRICT ? 4 :
         }
       rare2 = rare_rounds;
     } else {
+      if (wave_base < g.pstride) load_tile_xyz(P, base + (unsigned)(wave_base + lane), prej);
 #pragma clang loop unroll(disable)
       for (int sb = wave_base; sb < g.pstride; sb += NT, r++)
         if (jac_round(sb, std::false_type{})) rare2 |= 1ull << min(r, 63);
