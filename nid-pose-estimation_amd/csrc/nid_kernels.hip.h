@@ -1128,6 +1128,15 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu((STRICT || D
     return;
   }
   NID_STAMP(0);
+  const int copy = tid & (NC - 1);
+  const unsigned base = (unsigned)cl * (unsigned)g.pstride;
+  const unsigned plane = (unsigned)g.nloc * (unsigned)g.pstride;
+  // pstride is a multiple of 64, so a wave is either entirely inside the tile or entirely past
+  // it: the round loops run on a wave-uniform bound and the last round costs idle waves nothing
+  const int wave_base = __builtin_amdgcn_readfirstlane(tid & ~63);
+  const int lane = tid & 63;
+  TileIn pre, prej;  // loop form of the FAST pixel loops: the next round's point and bin index (see cost_round)
+  (void)pre; (void)prej;
   for (int i = tid; i < nbins * (NC + kFineLevels); i += NT) hist[i] = 0ull;  // the copies and the fine levels behind them
   if (STRICT) {
     if (tid < S * 6) {
@@ -1137,13 +1146,6 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu((STRICT || D
   } else {
     for (int i = tid; i < S * kCoefRow; i += NT) rtab[i] = P.ctab[i];
   }
-  const int copy = tid & (NC - 1);
-  const unsigned base = (unsigned)cl * (unsigned)g.pstride;
-  const unsigned plane = (unsigned)g.nloc * (unsigned)g.pstride;
-  // pstride is a multiple of 64, so a wave is either entirely inside the tile or entirely past
-  // it: the round loops run on a wave-uniform bound and the last round costs idle waves nothing
-  const int wave_base = __builtin_amdgcn_readfirstlane(tid & ~63);
-  const int lane = tid & 63;
   __syncthreads();
   NID_STAMP(1);
 
@@ -1231,7 +1233,6 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu((STRICT || D
     // worked on, and this round's reference weights are fetched behind its window loads: a round then exposes ONE
     // memory round trip (the window) instead of two.  Both phases; the Jacobian phase ends at 95 of its 96 VGPRs.
     // Measured: 1030 -> 1008 us per 256-pose launch (profiles/r02_ablations_A.txt).
-    TileIn pre;
     auto cost_round = [&](int sb, auto second_pass) -> bool {
       constexpr bool SECOND = decltype(second_pass)::value;
       const int s = sb + lane;
@@ -1507,7 +1508,6 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu((STRICT || D
     // Two passes like the cost phase, with the same classification on the same values (gradient_fast_interior's
     // centre sample IS sample_fast_interior's): both phases take the same decisions and use the same
     // intensity (Q7).
-    TileIn prej;  // next round's point and bin index, as in the cost phase
     auto jac_round = [&](int sb, auto second_pass) {
       constexpr bool SECOND = decltype(second_pass)::value;
       const int s = sb + lane;
