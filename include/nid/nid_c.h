@@ -151,7 +151,7 @@ int nid_normal_equations(nid_ctx *ctx, const double *pose7, int want_jac, double
 
 /* Non-blocking forms for pipelining and multi-GPU.  `slot` in [0, NID_SLOTS):
  * results of a launch stay in the slot until nid_wait() collects them. */
-#define NID_SLOTS 512
+#define NID_SLOTS 1024
 #define NID_MAX_BATCH 256 /* poses per launch (up to 16 travel as kernel arguments, more through a device array) */
 #define NID_REDUCED_LEN 32 /* [0]=chi2 [1..6]=b [7..27]=H upper triangle row-major [28]=n_active */
 int nid_launch(nid_ctx *ctx, int slot, const double *pose7, int want_jac, double huber_delta);

@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("NID_HIP_LIB") or os.path.join(_HERE, "libnid_hip.so")  # NID_HIP_LIB: experiment builds of the same C-ABI
 
 NID_OK = 0
-NID_SLOTS = 512
+NID_SLOTS = 1024
 NID_MAX_BATCH = 256
 NID_REDUCED_LEN = 32
 NID_CELL_OUT = 10

@@ -673,7 +673,8 @@ int nid_create(const nid_config *cfg, nid_ctx **out) {
   const int hs = std::min(62 - bits, 51);
   ctx->hist_scale = std::ldexp(1.0, hs);
   ctx->hist_inv_scale = std::ldexp(1.0, -hs);
-  if ((size_t)g.nloc * (size_t)g.pstride >= ((size_t)1 << 29)) { delete ctx; return NID_ERR_UNSUPPORTED; }
+  // 32-bit byte offsets into the four W planes (load_tile_w): 4 planes x 8 B x nloc x pstride < 2^32
+  if ((size_t)g.nloc * (size_t)g.pstride >= ((size_t)1 << 27)) { delete ctx; return NID_ERR_UNSUPPORTED; }
   if (const char *bt = getenv("NID_BLOCK_THREADS")) {  // tuning: both kinds of launches
     const int v = atoi(bt);
     if (v == 128 || v == 256 || v == 512 || v == 1024) ctx->jac_threads = ctx->cost_threads = v;

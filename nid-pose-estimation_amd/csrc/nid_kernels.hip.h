@@ -183,9 +183,16 @@ struct Win {
   int wx, wy;
 };
 
-__device__ __forceinline__ WRow load_row_unaligned(const int16_t *p) {
+// window loads as uniform 64-bit base + zero-extended 32-bit lane BYTE offset (the saddr + voffset form of global_load:
+// no per-lane 64-bit address arithmetic, one VGPR per address instead of two); `elem` counts int16 elements
+__device__ __forceinline__ WRow load_row_at(const int16_t *base, unsigned elem) {
   WRow v;
-  __builtin_memcpy(&v, p, 8);
+  __builtin_memcpy(&v, reinterpret_cast<const char *>(base) + (elem << 1), 8);
+  return v;
+}
+__device__ __forceinline__ unsigned load_u32_at(const int16_t *base, unsigned elem) {
+  unsigned v;
+  __builtin_memcpy(&v, reinterpret_cast<const char *>(base) + (elem << 1), 4);
   return v;
 }
 
@@ -818,9 +825,10 @@ __device__ __forceinline__ void load_tile_xyz(const EvalParams &P, unsigned gi, 
   t.x = ld_f64(P.t.X, bo); t.y = ld_f64(P.t.Y, bo); t.z = ld_f64(P.t.Z, bo);
 }
 __device__ __forceinline__ void load_tile_w(const EvalParams &P, unsigned gi, unsigned plane, TileIn &t) {
-  const unsigned bo = gi << 3;
+  // one uniform base, 32-bit lane offsets into the four planes (4 * 8 * nloc * pstride < 2^32, nid_create)
+  const unsigned bo = gi << 3, p8 = plane << 3;
 #pragma unroll
-  for (int k = 0; k < 4; k++) t.wr[k] = ld_f64(P.t.W + (size_t)k * plane, bo);
+  for (int k = 0; k < 4; k++) t.wr[k] = ld_f64(P.t.W, bo + (unsigned)k * p8);
 }
 __device__ __forceinline__ void load_tile(const EvalParams &P, unsigned gi, unsigned plane, TileIn &t) {
   load_tile_xyz(P, gi, t);
@@ -831,34 +839,29 @@ __device__ __forceinline__ void load_tile(const EvalParams &P, unsigned gi, unsi
 __device__ __forceinline__ void load_window(const EvalParams &P, Win &w) {
   const unsigned st = (unsigned)P.im1_stride;
   const unsigned po = (unsigned)(w.wy + 1) * st + (unsigned)(w.wx + 1);
-  w.r0 = load_row_unaligned(P.im1s + po);
-  w.r1 = load_row_unaligned(P.im1s + (po + st));
-  w.r2 = load_row_unaligned(P.im1s + (po + 2u * st));
-  w.r3 = load_row_unaligned(P.im1s + (po + 3u * st));
+  w.r0 = load_row_at(P.im1s, po);
+  w.r1 = load_row_at(P.im1s, po + st);
+  w.r2 = load_row_at(P.im1s, po + 2u * st);
+  w.r3 = load_row_at(P.im1s, po + 3u * st);
 }
 
 // What the FAST main passes load instead of the whole window.  Cost phase: the 2x2 cell of the sample = taps 1, 2
 // of window rows 1 and 2 (two unaligned dwords).  Jacobian phase: rows 1 and 2 whole, of rows 0 and 3 taps 1, 2.
 struct WinC { unsigned c1, c2; };
 struct WinJ { WRow r1, r2; unsigned c0, c3; };
-__device__ __forceinline__ unsigned load_u32_unaligned(const int16_t *p) {
-  unsigned v;
-  __builtin_memcpy(&v, p, 4);
-  return v;
-}
 __device__ __forceinline__ void load_win_centre(const EvalParams &P, int wx, int wy, WinC &w) {
   const unsigned st = (unsigned)P.im1_stride;
   const unsigned po = (unsigned)(wy + 2) * st + (unsigned)(wx + 2);  // row 1, tap 1
-  w.c1 = load_u32_unaligned(P.im1s + po);
-  w.c2 = load_u32_unaligned(P.im1s + (po + st));
+  w.c1 = load_u32_at(P.im1s, po);
+  w.c2 = load_u32_at(P.im1s, po + st);
 }
 __device__ __forceinline__ void load_win_jac(const EvalParams &P, int wx, int wy, WinJ &w) {
   const unsigned st = (unsigned)P.im1_stride;
   const unsigned po = (unsigned)(wy + 1) * st + (unsigned)(wx + 1);
-  w.c0 = load_u32_unaligned(P.im1s + (po + 1u));
-  w.r1 = load_row_unaligned(P.im1s + (po + st));
-  w.r2 = load_row_unaligned(P.im1s + (po + 2u * st));
-  w.c3 = load_u32_unaligned(P.im1s + (po + 3u * st + 1u));
+  w.c0 = load_u32_at(P.im1s, po + 1u);
+  w.r1 = load_row_at(P.im1s, po + st);
+  w.r2 = load_row_at(P.im1s, po + 2u * st);
+  w.c3 = load_u32_at(P.im1s, po + 3u * st + 1u);
 }
 __device__ __forceinline__ int lo16(unsigned w) { return __builtin_amdgcn_sbfe((int)w, 0u, 16u); }
 __device__ __forceinline__ int hi16(unsigned w) { return __builtin_amdgcn_sbfe((int)w, 16u, 16u); }
