@@ -251,8 +251,10 @@ def main():
         dist.init_process_group(backend="gloo", rank=rank, world_size=world)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback of the product path)")
-    if not rccl:
-        local_rank = local_rank % torch.cuda.device_count()
+    # one visible device per process (HIP_VISIBLE_DEVICES set per rank by a launcher) or all of them: either way the
+    # rank's device is LOCAL_RANK modulo what it can see.  With --backend gloo several ranks may share a device (tests);
+    # RCCL itself refuses two ranks on one device and the library reports that.
+    local_rank = local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
