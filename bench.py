@@ -58,6 +58,9 @@ def parse():
                          "clocks are up and the kernel instantiation it uses is in the instruction caches (0 = off)")
     ap.add_argument("--group", type=int, default=0,
                     help="N>1 / --shards: kernel launches per exchange (0 = 2 launches of --batch poses)")
+    ap.add_argument("--partition", choices=["interleaved", "contiguous"], default="interleaved",
+                    help="N>1 / --shards: which cells a rank owns -- every N-th cell (balanced: inactive and border cells "
+                         "cluster in the image) or SURVEY 8e's contiguous range [k*cells/N, (k+1)*cells/N)")
     ap.add_argument("--shards", type=int, default=1,
                     help="N=1 only: shard the cells over SHARDS contexts on the one GPU through the multi-GPU layer "
                          "(host sum); exercises the N>1 code path on a one-GPU box, not the metric")
@@ -267,8 +270,9 @@ def main():
     multi = world > 1 or args.shards > 1 or args.rccl_one_rank
     rccl_ranks_seen = None
     if multi:
+        part = capi.PARTITION_INTERLEAVED if args.partition == "interleaved" else capi.PARTITION_CONTIGUOUS
         if world > 1:
-            m = capi.multi_from_pair(pair, args.bins, devices=[local_rank], rank=rank, world=world, math=math_mode)
+            m = capi.multi_from_pair(pair, args.bins, devices=[local_rank], rank=rank, world=world, math=math_mode, partition=part)
             if rccl:
                 ids = [capi.rccl_unique_id() if rank == 0 else None]
                 dist.broadcast_object_list(ids, src=0)
@@ -284,7 +288,7 @@ def main():
             m.comm_init(capi.rccl_unique_id())
             rccl_ranks_seen = m.comm_ranks()
         else:
-            m = capi.multi_from_pair(pair, args.bins, devices=[local_rank] * args.shards, math=math_mode)
+            m = capi.multi_from_pair(pair, args.bins, devices=[local_rank] * args.shards, math=math_mode, partition=part)
         if args.block_threads:
             m.set_block_threads(args.block_threads)
         ctx = None
@@ -512,7 +516,7 @@ def main():
                             f"histograms, cost+Jacobian+Huber 6x6 reduction per step, "
                             f"{int((cnt >= 300).sum())} active cells",
                 "cells": ncell, "bins": args.bins,
-                "parallelism": (f"cells/{world}" if world > 1 else (f"cells/{args.shards} shards on one GPU" if multi else "cells/1"))
+                "parallelism": ((f"cells/{world} ({args.partition})" if world > 1 else (f"cells/{args.shards} shards on one GPU ({args.partition})" if multi else "cells/1")))
                                + ("" if not multi else (f" + {'RCCL ncclAllReduce from C++' if ((world > 1 and rccl) or args.rccl_one_rank) else ('gloo exchange hook' if world > 1 else 'host sum')}"
                                                         f" of [{G * Bm},32] f64 per {G} launches")),
                 "pipelining": (f"{B} candidate poses per kernel launch, 2 launches in flight on 2 streams, each pose's 6x6 "

@@ -81,6 +81,9 @@ const char *nid_last_error(const nid_ctx *ctx); /* text of the last HIP error */
 int nid_device_count(void);                     /* 0 when no GPU; never initialises a context */
 
 int nid_create(const nid_config *cfg, nid_ctx **out);
+/* the same for a STRIDED cell set: the context owns cells cell_begin, cell_begin + stride, ... < cell_end
+ * (interleaved shards of include/nid/nid_multi.h); stride 1 = nid_create */
+int nid_create_strided(const nid_config *cfg, int32_t cell_stride, nid_ctx **out);
 int nid_destroy(nid_ctx *ctx);
 int nid_set_options(nid_ctx *ctx, int jac_bound_mode, int xform_mode);
 int nid_set_math_mode(nid_ctx *ctx, int mode);

@@ -53,6 +53,16 @@ int nid_multi_create(const nid_config *cfg, const int32_t *devices, int32_t n, n
 /* One process per GPU: this process is rank `rank` of `world` and owns that shard on `device`.  Evaluations
  * need nid_multi_comm_init (world > 1). */
 int nid_multi_create_rank(const nid_config *cfg, int32_t device, int32_t rank, int32_t world, nid_multi **out);
+/* Which cells a shard owns.  CONTIGUOUS (the two calls above): shard k of K owns [k*cells/K, (k+1)*cells/K).
+ * INTERLEAVED: shard k owns cells k, k + K, k + 2K, ... -- cells differ in cost (inactive ones cost nothing, border
+ * ones less than interior ones) and cluster in the image, so contiguous ranges load the shards unequally (measured:
+ * the last of 8 ranks holds every inactive cell of the test pair, profiles/r02_rank_rates.txt); interleaving spreads
+ * them.  Results do not depend on the partition beyond the order of the partial sums.  `rank` / `world` as in
+ * nid_multi_create_rank (world == 1: n shards in this process; world > 1: n must be 1). */
+#define NID_PARTITION_CONTIGUOUS 0
+#define NID_PARTITION_INTERLEAVED 1
+int nid_multi_create_partitioned(const nid_config *cfg, const int32_t *devices, int32_t n, int32_t rank, int32_t world,
+                                 int32_t partition, nid_multi **out);
 int nid_multi_destroy(nid_multi *m);
 const char *nid_multi_last_error(const nid_multi *m);
 int nid_multi_shards(const nid_multi *m);          /* shards in THIS process */

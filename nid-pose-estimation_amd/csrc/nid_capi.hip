@@ -542,7 +542,7 @@ int evaluate_common(nid_ctx *ctx, const Pose &pose, int want_jac, double *Ht, do
   if (ctx->dbg_enabled) NID_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the dump is read back by the runtime
   for (int cl = 0; cl < ctx->g.nloc; cl++) {
     const double *o = S.cellout_host + (size_t)cl * kCellOut;
-    const int c = ctx->g.cell_begin + cl;
+    const int c = ctx->g.cell_begin + cl * ctx->g.cell_stride;
     if (Ht) Ht[c] = o[0];
     if (Hj) Hj[c] = o[1];
     if (err) err[c] = o[2];
@@ -565,8 +565,8 @@ int href_common(nid_ctx *ctx, const Pose &pose, int32_t *bs_counter, double *Hre
   NID_HIP(ctx, hipMemcpyAsync(hr.data(), ctx->Href_dev, nloc * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   NID_HIP(ctx, hipStreamSynchronize(ctx->stream));
   for (int cl = 0; cl < nloc; cl++) {
-    if (bs_counter) bs_counter[ctx->g.cell_begin + cl] = nc[cl];
-    if (Href) Href[ctx->g.cell_begin + cl] = hr[cl];
+    if (bs_counter) bs_counter[ctx->g.cell_begin + cl * ctx->g.cell_stride] = nc[cl];
+    if (Href) Href[ctx->g.cell_begin + cl * ctx->g.cell_stride] = hr[cl];
   }
   if (bs_value || bs_index) {
     const Geometry &g = ctx->g;
@@ -576,7 +576,7 @@ int href_common(nid_ctx *ctx, const Pose &pose, int32_t *bs_counter, double *Hre
     if (bs_value) NID_HIP(ctx, hipMemcpy(W.data(), ctx->t.W, 4 * plane * sizeof(double), hipMemcpyDeviceToHost));
     NID_HIP(ctx, hipMemcpy(JR.data(), ctx->t.JR, plane, hipMemcpyDeviceToHost));
     for (int cl = 0; cl < g.nloc; cl++) {
-      const int c = g.cell_begin + cl, ci = c / g.cell_num, cj = c % g.cell_num;
+      const int c = g.cell_begin + cl * g.cell_stride, ci = c / g.cell_num, cj = c % g.cell_num;
       for (int s = 0; s < g.ps; s++) {
         const size_t id = (size_t)(ci * g.rb + s / g.cb) * g.cols + cj * g.cb + s % g.cb;
         const size_t gi = (size_t)cl * g.pstride + s;
@@ -643,8 +643,10 @@ int nid_device_count(void) {
   return n;
 }
 
-int nid_create(const nid_config *cfg, nid_ctx **out) {
-  if (!cfg || !out) return NID_ERR_INVALID_ARG;
+int nid_create(const nid_config *cfg, nid_ctx **out) { return nid_create_strided(cfg, 1, out); }
+
+int nid_create_strided(const nid_config *cfg, int32_t cell_stride, nid_ctx **out) {
+  if (!cfg || !out || cell_stride < 1) return NID_ERR_INVALID_ARG;
   *out = nullptr;
   if (cfg->bs_degree != 3 || cfg->bin_num < 4 || cfg->bin_num > kMaxBins || cfg->cell_num < 1 ||
       cfg->rows < cfg->cell_num || cfg->cols < cfg->cell_num)
@@ -663,7 +665,7 @@ int nid_create(const nid_config *cfg, nid_ctx **out) {
   g.rows = cfg->rows; g.cols = cfg->cols; g.cell_num = cfg->cell_num;
   g.rb = cfg->rows / cfg->cell_num; g.cb = cfg->cols / cfg->cell_num;
   g.ps = g.rb * g.cb; g.pstride = (g.ps + 63) & ~63;
-  g.cell_begin = cb_; g.nloc = ce_ - cb_;
+  g.cell_begin = cb_; g.cell_stride = cell_stride; g.nloc = (ce_ - cb_ + cell_stride - 1) / cell_stride;
   g.nb = cfg->bin_num; g.S = cfg->bin_num - 3;
   g.fx = cfg->fx; g.fy = cfg->fy; g.cx = cfg->cx; g.cy = cfg->cy;
   if (g.ps > (1 << 20)) { delete ctx; return NID_ERR_UNSUPPORTED; }  // fixed-point head-room of the histograms
@@ -987,7 +989,7 @@ int nid_plain_nid(nid_ctx *ctx, const double *pose7, int bins, double *Href, dou
   NID_HIP(ctx, e);
   double sum = 0.0;
   for (int cl = 0; cl < nloc; cl++) {
-    const int c = ctx->g.cell_begin + cl;
+    const int c = ctx->g.cell_begin + cl * ctx->g.cell_stride;
     const double *r = o.data() + (size_t)cl * 6;
     if (Href) Href[c] = r[0];
     if (Hcur) Hcur[c] = r[1];
@@ -1011,7 +1013,7 @@ int nid_set_href_state(nid_ctx *ctx, const int32_t *bs_counter, const double *Hr
   const size_t plane = (size_t)g.nloc * g.pstride;
   std::vector<double> W(4 * plane, 0.0);
   for (int cl = 0; cl < g.nloc; cl++) {
-    const int c = g.cell_begin + cl, ci = c / g.cell_num, cj = c % g.cell_num;
+    const int c = g.cell_begin + cl * g.cell_stride, ci = c / g.cell_num, cj = c % g.cell_num;
     for (int s = 0; s < g.ps; s++) {
       const size_t id = (size_t)(ci * g.rb + s / g.cb) * g.cols + cj * g.cb + s % g.cb;
       const size_t gi = (size_t)cl * g.pstride + s;
@@ -1022,8 +1024,11 @@ int nid_set_href_state(nid_ctx *ctx, const int32_t *bs_counter, const double *Hr
     }
   }
   NID_HIP(ctx, hipMemcpy(ctx->t.W, W.data(), 4 * plane * sizeof(double), hipMemcpyHostToDevice));
-  NID_HIP(ctx, hipMemcpy(ctx->Nc_dev, bs_counter + g.cell_begin, g.nloc * sizeof(int), hipMemcpyHostToDevice));
-  NID_HIP(ctx, hipMemcpy(ctx->Href_dev, Href + g.cell_begin, g.nloc * sizeof(double), hipMemcpyHostToDevice));
+  std::vector<int> nc(g.nloc);
+  std::vector<double> hr(g.nloc);
+  for (int cl = 0; cl < g.nloc; cl++) { nc[cl] = bs_counter[g.cell_begin + cl * g.cell_stride]; hr[cl] = Href[g.cell_begin + cl * g.cell_stride]; }
+  NID_HIP(ctx, hipMemcpy(ctx->Nc_dev, nc.data(), g.nloc * sizeof(int), hipMemcpyHostToDevice));
+  NID_HIP(ctx, hipMemcpy(ctx->Href_dev, hr.data(), g.nloc * sizeof(double), hipMemcpyHostToDevice));
   ctx->have_href = true;
   return NID_OK;
 }

@@ -48,7 +48,7 @@ struct Geometry {
   int rows, cols, cell_num, rb, cb;
   int ps;        // pixels per cell = rb*cb
   int pstride;   // ps rounded up to 64
-  int cell_begin, nloc;
+  int cell_begin, nloc, cell_stride;  // this context owns cells cell_begin + cl * cell_stride, cl = 0 .. nloc-1
   int nb, S;
   double fx, fy, cx, cy;
 };
@@ -472,7 +472,7 @@ __global__ void k_tile(Geometry g, const double *__restrict__ depth,
   int jr = -1;
   uint8_t i0 = 0;
   if (s < g.ps) {
-    const int c = g.cell_begin + cl;
+    const int c = g.cell_begin + cl * g.cell_stride;
     const int ci = c / g.cell_num, cj = c % g.cell_num;
     const int r = ci * g.rb + s / g.cb;
     const int col = cj * g.cb + s % g.cb;
@@ -1196,7 +1196,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu((STRICT || D
         atomicAdd(hj + (m * nb + k) * NC, fx_encode_raw(wr[m], wcs[k]));
   };
   auto dump_pixel = [&](int s, const PixelFront &f, double ic, int jc, const double (&wc)[4]) {
-    const int c = g.cell_begin + cl;
+    const int c = g.cell_begin + cl * g.cell_stride;
     const int r = (c / g.cell_num) * g.rb + s / g.cb;
     const int col = (c % g.cell_num) * g.cb + s % g.cb;
     const size_t id = (size_t)r * g.cols + col;
@@ -1466,7 +1466,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu((STRICT || D
   // Jacobian-phase dump (dbg_jac): for every sample that contributes, the image gradient in the reference's
   // convention (central difference / 2), the bin position, the span and the four B-spline derivatives
   auto dump_jac = [&](int s, double gx, double gy, double pc, int jc, const double (&dw)[4]) {
-    const int c = g.cell_begin + cl;
+    const int c = g.cell_begin + cl * g.cell_stride;
     const int r = (c / g.cell_num) * g.rb + s / g.cb;
     const int col = (c % g.cell_num) * g.cb + s % g.cb;
     const size_t id = (size_t)r * g.cols + col;

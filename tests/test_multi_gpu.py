@@ -69,6 +69,47 @@ def test_shards_equal_single_context(capi, synth, pair_A, nshards):
         capi.multi_from_pair(synth.make_pair("S"), nb, devices=[0] * 17)   # more shards than cells
 
 
+@pytest.mark.parametrize("nshards", [2, 3, 8])
+def test_interleaved_partition_equals_single_context(capi, synth, pair_A, nshards):
+    """NID_PARTITION_INTERLEAVED (shard k owns cells k, k + K, ...): per-cell outputs are the single context's bit for
+    bit, the summed 6x6 systems agree to rounding, the reference-stage outputs (counts, Href, per-pixel weights and bin
+    indices) land in the right cells, and the Href state handed back in (the legacy operator's path) gives the same
+    evaluation -- same checks as for contiguous ranges."""
+    pair, nb = pair_A, 8
+    one = capi.from_pair(pair, nb)
+    cnt, href, bsv1, bsi1 = one.compute_href(pair.pose_init, dump=True)
+    m = capi.multi_from_pair(pair, nb, devices=[0] * nshards, partition=capi.PARTITION_INTERLEAVED)
+    assert m.shards() == nshards
+    cnt_m, href_m, bsv, bsi = m.compute_href(pair.pose_init, dump=True)
+    assert np.array_equal(cnt, cnt_m) and np.array_equal(_bits(href), _bits(href_m))
+    assert np.array_equal(_bits(bsv), _bits(bsv1)) and np.array_equal(bsi, bsi1)
+    act = cnt >= 300
+    poses = [pair.pose_init, pair.pose_true, synth.perturb_pose7(pair.pose_init, [1e-3, 0, 2e-3], [0, 3e-3, 0])]
+    for pose in poses:
+        a, b = one.evaluate(pose, True), m.evaluate(pose, True)
+        for x, y in zip(a, b):
+            assert np.array_equal(_bits(x[act]), _bits(y[act])) and np.isnan(y[~act]).all()
+        H, bb, chi2, na = one.normal_equations(pose, DELTA)
+        Hm, bm, chi2m, nam = m.normal_equations(pose, DELTA)
+        assert na == nam == int(act.sum())
+        np.testing.assert_allclose(chi2m, chi2, rtol=1e-13)
+        np.testing.assert_allclose(Hm, H, rtol=0, atol=1e-12 * np.abs(H).max())
+        np.testing.assert_allclose(bm, bb, rtol=0, atol=1e-12 * np.abs(bb).max())
+    m2 = capi.multi_from_pair(pair, nb, devices=[0] * nshards, partition=capi.PARTITION_INTERLEAVED)
+    m2.set_href_state(cnt, href, bsv1, bsi1)
+    for x, y in zip(one.evaluate(poses[2], True), m2.evaluate(poses[2], True)):
+        assert np.array_equal(_bits(x[act]), _bits(y[act]))
+    seq = np.stack([poses[i % 3] for i in range(200)])
+    ra = m.run_sequence(seq, DELTA, batch=64, group=2)
+    for i in (0, 100, 199):
+        Hs, bs, chis, _ = m.normal_equations(seq[i], DELTA)
+        assert np.array_equal(_bits(capi.unpack_reduced(ra[i])[0]), _bits(Hs))
+    with pytest.raises(capi.NidError):
+        capi.multi_from_pair(pair, nb, devices=[0, 0], rank=0, world=2, partition=capi.PARTITION_INTERLEAVED)   # one shard per process
+    with pytest.raises(capi.NidError):
+        capi.multi_from_pair(pair, nb, devices=[0], partition=7)
+
+
 def test_rccl_one_rank_communicator(capi, synth, pair_A):
     """RCCL from C++: ncclCommInitRank (1 rank) through the library, ncclAllReduce(ncclDouble) in-stream behind the
     evaluation kernel, result copied to pinned host memory -- equal to the host-summed path bit for bit (a sum
