@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define NID_ABI_VERSION 1
+#define NID_ABI_VERSION 2 /* 2: NID_SLOTS 128 -> 1024, NID_MAX_BATCH 64 -> 256, launch shapes, launch chains, strided cell sets, nid_multi.h */
 
 typedef enum {
   NID_OK = 0,
