@@ -19,6 +19,17 @@ def cell_range(rank: int, world: int, ncell: int):
     return rank * ncell // world, (rank + 1) * ncell // world
 
 
+def cell_set(rank: int, world: int, ncell: int, interleaved: bool = False):
+    """The cell ids a rank owns: the contiguous range above, or -- NID_PARTITION_INTERLEAVED of nid_multi.h -- every
+    world-th cell starting at `rank` (nid_create_strided)."""
+    if not interleaved:
+        lo, hi = cell_range(rank, world, ncell)
+        return np.arange(lo, hi)
+    if not (0 <= rank < world) or world > ncell:
+        raise ValueError(f"bad shard {rank}/{world} of {ncell} cells")
+    return np.arange(rank, ncell, world)
+
+
 def all_ranges(world: int, ncell: int):
     return [cell_range(r, world, ncell) for r in range(world)]
 

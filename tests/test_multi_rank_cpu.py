@@ -44,6 +44,12 @@ def _worker(rank, world, port, q):
     H, b, chi2, na = oracle_py.normal_equations(e_loc, J, delta)
     block = torch.from_numpy(parallel.pack_reduced_np(H, b, chi2, na))
     parallel.allreduce_reduced(block)
+    # the interleaved partition (NID_PARTITION_INTERLEAVED): other cell sets, the same sum
+    own = parallel.cell_set(rank, world, ncell, interleaved=True)
+    e_int = np.full(ncell, np.nan); e_int[own] = err[own]
+    Hi, bi, chi2i, nai = oracle_py.normal_equations(e_int, J, delta)
+    block_i = torch.from_numpy(parallel.pack_reduced_np(Hi, bi, chi2i, nai))
+    parallel.allreduce_reduced(block_i)
     # per-cell form
     cells = torch.from_numpy(np.concatenate([err[lo:hi, None], J[lo:hi]], axis=1))
     gathered = parallel.allgather_cells(cells, world) if (hi - lo) * world == ncell else None
@@ -51,6 +57,9 @@ def _worker(rank, world, port, q):
     Hs, bs, cs, ns = parallel.unpack_reduced_np(block.numpy())
     ok = (ns == nf and np.allclose(cs, cf, rtol=1e-13) and np.allclose(Hs, Hf, rtol=1e-12, atol=1e-13)
           and np.allclose(bs, bf, rtol=1e-12, atol=1e-13))
+    Hq, bq, cq, nq = parallel.unpack_reduced_np(block_i.numpy())
+    ok = ok and nq == nf and np.allclose(cq, cf, rtol=1e-13) and np.allclose(Hq, Hf, rtol=1e-12, atol=1e-13) \
+        and np.allclose(bq, bf, rtol=1e-12, atol=1e-13)
     if gathered is not None:
         ok = ok and np.array_equal(np.isnan(gathered[:, 0].numpy()), np.isnan(err)) \
             and np.array_equal(np.nan_to_num(gathered[:, 1:].numpy()), np.nan_to_num(J))
@@ -95,3 +104,16 @@ def test_pack_unpack_roundtrip(capi):
     assert np.array_equal(H, H2) and np.array_equal(b, b2) and c2 == 1.25 and n2 == 7
     H3, b3, c3, n3 = capi.unpack_reduced(r)     # the C-ABI's layout is the same
     assert np.array_equal(H, H3) and np.array_equal(b, b3) and c3 == 1.25 and n3 == 7
+
+
+def test_interleaved_cell_sets_partition():
+    parallel = importlib.import_module("nid-pose-estimation_amd.parallel")
+    for ncell in (16, 256, 1024, 250):
+        for world in (1, 2, 3, 4, 8):
+            sets = [parallel.cell_set(r, world, ncell, interleaved=True) for r in range(world)]
+            allc = np.sort(np.concatenate(sets))
+            assert np.array_equal(allc, np.arange(ncell))                    # exhaustive, disjoint
+            assert max(len(x) for x in sets) - min(len(x) for x in sets) <= 1  # balanced
+            assert all(np.all(np.diff(x) == world) for x in sets if len(x) > 1)
+    with pytest.raises(ValueError):
+        parallel.cell_set(0, 17, 16, interleaved=True)
