@@ -269,12 +269,29 @@ def main():
     B = max(1, min(args.batch, capi.NID_MAX_BATCH))
     multi = world > 1 or args.shards > 1 or args.rccl_one_rank
     rccl_ranks_seen = None
+    rccl_fallback = None
     if multi:
         part = capi.PARTITION_INTERLEAVED if args.partition == "interleaved" else capi.PARTITION_CONTIGUOUS
         if world > 1:
             m = capi.multi_from_pair(pair, args.bins, devices=[local_rank], rank=rank, world=world, math=math_mode, partition=part)
             if rccl:
-                ids = [capi.rccl_unique_id() if rank == 0 else None]
+                # every rank loads librccl first (ncclGetUniqueId) and the ranks agree on the outcome: a rank that cannot
+                # load it must not leave the others waiting inside ncclCommInitRank.  If any rank fails, ALL of them take
+                # the exchange hook over the gloo control group instead -- another transport for the same 32-double
+                # blocks, reported in the line; the kernels are the same.
+                my_id, why = None, ""
+                try:
+                    my_id = capi.rccl_unique_id()
+                except Exception as e:   # noqa: BLE001 -- whatever keeps librccl from loading
+                    why = str(e)
+                flag = torch.tensor([1.0 if my_id is not None else 0.0], dtype=torch.float64)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                if flag.item() == 0.0:
+                    rccl = False
+                    rccl_fallback = why or "librccl failed to load on another rank"
+                    print(f"[bench] rank {rank}: RCCL unavailable ({rccl_fallback}); exchanging over gloo", file=sys.stderr)
+            if rccl:
+                ids = [my_id if rank == 0 else None]
                 dist.broadcast_object_list(ids, src=0)
                 m.comm_init(ids[0])
                 rccl_ranks_seen = m.comm_ranks()
@@ -528,6 +545,8 @@ def main():
         }
         if rccl_ranks_seen is not None:
             out["rccl_ranks_seen"] = rccl_ranks_seen
+        if rccl_fallback is not None:
+            out["rccl_unavailable"] = rccl_fallback
         out["check"] = {"chi2": chi2, "n_active": int(na), "H00": float(H[0, 0]), "b0": float(b[0])}
         if not args.no_cpu_baseline and not multi:   # CPU legs: rank 0 at N=1 only
             out["cpu_baseline"] = cpu_baseline(pair, args.bins, args.cpu_seconds)

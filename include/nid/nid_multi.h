@@ -20,7 +20,8 @@
  *   NID_REDUCE_RCCL  the partial blocks stay on the device, ncclAllReduce(ncclDouble, ncclSum) over xGMI sums
  *                    them in-stream across the shards of this process (ncclCommInitAll: distinct devices) or
  *                    across the processes of the job (ncclCommInitRank with an id the ranks exchange), then
- *                    the result is copied to pinned host memory.  librccl is loaded on first use.
+ *                    the result is copied to pinned host memory.  librccl is loaded on first use (from the directory of the
+ *                    HIP runtime the process runs on; NID_RCCL_LIBRARY=<path> names another one).
  * Per-cell outputs (the legacy CudaComputeH contract) need no exchange inside a process -- each shard writes
  * its own cell range of the caller's arrays --; across processes they are summed by RCCL over a zero-filled
  * per-cell buffer (NaN = inactive survives the sum).

@@ -378,6 +378,15 @@ def test_bench_multi_rank_code_path_on_one_gpu(tmp_path):
     assert len(rc.stdout.strip().splitlines()) == 1, rc.stdout     # RCCL's own banner must not land on stdout
     rj = json.loads(rc.stdout.strip().splitlines()[-1])
     assert rj["rccl_ranks_seen"] == 1 and "RCCL" in rj["config"]["parallelism"]
+    # RCCL that cannot be loaded (here: forced to a missing file): every rank notices, they agree, and the job exchanges
+    # over the gloo control group instead of hanging in ncclCommInitRank -- the default backend, 2 ranks on this GPU
+    nb_env = dict(env, NID_RCCL_LIBRARY="/nonexistent/librccl.so")
+    fb = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                         "--master-addr", "127.0.0.1", "--master-port", "29516", bench, "--gpus", "2", "--no-cpu-baseline",
+                         "--quick", "--steps", "20", "--warmup", "5"], capture_output=True, text=True, env=nb_env, timeout=900)
+    assert fb.returncode == 0, fb.stderr[-3000:]
+    rf = json.loads([l for l in fb.stdout.strip().splitlines() if l.startswith("{")][-1])
+    assert "rccl_unavailable" in rf and "gloo" in rf["config"]["parallelism"] and rf["n_gpus"] == 2
     for port, world, extra in ((29517, 2, ["--steps", "20", "--warmup", "5"]),
                                (29518, 2, ["--steps", "300", "--warmup", "70"]),
                                (29519, 2, ["--steps", "300", "--warmup", "70", "--group", "8", "--batch", "16"]),
