@@ -293,9 +293,19 @@ def main():
             if rccl:
                 ids = [my_id if rank == 0 else None]
                 dist.broadcast_object_list(ids, src=0)
-                m.comm_init(ids[0])
-                rccl_ranks_seen = m.comm_ranks()
-            else:
+                why = ""
+                try:
+                    m.comm_init(ids[0])
+                    rccl_ranks_seen = m.comm_ranks()
+                except Exception as e:   # noqa: BLE001 -- ncclCommInitRank said no (it may also never return: not catchable)
+                    why = str(e)
+                flag = torch.tensor([0.0 if why else 1.0], dtype=torch.float64)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                if flag.item() == 0.0:   # same decision on every rank
+                    rccl, rccl_ranks_seen = False, None
+                    rccl_fallback = why or "ncclCommInitRank failed on another rank"
+                    print(f"[bench] rank {rank}: RCCL communicator unavailable ({rccl_fallback}); exchanging over gloo", file=sys.stderr)
+            if not rccl:
                 def gloo_sum(a):
                     t = torch.from_numpy(a)
                     dist.all_reduce(t)

@@ -387,6 +387,13 @@ def test_bench_multi_rank_code_path_on_one_gpu(tmp_path):
     assert fb.returncode == 0, fb.stderr[-3000:]
     rf = json.loads([l for l in fb.stdout.strip().splitlines() if l.startswith("{")][-1])
     assert "rccl_unavailable" in rf and "gloo" in rf["config"]["parallelism"] and rf["n_gpus"] == 2
+    # ... and a communicator RCCL refuses (two ranks on ONE device: ncclCommInitRank fails on both): same agreement
+    dup = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29515", bench, "--gpus", "2", "--no-cpu-baseline",
+                          "--quick", "--steps", "20", "--warmup", "5"], capture_output=True, text=True, env=env, timeout=900)
+    assert dup.returncode == 0, dup.stderr[-3000:]
+    rd = json.loads([l for l in dup.stdout.strip().splitlines() if l.startswith("{")][-1])
+    assert "ncclCommInitRank" in rd["rccl_unavailable"] and "gloo" in rd["config"]["parallelism"]
     for port, world, extra in ((29517, 2, ["--steps", "20", "--warmup", "5"]),
                                (29518, 2, ["--steps", "300", "--warmup", "70"]),
                                (29519, 2, ["--steps", "300", "--warmup", "70", "--group", "8", "--batch", "16"]),
