@@ -175,8 +175,10 @@ int nid_launch_chain(nid_ctx *ctx, int first_slot, int n, const double *poses7, 
 int nid_launch_batch_to(nid_ctx *ctx, int first_slot, int n, const double *poses7, int want_jac,
                         double huber_delta, void *reduced_dev);
 /* Host-side pipeline over a sequence of n candidate poses: `batch` poses per launch (batch
- * divides NID_SLOTS), NID_SLOTS/batch launches in flight; reduced_out (n x NID_REDUCED_LEN,
- * may be NULL) receives every pose's [chi2, b, H upper, n_active] block.  Blocking. */
+ * divides NID_SLOTS), min(16, NID_SLOTS/batch) launches in flight on the context's two streams, each
+ * launch's result blocks written to a device buffer and brought home by one copy behind it;
+ * reduced_out (n x NID_REDUCED_LEN, may be NULL) receives every pose's [chi2, b, H upper, n_active]
+ * block.  Blocking. */
 int nid_run_sequence(nid_ctx *ctx, const double *poses7, int n, int batch, int want_jac,
                      double huber_delta, double *reduced_out);
 /* A DEPENDENT chain of n evaluations, the way a Gauss-Newton / LM loop issues them: one pose per launch, the host

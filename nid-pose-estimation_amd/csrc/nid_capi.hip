@@ -40,6 +40,7 @@ struct Slot {
   bool pending = false;
   bool timed = false;
   bool external_target = false;
+  int done_slot = 0;               // external targets: the slot whose `done` event covers this one's launch
 };
 
 }  // namespace
@@ -83,6 +84,12 @@ struct nid_ctx {
   int math_mode = NID_MATH_FAST;
   double *ctab_dev = nullptr;
   Slot slots[NID_SLOTS];
+  // nid_run_sequence: result buffers of the launches in flight (device + pinned host), their copy stream and events
+  static constexpr int kSeqRing = 16;  // launches in flight: min(kSeqRing, NID_SLOTS / batch)
+  double *seq_dev[kSeqRing] = {}, *seq_host[kSeqRing] = {};
+  hipEvent_t seq_done[kSeqRing] = {}, seq_fence[kSeqRing] = {};
+  size_t seq_cap = 0;
+  hipStream_t copy_stream = nullptr;
   // what the slots' buffers are carved from (one allocation per kind)
   double *slab_cellout = nullptr, *slab_reduced = nullptr, *slab_quad = nullptr, *slab_gpart = nullptr, *slab_reduced_host = nullptr;
   unsigned *slab_ticket = nullptr;
@@ -421,6 +428,7 @@ int launch_slot(nid_ctx *ctx, int slot, const Pose &pose, int want_jac, double d
   if (rc) return rc;
   if (S.timed) NID_HIP(ctx, hipEventRecord(S.e1, st));
   if (S.external_target) NID_HIP(ctx, hipEventRecord(S.done, st));
+  S.done_slot = slot;
   S.pending = true;
   return NID_OK;
 }
@@ -480,11 +488,14 @@ int launch_batch(nid_ctx *ctx, int first_slot, int n, const Pose *poses, int wan
     ctx->ext_busy[ring] = true;
   }
   if (S0.timed) NID_HIP(ctx, hipEventRecord(S0.e1, st));
+  // caller-owned result buffer: the launch is over when its ONE event is (recorded on the batch's first slot; the
+  // other slots point at it -- an event record per pose cost ~4 us each, 1 ms of host time per 256-pose launch)
+  if (S0.external_target) NID_HIP(ctx, hipEventRecord(S0.done, st));
   for (int k = 0; k < n; k++) {
     Slot &S = ctx->slots[first_slot + k];
     S.pending = true;
+    S.done_slot = first_slot;
     if (k) S.timed = false;
-    if (S.external_target) NID_HIP(ctx, hipEventRecord(S.done, st));
   }
   return NID_OK;
 }
@@ -775,6 +786,13 @@ int nid_destroy(nid_ctx *ctx) {
   (void)hipFree(ctx->Nc_dev); (void)hipFree(ctx->Href_dev); (void)hipFree(ctx->ctab_dev);
   (void)hipFree(ctx->dbg_u); (void)hipFree(ctx->dbg_v); (void)hipFree(ctx->dbg_ic);
   (void)hipFree(ctx->dbg_wc); (void)hipFree(ctx->dbg_jc); (void)hipFree(ctx->dbg_stamps);
+  for (int r = 0; r < nid_ctx::kSeqRing; r++) {
+    (void)hipFree(ctx->seq_dev[r]);
+    if (ctx->seq_host[r]) (void)hipHostFree(ctx->seq_host[r]);
+    if (ctx->seq_done[r]) (void)hipEventDestroy(ctx->seq_done[r]);
+    if (ctx->seq_fence[r]) (void)hipEventDestroy(ctx->seq_fence[r]);
+  }
+  if (ctx->copy_stream) { (void)hipStreamSynchronize(ctx->copy_stream); (void)hipStreamDestroy(ctx->copy_stream); }
   (void)hipFree(ctx->slab_cellout); (void)hipFree(ctx->slab_reduced); (void)hipFree(ctx->slab_quad);
   (void)hipFree(ctx->slab_ticket); (void)hipFree(ctx->slab_gpart);
   if (ctx->slab_reduced_host) (void)hipHostFree(ctx->slab_reduced_host);
@@ -1098,40 +1116,79 @@ int nid_launch_batch_to(nid_ctx *ctx, int first_slot, int n, const double *poses
 
 int nid_run_sequence(nid_ctx *ctx, const double *poses7, int n, int batch, int want_jac, double delta,
                      double *reduced_out) {
-  // host-side pipeline: `batch` poses per launch, NID_SLOTS / batch launches in flight, every
-  // pose's 32-double result block collected from pinned host memory in order
+  // Host-side pipeline: `batch` poses per launch, up to kSeqRing launches in flight on the context's two streams.
+  // A launch writes its result blocks to a DEVICE buffer and ONE copy brings them to pinned host memory behind it
+  // (copy stream + event).  (The blocking calls let the kernel write each pose's block straight to host memory --
+  // lowest latency; for a stream of launches that is 256 system-scope fences and PCIe writes per launch from
+  // inside the kernel: this form measured 254 k -> 270-280 k evaluations/s on 640x480.)
   if (!ctx || !poses7 || n < 0 || batch < 1 || batch > kMaxBatchExt || NID_SLOTS % batch) return NID_ERR_INVALID_ARG;
   NID_HIP(ctx, hipSetDevice(ctx->cfg.device));
   for (int s = 0; s < NID_SLOTS; s++) if (ctx->slots[s].pending) return NID_ERR_STATE;
-  // Consecutive launches alternate between the context's two streams: the kernel is VALU-bound and
-  // its last workgroups leave most CUs idle for ~1/4 of its duration; the next launch's workgroups
-  // fill that tail (measured on MI355X, 8 poses per launch: 151k -> 197k evaluations/s).  Launches
-  // are independent (own slots, own result blocks), so no cross-stream ordering is needed.
-  static const bool one_stream = getenv("NID_ONE_STREAM") != nullptr;
-  Pose p[kMaxBatchExt];
-  int launched = 0, collected = 0, launches = 0;
-  auto collect = [&](int upto) -> int {
-    for (; collected < upto; collected++) {
-      const int slot = collected % NID_SLOTS;
-      int rc = nid_wait(ctx, slot, nullptr, nullptr, nullptr, nullptr);
+  if (n <= batch) {
+    // ONE launch: nothing to pipeline, latency is what counts -- the kernel writes every pose's block straight to
+    // pinned host memory and the host spins on the sequence words (no copy, no event: 128 us instead of 193 us
+    // from the enqueue to the last of 20 results)
+    if (n == 0) return NID_OK;
+    Pose q[kMaxBatchExt];
+    for (int k = 0; k < n; k++) pose_from_pose7(poses7 + 7 * (size_t)k, ctx->xform, &q[k]);
+    int rc = launch_batch(ctx, 0, n, q, want_jac, delta);
+    if (rc) return rc;
+    for (int k = 0; k < n; k++) {
+      rc = nid_wait(ctx, k, nullptr, nullptr, nullptr, nullptr);
       if (rc) return rc;
-      if (reduced_out) std::memcpy(reduced_out + (size_t)collected * kReducedLen, ctx->slots[slot].reduced_host,
-                                   kReducedLen * sizeof(double));
+      if (reduced_out) std::memcpy(reduced_out + (size_t)k * kReducedLen, ctx->slots[k].reduced_host, kReducedLen * sizeof(double));
     }
     return NID_OK;
-  };
-  while (launched < n) {
-    const int nb = std::min(batch, n - launched);
-    const int first_slot = launched % NID_SLOTS;
-    int rc = collect(launched + nb - NID_SLOTS);  // free the slots this launch will reuse
-    if (rc) return rc;
-    for (int k = 0; k < nb; k++) pose_from_pose7(poses7 + 7 * (size_t)(launched + k), ctx->xform, &p[k]);
-    rc = launch_batch(ctx, first_slot, nb, p, want_jac, delta, nullptr, !one_stream && (launches & 1));
-    if (rc) return rc;
-    launched += nb;
-    launches++;
   }
-  return collect(n);
+  const int depth = std::min((int)nid_ctx::kSeqRing, NID_SLOTS / batch);
+  if (ctx->seq_cap < (size_t)batch) {
+    for (int r = 0; r < nid_ctx::kSeqRing; r++) {
+      (void)hipFree(ctx->seq_dev[r]); ctx->seq_dev[r] = nullptr;
+      if (ctx->seq_host[r]) (void)hipHostFree(ctx->seq_host[r]);
+      ctx->seq_host[r] = nullptr;
+      int rc = dev_alloc(ctx, &ctx->seq_dev[r], (size_t)batch * kReducedLen);
+      if (rc) return rc;
+      if (hipHostMalloc(reinterpret_cast<void **>(&ctx->seq_host[r]), (size_t)batch * kReducedLen * sizeof(double),
+                        hipHostMallocDefault) != hipSuccess) return NID_ERR_NOMEM;
+      if (!ctx->seq_done[r]) NID_HIP(ctx, hipEventCreateWithFlags(&ctx->seq_done[r], hipEventDisableTiming));
+      if (!ctx->seq_fence[r]) NID_HIP(ctx, hipEventCreateWithFlags(&ctx->seq_fence[r], hipEventDisableTiming));
+    }
+    if (!ctx->copy_stream) NID_HIP(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+    ctx->seq_cap = (size_t)batch;
+  }
+  // Consecutive launches alternate between the context's two streams: a launch's last workgroups leave most CUs
+  // idle for a while and the next launch's workgroups fill that tail.  Launches are independent (own slots, own
+  // result buffers), so no cross-stream ordering is needed.
+  static const bool one_stream = getenv("NID_ONE_STREAM") != nullptr;
+  Pose p[kMaxBatchExt];
+  const int launches = (n + batch - 1) / batch;
+  auto collect = [&](int l) -> int {  // launch l has landed in seq_host[l % depth]
+    const int r = l % depth;
+    NID_HIP(ctx, hipEventSynchronize(ctx->seq_done[r]));
+    const int first = l * batch, cnt = std::min(batch, n - first);
+    if (reduced_out) std::memcpy(reduced_out + (size_t)first * kReducedLen, ctx->seq_host[r], (size_t)cnt * kReducedLen * sizeof(double));
+    for (int k = 0; k < cnt; k++) ctx->slots[r * batch + k].pending = false;
+    return NID_OK;
+  };
+  for (int l = 0; l < launches; l++) {
+    const int r = l % depth;
+    if (l >= depth) { int rc = collect(l - depth); if (rc) return rc; }  // frees ring entry r and its slots
+    const int first = l * batch, nb = std::min(batch, n - first);
+    for (int k = 0; k < nb; k++) pose_from_pose7(poses7 + 7 * (size_t)(first + k), ctx->xform, &p[k]);
+    const bool aux = !one_stream && (l & 1) && !ctx->external_stream;
+    int rc = launch_batch(ctx, r * batch, nb, p, want_jac, delta, ctx->seq_dev[r], aux);
+    if (rc) return rc;
+    hipStream_t ls = aux ? ctx->aux_stream : ctx->stream;
+    hipStream_t cs = ctx->external_stream ? ctx->stream : ctx->copy_stream;
+    if (cs != ls) {
+      NID_HIP(ctx, hipEventRecord(ctx->seq_fence[r], ls));
+      NID_HIP(ctx, hipStreamWaitEvent(cs, ctx->seq_fence[r], 0));
+    }
+    NID_HIP(ctx, hipMemcpyAsync(ctx->seq_host[r], ctx->seq_dev[r], (size_t)nb * kReducedLen * sizeof(double), hipMemcpyDeviceToHost, cs));
+    NID_HIP(ctx, hipEventRecord(ctx->seq_done[r], cs));
+  }
+  for (int l = std::max(0, launches - depth); l < launches; l++) { int rc = collect(l); if (rc) return rc; }
+  return NID_OK;
 }
 
 int nid_run_chain(nid_ctx *ctx, const double *poses7, int n, int want_jac, double delta, double *reduced_out, double *seconds) {
@@ -1163,7 +1220,7 @@ int nid_wait(nid_ctx *ctx, int slot, double *H36, double *b6, double *chi2, int3
   // pending (a retry is possible, a relaunch is refused)
   if (S.external_target) {
     NID_HIP(ctx, hipSetDevice(ctx->cfg.device));
-    NID_HIP(ctx, hipEventSynchronize(S.done));
+    NID_HIP(ctx, hipEventSynchronize(ctx->slots[S.done_slot].done));
     S.pending = false;
     return NID_OK;
   }

@@ -15,5 +15,6 @@ for cfg in "AB":
     for b in (16, 32, 64, 128, 256):
         ms = float(np.median([ctx.time_launches(poses[:b], delta, repeats=6) for _ in range(9)]))
         seq = poses[np.arange(256 * 40 if cfg == "A" else 256 * 12) % 256]
+        ctx.run_sequence(seq[:4 * b], delta, batch=b, collect=False)   # (ring buffers of this launch size exist now)
         t0 = time.perf_counter(); ctx.run_sequence(seq, delta, batch=b, collect=False); el = time.perf_counter() - t0
         print(f"  batch {b:3d}: kernel {ms*1e3:8.1f} us = {ms*1e3/b:6.3f} us/pose, frac {contract*b/(ms*1e-3)/8e12:.3f}; pipelined {len(seq)/el:9.0f} it/s")
