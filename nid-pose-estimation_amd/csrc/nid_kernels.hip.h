@@ -436,11 +436,15 @@ constexpr unsigned kFxHiMask = 0x000FFFFFu;
 // saturated sample, or any sample at an integer position of an identity-like pose) carries an O(1) derivative:
 // the bin mass must then be right to ~1e-9 RELATIVE.  Integer accumulation (order-independent, bitwise
 // reproducible) with that dynamic range = several fixed-point levels: a weight w < 2^-8 of such a sample goes to
-// level L = min(floor((-8 - e) / 24), 4), e = its binary exponent, scaled by 2^(59 + 24 L): at least 27 bits of
-// every addend survive, at most 2^51 per addend and 2^62 per bin.  Weights >= 2^-8 stay in the coarse copies
+// level L = min(floor((-8 - e) / 24), 4), e = its binary exponent, scaled by 2^(59 + 24 L) -- and every joint addend
+// wr[m] * w below 2^-8 of a sample whose target OR reference sample sits next to a knot to the level of THAT
+// product's exponent: at least 27 bits of every addend survive, at most 2^51 per addend and 2^62 per bin.  Weights >= 2^-8 stay in the coarse copies
 // (error of the Jacobian term there <= quantum * |dw| / w = 2.8e-14 * 3 * 256 = 2e-11).  kTinyW: the smaller
-// outer weight of a sample is below it iff the sample sits within ~2.8e-3 of a knot.
-constexpr double kTinyW = 0x1p-28;
+// outer weight of a sample (target or reference) is below it iff the sample sits within ~2.8e-3 of a knot.
+#ifndef NID_TINY_W_EXP
+#define NID_TINY_W_EXP 28
+#endif
+constexpr double kTinyW = 1.0 / (double)(1ull << NID_TINY_W_EXP);
 constexpr double kFineW = 0x1p-8;
 constexpr int kFineLevels = 5;
 __device__ __forceinline__ int fine_level(double w) {
@@ -1164,24 +1168,65 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu((STRICT || D
     unsigned long long *hc = hist + ((unsigned)jc * NC + (unsigned)copy);
     unsigned long long *hj = hist + (((unsigned)nb + hrow) * NC + (unsigned)copy);
 #ifndef NID_EXP_NO_LO
-    if (fmin(wc[0], wc[3]) < kTinyW) {
-      // rare: the sample sits next to a knot (also: clamped saturated, black, integer-position samples): its
-      // small weights go to the fine levels, the others as usual
+    // Rare: the TARGET sample sits next to a knot (also: clamped saturated, black, integer-position samples) -- its
+    // small weights, and their products with the reference weights, go to the fine level of their own exponent --
+    // or the REFERENCE sample does with NON-ZERO tiny weights (a saturated reference pixel: I0 = 255 -> 254.999 has
+    // outer weights of 1e-13 / 1e-8; exactly zero weights -- a reference sample ON a knot, or out of frame at the
+    // initial pose -- lose nothing): then every product below 2^-8 goes to its own level.  (Why the reference side:
+    // a joint bin can consist of one end-span target sample's 1e-15 weight with an O(1) derivative PLUS hundreds of
+    // 1e-16 products of tiny reference weights; lost in the coarse quantum they shifted that bin's W by 2.8 and
+    // one cell's Jacobian by 0.7 % -- 3 of 2 500 random cases, tools/random_parity_sweep.py.)
+    const double wr_min = fmin(wr[0], wr[3]);
+    const bool ref_tiny = wr_min < kTinyW && wr_min != 0.0;
+    if (fmin(wc[0], wc[3]) < kTinyW || ref_tiny) {
+      if (!ref_tiny) {
+        // target side only (about one sample in 90 on a smooth image: every other wave-round gets here)
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          if (wc[k] < kFineW) {
+            if (wc[k] != 0.0) {
+              const int lv = fine_level(fabs(wc[k]));
+              atomicAdd(hist_lo + lv * nbins + (unsigned)(jc + k), fx_encode(wc[k], fine_scale(lv)));
+#pragma unroll
+              for (int m = 0; m < 4; m++) {
+                const double pr = wr[m] * wc[k];  // the reference's own product, rounded once like there
+                if (pr != 0.0) {
+                  const int lm = fine_level(fabs(pr));
+                  atomicAdd(hist_lo + lm * nbins + ((unsigned)nb + hrow + (unsigned)(m * nb + k)), fx_encode(pr, fine_scale(lm)));
+                }
+              }
+            }
+          } else {
+            atomicAdd(hc + k * NC, fx_encode_raw(wcs[k], 1.0));
+#pragma unroll
+            for (int m = 0; m < 4; m++) atomicAdd(hj + (m * nb + k) * NC, fx_encode_raw(wr[m], wcs[k]));
+          }
+        }
+        return;
+      }
+      // saturated reference pixel: every product below 2^-8 to its own level, whichever factor is small
 #pragma unroll
       for (int k = 0; k < 4; k++) {
-        if (wc[k] < kFineW) {
+        const bool small_c = wc[k] < kFineW;
+        if (small_c) {
           if (wc[k] != 0.0) {
             const int lv = fine_level(fabs(wc[k]));
-            const double wl = wc[k] * fine_scale(lv);
-            unsigned long long *hl = hist_lo + lv * nbins;
-            atomicAdd(hl + (unsigned)(jc + k), fx_encode(wl, 1.0));
-#pragma unroll
-            for (int m = 0; m < 4; m++) atomicAdd(hl + ((unsigned)nb + hrow + (unsigned)(m * nb + k)), fx_encode(wr[m], wl));
+            atomicAdd(hist_lo + lv * nbins + (unsigned)(jc + k), fx_encode(wc[k], fine_scale(lv)));
           }
         } else {
           atomicAdd(hc + k * NC, fx_encode_raw(wcs[k], 1.0));
+        }
 #pragma unroll
-          for (int m = 0; m < 4; m++) atomicAdd(hj + (m * nb + k) * NC, fx_encode_raw(wr[m], wcs[k]));
+        for (int m = 0; m < 4; m++) {
+          if (small_c || wr[m] < kFineW) {
+            const double pr = wr[m] * wc[k];
+            if (pr != 0.0) {
+              const int lm = fine_level(fabs(pr));
+              atomicAdd(hist_lo + lm * nbins + ((unsigned)nb + hrow + (unsigned)(m * nb + k)), fx_encode(pr, fine_scale(lm)));
+            }
+          } else {
+            atomicAdd(hj + (m * nb + k) * NC, fx_encode_raw(wr[m], wcs[k]));
+          }
         }
       }
       return;

@@ -709,8 +709,15 @@ def _random_case(synth, seed):
     return pair, nb, poses
 
 
+# seeds beyond the first 64 that a 4 000-case sweep (tools/random_parity_sweep.py) found in violation before the fine
+# fixed-point levels took (i) the joint addends of a small target weight at the level of the PRODUCT's exponent
+# (372, 630: one cell 1e-6 off) and (ii) the products of a saturated reference pixel's tiny weights (1324, 1496, 2409:
+# one cell 0.7-2.6 % off).  Left after that: seed 3013, one cell at 3.9e-9 of its own scale (2e-9 absolute).
+SWEEP_SEEDS = [372, 630, 1324, 1496, 2409]
+
+
 @pytest.mark.gpu
-@pytest.mark.parametrize("seed", list(range(64)))
+@pytest.mark.parametrize("seed", list(range(64)) + SWEEP_SEEDS)
 def test_randomised_pairs(capi, oracle, synth, seed):
     """Randomised parity (fixed seeds): geometry, bins, images (noise, few grey levels on bin boundaries,
     constant, saturated blobs), depth holes, small and large pose perturbations -- both math modes against

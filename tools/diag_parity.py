@@ -106,6 +106,15 @@ if __name__ == "__main__":
                   f"max|db|/max|b| {np.abs(b - bo).max() / np.abs(bo).max():.3e}  cond(H) {np.linalg.cond(Ho):.3e}  "
                   f"nonfinite cells oracle {int((~np.isfinite(ref[3]).all(axis=1) & (np.isfinite(ref[2]))).sum())}")
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "seed":   # a case of tests/test_parity_gpu.py::_random_case (tools/random_parity_sweep.py)
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import test_parity_gpu as T
+        for seed in [int(x) for x in sys.argv[2:]]:
+            pair, nb, poses = T._random_case(synth, 1000 + seed)
+            print(f"=== seed {seed}: {pair.rows}x{pair.cols}, {pair.cell}x{pair.cell} cells, {nb} bins")
+            for k, pose in enumerate(poses):
+                run(pair, nb, pose, f"seed {seed} pose {k}", jacdump=True)
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "ident":
         S = synth.make_pair("S", edge_cases=True)
         run(S, 8, ident_pose(S), "S-edge identity", href_pose=ident_pose(S), jacdump=True)
