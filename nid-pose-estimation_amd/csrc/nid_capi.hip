@@ -1114,6 +1114,31 @@ int nid_launch_batch_to(nid_ctx *ctx, int first_slot, int n, const double *poses
   return launch_batch(ctx, first_slot, n, p, want_jac, delta, static_cast<double *>(reduced_dev));
 }
 
+}  // extern "C"
+
+namespace {
+// result buffers (device + pinned host), events and the copy stream of the pipelined loop, for launches of `batch` poses
+int ensure_seq_ring(nid_ctx *ctx, int batch) {
+  if (ctx->seq_cap >= (size_t)batch) return NID_OK;
+  for (int r = 0; r < nid_ctx::kSeqRing; r++) {
+    (void)hipFree(ctx->seq_dev[r]); ctx->seq_dev[r] = nullptr;
+    if (ctx->seq_host[r]) (void)hipHostFree(ctx->seq_host[r]);
+    ctx->seq_host[r] = nullptr;
+    int rc = dev_alloc(ctx, &ctx->seq_dev[r], (size_t)batch * kReducedLen);
+    if (rc) return rc;
+    if (hipHostMalloc(reinterpret_cast<void **>(&ctx->seq_host[r]), (size_t)batch * kReducedLen * sizeof(double),
+                      hipHostMallocDefault) != hipSuccess) return NID_ERR_NOMEM;
+    if (!ctx->seq_done[r]) NID_HIP(ctx, hipEventCreateWithFlags(&ctx->seq_done[r], hipEventDisableTiming));
+    if (!ctx->seq_fence[r]) NID_HIP(ctx, hipEventCreateWithFlags(&ctx->seq_fence[r], hipEventDisableTiming));
+  }
+  if (!ctx->copy_stream) NID_HIP(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+  ctx->seq_cap = (size_t)batch;
+  return NID_OK;
+}
+}  // namespace
+
+extern "C" {
+
 int nid_run_sequence(nid_ctx *ctx, const double *poses7, int n, int batch, int want_jac, double delta,
                      double *reduced_out) {
   // Host-side pipeline: `batch` poses per launch, up to kSeqRing launches in flight on the context's two streams.
@@ -1141,21 +1166,7 @@ int nid_run_sequence(nid_ctx *ctx, const double *poses7, int n, int batch, int w
     return NID_OK;
   }
   const int depth = std::min((int)nid_ctx::kSeqRing, NID_SLOTS / batch);
-  if (ctx->seq_cap < (size_t)batch) {
-    for (int r = 0; r < nid_ctx::kSeqRing; r++) {
-      (void)hipFree(ctx->seq_dev[r]); ctx->seq_dev[r] = nullptr;
-      if (ctx->seq_host[r]) (void)hipHostFree(ctx->seq_host[r]);
-      ctx->seq_host[r] = nullptr;
-      int rc = dev_alloc(ctx, &ctx->seq_dev[r], (size_t)batch * kReducedLen);
-      if (rc) return rc;
-      if (hipHostMalloc(reinterpret_cast<void **>(&ctx->seq_host[r]), (size_t)batch * kReducedLen * sizeof(double),
-                        hipHostMallocDefault) != hipSuccess) return NID_ERR_NOMEM;
-      if (!ctx->seq_done[r]) NID_HIP(ctx, hipEventCreateWithFlags(&ctx->seq_done[r], hipEventDisableTiming));
-      if (!ctx->seq_fence[r]) NID_HIP(ctx, hipEventCreateWithFlags(&ctx->seq_fence[r], hipEventDisableTiming));
-    }
-    if (!ctx->copy_stream) NID_HIP(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
-    ctx->seq_cap = (size_t)batch;
-  }
+  { int rc = ensure_seq_ring(ctx, batch); if (rc) return rc; }
   // Consecutive launches alternate between the context's two streams: a launch's last workgroups leave most CUs
   // idle for a while and the next launch's workgroups fill that tail.  Launches are independent (own slots, own
   // result buffers), so no cross-stream ordering is needed.
@@ -1344,9 +1355,17 @@ int nid_time_launches(nid_ctx *ctx, int n, const double *poses7, int want_jac, d
   for (int k = 0; k < n; k++) pose_from_pose7(poses7 + 7 * k, ctx->xform, &p[k]);
   Slot &S0 = ctx->slots[0];
   { int rc = timing_events(ctx, S0); if (rc) return rc; }
+  // launches of more than kMaxBatch poses are what the pipelined loop issues: they write their result blocks to a
+  // device buffer like there (nid_run_sequence); smaller ones to pinned host memory like the blocking calls
+  double *target = nullptr;
+  if (n > kMaxBatch) {
+    int rc = ensure_seq_ring(ctx, n);
+    if (rc) return rc;
+    target = ctx->seq_dev[0];
+  }
   NID_HIP(ctx, hipEventRecord(S0.e0, ctx->stream));
   for (int r = 0; r < repeats; r++) {
-    int rc = launch_batch(ctx, 0, n, p, want_jac, delta, nullptr, false, /*relaunch_ok=*/r > 0);
+    int rc = launch_batch(ctx, 0, n, p, want_jac, delta, target, false, /*relaunch_ok=*/r > 0);
     if (rc) return rc;
   }
   NID_HIP(ctx, hipEventRecord(S0.e1, ctx->stream));
