@@ -8,7 +8,7 @@ Workload at N=1 is BASELINE.json configs[1]: the 640x480 pair, 16x16 cells, 8-bi
 
 `value` is PIPELINED EVALUATION THROUGHPUT: the K steps are K independent candidate poses pushed through the
 library's own host pipeline (nid_run_sequence: 256 poses per kernel launch, launches alternating between two
-streams, every pose's 6x6 system collected from pinned host memory).  A Gauss-Newton / LM loop is sequentially
+streams, each launch's 6x6 systems copied to pinned host memory behind it).  A Gauss-Newton / LM loop is sequentially
 dependent; its rates are reported next to it (roofline.sequential: one blocking evaluation per launch;
 pose_error_vs_ref.lm_outer_iterations_per_s: the reference's LM schedule), as are the kernel-alone, cold and
 >= 1 s sustained numbers, so that a short driver invocation (--steps 20: one launch) still carries them.
@@ -546,8 +546,8 @@ def main():
                 "parallelism": ((f"cells/{world} ({args.partition})" if world > 1 else (f"cells/{args.shards} shards on one GPU ({args.partition})" if multi else "cells/1")))
                                + ("" if not multi else (f" + {'RCCL ncclAllReduce from C++' if ((world > 1 and rccl) or args.rccl_one_rank) else ('gloo exchange hook' if world > 1 else 'host sum')}"
                                                         f" of [{G * Bm},32] f64 per {G} launches")),
-                "pipelining": (f"{B} candidate poses per kernel launch, 2 launches in flight on 2 streams, each pose's 6x6 "
-                               f"system lands in pinned host memory") if not multi else
+                "pipelining": (f"{B} candidate poses per kernel launch, up to {min(16, capi.NID_SLOTS // B)} launches in flight on 2 "
+                               f"streams, each launch's 6x6 systems copied to pinned host memory behind it (nid_run_sequence)") if not multi else
                               (f"{Bm} poses per launch, launches alternate between 2 compute streams per shard, one exchange per "
                                f"{G} launches + D2H to pinned memory on a comm stream, 2 groups in flight (nid_multi_run_sequence)"),
             },
