@@ -591,7 +591,7 @@ int href_common(nid_ctx *ctx, const Pose &pose, int32_t *bs_counter, double *Hre
       for (int s = 0; s < g.ps; s++) {
         const size_t id = (size_t)(ci * g.rb + s / g.cb) * g.cols + cj * g.cb + s % g.cb;
         const size_t gi = (size_t)cl * g.pstride + s;
-        if (bs_value) for (int k = 0; k < 4; k++) bs_value[4 * id + k] = W[k * plane + gi];
+        if (bs_value) for (int k = 0; k < 4; k++) bs_value[4 * id + k] = k == 0 ? std::fabs(W[4 * gi]) : W[4 * gi + k];  // sign of the first weight: the kernel's knot flag (k_href)
         if (bs_index) bs_index[id] = JR[gi];
       }
     }
@@ -686,7 +686,7 @@ int nid_create_strided(const nid_config *cfg, int32_t cell_stride, nid_ctx **out
   const int hs = std::min(62 - bits, 51);
   ctx->hist_scale = std::ldexp(1.0, hs);
   ctx->hist_inv_scale = std::ldexp(1.0, -hs);
-  // 32-bit byte offsets into the four W planes (load_tile_w): 4 planes x 8 B x nloc x pstride < 2^32
+  // 32-bit byte offsets into the reference weights (load_tile_w): 4 x 8 B x nloc x pstride < 2^32
   if ((size_t)g.nloc * (size_t)g.pstride >= ((size_t)1 << 27)) { delete ctx; return NID_ERR_UNSUPPORTED; }
   if (const char *bt = getenv("NID_BLOCK_THREADS")) {  // tuning: both kinds of launches
     const int v = atoi(bt);
@@ -1037,8 +1037,11 @@ int nid_set_href_state(nid_ctx *ctx, const int32_t *bs_counter, const double *Hr
       const size_t gi = (size_t)cl * g.pstride + s;
       for (int k = 0; k < 4; k++) {
         const double w = bs_value[4 * id + k];
-        W[k * plane + gi] = std::isnan(w) ? 0.0 : w;  // CUDA-path NaN marker -> CPU-edge zero (D2)
+        W[4 * gi + k] = std::isnan(w) ? 0.0 : w;  // CUDA-path NaN marker -> CPU-edge zero (D2)
       }
+      // the evaluation kernel's flag for tiny non-zero outer weights, as k_href leaves it: the sign of the first weight
+      const double wmin = std::fmin(W[4 * gi], W[4 * gi + 3]);
+      if (wmin < nid::kTinyW && wmin != 0.0) W[4 * gi] = -W[4 * gi];
     }
   }
   NID_HIP(ctx, hipMemcpy(ctx->t.W, W.data(), 4 * plane * sizeof(double), hipMemcpyHostToDevice));

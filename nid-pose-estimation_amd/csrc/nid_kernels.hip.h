@@ -62,7 +62,8 @@ constexpr unsigned kPoseQuatDwords = 14;  // q[7] leads the record
 
 struct Tiles {
   double *X, *Y, *Z;  // [nloc*pstride]; NaN where depth invalid / padding
-  double *W;          // 4 planes of nloc*pstride reference weights
+  double *W;          // [nloc*pstride][4] reference weights (slot-major: a slot's four weights are adjacent); the first
+                      // one carries a flag in its sign (negative: see hist_add) -- its value is the magnitude
   int8_t *JR;         // reference bin index, -1 = invalid depth / padding
   uint8_t *I0;        // reference intensity
 };
@@ -295,10 +296,45 @@ __device__ __forceinline__ void gradient_fast_interior(const Win &w, double u, d
 // B-spline values/derivatives from the per-span polynomial table (kCoefRow doubles per span):
 // row layout [k][a0 a1 a2 a3 d0 d1 d2], k = 0..3.  t = u - jc in [0,1).  The reference's u == 0
 // quirk (derivative identically 0 at exactly 0, Q5) is kept by a select.
-template <bool WANT_DER>
+// Experiment switches of the LDS read scheduling (tools/build_variant.sh; profiles/r02_ablations_A.txt): left to itself
+// the scheduler sends the table reads of a sample through one register quad, one dependent LDS round trip after the
+// other.  NID_BS_BATCH (cost phase, 16 value coefficients; 2 or 4 rows per wait), NID_BSD_BATCH (Jacobian phase, 12
+// derivative coefficients at once), NID_LDS_BATCH (Jacobian contraction, rows of the weight table per wait).
+#ifndef NID_BS_BATCH
+#define NID_BS_BATCH 0
+#endif
+#ifndef NID_BSD_BATCH
+#define NID_BSD_BATCH 0
+#endif
+#ifndef NID_LDS_BATCH
+#define NID_LDS_BATCH 0
+#endif
+template <bool WANT_DER, bool BATCH = false>
 __device__ __forceinline__ void bspline4_poly(double u, int jc, const double *ctab, double B[4], double D[4]) {
   const double t = u - (double)jc;
   const double *c = ctab + __mul24(jc, kCoefRow);
+#if NID_BS_BATCH
+  if (!WANT_DER && BATCH) {
+    // the value coefficients requested together and waited for once per NID_BS_BATCH rows; the empty asm statements
+    // make the loaded values "used" at that point, so the reads cannot sink below them
+    double cf[4][4];
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+#pragma unroll
+      for (int p = 0; p < 4; p++) cf[k][p] = c[7 * k + p];
+    if (NID_BS_BATCH == 4) {
+      asm volatile("" : "+v"(cf[0][0]), "+v"(cf[0][1]), "+v"(cf[0][2]), "+v"(cf[0][3]), "+v"(cf[1][0]), "+v"(cf[1][1]), "+v"(cf[1][2]), "+v"(cf[1][3]),
+                        "+v"(cf[2][0]), "+v"(cf[2][1]), "+v"(cf[2][2]), "+v"(cf[2][3]), "+v"(cf[3][0]), "+v"(cf[3][1]), "+v"(cf[3][2]), "+v"(cf[3][3]));
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; k += 2)
+        asm volatile("" : "+v"(cf[k][0]), "+v"(cf[k][1]), "+v"(cf[k][2]), "+v"(cf[k][3]), "+v"(cf[k + 1][0]), "+v"(cf[k + 1][1]), "+v"(cf[k + 1][2]), "+v"(cf[k + 1][3]));
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) B[k] = fma(fma(fma(cf[k][3], t, cf[k][2]), t, cf[k][1]), t, cf[k][0]);
+    return;
+  }
+#endif
 #pragma unroll
   for (int k = 0; k < 4; k++) {
     const double *ck = c + 7 * k;
@@ -315,6 +351,20 @@ __device__ __forceinline__ void bspline4_poly(double u, int jc, const double *ct
 __device__ __forceinline__ void bspline4_poly_der(double u, int jc, const double *ctab, double D[4]) {
   const double t = u - (double)jc;
   const double *c = ctab + __mul24(jc, kCoefRow);
+#if NID_BSD_BATCH
+  {
+    double cf[4][3];
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+#pragma unroll
+      for (int p = 0; p < 3; p++) cf[k][p] = c[7 * k + 4 + p];
+    asm volatile("" : "+v"(cf[0][0]), "+v"(cf[0][1]), "+v"(cf[0][2]), "+v"(cf[1][0]), "+v"(cf[1][1]), "+v"(cf[1][2]),
+                      "+v"(cf[2][0]), "+v"(cf[2][1]), "+v"(cf[2][2]), "+v"(cf[3][0]), "+v"(cf[3][1]), "+v"(cf[3][2]));
+#pragma unroll
+    for (int k = 0; k < 4; k++) D[k] = fma(fma(cf[k][2], t, cf[k][1]), t, cf[k][0]);
+    return;
+  }
+#endif
 #pragma unroll
   for (int k = 0; k < 4; k++) {
     const double *ck = c + 7 * k;
@@ -351,13 +401,19 @@ __device__ __forceinline__ double bilinear_w(const Win &w, double x, double y) {
 
 // Wave64 sum by DPP (VALU cross-lane moves, no LDS traffic): quad swaps, row
 // (half-)mirror, then row_bcast15 / row_bcast31.  The total ends in lane 63.
+// Lanes the move does not write (rows outside ROW_MASK) are left UNDEFINED (no `old` operand, so no v_mov 0 per
+// half in front of every v_mov_dpp: 12 VALU instructions less per summed value): wave_sum_to_lane63 only promises
+// lane 63, and no value that reaches lane 63 ever passes through such a lane (see there).
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ double dpp_mov_f64(double x) {
   int lo = __double2loint(x), hi = __double2hiint(x);
-  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xf, false);
-  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xf, false);
+  lo = __builtin_amdgcn_mov_dpp(lo, CTRL, ROW_MASK, 0xf, false);
+  hi = __builtin_amdgcn_mov_dpp(hi, CTRL, ROW_MASK, 0xf, false);
   return __hiloint2double(hi, lo);
 }
+// (Steps 1-4 write every lane.  row_bcast15 writes rows 1, 3 from lane 15 of rows 0, 2; row_bcast31 writes rows 2, 3
+// from lane 31: rows 0 and 2 hold garbage after step 5, lane 31 (row 1) and lane 63 (row 3) do not, and step 6
+// reads lane 31 only.)
 __device__ __forceinline__ double wave_sum_to_lane63(double v) {
   v += dpp_mov_f64<0xB1, 0xf>(v);   // quad_perm [1,0,3,2]
   v += dpp_mov_f64<0x4E, 0xf>(v);   // quad_perm [2,3,0,1]
@@ -563,7 +619,6 @@ __global__ __launch_bounds__(NT) void k_href(Geometry g, Pose pose, Tiles t, int
   for (int i = tid; i < g.nb * kHistCopies; i += NT) hist[i] = 0ull;
   __syncthreads();
   const size_t base = (size_t)cl * g.pstride;
-  const size_t plane = (size_t)g.nloc * g.pstride;
   int count = 0;
   for (int s = tid; s < g.pstride; s += NT) {
     const size_t gi = base + s;
@@ -585,8 +640,13 @@ __global__ __launch_bounds__(NT) void k_href(Geometry g, Pose pose, Tiles t, int
         for (int k = 0; k < 4; k++) atomicAdd(&hist[(jr + k) * kHistCopies + copy], fx_encode(w[k], hist_scale));
       }
     }
+    // the evaluation kernel's "tiny non-zero reference weights" flag rides in the sign of the first weight (hist_add)
+    {
+      const double wmin = fmin(w[0], w[3]);
+      if (wmin < kTinyW && wmin != 0.0) w[0] = -w[0];
+    }
 #pragma unroll
-    for (int k = 0; k < 4; k++) t.W[k * plane + gi] = w[k];
+    for (int k = 0; k < 4; k++) t.W[4 * gi + k] = w[k];  // slot-major: see load_tile_w
   }
   double v2[2] = {(double)count, 0.0};
   block_sum<NT, 2>(v2, red, tid);
@@ -799,6 +859,14 @@ __device__ __forceinline__ void finish_and_reduce_w0(const EvalParams &P, const 
 // guard bands of the FAST-mode decision re-check (see exact_decisions)
 // clamp guard: ic within 1e-4 of 0 or of 255 (the clamp replaces ic >= 255 by 254.999), as ONE compare |ic - mid| > half
 constexpr double kGuardMid = 127.5, kGuardHalf = 127.4999;
+// A sample the FAST main passes take lies inside the clamp guard: 1e-4 <= ic <= 254.9999, so the clamp ic >= 255 and
+// the u == 0 quirk of the B-spline derivative (pc == 0) cannot apply to it; only the second passes (exact_decisions)
+// carry those selects.  (The NID_EXP_NO_GUARD experiment build has no guard and keeps them everywhere.)
+#ifdef NID_EXP_NO_GUARD
+constexpr bool kMainPassClamps = true;
+#else
+constexpr bool kMainPassClamps = false;
+#endif
 constexpr double kBorderEps = 0x1p-20;  // FAST u, v are within ~1e-12 of the reference's (|u| < 2^11): a wide margin
 struct PixelFront {
   bool in, jin;
@@ -828,11 +896,14 @@ __device__ __forceinline__ void load_tile_xyz(const EvalParams &P, unsigned gi, 
   const unsigned bo = gi << 3;  // nloc * pstride * 8 < 2^32 (nid_create)
   t.x = ld_f64(P.t.X, bo); t.y = ld_f64(P.t.Y, bo); t.z = ld_f64(P.t.Z, bo);
 }
+typedef double f64x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void load_tile_w(const EvalParams &P, unsigned gi, unsigned plane, TileIn &t) {
-  // one uniform base, 32-bit lane offsets into the four planes (4 * 8 * nloc * pstride < 2^32, nid_create)
-  const unsigned bo = gi << 3, p8 = plane << 3;
-#pragma unroll
-  for (int k = 0; k < 4; k++) t.wr[k] = ld_f64(P.t.W, bo + (unsigned)k * p8);
+  // the four reference weights of a slot are adjacent (32 B): two 16-byte loads on one uniform base and one 32-bit
+  // lane offset, no per-plane address arithmetic (32 * nloc * pstride < 2^32, nid_create); a wave reads 2 KB in a row
+  (void)plane;
+  const f64x2 *w = reinterpret_cast<const f64x2 *>(reinterpret_cast<const char *>(P.t.W) + (gi << 5));
+  const f64x2 a = w[0], b = w[1];
+  t.wr[0] = a.x; t.wr[1] = a.y; t.wr[2] = b.x; t.wr[3] = b.y;
 }
 __device__ __forceinline__ void load_tile(const EvalParams &P, unsigned gi, unsigned plane, TileIn &t) {
   load_tile_xyz(P, gi, t);
@@ -1017,9 +1088,12 @@ __device__ __forceinline__ void exact_decisions(const EvalParams &P, const SlotA
   f.in = in; f.jin = jin; f.u = u; f.v = v;
 }
 
-// FAST: clamped centre sample -> bin position -> span; returns jc, pc
+// FAST: clamped centre sample -> bin position -> span; returns jc, pc.  CLAMP = false: the caller knows
+// ic < 255 (the main passes only take samples inside the clamp guard |ic - 127.5| <= kGuardHalf; the clamp's
+// compare and two selects then cost nothing)
+template <bool CLAMP = true>
 __device__ __forceinline__ int fast_bin(double &ic, int S, double &pc) {
-  if (ic >= 255) ic = 254.999;
+  if (CLAMP) { if (ic >= 255) ic = 254.999; }
   pc = ic * ((double)S / 255.0);
   return (int)pc;
 }
@@ -1069,6 +1143,10 @@ struct LatPix {
 #endif
 #ifndef NID_FAST_WAVES
 #define NID_FAST_WAVES 5
+#endif
+// main loops unrolled by two with ping-pong prefetch registers (see `pre2`); 0 = one round per trip, registers copied
+#ifndef NID_PINGPONG
+#define NID_PINGPONG 0
 #endif
 // EXT: the launch has more than kMaxBatch poses and their records live in P.slots_ext (device memory); the
 // workgroup's record is then pulled into scalar registers once, dword by dword, so that the pose matrix and
@@ -1142,8 +1220,11 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu((STRICT || D
   // it: the round loops run on a wave-uniform bound and the last round costs idle waves nothing
   const int wave_base = __builtin_amdgcn_readfirstlane(tid & ~63);
   const int lane = tid & 63;
-  TileIn pre, prej;  // loop form of the FAST pixel loops: the next round's point and bin index (see cost_round)
-  (void)pre; (void)prej;
+  // loop form of the FAST pixel loops: the next round's point and bin index (see cost_round).  Two of each: the main
+  // loops are unrolled by two by hand with the roles swapped, so no registers are copied from round to round
+  // (7 dwords per round and phase otherwise; clang does not unroll these loops itself: they hold convergent operations)
+  TileIn pre, pre2, prej, prej2;
+  (void)pre; (void)pre2; (void)prej; (void)prej2;
   for (int i = tid; i < nbins * (NC + kFineLevels); i += NT) hist[i] = 0ull;  // the copies and the fine levels behind them
   if (STRICT) {
     if (tid < S * 6) {
@@ -1151,19 +1232,26 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu((STRICT || D
       rtab[jj * kRcpRow + e] = 1.0 / span_denominator(jj, e, S);
     }
   } else {
-    for (int i = tid; i < S * kCoefRow; i += NT) rtab[i] = P.ctab[i];
+    // value coefficients (entries 0..3 of every 7-entry row) times hist_scale, see hist_add
+    for (int i = tid; i < S * kCoefRow; i += NT) rtab[i] = P.ctab[i] * ((i % 7) < 4 ? P.hist_scale : 1.0);
   }
   __syncthreads();
   NID_STAMP(1);
 
   // ---- phase 1: cost ---------------------------------------------------------------
   // One round = 64 consecutive tile slots per wave.  The histogram update of one in-frame sample:
-  auto hist_add = [&](int jr, int jc, const double (&wr)[4], const double (&wc)[4]) {
+  // FAST math: the value polynomials of the LDS copy of the B-spline table carry hist_scale (a power of two: every
+  // Horner step is the unscaled step times the scale, bit for bit), so the target weights arrive scaled (`win`
+  // = wc * hist_scale, PRESCALED) and the four multiplications per sample are gone; the rare branches below get the
+  // plain weights back by the inverse scale (exact).
+  const double tiny_scaled = kTinyW * P.hist_scale;
+  auto hist_add = [&](int jr, int jc, const double (&wr_in)[4], const double (&win)[4], auto prescaled) {
+    constexpr bool PRESCALED = decltype(prescaled)::value;
     // fixed-point encode: the scale is a power of two, so wcs = wc*scale is exact and
     // fma(wr, wcs, 2^52) rounds wr*wc*scale once
     double wcs[4];
 #pragma unroll
-    for (int k = 0; k < 4; k++) wcs[k] = wc[k] * P.hist_scale;
+    for (int k = 0; k < 4; k++) wcs[k] = PRESCALED ? win[k] : win[k] * P.hist_scale;
     const unsigned hrow = (unsigned)(__mul24(jr, nb) + jc);
     unsigned long long *hc = hist + ((unsigned)jc * NC + (unsigned)copy);
     unsigned long long *hj = hist + (((unsigned)nb + hrow) * NC + (unsigned)copy);
@@ -1176,9 +1264,16 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu((STRICT || D
     // a joint bin can consist of one end-span target sample's 1e-15 weight with an O(1) derivative PLUS hundreds of
     // 1e-16 products of tiny reference weights; lost in the coarse quantum they shifted that bin's W by 2.8 and
     // one cell's Jacobian by 0.7 % -- 3 of 2 500 random cases, tools/random_parity_sweep.py.)
-    const double wr_min = fmin(wr[0], wr[3]);
-    const bool ref_tiny = wr_min < kTinyW && wr_min != 0.0;
-    if (fmin(wc[0], wc[3]) < kTinyW || ref_tiny) {
+    // k_href leaves the "reference sample next to a knot with non-zero tiny weights" decision in the SIGN of the
+    // first stored weight (min(wr[0], wr[3]) < kTinyW and != 0 <=> wr_in[0] < 0): one compare here instead of
+    // five instructions per sample; |wr_in[0]| is a free source modifier of the products below
+    const bool ref_tiny = wr_in[0] < 0.0;
+    double wr[4] = {wr_in[0], wr_in[1], wr_in[2], wr_in[3]};
+    if (fmin(wcs[0], wcs[3]) < tiny_scaled || ref_tiny) {
+      double wc[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) wc[k] = PRESCALED ? win[k] * P.hist_inv_scale : win[k];
+      wr[0] = fabs(wr[0]);
       if (!ref_tiny) {
         // target side only (about one sample in 90 on a smooth image: every other wave-round gets here)
 #pragma unroll
@@ -1238,7 +1333,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu((STRICT || D
     for (int m = 0; m < 4; m++)
 #pragma unroll
       for (int k = 0; k < 4; k++)
-        atomicAdd(hj + (m * nb + k) * NC, fx_encode_raw(wr[m], wcs[k]));
+        atomicAdd(hj + (m * nb + k) * NC, fx_encode_raw(wr[m], wcs[k]));  // wr[0] >= 0 here (ref_tiny is false)
   };
   auto dump_pixel = [&](int s, const PixelFront &f, double ic, int jc, const double (&wc)[4]) {
     const int c = g.cell_begin + cl * g.cell_stride;
@@ -1272,7 +1367,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu((STRICT || D
       int jc = -1;
       if (f.in) {
         jc = pixel_sample<true, false>(f, nb, S, rtab, ic, wc, dw);
-        hist_add(f.jr, jc, f.wr, wc);
+        hist_add(f.jr, jc, f.wr, wc, std::false_type{});
       }
       if (DBG && P.dbg_u && !P.dbg_jac && pose_idx == 0 && f.jr >= 0) dump_pixel(s, f, ic, jc, wc);
     }
@@ -1281,20 +1376,22 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu((STRICT || D
     // worked on, and this round's reference weights are fetched behind its window loads: a round then exposes ONE
     // memory round trip (the window) instead of two.  Both phases; the Jacobian phase ends at 95 of its 96 VGPRs.
     // Measured: 1030 -> 1008 us per 256-pose launch (profiles/r02_ablations_A.txt).
-    auto cost_round = [&](int sb, auto second_pass) -> bool {
+    auto cost_round = [&](int sb, const TileIn &cur, TileIn &nxt, auto second_pass) -> bool {
       constexpr bool SECOND = decltype(second_pass)::value;
       const int s = sb + lane;
       TileIn tin;
       PixelFront f;
       if (!SECOND) {
-        tin = pre;
-        if (sb + NT < g.pstride) load_tile_xyz(P, base + (unsigned)(s + NT), pre);
+        tin = cur;
 #pragma unroll
         for (int k = 0; k < 4; k++) tin.wr[k] = 0.0;
       } else {
         load_tile(P, base + (unsigned)s, plane, tin);
       }
       pixel_front<false>(P, SA, tin, f);
+      // the next round's point is requested BEHIND this round's warp: x, y, z are dead by then, so the loads land in
+      // the registers they come from and nothing is copied from round to round
+      if (!SECOND && sb + NT < g.pstride) load_tile_xyz(P, base + (unsigned)(s + NT), nxt);
       WinC wc2;
       load_win_centre(P, f.w.wx, f.w.wy, wc2);
       if (!SECOND) load_tile_w(P, base + (unsigned)s, plane, tin);
@@ -1319,13 +1416,17 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu((STRICT || D
       int jc = -1;
       if (go) {
         double pc;
-        jc = fast_bin(ic, S, pc);
-        bspline4_poly<false>(pc, jc, rtab, wc, dw);
-        hist_add(f.jr, jc, SECOND ? f.wr : tin.wr, wc);
+        jc = fast_bin<SECOND || kMainPassClamps>(ic, S, pc);
+        bspline4_poly<false, JAC && !SECOND>(pc, jc, rtab, wc, dw);
+        hist_add(f.jr, jc, SECOND ? f.wr : tin.wr, wc, std::true_type{});
       } else {
         ic = NAN;
       }
-      if (DBG && P.dbg_u && !P.dbg_jac && pose_idx == 0 && f.jr >= 0 && rare == SECOND) dump_pixel(s, f, ic, jc, wc);
+      if (DBG && P.dbg_u && !P.dbg_jac && pose_idx == 0 && f.jr >= 0 && rare == SECOND) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) wc[k] *= P.hist_inv_scale;  // NaN stays NaN
+        dump_pixel(s, f, ic, jc, wc);
+      }
       return !SECOND && __builtin_amdgcn_ballot_w64(rare) != 0ull;
     };
     int r = 0;
@@ -1358,16 +1459,16 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu((STRICT || D
           double wc[4], dw[4], pc = 0.0;
           int jc = -1;
           if (f.in && !rare) {
-            jc = fast_bin(ic, S, pc);
+            jc = fast_bin<kMainPassClamps>(ic, S, pc);
             bspline4_poly<false>(pc, jc, rtab, wc, dw);
-            hist_add(f.jr, jc, f.wr, wc);
+            hist_add(f.jr, jc, f.wr, wc, std::true_type{});
           }
           if (__builtin_amdgcn_ballot_w64(rare) != 0ull) rare_rounds |= 1ull << q;
           if (JAC) {
             LatPix &l = lat[q];
             l.x = f.x; l.y = f.y; l.iz = f.zq; l.gx = gx; l.gy = gy; l.pc = pc;
 #pragma unroll
-            for (int k = 0; k < 4; k++) l.wr[k] = f.wr[k];
+            for (int k = 0; k < 4; k++) l.wr[k] = k == 0 ? fabs(f.wr[0]) : f.wr[k];  // sign: k_href's knot flag
             l.jr = f.jr; l.jc = jc;
             l.go = f.jin && !rare;
           }
@@ -1375,15 +1476,24 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu((STRICT || D
       }
     } else {
       if (wave_base < g.pstride) load_tile_xyz(P, base + (unsigned)(wave_base + lane), pre);
+      if constexpr (JAC && NID_PINGPONG) {
 #pragma clang loop unroll(disable)
-      for (int sb = wave_base; sb < g.pstride; sb += NT, r++)
-        if (cost_round(sb, std::false_type{})) rare_rounds |= 1ull << min(r, 63);
+        for (int sb = wave_base; sb < g.pstride; sb += 2 * NT, r += 2) {
+          if (cost_round(sb, pre, pre2, std::false_type{})) rare_rounds |= 1ull << min(r, 63);
+          if (sb + NT >= g.pstride) break;
+          if (cost_round(sb + NT, pre2, pre, std::false_type{})) rare_rounds |= 1ull << min(r + 1, 63);
+        }
+      } else {  // cost-only kernels: the plain loop keeps them at 72 VGPRs (7 waves per SIMD)
+#pragma clang loop unroll(disable)
+        for (int sb = wave_base; sb < g.pstride; sb += NT, r++)
+          if (cost_round(sb, pre, pre, std::false_type{})) rare_rounds |= 1ull << min(r, 63);
+      }
     }
     if (rare_rounds != 0ull) {
       r = 0;
 #pragma clang loop unroll(disable)
       for (int sb = wave_base; sb < g.pstride; sb += NT, r++)
-        if ((rare_rounds >> min(r, 63)) & 1ull) cost_round(sb, std::true_type{});
+        if ((rare_rounds >> min(r, 63)) & 1ull) cost_round(sb, pre, pre, std::true_type{});
     }
   }
   NID_STAMP(2);
@@ -1463,9 +1573,44 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu((STRICT || D
   // FAST-mode constants: the gradient helper returns twice the gradient, so 1/2 rides on fx, fy
   const double cAx = wave_uniform(cA * (0.5 * g.fx)), cBx = wave_uniform(cB * (0.5 * g.fx));
   const double cAy = wave_uniform(cA * (0.5 * g.fy)), cBy = wave_uniform(cB * (0.5 * g.fy));
-  auto jac_accumulate = [&](const auto &f, double invz, double gx, double gy, double pc, int jc, const double (&dw)[4]) {
+  auto jac_accumulate = [&](const auto &f, double invz, double gx, double gy, double pc, int jc, const double (&dw)[4], auto q5_possible) {
     const double *tj = tab + ((unsigned)nb + (unsigned)(__mul24(f.jr, nb) + jc));
     double tt = 0.0, ss = 0.0;
+#if NID_LDS_BATCH
+    // EXPERIMENT (tools/build_variant.sh -DNID_LDS_BATCH=1|2): the 20 table values in batches of NID_LDS_BATCH rows, a
+    // batch's reads issued together and waited for once (left to itself the scheduler sends every ds_read2 through one
+    // register quad: ten dependent LDS round trips per sample).  The empty asm statements pin the order.
+    {
+      unsigned tjo = (unsigned)nb + (unsigned)(__mul24(f.jr, nb) + jc);  // an offset, not a pointer: the reads stay ds_read
+#pragma unroll
+      for (int k0 = 0; k0 < 4; k0 += NID_LDS_BATCH) {
+        asm volatile("" : "+v"(tjo), "+v"(ss));
+        double tv[NID_LDS_BATCH][4], tc[4];
+        if (k0 == 0) {
+#pragma unroll
+          for (int m = 0; m < 4; m++) tc[m] = tab[jc + m];
+        }
+#pragma unroll
+        for (int k = 0; k < NID_LDS_BATCH; k++)
+#pragma unroll
+          for (int m = 0; m < 4; m++) tv[k][m] = tab[tjo + (unsigned)((k0 + k) * nb + m)];
+        if (k0 == 0) asm volatile("" : "+v"(tc[0]), "+v"(tc[1]), "+v"(tc[2]), "+v"(tc[3]));
+#pragma unroll
+        for (int k = 0; k < NID_LDS_BATCH; k++) asm volatile("" : "+v"(tv[k][0]), "+v"(tv[k][1]), "+v"(tv[k][2]), "+v"(tv[k][3]));
+        if (k0 == 0) {
+#pragma unroll
+          for (int m = 0; m < 4; m++) tt = fma(tc[m], dw[m], tt);
+        }
+#pragma unroll
+        for (int k = 0; k < NID_LDS_BATCH; k++) {
+          double inner = 0.0;
+#pragma unroll
+          for (int m = 0; m < 4; m++) inner = fma(tv[k][m], dw[m], inner);
+          ss = fma(f.wr[k0 + k], inner, ss);
+        }
+      }
+    }
+#else
 #pragma unroll
     for (int m = 0; m < 4; m++) tt = fma(tab[jc + m], dw[m], tt);
 #pragma unroll
@@ -1475,12 +1620,15 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu((STRICT || D
       for (int m = 0; m < 4; m++) inner = fma(tj[k * nb + m], dw[m], inner);
       ss = fma(f.wr[k], inner, ss);
     }
+#endif
     if (!STRICT) {
       // d(u,v)/d(xi) with a = x/z, b = y/z (types_six_dof_expmap.cpp:438-450 regrouped):
       //   Ju = fx [-ab, 1+a^2, -b, 1/z, 0, -a/z],  Jv = fy [-(1+b^2), ab, a, 0, 1/z, -b/z]
       // acc[0] and acc[5] accumulate the NEGATED sums (fixed after the loop).
       double cP = fma(ss, cAx, -(tt * cBx)), cQ = fma(ss, cAy, -(tt * cBy));
-      if (pc == 0.0) { cP = 0.0; cQ = 0.0; }  // Q5: B-spline derivative identically 0 at u == 0
+      if (decltype(q5_possible)::value) {
+        if (pc == 0.0) { cP = 0.0; cQ = 0.0; }  // Q5: B-spline derivative identically 0 at u == 0 (second passes only, see kMainPassClamps)
+      }
       const double Pg = cP * gx, Qg = cQ * gy;
       const double a = f.x * invz, b = f.y * invz;
       const double Pa = Pg * a, Qb = Qg * b;
@@ -1527,6 +1675,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu((STRICT || D
       PixelFront f;
       load_tile(P, base + (unsigned)s, plane, tin);
       pixel_front<true>(P, SA, tin, f);
+      f.wr[0] = fabs(f.wr[0]);  // the sign of the first reference weight is k_href's knot flag (hist_add)
       load_window(P, f.w);
       if (f.in) {
         // linearizeOplus: fx*(x/z)+cx (types_six_dof_expmap.cpp:407-422, Q6)
@@ -1547,7 +1696,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu((STRICT || D
           const double gx = (bilinear_rows(r0, f.w.wx, u + 1) - bilinear_rows(r0, f.w.wx, u - 1)) / 2;
           const RowPair rp = win_rows(f.w, v + 1), rm = win_rows(f.w, v - 1);
           const double gy = (bilinear_rows(rp, f.w.wx, u) - bilinear_rows(rm, f.w.wx, u)) / 2;
-          jac_accumulate(f, invz, gx, gy, 1.0, jc, dw);
+          jac_accumulate(f, invz, gx, gy, 1.0, jc, dw, std::false_type{});
           if (DBG && P.dbg_u && P.dbg_jac && pose_idx == 0) dump_jac(s, gx, gy, ic * ((double)nb - 3.0) / 255.0, jc, dw);
         }
       }
@@ -1556,20 +1705,22 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu((STRICT || D
     // Two passes like the cost phase, with the same classification on the same values (gradient_fast_interior's
     // centre sample IS sample_fast_interior's): both phases take the same decisions and use the same
     // intensity (Q7).
-    auto jac_round = [&](int sb, auto second_pass) {
+    auto jac_round = [&](int sb, const TileIn &cur, TileIn &nxt, auto second_pass) {
       constexpr bool SECOND = decltype(second_pass)::value;
       const int s = sb + lane;
       TileIn tin;
       PixelFront f;
       if (!SECOND) {
-        tin = prej;
-        if (sb + NT < g.pstride) load_tile_xyz(P, base + (unsigned)(s + NT), prej);
+        tin = cur;
 #pragma unroll
         for (int k = 0; k < 4; k++) tin.wr[k] = 0.0;
       } else {
         load_tile(P, base + (unsigned)s, plane, tin);
       }
       pixel_front<false>(P, SA, tin, f);
+      // the next round's point is requested BEHIND this round's warp: x, y, z are dead by then, so the loads land in
+      // the registers they come from and nothing is copied from round to round
+      if (!SECOND && sb + NT < g.pstride) load_tile_xyz(P, base + (unsigned)(s + NT), nxt);
       WinJ wj;
       load_win_jac(P, f.w.wx, f.w.wy, wj);
       if (!SECOND) {
@@ -1577,6 +1728,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu((STRICT || D
 #pragma unroll
         for (int k = 0; k < 4; k++) f.wr[k] = tin.wr[k];
       }
+      f.wr[0] = fabs(f.wr[0]);  // the sign of the first reference weight is k_href's knot flag (hist_add)
       double ic, gx, gy;
       gradient_fast_j(wj, f.u, f.v, gx, gy, ic);  // every lane, see the cost phase
 #ifdef NID_EXP_NO_GUARD
@@ -1599,9 +1751,9 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu((STRICT || D
       }
       if (go) {
         double pc, dw[4];
-        const int jc = fast_bin(ic, S, pc);
+        const int jc = fast_bin<SECOND || kMainPassClamps>(ic, S, pc);
         bspline4_poly_der(pc, jc, rtab, dw);
-        jac_accumulate(f, f.zq, gx, gy, pc, jc, dw);
+        jac_accumulate(f, f.zq, gx, gy, pc, jc, dw, std::integral_constant<bool, SECOND || kMainPassClamps>{});
         if (DBG && P.dbg_u && P.dbg_jac && pose_idx == 0) {
           double dq[4];
 #pragma unroll
@@ -1621,20 +1773,29 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu((STRICT || D
         if (lat[q].go) {
           double dw[4];
           bspline4_poly_der(lat[q].pc, lat[q].jc, rtab, dw);
-          jac_accumulate(lat[q], lat[q].iz, lat[q].gx, lat[q].gy, lat[q].pc, lat[q].jc, dw);
+          jac_accumulate(lat[q], lat[q].iz, lat[q].gx, lat[q].gy, lat[q].pc, lat[q].jc, dw, std::integral_constant<bool, kMainPassClamps>{});
         }
       rare2 = rare_rounds;
     } else {
       if (wave_base < g.pstride) load_tile_xyz(P, base + (unsigned)(wave_base + lane), prej);
+      if constexpr (NID_PINGPONG) {
 #pragma clang loop unroll(disable)
-      for (int sb = wave_base; sb < g.pstride; sb += NT, r++)
-        if (jac_round(sb, std::false_type{})) rare2 |= 1ull << min(r, 63);
+        for (int sb = wave_base; sb < g.pstride; sb += 2 * NT, r += 2) {
+          if (jac_round(sb, prej, prej2, std::false_type{})) rare2 |= 1ull << min(r, 63);
+          if (sb + NT >= g.pstride) break;
+          if (jac_round(sb + NT, prej2, prej, std::false_type{})) rare2 |= 1ull << min(r + 1, 63);
+        }
+      } else {
+#pragma clang loop unroll(disable)
+        for (int sb = wave_base; sb < g.pstride; sb += NT, r++)
+          if (jac_round(sb, prej, prej, std::false_type{})) rare2 |= 1ull << min(r, 63);
+      }
     }
     if (rare2 != 0ull) {
       r = 0;
 #pragma clang loop unroll(disable)
       for (int sb = wave_base; sb < g.pstride; sb += NT, r++)
-        if ((rare2 >> min(r, 63)) & 1ull) jac_round(sb, std::true_type{});
+        if ((rare2 >> min(r, 63)) & 1ull) jac_round(sb, prej, prej, std::true_type{});
     }
   }
   if (!STRICT) { acc[0] = -acc[0]; acc[5] = -acc[5]; }
