@@ -190,8 +190,9 @@ void build_coef_table(int S, std::vector<double> *out) {
 
 size_t eval_lds_bytes(const Geometry &g, int nt) {
   const int nbins = g.nb * g.nb + g.nb;
-  return (size_t)nbins * (eval_hist_copies(nt) + kFineLevels) * 8 + 2 * (size_t)((nbins + 1) & ~1) * 8 +  // copies + fine levels; tab + term
-         (size_t)g.S * kCoefRow * 8 + (size_t)kRedDoubles(nt) * 8;
+  // copies + fine levels (the Jacobian block sum of the throughput shapes reuses the area: at least kXposeDoubles); tab + term
+  const size_t hist_bytes = std::max((size_t)nbins * (eval_hist_copies(nt) + kFineLevels), (size_t)kXposeDoubles(nt)) * 8;
+  return hist_bytes + 2 * (size_t)((nbins + 1) & ~1) * 8 + (size_t)g.S * kCoefRow * 8 + (size_t)kRedDoubles(nt) * 8;
 }
 
 // k_eval2 (occupancy-organised, runtime pixel loop): one workgroup shape for every cell size.

@@ -763,6 +763,13 @@ __device__ __forceinline__ double load_sc1(const double *p) {
 }
 
 constexpr int kRedDoubles(int nt) { return (6 * (nt / 64) + 1) & ~1; }  // the six Jacobian sums of every wave
+// 128- / 256-thread shapes: the six sums go through a [6][kXposeStride] array of doubles that reuses the histogram area
+// (rows padded by 8 doubles so that the six row groups of a read do not share banks); 0 = the DPP form everywhere
+#ifndef NID_XPOSE_SUM
+#define NID_XPOSE_SUM 1
+#endif
+constexpr int kXposeStride(int nt) { return nt + 8; }
+constexpr int kXposeDoubles(int nt) { return (nt <= 256 && NID_XPOSE_SUM) ? 6 * kXposeStride(nt) : 0; }
 constexpr int kQuad = 32;  // per-cell block: rho0 | b[6] | H upper[21] | 1.0 | 0 0 0
 
 // which (a,b) of the upper triangle a quad slot 7..27 holds
@@ -1804,7 +1811,32 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu((STRICT || D
   // Block sum of the six accumulators: every wave reduces its own (DPP), lane 63 leaves the partials in LDS;
   // after the barrier waves 1..3 retire -- the cell's tail (quadratic form, hand-off, reductions) is
   // wave 0's business, and the retired waves' slots go to the next workgroup ~5 k cycles earlier.
-  {
+  if constexpr (NT <= 256 && NID_XPOSE_SUM) {
+    // Throughput shapes: the sums go through LDS instead of six 64-lane DPP trees per wave (108 VALU instructions per
+    // wave, 250 per workgroup with the cross-wave part): every thread leaves its six accumulators in the (free by
+    // now) histogram area, row k = accumulator k; after the barrier the other waves retire and wave 0 sums row k with
+    // eight lanes -- lane 8k + j adds the elements j, j + 8, ... in ascending order (NT / 8 independent reads in
+    // flight), three DPP steps inside the group of eight add the parts.  One fixed order per workgroup shape.
+    double *xs = reinterpret_cast<double *>(hist);
+#pragma unroll
+    for (int k = 0; k < 6; k++) xs[k * kXposeStride(NT) + tid] = acc[k];
+    __syncthreads();
+    if (tid >= 64) return;
+    double part = 0.0;
+    if (tid < 48) {
+      const double *row = xs + (tid >> 3) * kXposeStride(NT) + (tid & 7);
+      double v[NT / 8];
+#pragma unroll
+      for (int i = 0; i < NT / 8; i++) v[i] = row[i * 8];
+#pragma unroll
+      for (int i = 0; i < NT / 8; i++) part += v[i];
+    }
+    part += dpp_mov_f64<0xB1, 0xf>(part);   // quad_perm [1,0,3,2]
+    part += dpp_mov_f64<0x4E, 0xf>(part);   // quad_perm [2,3,0,1]
+    part += dpp_mov_f64<0x141, 0xf>(part);  // row_half_mirror: all eight lanes of a group hold the group's sum
+    acc[0] = wave_lane<0>(part); acc[1] = wave_lane<8>(part); acc[2] = wave_lane<16>(part);
+    acc[3] = wave_lane<24>(part); acc[4] = wave_lane<32>(part); acc[5] = wave_lane<40>(part);
+  } else {
     constexpr int NW = NT / 64;
 #pragma unroll
     for (int k = 0; k < 6; k++) acc[k] = wave_sum_to_lane63(acc[k]);
