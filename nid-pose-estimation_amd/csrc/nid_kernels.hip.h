@@ -975,6 +975,22 @@ __device__ __forceinline__ void gradient_fast_j(const WinJ &w, double u, double 
   ic = fma(dy, m2 - m1, m1);
 }
 
+// FAST warp of one tile entry: f.jr, f.x, f.y, f.zq = 1/z, f.u, f.v -- pixel_front<false> without its border tests
+// (the same operations on the same values: the two give the same bits)
+__device__ __forceinline__ void warp_fast(const EvalParams &P, const SlotArgs &SA, const TileIn &t, PixelFront &f) {
+  const Geometry &g = P.g;
+  const double *M = SA.pose.M;
+  const double lx = t.x, ly = t.y, lz = t.z;
+  const double qx = fma(M[0], lx, fma(M[1], ly, fma(M[2], lz, M[3])));
+  const double qy = fma(M[4], lx, fma(M[5], ly, fma(M[6], lz, M[7])));
+  const double qz = fma(M[8], lx, fma(M[9], ly, fma(M[10], lz, M[11])));
+  const double iz = rcp_fast(qz);
+  f.jr = t.jr;
+  f.x = qx; f.y = qy; f.zq = iz;
+  f.u = fma(g.fx * qx, iz, g.cx);
+  f.v = fma(g.fy * qy, iz, g.cy);
+}
+
 template <bool STRICT>
 __device__ __forceinline__ void pixel_front(const EvalParams &P, const SlotArgs &SA, const TileIn &t, PixelFront &f) {
   const Geometry &g = P.g;
@@ -1151,10 +1167,6 @@ struct LatPix {
 #ifndef NID_FAST_WAVES
 #define NID_FAST_WAVES 5
 #endif
-// main loops unrolled by two with ping-pong prefetch registers (see `pre2`); 0 = one round per trip, registers copied
-#ifndef NID_PINGPONG
-#define NID_PINGPONG 0
-#endif
 // EXT: the launch has more than kMaxBatch poses and their records live in P.slots_ext (device memory); the
 // workgroup's record is then pulled into scalar registers once, dword by dword, so that the pose matrix and
 // the pointers are SGPR operands exactly as when they come from the kernel arguments.
@@ -1166,7 +1178,8 @@ struct LatPix {
 // the bin position, the reference weights: LatPix) stays in registers across the fold, so the Jacobian phase of
 // the main pass touches no global memory at all.  One workgroup per CU leaves 128+ VGPRs per lane for that.
 // Same operations on the same values in the same per-lane order as the loop form: bit-identical results (tested).
-template <int NT, bool JAC, bool STRICT, int NB, bool DBG, bool EXT = false, int LAT = 0>
+// BIG: cells of more than 32 * NT slots (more rounds per wave than a lane's 32-bit gomask has bits).
+template <int NT, bool JAC, bool STRICT, int NB, bool DBG, bool EXT = false, int LAT = 0, bool BIG = false>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu((STRICT || DBG || LAT || NT >= 512) ? 4 : NID_FAST_WAVES))) void k_eval2(EvalParams P) {
   static_assert(LAT == 0 || (!STRICT && !EXT), "the latency form exists for FAST math launches of <= kMaxBatch poses (DBG: phase stamps only)");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1227,11 +1240,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu((STRICT || D
   // it: the round loops run on a wave-uniform bound and the last round costs idle waves nothing
   const int wave_base = __builtin_amdgcn_readfirstlane(tid & ~63);
   const int lane = tid & 63;
-  // loop form of the FAST pixel loops: the next round's point and bin index (see cost_round).  Two of each: the main
-  // loops are unrolled by two by hand with the roles swapped, so no registers are copied from round to round
-  // (7 dwords per round and phase otherwise; clang does not unroll these loops itself: they hold convergent operations)
-  TileIn pre, pre2, prej, prej2;
-  (void)pre; (void)pre2; (void)prej; (void)prej2;
+  TileIn pre, prej;  // loop form of the FAST pixel loops: the next round's point and bin index (see cost_round)
+  (void)pre; (void)prej;
   for (int i = tid; i < nbins * (NC + kFineLevels); i += NT) hist[i] = 0ull;  // the copies and the fine levels behind them
   if (STRICT) {
     if (tid < S * 6) {
@@ -1359,6 +1369,20 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu((STRICT || D
   // the sums stay run-to-run reproducible), and integer histogram adds do not care about the order.
   // rounds: bit min(r, 63) of a wave-uniform mask; a cell of more than 64 rounds per wave shares the last bit.
   unsigned long long rare_rounds = 0ull;
+  // Loop form, cost + Jacobian: bit r of a lane's gomask = "the main pass of the cost phase took this lane's sample of
+  // round r".  The Jacobian phase redoes the identical warp and sample, so its main pass takes exactly those samples
+  // (minus the ones outside linearizeOplus' narrower frame) and revisits exactly the cost phase's rare rounds: five f64
+  // compares, the clamp guard, the ballot and the mask bookkeeping per round are replaced by one bit test.
+  // 32 rounds per wave cover cells of up to 32 * NT pixels; for larger cells the host launches the BIG instantiation,
+  // which classifies again (jac_round).  (A run-time switch between the two loops costs spills around the cold one,
+  // and a kernel with scratch measured 4 % slower: profiles/r02_ablations_A.txt.)
+  unsigned gomask = 0u;
+  (void)gomask;
+#ifdef NID_EXP_NO_GUARD
+  constexpr bool use_gomask = false;
+#else
+  constexpr bool use_gomask = JAC && !STRICT && LAT == 0 && !DBG && !BIG;
+#endif
   LatPix lat[LAT > 0 ? LAT : 1];  // LAT + JAC: the cost phase's hand-over to the Jacobian phase
   (void)lat;
   if constexpr (STRICT) {
@@ -1383,7 +1407,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu((STRICT || D
     // worked on, and this round's reference weights are fetched behind its window loads: a round then exposes ONE
     // memory round trip (the window) instead of two.  Both phases; the Jacobian phase ends at 95 of its 96 VGPRs.
     // Measured: 1030 -> 1008 us per 256-pose launch (profiles/r02_ablations_A.txt).
-    auto cost_round = [&](int sb, const TileIn &cur, TileIn &nxt, auto second_pass) -> bool {
+    auto cost_round = [&](int sb, int r, const TileIn &cur, TileIn &nxt, auto second_pass) -> bool {
       constexpr bool SECOND = decltype(second_pass)::value;
       const int s = sb + lane;
       TileIn tin;
@@ -1412,6 +1436,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu((STRICT || D
 #endif
       if (f.redo && classify_redo(P, f)) rare = true;  // (waves that meet the frame border)
       bool go = f.in && !rare;
+      if (use_gomask && !SECOND) gomask |= (go ? 1u : 0u) << r;  // for the Jacobian phase (jac_round_masked); r < 32
       if (SECOND) {
         go = false;
         if (rare) {
@@ -1483,24 +1508,15 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu((STRICT || D
       }
     } else {
       if (wave_base < g.pstride) load_tile_xyz(P, base + (unsigned)(wave_base + lane), pre);
-      if constexpr (JAC && NID_PINGPONG) {
 #pragma clang loop unroll(disable)
-        for (int sb = wave_base; sb < g.pstride; sb += 2 * NT, r += 2) {
-          if (cost_round(sb, pre, pre2, std::false_type{})) rare_rounds |= 1ull << min(r, 63);
-          if (sb + NT >= g.pstride) break;
-          if (cost_round(sb + NT, pre2, pre, std::false_type{})) rare_rounds |= 1ull << min(r + 1, 63);
-        }
-      } else {  // cost-only kernels: the plain loop keeps them at 72 VGPRs (7 waves per SIMD)
-#pragma clang loop unroll(disable)
-        for (int sb = wave_base; sb < g.pstride; sb += NT, r++)
-          if (cost_round(sb, pre, pre, std::false_type{})) rare_rounds |= 1ull << min(r, 63);
-      }
+      for (int sb = wave_base; sb < g.pstride; sb += NT, r++)
+        if (cost_round(sb, r, pre, pre, std::false_type{})) rare_rounds |= 1ull << min(r, 63);
     }
     if (rare_rounds != 0ull) {
       r = 0;
 #pragma clang loop unroll(disable)
       for (int sb = wave_base; sb < g.pstride; sb += NT, r++)
-        if ((rare_rounds >> min(r, 63)) & 1ull) cost_round(sb, pre, pre, std::true_type{});
+        if ((rare_rounds >> min(r, 63)) & 1ull) cost_round(sb, r, pre, pre, std::true_type{});
     }
   }
   NID_STAMP(2);
@@ -1770,6 +1786,31 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu((STRICT || D
       }
       return !SECOND && __builtin_amdgcn_ballot_w64(exact) != 0ull;
     };
+    auto jac_round_masked = [&](int sb, int r, const TileIn &cur, TileIn &nxt) {
+      const int s = sb + lane;
+      PixelFront f;
+      warp_fast(P, SA, cur, f);
+      // (the whole warp before the branch on `go`: left alone the compiler sinks v's arithmetic into the branch, the
+      // point then lives across the prefetch and is copied from round to round again)
+      asm volatile("" : "+v"(f.u), "+v"(f.v));
+      if (sb + NT < g.pstride) load_tile_xyz(P, base + (unsigned)(s + NT), nxt);
+      const bool go = ((gomask >> r) & 1u) != 0u && f.u <= P.u_jin;
+      WinJ wj;
+      load_win_jac(P, go ? (int)f.u - 1 : 0, go ? (int)f.v - 1 : 0, wj);
+      TileIn tw;
+      load_tile_w(P, base + (unsigned)s, plane, tw);
+#pragma unroll
+      for (int k = 0; k < 4; k++) f.wr[k] = tw.wr[k];
+      f.wr[0] = fabs(f.wr[0]);  // the sign of the first reference weight is k_href's knot flag (hist_add)
+      double ic, gx, gy;
+      gradient_fast_j(wj, f.u, f.v, gx, gy, ic);
+      if (go) {
+        double pc, dw[4];
+        const int jc = fast_bin<false>(ic, S, pc);
+        bspline4_poly_der(pc, jc, rtab, dw);
+        jac_accumulate(f, f.zq, gx, gy, pc, jc, dw, std::false_type{});
+      }
+    };
     unsigned long long rare2 = 0ull;
     int r = 0;
     if constexpr (LAT > 0) {
@@ -1785,13 +1826,12 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu((STRICT || D
       rare2 = rare_rounds;
     } else {
       if (wave_base < g.pstride) load_tile_xyz(P, base + (unsigned)(wave_base + lane), prej);
-      if constexpr (NID_PINGPONG) {
+      if constexpr (use_gomask) {
+        // the cost phase's decisions (gomask) instead of a second classification; the rounds with rare samples are
+        // the cost phase's too (same classification on the same values)
 #pragma clang loop unroll(disable)
-        for (int sb = wave_base; sb < g.pstride; sb += 2 * NT, r += 2) {
-          if (jac_round(sb, prej, prej2, std::false_type{})) rare2 |= 1ull << min(r, 63);
-          if (sb + NT >= g.pstride) break;
-          if (jac_round(sb + NT, prej2, prej, std::false_type{})) rare2 |= 1ull << min(r + 1, 63);
-        }
+        for (int sb = wave_base; sb < g.pstride; sb += NT, r++) jac_round_masked(sb, r, prej, prej);
+        rare2 = rare_rounds;
       } else {
 #pragma clang loop unroll(disable)
         for (int sb = wave_base; sb < g.pstride; sb += NT, r++)
