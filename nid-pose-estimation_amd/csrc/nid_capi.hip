@@ -253,18 +253,20 @@ void launch_eval2_nb(const EvalParams &P, bool jac, bool strict, size_t lds, hip
 //    histograms, entropy sums in a fixed order --, so unless the context pins their shape they take the one that
 //    fills the chip: ~8 waves per SIMD at most, i.e. 1024 threads for a single pose of 256 cells (a cell's
 //    1200 pixels in two rounds instead of ten), 128 from 16 poses on.  Measured: tools/latency_sweep.py.
-// Cells of more than 32 * NT slots (test geometries: a single cell of 6 144 / 19 200 pixels): the FAST cost + Jacobian
-// kernels' BIG instantiation (k_eval2), generic bin count only.
+// Cells of more than 32 * NT slots (test geometries: a single cell of 6 144 / 19 200 pixels): the FAST kernels' BIG
+// instantiation (k_eval2), generic bin count only.
 template <int NT>
-void launch_eval2_big(const EvalParams &P, size_t lds, hipStream_t s, int batch) {
+void launch_eval2_big(const EvalParams &P, bool jac, size_t lds, hipStream_t s, int batch) {
   const dim3 grid((unsigned)(((P.g.nloc + 7) / 8) * 8 * batch)), block(NT);
   if constexpr (NT <= 256) {
     if (P.slots_ext) {
-      hipLaunchKernelGGL((k_eval2<NT, true, false, 0, false, true, 0, true>), grid, block, lds, s, P);
+      if (jac) hipLaunchKernelGGL((k_eval2<NT, true, false, 0, false, true, 0, true>), grid, block, lds, s, P);
+      else hipLaunchKernelGGL((k_eval2<NT, false, false, 0, false, true, 0, true>), grid, block, lds, s, P);
       return;
     }
   }
-  hipLaunchKernelGGL((k_eval2<NT, true, false, 0, false, false, 0, true>), grid, block, lds, s, P);
+  if (jac) hipLaunchKernelGGL((k_eval2<NT, true, false, 0, false, false, 0, true>), grid, block, lds, s, P);
+  else hipLaunchKernelGGL((k_eval2<NT, false, false, 0, false, false, 0, true>), grid, block, lds, s, P);
 }
 
 int pick_threads(const nid_ctx *ctx, bool jac, int batch) {
@@ -318,11 +320,11 @@ int launch_eval2(nid_ctx *ctx, EvalParams &P, bool jac, hipStream_t stream, int 
   } else if (dbg) {  // diagnostics keep the workgroup shape: the Jacobian sums depend on it in their last bits
     if (nt == 128) launch_eval2_v<128, 0, true>(P, jac, strict, lds, stream, batch);
     else launch_eval2_v<256, 0, true>(P, jac, strict, lds, stream, batch);
-  } else if (jac && !strict && P.g.pstride > 32 * nt) {
-    if (nt == 128) launch_eval2_big<128>(P, lds, stream, batch);
-    else if (nt == 256) launch_eval2_big<256>(P, lds, stream, batch);
-    else if (nt == 512) launch_eval2_big<512>(P, lds, stream, batch);
-    else launch_eval2_big<1024>(P, lds, stream, batch);
+  } else if (!strict && P.g.pstride > 32 * nt) {
+    if (nt == 128) launch_eval2_big<128>(P, jac, lds, stream, batch);
+    else if (nt == 256) launch_eval2_big<256>(P, jac, lds, stream, batch);
+    else if (nt == 512) launch_eval2_big<512>(P, jac, lds, stream, batch);
+    else launch_eval2_big<1024>(P, jac, lds, stream, batch);
   } else if (nt == 128) {
     launch_eval2_nb<128, true>(P, jac, strict, lds, stream, batch);
   } else if (nt == 256) {

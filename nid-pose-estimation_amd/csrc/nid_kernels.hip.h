@@ -438,6 +438,21 @@ __device__ __forceinline__ double wave_lane63(double x) {
   return __hiloint2double(hi, lo);
 }
 
+// OR of a 32-bit value over the wave's 64 lanes, in a scalar register (same DPP ladder as wave_sum_to_lane63)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ unsigned dpp_or_u32(unsigned x) {
+  return x | (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, CTRL, ROW_MASK, 0xf, false);
+}
+__device__ __forceinline__ unsigned wave_or_u32(unsigned v) {
+  v = dpp_or_u32<0xB1, 0xf>(v);
+  v = dpp_or_u32<0x4E, 0xf>(v);
+  v = dpp_or_u32<0x141, 0xf>(v);
+  v = dpp_or_u32<0x140, 0xf>(v);
+  v = dpp_or_u32<0x142, 0xa>(v);
+  v = dpp_or_u32<0x143, 0xc>(v);
+  return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+
 // the value lane `l` (a constant) holds, in scalar registers
 template <int L>
 __device__ __forceinline__ double wave_lane(double x) {
@@ -1028,7 +1043,8 @@ __device__ __forceinline__ void pixel_front(const EvalParams &P, const SlotArgs 
     // of frame, clearly outside the Jacobian's narrower bound, or within kBorderEps of a border -> exact_decisions).
     // The window origin is NOT clamped: ((int)u - 1, (int)v - 1) may be -1 (the image buffer has zeroed
     // margins), so the fixed-tap sample applies to every in-frame pixel.
-    const bool in = (f.jr >= 0) && (u >= kBorderEps && u <= P.u_in && v >= kBorderEps && v <= P.v_in);
+    // (plain `&`: five compares in a row; `&&` makes the compiler branch around the later ones)
+    const bool in = (f.jr >= 0) & (u >= kBorderEps) & (u <= P.u_in) & (v >= kBorderEps) & (v <= P.v_in);
     f.in = in;
     f.jin = in && (u <= P.u_jin);
     f.redo = (f.jr >= 0) && !f.jin;
@@ -1378,11 +1394,16 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu((STRICT || D
   // and a kernel with scratch measured 4 % slower: profiles/r02_ablations_A.txt.)
   unsigned gomask = 0u;
   (void)gomask;
+  // raremask, likewise: bit r = "this lane's sample of round r is rare"; the wave's rare rounds are the OR over the
+  // lanes, taken once after the loop (instead of a ballot and six scalar instructions per round).
+  unsigned raremask = 0u;
+  (void)raremask;
 #ifdef NID_EXP_NO_GUARD
-  constexpr bool use_gomask = false;
+  constexpr bool use_lane_masks = false;
 #else
-  constexpr bool use_gomask = JAC && !STRICT && LAT == 0 && !DBG && !BIG;
+  constexpr bool use_lane_masks = !STRICT && LAT == 0 && !DBG && !BIG;
 #endif
+  constexpr bool use_gomask = JAC && use_lane_masks;
   LatPix lat[LAT > 0 ? LAT : 1];  // LAT + JAC: the cost phase's hand-over to the Jacobian phase
   (void)lat;
   if constexpr (STRICT) {
@@ -1421,7 +1442,9 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu((STRICT || D
       }
       pixel_front<false>(P, SA, tin, f);
       // the next round's point is requested BEHIND this round's warp: x, y, z are dead by then, so the loads land in
-      // the registers they come from and nothing is copied from round to round
+      // the registers they come from and nothing is copied from round to round (the empty asm keeps the scheduler
+      // from hoisting the loads above the warp again)
+      if (!SECOND) asm volatile("" : "+v"(f.u), "+v"(f.v));
       if (!SECOND && sb + NT < g.pstride) load_tile_xyz(P, base + (unsigned)(s + NT), nxt);
       WinC wc2;
       load_win_centre(P, f.w.wx, f.w.wy, wc2);
@@ -1436,7 +1459,11 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu((STRICT || D
 #endif
       if (f.redo && classify_redo(P, f)) rare = true;  // (waves that meet the frame border)
       bool go = f.in && !rare;
-      if (use_gomask && !SECOND) gomask |= (go ? 1u : 0u) << r;  // for the Jacobian phase (jac_round_masked); r < 32
+      if (use_lane_masks && !SECOND) {  // r < 32
+        const unsigned bit = 1u << r;
+        raremask |= rare ? bit : 0u;
+        if (use_gomask) gomask |= go ? bit : 0u;  // for the Jacobian phase (jac_round_masked)
+      }
       if (SECOND) {
         go = false;
         if (rare) {
@@ -1459,6 +1486,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu((STRICT || D
         for (int k = 0; k < 4; k++) wc[k] *= P.hist_inv_scale;  // NaN stays NaN
         dump_pixel(s, f, ic, jc, wc);
       }
+      if (use_lane_masks) return false;
       return !SECOND && __builtin_amdgcn_ballot_w64(rare) != 0ull;
     };
     int r = 0;
@@ -1511,6 +1539,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu((STRICT || D
 #pragma clang loop unroll(disable)
       for (int sb = wave_base; sb < g.pstride; sb += NT, r++)
         if (cost_round(sb, r, pre, pre, std::false_type{})) rare_rounds |= 1ull << min(r, 63);
+      if (use_lane_masks) rare_rounds = wave_or_u32(raremask);
     }
     if (rare_rounds != 0ull) {
       r = 0;
@@ -1742,7 +1771,9 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu((STRICT || D
       }
       pixel_front<false>(P, SA, tin, f);
       // the next round's point is requested BEHIND this round's warp: x, y, z are dead by then, so the loads land in
-      // the registers they come from and nothing is copied from round to round
+      // the registers they come from and nothing is copied from round to round (the empty asm keeps the scheduler
+      // from hoisting the loads above the warp again)
+      if (!SECOND) asm volatile("" : "+v"(f.u), "+v"(f.v));
       if (!SECOND && sb + NT < g.pstride) load_tile_xyz(P, base + (unsigned)(s + NT), nxt);
       WinJ wj;
       load_win_jac(P, f.w.wx, f.w.wy, wj);
