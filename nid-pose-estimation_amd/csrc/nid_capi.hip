@@ -83,6 +83,7 @@ struct nid_ctx {
   int group_size = 1, ngroups = 1;
   int math_mode = NID_MATH_FAST;
   double *ctab_dev = nullptr;
+  double ctab_scale = 0.0;  // hist_scale folded into ctab_dev's value coefficients
   Slot slots[NID_SLOTS];
   // nid_run_sequence: result buffers of the launches in flight (device + pinned host), their copy stream and events
   static constexpr int kSeqRing = 16;  // launches in flight: min(kSeqRing, NID_SLOTS / batch)
@@ -186,6 +187,16 @@ void build_coef_table(int S, std::vector<double> *out) {
       row[6] = (double)(3.0L * cur[k][3]);
     }
   }
+}
+
+// k_eval2 accumulates raw 2^52-magic bit patterns and masks the top 12 bits per copy in the fold, so no copy may
+// carry out of 52 bits: a copy receives at most ceil(pstride / copies) weights (each <= 1) per bin
+double eval_hist_scale(const Geometry &g, int nt, double *inv) {
+  const int per_copy = (g.pstride + eval_hist_copies(nt) - 1) / eval_hist_copies(nt);
+  int cb2 = 0;
+  while ((1 << cb2) < per_copy + 1) cb2++;
+  if (inv) *inv = std::ldexp(1.0, -(52 - cb2));
+  return std::ldexp(1.0, 52 - cb2);
 }
 
 size_t eval_lds_bytes(const Geometry &g, int nt) {
@@ -295,15 +306,8 @@ int launch_eval2(nid_ctx *ctx, EvalParams &P, bool jac, hipStream_t stream, int 
                           P.g.pstride <= lat_rounds(nt) * nt && batch <= kMaxBatch;
   if (dbg && nt > 256 && !stamps_lat) nt = 256;
   size_t lds = eval_lds_bytes(P.g, nt);
-  {
-    // k_eval2 accumulates raw 2^52-magic bit patterns and masks the top 12 bits per copy in the fold, so no
-    // copy may carry out of 52 bits: a copy receives at most ceil(pstride / copies) weights (each <= 1) per bin
-    const int per_copy = (P.g.pstride + eval_hist_copies(nt) - 1) / eval_hist_copies(nt);
-    int cb2 = 0;
-    while ((1 << cb2) < per_copy + 1) cb2++;
-    P.hist_scale = std::ldexp(1.0, 52 - cb2);
-    P.hist_inv_scale = std::ldexp(1.0, -(52 - cb2));
-  }
+  P.hist_scale = eval_hist_scale(P.g, nt, &P.hist_inv_scale);
+  if (P.hist_scale != ctx->ctab_scale) return NID_ERR_STATE;  // the B-spline table on the device carries the scale
   if (lds > 160 * 1024) return NID_ERR_UNSUPPORTED;
   static const char *pad_env = getenv("NID_EXP_LDS_PAD");  // occupancy experiments: pad the LDS request
   if (pad_env) lds = std::min<size_t>(160 * 1024, lds + (size_t)atoi(pad_env));
@@ -746,8 +750,12 @@ int nid_create_strided(const nid_config *cfg, int32_t cell_stride, nid_ctx **out
   if ((rc = dev_alloc(ctx, &ctx->Nc_dev, g.nloc))) return fail(rc);
   if ((rc = dev_alloc(ctx, &ctx->Href_dev, g.nloc))) return fail(rc);
   {
+    // the evaluation kernels read the table with hist_scale on its value coefficients (k_eval2's hist_add); every
+    // workgroup shape has 16 histogram copies, so the scale is a property of the geometry
     std::vector<double> coef;
     build_coef_table(g.S, &coef);
+    ctx->ctab_scale = eval_hist_scale(g, 128, nullptr);
+    for (size_t i = 0; i < coef.size(); i++) if ((i % 7) < 4) coef[i] *= ctx->ctab_scale;
     if ((rc = dev_alloc(ctx, &ctx->ctab_dev, coef.size()))) return fail(rc);
     if (hipMemcpy(ctx->ctab_dev, coef.data(), coef.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess)
       return fail(NID_ERR_HIP);

@@ -104,7 +104,8 @@ struct EvalParams {
   float huber_dsqr;
   int group_size;                  // cells per first-level group
   int batch;                       // poses in this launch (slot[0..batch-1])
-  const double *ctab;              // FAST mode: per-span B-spline polynomial coefficients [S][kCoefRow]
+  const double *ctab;              // FAST mode: per-span B-spline polynomial coefficients [S][kCoefRow], the value
+                                   // coefficients (entries 0..3 of every 7-entry row) times hist_scale
   SlotArgs slot[kMaxBatch];        // per-pose arguments of launches of <= kMaxBatch poses (3.7 KB of kernel arguments)
   const SlotArgs *slots_ext;       // larger launches: the same records in device memory (copied in-stream); else null
   // optional per-pixel dump (image order), null when disabled
@@ -1227,14 +1228,17 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu((STRICT || D
   SlotArgs sa_ext;
   if (EXT) {
     static_assert(sizeof(SlotArgs) % 4 == 0, "SlotArgs is copied dword by dword");
-    const unsigned *src = reinterpret_cast<const unsigned *>(P.slots_ext + pose_idx);
+    // The record array is written before the launch (in-stream copy) and never during it: read it through the CONSTANT
+    // address space, i.e. with a handful of scalar loads (s_load_dwordx16 ...) instead of one vector load and one
+    // v_readfirstlane per dword (84 instructions at the head of every wave).  pose_idx is uniform (from blockIdx).
+    typedef const unsigned __attribute__((address_space(4))) *ConstDwords;
+    ConstDwords src = (ConstDwords)(reinterpret_cast<uintptr_t>(P.slots_ext + pose_idx));
     unsigned *dst = reinterpret_cast<unsigned *>(&sa_ext);
     // FAST math transforms with the matrix; the quaternion (the first kPoseQuatDwords of the record) is only
     // needed by exact_decisions, which fetches it itself: 14 scalar registers less across the pixel loops
     static_assert(offsetof(SlotArgs, pose) == 0 && offsetof(Pose, q) == 0 && offsetof(Pose, M) == 4 * kPoseQuatDwords, "record layout");
 #pragma unroll
-    for (unsigned i = STRICT ? 0u : kPoseQuatDwords; i < sizeof(SlotArgs) / 4; i++)
-      dst[i] = (unsigned)__builtin_amdgcn_readfirstlane((int)src[i]);
+    for (unsigned i = STRICT ? 0u : kPoseQuatDwords; i < sizeof(SlotArgs) / 4; i++) dst[i] = src[i];
   }
   const SlotArgs &SA = EXT ? sa_ext : P.slot[pose_idx];
   const int n_c = P.Nc[cl];
@@ -1258,15 +1262,25 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu((STRICT || D
   const int lane = tid & 63;
   TileIn pre, prej;  // loop form of the FAST pixel loops: the next round's point and bin index (see cost_round)
   (void)pre; (void)prej;
-  for (int i = tid; i < nbins * (NC + kFineLevels); i += NT) hist[i] = 0ull;  // the copies and the fine levels behind them
+  {  // the copies and the fine levels behind them, 16 bytes per store (nbins is even, hist is 16-byte aligned)
+    uint4 *h4 = reinterpret_cast<uint4 *>(hist);
+    const int n4 = nbins * (NC + kFineLevels) / 2;
+    if (NB > 0) {
+#pragma unroll
+      for (int i = 0; i < (n4 + NT - 1) / NT; i++)
+        if (i * NT + tid < n4) h4[i * NT + tid] = make_uint4(0u, 0u, 0u, 0u);
+    } else {
+      for (int i = tid; i < n4; i += NT) h4[i] = make_uint4(0u, 0u, 0u, 0u);
+    }
+  }
   if (STRICT) {
     if (tid < S * 6) {
       const int jj = tid / 6, e = tid % 6;
       rtab[jj * kRcpRow + e] = 1.0 / span_denominator(jj, e, S);
     }
   } else {
-    // value coefficients (entries 0..3 of every 7-entry row) times hist_scale, see hist_add
-    for (int i = tid; i < S * kCoefRow; i += NT) rtab[i] = P.ctab[i] * ((i % 7) < 4 ? P.hist_scale : 1.0);
+    // (the host's table carries hist_scale on its value coefficients, see hist_add)
+    for (int i = tid; i < S * kCoefRow; i += NT) rtab[i] = P.ctab[i];
   }
   __syncthreads();
   NID_STAMP(1);
@@ -1555,17 +1569,23 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu((STRICT || D
   double ent[2] = {0.0, 0.0};
   for (int b = tid; b < nbins; b += NT) {
     const uint4 *hv = reinterpret_cast<const uint4 *>(hist + (size_t)b * NC);
-    unsigned long long acc = 0;
+    // low dwords and masked high dwords (20 bits each) summed apart: 32-bit adds for the high parts, one carry chain
+    // for the low parts, joined once (the same integer as the 64-bit sum of the masked values)
+    unsigned long long acc_lo = 0;
+    unsigned acc_hi = 0;
 #pragma unroll
     for (int c = 0; c < NC / 2; c++) {
       const uint4 q = hv[(c + b) & (NC / 2 - 1)];
-      acc += ((unsigned long long)(q.y & kFxHiMask) << 32 | q.x) + ((unsigned long long)(q.w & kFxHiMask) << 32 | q.z);
+      acc_lo += q.x;
+      acc_lo += q.z;
+      acc_hi += (q.y & kFxHiMask) + (q.w & kFxHiMask);
     }
+    const unsigned long long acc = acc_lo + ((unsigned long long)acc_hi << 32);
     double mass = (double)(long long)acc * P.hist_inv_scale;
 #pragma unroll
     for (int lv = 0; lv < kFineLevels; lv++) {  // small target weights (kTinyW); all zero leaves `mass` bit for bit
-      const long long lo = (long long)hist_lo[lv * nbins + b];
-      if (lo != 0) mass += (double)lo * fine_inv_scale(lv);
+      const long long lo = (long long)hist_lo[lv * nbins + b];  // (0 * scale + mass = mass: no test needed)
+      mass = fma((double)lo, fine_inv_scale(lv), mass);         // a power-of-two scale: the product is exact, one rounding
     }
     const double p = mass / (double)n_c;  // Q1: N_c of the initial pose
     double w = 0.0, pl = 0.0;
