@@ -1166,7 +1166,10 @@ __device__ __forceinline__ int pixel_sample(const PixelFront &f, int nb, int S, 
 // round's reference weights behind the window loads.  With 256-thread workgroups 2/2 measured +6 %; with
 // the default 128-thread workgroups (ten per CU) the latency is hidden anyway: 0/0 258.8 k it/s at 1 272 W,
 // 2/2 256.4 k at 1 335 W, 1/1 250.8 k -- so the default is 0/0.  NID_FAST_WAVES: occupancy target of the
-// FAST kernels (5 waves/SIMD = 96 VGPRs; 6 spills inside the loops: 216.8 k).
+// FAST kernels (5 waves/SIMD = 96 VGPRs; 6 spills inside the loops: 216.8 k).  The EXT kernels (the throughput
+// launches) are compiled with a budget of 128 registers: the cost + Jacobian kernel still ends at 95 (five waves per
+// SIMD), but the scheduler, no longer at its limit, orders the window loads and their first uses better -- the same
+// instructions, 6 % less time per launch (profiles/r02_ablations_A.txt, "w4").
 // LAT kernels: what the Jacobian phase needs of a pixel the cost phase has already worked out
 struct LatPix {
   double x, y, iz, gx, gy, pc;
@@ -1197,7 +1200,7 @@ struct LatPix {
 // Same operations on the same values in the same per-lane order as the loop form: bit-identical results (tested).
 // BIG: cells of more than 32 * NT slots (more rounds per wave than a lane's 32-bit gomask has bits).
 template <int NT, bool JAC, bool STRICT, int NB, bool DBG, bool EXT = false, int LAT = 0, bool BIG = false>
-__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu((STRICT || DBG || LAT || NT >= 512) ? 4 : NID_FAST_WAVES))) void k_eval2(EvalParams P) {
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu((STRICT || DBG || LAT || NT >= 512 || EXT) ? 4 : NID_FAST_WAVES))) void k_eval2(EvalParams P) {
   static_assert(LAT == 0 || (!STRICT && !EXT), "the latency form exists for FAST math launches of <= kMaxBatch poses (DBG: phase stamps only)");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int NC = eval_hist_copies(NT);

@@ -1,0 +1,14 @@
+#!/bin/bash
+# tools/final_round.sh TAG: the measurements DESIGN.md section 7 quotes, in one go on the GPU box (through gpurun):
+# rocprofv3 kernel stats + HBM counter passes (tools/profile_round.sh), SQ counters (tools/pmc_round.sh), the bench lines
+# (default flags, config B, driver-style flags) and the latency sweeps.  Output under gpurun_out/.
+tag=$1
+mkdir -p gpurun_out/$tag
+python bench.py > gpurun_out/$tag/bench_A.json 2> gpurun_out/$tag/bench_A.err; echo "bench A rc=$?"
+python bench.py --config B > gpurun_out/$tag/bench_B.json 2> gpurun_out/$tag/bench_B.err; echo "bench B rc=$?"
+python bench.py --steps 20 --warmup 5 > gpurun_out/$tag/bench_A_driver_flags.json 2> gpurun_out/$tag/bench_A_driver_flags.err; echo "bench driver rc=$?"
+bash tools/profile_round.sh $tag > gpurun_out/$tag/profile_round.log 2>&1; echo "profile rc=$?"
+bash tools/pmc_round.sh $tag A > gpurun_out/$tag/pmc_round.log 2>&1; echo "pmc rc=$?"
+python tools/latency_sweep.py A 8 > gpurun_out/$tag/launch_cost_A.txt 2> gpurun_out/$tag/launch_cost_A.err; echo "lat A rc=$?"
+python tools/latency_sweep.py B 8 > gpurun_out/$tag/launch_cost_B.txt 2> gpurun_out/$tag/launch_cost_B.err; echo "lat B rc=$?"
+python tools/batch_sweep.py > gpurun_out/$tag/batch_sweep.txt 2> gpurun_out/$tag/batch_sweep.err; echo "batch rc=$?"

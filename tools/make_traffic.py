@@ -12,7 +12,7 @@ for c in "AB":
     d = json.load(open(os.path.join(ROOT, "profiles", f"{tag}_{c}_summary.json")))
     for k, e in d["kernels"].items():
         # the launches of the timed region: > 16 poses -> the EXT = true instantiation
-        if re.search(rf"k_eval2<\d+, true, false, {bins}, false, {'true' if ppl > 16 else 'false'}(, \d+)?>", k) \
+        if re.search(rf"k_eval2<\d+, true, false, {bins}, false, {'true' if ppl > 16 else 'false'}(, \d+)?(, (true|false))?>", k) \
                 and "hbm_bytes_per_dispatch_corrected" in e:
             out[f"{c}:{bins}"] = {
                 "kernel": k, "poses_per_launch": ppl,
