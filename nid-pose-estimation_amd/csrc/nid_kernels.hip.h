@@ -1187,6 +1187,9 @@ struct LatPix {
 #ifndef NID_FAST_WAVES
 #define NID_FAST_WAVES 5
 #endif
+#ifndef NID_EXT_WAVES
+#define NID_EXT_WAVES 4
+#endif
 // EXT: the launch has more than kMaxBatch poses and their records live in P.slots_ext (device memory); the
 // workgroup's record is then pulled into scalar registers once, dword by dword, so that the pose matrix and
 // the pointers are SGPR operands exactly as when they come from the kernel arguments.
@@ -1200,7 +1203,7 @@ struct LatPix {
 // Same operations on the same values in the same per-lane order as the loop form: bit-identical results (tested).
 // BIG: cells of more than 32 * NT slots (more rounds per wave than a lane's 32-bit gomask has bits).
 template <int NT, bool JAC, bool STRICT, int NB, bool DBG, bool EXT = false, int LAT = 0, bool BIG = false>
-__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu((STRICT || DBG || LAT || NT >= 512 || EXT) ? 4 : NID_FAST_WAVES))) void k_eval2(EvalParams P) {
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu((STRICT || DBG || LAT || NT >= 512) ? 4 : (EXT ? NID_EXT_WAVES : NID_FAST_WAVES)))) void k_eval2(EvalParams P) {
   static_assert(LAT == 0 || (!STRICT && !EXT), "the latency form exists for FAST math launches of <= kMaxBatch poses (DBG: phase stamps only)");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int NC = eval_hist_copies(NT);
