@@ -442,8 +442,10 @@ def main():
             "compact_bytes_per_evaluation": compact_bytes,
             "achieved_pipelined": (contract / Bk) * (K / elapsed) / 1e9,
             # what actually limits the kernel: the tile is L2/MALL resident after the first launch (measured HBM
-            # traffic is ~2 % of the contract bytes), the waves are bound by instruction issue + exposed latency
-            "limiter": "valu_issue",
+            # traffic is ~1 % of the contract bytes); the waves sit between instruction issue and exposed latency
+            # (SQ counters, profiles/r02_A_pmc_counters.txt: 28 % of a wave's life issuing, 34 % waiting to issue,
+            # 38 % in s_waitcnt)
+            "limiter": "wave_instruction_issue_and_latency",
             "note": "achieved = contract bytes (68 B/px + 64 B/cell, SURVEY 8d) / median per-launch duration of "
                     "evaluation launches running one at a time (10 back to back per HIP event pair; what "
                     "rocprofv3 reports per kernel); achieved_pipelined = the same bytes / (timed region / launches); "

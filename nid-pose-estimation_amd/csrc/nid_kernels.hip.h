@@ -1160,13 +1160,8 @@ __device__ __forceinline__ int pixel_sample(const PixelFront &f, int nb, int S, 
   return jc;
 }
 
-// Tuning switches (tools/build_variant.sh + tools/power_probe.sh; results in DESIGN.md section 7).
-// NID_PREFETCH_P1 / _P2 (cost / Jacobian phase): 0 = load the tile entry at the top of the round,
-// 1 = request the NEXT round's entry during the current round, 2 = as 1 for the point, the current
-// round's reference weights behind the window loads.  With 256-thread workgroups 2/2 measured +6 %; with
-// the default 128-thread workgroups (ten per CU) the latency is hidden anyway: 0/0 258.8 k it/s at 1 272 W,
-// 2/2 256.4 k at 1 335 W, 1/1 250.8 k -- so the default is 0/0.  NID_FAST_WAVES: occupancy target of the
-// FAST kernels (5 waves/SIMD = 96 VGPRs; 6 spills inside the loops: 216.8 k).  The EXT kernels (the throughput
+// Tuning switches (tools/build_variant.sh; results in profiles/r02_ablations_A.txt).  NID_FAST_WAVES: occupancy target
+// of the FAST kernels (5 waves/SIMD = 96 VGPRs; 6 spills inside the loops: 216.8 k).  The EXT kernels (the throughput
 // launches) are compiled with a budget of 128 registers: the cost + Jacobian kernel still ends at 95 (five waves per
 // SIMD), but the scheduler, no longer at its limit, orders the window loads and their first uses better -- the same
 // instructions, 6 % less time per launch (profiles/r02_ablations_A.txt, "w4").
@@ -1178,12 +1173,6 @@ struct LatPix {
   bool go;  // contributes to the Jacobian in the main pass: inside linearizeOplus' frame and decided by FAST arithmetic
 };
 
-#ifndef NID_PREFETCH_P1
-#define NID_PREFETCH_P1 0
-#endif
-#ifndef NID_PREFETCH_P2
-#define NID_PREFETCH_P2 0
-#endif
 #ifndef NID_FAST_WAVES
 #define NID_FAST_WAVES 5
 #endif
@@ -1191,8 +1180,8 @@ struct LatPix {
 #define NID_EXT_WAVES 4
 #endif
 // EXT: the launch has more than kMaxBatch poses and their records live in P.slots_ext (device memory); the
-// workgroup's record is then pulled into scalar registers once, dword by dword, so that the pose matrix and
-// the pointers are SGPR operands exactly as when they come from the kernel arguments.
+// workgroup's record is then pulled into scalar registers once (scalar loads through the constant address space), so
+// that the pose matrix and the pointers are SGPR operands exactly as when they come from the kernel arguments.
 // LAT > 0 (FAST math, launches of few poses: one workgroup per CU or less): the latency form of the pixel loops.
 // A launch that cannot fill the chip is bound by the DEPENDENT memory round trips of one wave -- tile entry ->
 // projection -> target window -> sample -- once per round and phase.  With NT >= 512 a cell is LAT <= 3 rounds,
