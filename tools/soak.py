@@ -33,6 +33,18 @@ ctx = capi.from_pair(pair, 8)
 ctx.compute_href(pair.pose_init)
 bad = soak("one context, batch 256", lambda s: ctx.run_sequence(s, delta, batch=256), 256 * 200)
 bad += soak("one context, batch 64", lambda s: ctx.run_sequence(s, delta, batch=64), 256 * 200)
+# every launch carries a different set of per-pose records (period 251 against launches of 256 / 32 poses): a record
+# array entry that a kernel read stale (scalar cache, ring reuse) would show up as another pose's block
+ref1 = ctx.run_sequence(poses, delta, batch=256)
+for b in (256, 32):
+    idx = np.arange(b * 400) % 251
+    t0 = time.perf_counter(); n_bad = 0; total = 0
+    while time.perf_counter() - t0 < seconds / 2:
+        out = ctx.run_sequence(poses[idx], delta, batch=b)
+        n_bad += int((bits(out) != bits(ref1[idx])).any(axis=1).sum()); total += len(idx)
+        idx = (idx + 17) % 251
+    print(f"rotating records, batch {b:3d}    {total:9d} evaluations, mismatching blocks: {n_bad}")
+    bad += n_bad
 m = capi.multi_from_pair(pair, 8, devices=[0, 0, 0], partition=capi.PARTITION_INTERLEAVED)
 m.compute_href(pair.pose_init)
 bad += soak("3 interleaved shards, host sum", lambda s: m.run_sequence(s, delta, batch=256, group=2), 256 * 100)
