@@ -1,9 +1,10 @@
 // nid_kernels.hip.h -- hand-written gfx950 kernels of the NID path.
 //
 // Design (DESIGN.md has the long form):
-//  * one workgroup per cell (a cell is rb x cb pixels, 30x40 = 1200 in both
-//    BASELINE configs), NT threads, PPT pixels per thread kept in registers
-//    across the two phases;
+//  * one workgroup per cell and candidate pose (a cell is rb x cb pixels, 30x40 = 1200 in both
+//    BASELINE configs), NT threads, a run-time loop over rounds of NT pixels; nothing per pixel is
+//    kept from the cost phase to the Jacobian phase except one decision bit per round and lane
+//    (the latency form of the 512 / 1024-thread shapes keeps a pixel's gradient and projection);
 //  * operands are read from a cell-major, pixel-minor SoA tile built once per
 //    frame pair, so every wave issues fully coalesced 512-B (f64) rows;
 //  * phase 1 (cost): warp -> bilinear -> target B-spline weights -> per-cell
@@ -14,7 +15,7 @@
 //  * entropies + weight tables W = -(1 + log2 p) are formed once per cell;
 //  * phase 2 (Jacobian): per pixel two scalars s = sum Wj*wr*dw, t = sum Wc*dw
 //    replace the reference's 6*bin^2 derivative tensor (same algebra, only the
-//    summation order differs), then a 12-value wavefront + LDS reduction;
+//    summation order differs), then six sums over the workgroup (through LDS, or DPP + LDS);
 //  * each cell's Huber-weighted quadratic form is written write-through and the
 //    workgroup that arrives last sums them (fixed order) into the 6x6 system.
 //
