@@ -1,0 +1,27 @@
+import importlib, os, sys
+import numpy as np
+ROOT = os.getcwd()
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+capi = importlib.import_module("nid-pose-estimation_amd.capi")
+synth = importlib.import_module("nid-pose-estimation_amd.synth")
+from oracle import oracle_py as oracle
+import test_parity_gpu as T
+seed = int(sys.argv[1])
+pair, nb, poses = T._random_case(synth, 1000 + seed)
+print("rows cols cell nb", pair.rows, pair.cols, pair.cell, nb, "im0 levels", len(np.unique(pair.im0)), "im1 levels", len(np.unique(pair.im1)))
+o = oracle.from_pair(pair, nb)
+cnt_o, href_o = o.compute_href(pair.pose_init)
+orev = oracle.from_pair(pair, nb, reverse=True) if "reverse" in oracle.from_pair.__code__.co_varnames else None
+for math in T.MODES:
+    for shape in (128, 256, 512):
+        ctx = capi.from_pair(pair, nb, math=T._mode(capi, math)); ctx.set_launch_shape(shape, shape)
+        ctx.compute_href(pair.pose_init)
+        for ip, pose in enumerate(poses):
+            Hc, Hj, err, J = ctx.evaluate(pose, True)
+            Hc_o, Hj_o, err_o, J_o = o.evaluate(pose, True)
+            if orev is not None:
+                J_r = orev.evaluate(pose, True)[3]
+            act = cnt_o >= 300
+            d = np.abs(J - J_o)[act].max(); 
+            print(math, shape, "pose", ip, "max|J_o|", np.abs(J_o[act]).max(), "max|J|", np.abs(J[act]).max(), "max|dJ|", d, ("max|J_o - J_rev| %.3e" % np.abs(J_o - J_r)[act].max()) if orev is not None else "")
+        ctx.close()
