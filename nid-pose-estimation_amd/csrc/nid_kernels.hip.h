@@ -32,6 +32,11 @@
 
 #include "nid_bspline.h"
 
+// 1: wave-uniform fine-level adds of the target histogram are added once per wave (hist_add); 0: one atomic per lane
+#ifndef NID_LO_AGGREGATE
+#define NID_LO_AGGREGATE 1
+#endif
+
 namespace nid {
 
 // NC: lane-interleaved histogram copies.  The LDS services a 64-bit access in four groups of 16
@@ -1298,7 +1303,30 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu((STRICT || D
     const unsigned hrow = (unsigned)(__mul24(jr, nb) + jc);
     unsigned long long *hc = hist + ((unsigned)jc * NC + (unsigned)copy);
     unsigned long long *hj = hist + (((unsigned)nb + hrow) * NC + (unsigned)copy);
-#ifndef NID_EXP_NO_LO
+    double wr[4] = {wr_in[0], wr_in[1], wr_in[2], wr_in[3]};
+    // A fine-level add of the TARGET histogram.  The fine levels are single copies; the lanes of a saturated (clamped:
+    // one constant intensity) or black region all add the SAME value to the SAME bin -- a 64-way serialised LDS atomic
+    // per weight and round (the flash pair ran 1.8x slower than the plain pair mostly for this).  If every active
+    // lane agrees on address and value, one lane adds count * value (integers: the same sum).
+    auto lo_add_marginal = [&](unsigned idx, unsigned long long val) {
+#if NID_LO_AGGREGATE
+      const unsigned i0 = (unsigned)__builtin_amdgcn_readfirstlane((int)idx);
+      const unsigned v0l = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)val);
+      const unsigned v0h = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(val >> 32));
+      const unsigned long long v0 = ((unsigned long long)v0h << 32) | v0l;
+      const unsigned long long act = __builtin_amdgcn_ballot_w64(true);
+      const unsigned long long eq = __builtin_amdgcn_ballot_w64(idx == i0 && val == v0);
+      if (eq == act) {
+        if ((unsigned)__builtin_ctzll(act) == (unsigned)(tid & 63))
+          atomicAdd(hist_lo + idx, val * (unsigned long long)__builtin_popcountll(act));
+        return;
+      }
+#endif
+      atomicAdd(hist_lo + idx, val);
+    };
+#ifdef NID_EXP_NO_LO
+    wr[0] = fabs(wr[0]);
+#else
     // Rare: the TARGET sample sits next to a knot (also: clamped saturated, black, integer-position samples) -- its
     // small weights, and their products with the reference weights, go to the fine level of their own exponent --
     // or the REFERENCE sample does with NON-ZERO tiny weights (a saturated reference pixel: I0 = 255 -> 254.999 has
@@ -1311,7 +1339,6 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu((STRICT || D
     // first stored weight (min(wr[0], wr[3]) < kTinyW and != 0 <=> wr_in[0] < 0): one compare here instead of
     // five instructions per sample; |wr_in[0]| is a free source modifier of the products below
     const bool ref_tiny = wr_in[0] < 0.0;
-    double wr[4] = {wr_in[0], wr_in[1], wr_in[2], wr_in[3]};
     if (fmin(wcs[0], wcs[3]) < tiny_scaled || ref_tiny) {
       double wc[4];
 #pragma unroll
@@ -1324,7 +1351,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu((STRICT || D
           if (wc[k] < kFineW) {
             if (wc[k] != 0.0) {
               const int lv = fine_level(fabs(wc[k]));
-              atomicAdd(hist_lo + lv * nbins + (unsigned)(jc + k), fx_encode(wc[k], fine_scale(lv)));
+              lo_add_marginal(lv * nbins + (unsigned)(jc + k), fx_encode(wc[k], fine_scale(lv)));
 #pragma unroll
               for (int m = 0; m < 4; m++) {
                 const double pr = wr[m] * wc[k];  // the reference's own product, rounded once like there
@@ -1349,7 +1376,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu((STRICT || D
         if (small_c) {
           if (wc[k] != 0.0) {
             const int lv = fine_level(fabs(wc[k]));
-            atomicAdd(hist_lo + lv * nbins + (unsigned)(jc + k), fx_encode(wc[k], fine_scale(lv)));
+            lo_add_marginal(lv * nbins + (unsigned)(jc + k), fx_encode(wc[k], fine_scale(lv)));
           }
         } else {
           atomicAdd(hc + k * NC, fx_encode_raw(wcs[k], 1.0));
