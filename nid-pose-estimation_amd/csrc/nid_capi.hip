@@ -202,7 +202,8 @@ double eval_hist_scale(const Geometry &g, int nt, double *inv) {
 size_t eval_lds_bytes(const Geometry &g, int nt) {
   const int nbins = g.nb * g.nb + g.nb;
   // copies + fine levels (the Jacobian block sum of the throughput shapes reuses the area: at least kXposeDoubles); tab + term
-  const size_t hist_bytes = std::max((size_t)nbins * (eval_hist_copies(nt) + kFineLevels), (size_t)kXposeDoubles(nt)) * 8;
+  const size_t clamp_bytes = (size_t)kClampBins(g.nb) * (kClampCopies + kFineLevels + 1) * 8 + 8;  // coarse copies, fine levels, folded sums, flag
+  const size_t hist_bytes = std::max((size_t)nbins * (eval_hist_copies(nt) + kFineLevels) * 8 + clamp_bytes, (size_t)kXposeDoubles(nt) * 8);
   return hist_bytes + 2 * (size_t)((nbins + 1) & ~1) * 8 + (size_t)g.S * kCoefRow * 8 + (size_t)kRedDoubles(nt) * 8;
 }
 

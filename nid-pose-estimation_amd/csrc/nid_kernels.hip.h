@@ -32,6 +32,10 @@
 
 #include "nid_bspline.h"
 
+// 1: clamped target samples are summed per reference bin and folded in with their constant weights (kClampBins)
+#ifndef NID_CLAMP_BINS
+#define NID_CLAMP_BINS 1
+#endif
 // 1: wave-uniform fine-level adds of the target histogram are added once per wave (hist_add); 0: one atomic per lane
 #ifndef NID_LO_AGGREGATE
 #define NID_LO_AGGREGATE 1
@@ -790,6 +794,14 @@ constexpr int kRedDoubles(int nt) { return (6 * (nt / 64) + 1) & ~1; }  // the s
 #ifndef NID_XPOSE_SUM
 #define NID_XPOSE_SUM 1
 #endif
+// Clamped target samples (ic >= 255 -> 254.999, types_six_dof_expmap.cpp:572-573) all have the SAME four target weights:
+// instead of 20 histogram adds each (15 of them fine-level adds), FAST math sums their reference weights per reference bin
+// (nb bins) and counts them (one more bin), NC copies like the histograms; the fold adds c_k * sum to the bins they feed.
+// The coarse sums have kClampCopies copies (their scale is hist_scale * kClampCopies / NC, so a copy still cannot carry
+// out of 52 bits); reference weights below 2^-8 go to fine levels of their own exponent like everywhere else (a joint bin
+// fed only by clamped samples is c_k * this sum: it needs the sum to ~1e-9 relative even when it is one weight of 1e-8).
+constexpr int kClampBins(int nb) { return (nb + 2) & ~1; }
+constexpr int kClampCopies = 4;
 constexpr int kXposeStride(int nt) { return nt + 8; }
 constexpr int kXposeDoubles(int nt) { return (nt <= 256 && NID_XPOSE_SUM) ? 6 * kXposeStride(nt) : 0; }
 constexpr int kQuad = 32;  // per-cell block: rho0 | b[6] | H upper[21] | 1.0 | 0 0 0
@@ -1214,6 +1226,10 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu((STRICT || D
   double *red = rtab + S * kCoefRow;  // S rows of kCoefRow (FAST) or kRcpRow <= kCoefRow (STRICT) doubles
   unsigned long long *hist = reinterpret_cast<unsigned long long *>(red + kRedDoubles(NT));
   unsigned long long *hist_lo = hist + nbins * NC;  // [kFineLevels][nbins], single copies (see kTinyW)
+  unsigned long long *clampb = hist_lo + kFineLevels * nbins;                   // [kClampBins(nb)][kClampCopies]: see kClampBins
+  unsigned long long *clamp_lo = clampb + kClampBins(nb) * kClampCopies;         // [kFineLevels][kClampBins(nb)], single copies
+  double *rclamp = reinterpret_cast<double *>(clamp_lo + kFineLevels * kClampBins(nb));  // [kClampBins(nb)] folded sums, then the flag
+  unsigned *clamp_flag = reinterpret_cast<unsigned *>(rclamp + kClampBins(nb));
 
   // XCD-aware block -> (cell, pose) map: workgroups are dealt round-robin over the 8 XCDs, so
   // id % 8 fixes the XCD; all `batch` poses of a cell get the same id % 8 and consecutive slots
@@ -1265,7 +1281,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu((STRICT || D
   (void)pre; (void)prej;
   {  // the copies and the fine levels behind them, 16 bytes per store (nbins is even, hist is 16-byte aligned)
     uint4 *h4 = reinterpret_cast<uint4 *>(hist);
-    const int n4 = nbins * (NC + kFineLevels) / 2;
+    const int n4 = (nbins * (NC + kFineLevels) + kClampBins(nb) * (kClampCopies + kFineLevels)) / 2;  // ... and the clamped samples' bins
+    if (tid == 0) { clamp_flag[0] = 0u; clamp_flag[1] = 0u; }
     if (NB > 0) {
 #pragma unroll
       for (int i = 0; i < (n4 + NT - 1) / NT; i++)
@@ -1293,8 +1310,25 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu((STRICT || D
   // = wc * hist_scale, PRESCALED) and the four multiplications per sample are gone; the rare branches below get the
   // plain weights back by the inverse scale (exact).
   const double tiny_scaled = kTinyW * P.hist_scale;
-  auto hist_add = [&](int jr, int jc, const double (&wr_in)[4], const double (&win)[4], auto prescaled) {
+  auto hist_add = [&](int jr, int jc, const double (&wr_in)[4], const double (&win)[4], auto prescaled, bool clamped = false) {
     constexpr bool PRESCALED = decltype(prescaled)::value;
+    if (clamped) {  // FAST second passes only: see kClampBins
+      const double cscale = P.hist_scale * ((double)kClampCopies / (double)NC);
+      unsigned long long *hx = clampb + ((unsigned)copy & (kClampCopies - 1));
+      atomicAdd(hx + nb * kClampCopies, fx_encode_raw(1.0, cscale));
+#pragma unroll
+      for (int m = 0; m < 4; m++) {
+        const double w = m == 0 ? fabs(wr_in[0]) : wr_in[m];
+        if (w >= kFineW) {
+          atomicAdd(hx + (jr + m) * kClampCopies, fx_encode_raw(w, cscale));
+        } else if (w != 0.0) {
+          const int lv = fine_level(w);
+          atomicAdd(clamp_lo + lv * kClampBins(nb) + (unsigned)(jr + m), fx_encode(w, fine_scale(lv)));
+        }
+      }
+      clamp_flag[0] = 1u;
+      return;
+    }
     // fixed-point encode: the scale is a power of two, so wcs = wc*scale is exact and
     // fma(wr, wcs, 2^52) rounds wr*wc*scale once
     double wcs[4];
@@ -1514,7 +1548,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu((STRICT || D
         double pc;
         jc = fast_bin<SECOND || kMainPassClamps>(ic, S, pc);
         bspline4_poly<false, JAC && !SECOND>(pc, jc, rtab, wc, dw);
-        hist_add(f.jr, jc, SECOND ? f.wr : tin.wr, wc, std::true_type{});
+        hist_add(f.jr, jc, SECOND ? f.wr : tin.wr, wc, std::true_type{}, SECOND && NID_CLAMP_BINS && ic == 254.999);
       } else {
         ic = NAN;
       }
@@ -1589,6 +1623,35 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu((STRICT || D
   __syncthreads();
 
   // ---- fold the copies, probabilities, entropies, weight tables ----------------------
+  // clamped samples first (flash data only: the flag is workgroup-uniform): their sums per reference bin and their count
+  const bool any_clamped = !STRICT && NID_CLAMP_BINS && clamp_flag[0] != 0u;
+  double cw[4] = {0.0, 0.0, 0.0, 0.0};  // their four target weights, as the sample path computes them
+  int jc_cl = 0;
+  if (any_clamped) {
+    for (int e = tid; e <= nb; e += NT) {
+      const uint4 *hv = reinterpret_cast<const uint4 *>(clampb + (size_t)e * kClampCopies);
+      unsigned long long acc_lo = 0;
+      unsigned acc_hi = 0;
+#pragma unroll
+      for (int c = 0; c < kClampCopies / 2; c++) {
+        const uint4 q = hv[c];
+        acc_lo += q.x;
+        acc_lo += q.z;
+        acc_hi += (q.y & kFxHiMask) + (q.w & kFxHiMask);
+      }
+      double sum = (double)(long long)(acc_lo + ((unsigned long long)acc_hi << 32)) * (P.hist_inv_scale * ((double)NC / (double)kClampCopies));
+#pragma unroll
+      for (int lv = 0; lv < kFineLevels; lv++)
+        sum = fma((double)(long long)clamp_lo[lv * kClampBins(nb) + e], fine_inv_scale(lv), sum);
+      rclamp[e] = sum;
+    }
+    double ic_cl = 254.999, pc_cl, dd[4];
+    jc_cl = fast_bin<false>(ic_cl, S, pc_cl);
+    bspline4_poly<false>(pc_cl, jc_cl, rtab, cw, dd);
+#pragma unroll
+    for (int k = 0; k < 4; k++) cw[k] *= P.hist_inv_scale;  // rtab's value polynomials carry hist_scale
+    __syncthreads();
+  }
   double ent[2] = {0.0, 0.0};
   for (int b = tid; b < nbins; b += NT) {
     const uint4 *hv = reinterpret_cast<const uint4 *>(hist + (size_t)b * NC);
@@ -1609,6 +1672,14 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu((STRICT || D
     for (int lv = 0; lv < kFineLevels; lv++) {  // small target weights (kTinyW); all zero leaves `mass` bit for bit
       const long long lo = (long long)hist_lo[lv * nbins + b];  // (0 * scale + mass = mass: no test needed)
       mass = fma((double)lo, fine_inv_scale(lv), mass);         // a power-of-two scale: the product is exact, one rounding
+    }
+    if (any_clamped) {
+      const int col = b < nb ? b : (b - nb) % nb;
+      const int k = col - jc_cl;
+      if (k >= 0 && k < 4) {
+        const double ck = k == 0 ? cw[0] : (k == 1 ? cw[1] : (k == 2 ? cw[2] : cw[3]));
+        mass = fma(ck, b < nb ? rclamp[nb] : rclamp[(b - nb) / nb], mass);
+      }
     }
     const double p = mass / (double)n_c;  // Q1: N_c of the initial pose
     double w = 0.0, pl = 0.0;
