@@ -519,6 +519,27 @@ def main():
             el = time.perf_counter() - t0
             ctx.set_math_mode(math_mode)
             roof["other_math_mode"] = {"mode": "FAST" if args.strict else "STRICT", "it_per_s": n_o / el, "steps": n_o}
+            # the same pipeline on the pair WITH a flash (BASELINE configs[0] is a flash pair): a saturating hot spot,
+            # black / saturated patches, depth holes -- what the exact-decision second passes and the clamped-sample
+            # accumulation cost on such data
+            try:
+                fpair = synth.make_pair(args.config, flash=True, edge_cases=True)
+                fctx = capi.from_pair(fpair, args.bins, device=local_rank)
+                fctx.set_math_mode(math_mode)
+                fctx.compute_href(fpair.pose_init)
+                fposes = np.stack(pose_trajectory(synth, fpair, 256))
+                fseq = fposes[np.arange(B * 40) % 256]
+                fctx.run_sequence(fseq[:B * 4], delta, batch=B, want_jac=want_jac, collect=False)
+                t0 = time.perf_counter()
+                fctx.run_sequence(fseq, delta, batch=B, want_jac=want_jac, collect=False)
+                el_f = time.perf_counter() - t0
+                roof["flash_pair"] = {"it_per_s": len(fseq) / el_f, "saturated_target_fraction": float((fpair.im1 >= 255).mean()),
+                                      "relative_to_value": (len(fseq) / el_f) / (K / elapsed) if K >= B * 4 else None,
+                                      "note": "same workload on the synthetic pair with a flash (saturated hot spot, black / "
+                                              "saturated patches, 5 % depth holes); synthetic substitute for BASELINE configs[0]"}
+                fctx.close()
+            except Exception as e:   # noqa: BLE001 -- a side measurement must not take the line down
+                roof["flash_pair"] = {"error": str(e)[:200]}
         out = {
             "metric": "NID GN iterations/sec (640x480 dense pair)" if args.config == "A" else
                       f"NID GN iterations/sec ({pair.cols}x{pair.rows} dense pair)",
