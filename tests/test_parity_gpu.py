@@ -384,14 +384,15 @@ def test_error_paths(capi, pair_S):
 
 
 @pytest.mark.parametrize("math", MODES)
-@pytest.mark.parametrize("cfg,nb", [("S", 10), ("A", 8), ("A", 16)])
+@pytest.mark.parametrize("cfg,nb", [("S", 10), ("A", 8), ("A", 16), ("F", 8)])
 def test_launch_shapes(capi, oracle, synth, cfg, nb, math):
     """nid_set_launch_shape: the latency shapes (512 / 1024 threads per cell) and the throughput shapes (128 / 256)
     evaluate the same sums.  Cost-only results -- chi2, active count, per-cell Hc / Hj / err -- are the SAME BITS in
     every shape (fixed-point histograms; the entropy sums are taken in one fixed order whatever the wave count);
     the Jacobian and the 6x6 system depend on the shape in their last bits and are held to the parity tolerances
-    against the oracle in every shape."""
-    pair = synth.make_pair(cfg)
+    against the oracle in every shape.  "F" = the 640x480 pair with the flash: the clamped samples' accumulator (their
+    reference weights per reference bin, folded in with four constant target weights) is integer too."""
+    pair = synth.make_pair("A", flash=True, edge_cases=True) if cfg == "F" else synth.make_pair(cfg)
     o = oracle.from_pair(pair, nb)
     cnt, _ = o.compute_href(pair.pose_init)
     pose = _poses(synth, pair)["near"]
