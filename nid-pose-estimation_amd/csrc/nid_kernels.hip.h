@@ -1112,18 +1112,19 @@ __device__ __forceinline__ bool classify_redo(const EvalParams &P, PixelFront &f
 // EXT launches keep only the matrix of the pose in scalar registers (see k_eval2); the quaternion is fetched here,
 // where it is needed, from the launch's record array.
 template <bool EXT>
-__device__ __forceinline__ void exact_decisions(const EvalParams &P, const SlotArgs &SA, int pose_idx, unsigned gi,
+__device__ __forceinline__ void exact_decisions(const EvalParams &P, const SlotArgs &SA, int pose_idx, const TileIn &t,
                                                 PixelFront &f, double &ic) {
   const Geometry &g = P.g;
-  const unsigned bo = gi << 3;
-  const double lx = ld_f64(P.t.X, bo), ly = ld_f64(P.t.Y, bo), lz = ld_f64(P.t.Z, bo);
+  const double lx = t.x, ly = t.y, lz = t.z;  // the second pass has the tile entry already
   double qx, qy, qz;
   if (EXT && SA.pose.mode == 0) {
     Pose pq;
-    const unsigned *src = reinterpret_cast<const unsigned *>(&P.slots_ext[pose_idx].pose);
+    // scalar loads through the constant address space, like the rest of the record (k_eval2)
+    typedef const unsigned __attribute__((address_space(4))) *ConstDwords;
+    ConstDwords src = (ConstDwords)(reinterpret_cast<uintptr_t>(&P.slots_ext[pose_idx].pose));
     unsigned *dst = reinterpret_cast<unsigned *>(&pq);
 #pragma unroll
-    for (unsigned i = 0; i < kPoseQuatDwords; i++) dst[i] = (unsigned)__builtin_amdgcn_readfirstlane((int)src[i]);
+    for (unsigned i = 0; i < kPoseQuatDwords; i++) dst[i] = src[i];
     pq.mode = 0;
     xform_point(pq, lx, ly, lz, qx, qy, qz);
   } else {
@@ -1538,7 +1539,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu((STRICT || D
       if (SECOND) {
         go = false;
         if (rare) {
-          exact_decisions<EXT>(P, SA, pose_idx, base + (unsigned)s, f, ic);
+          exact_decisions<EXT>(P, SA, pose_idx, tin, f, ic);
           go = f.in;
         }
       }
@@ -1909,7 +1910,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu((STRICT || D
       if (SECOND) {
         go = false;
         if (exact) {
-          exact_decisions<EXT>(P, SA, pose_idx, base + (unsigned)s, f, ic);
+          exact_decisions<EXT>(P, SA, pose_idx, tin, f, ic);
           go = f.jin;
           if (go) {  // the gradient again, on the window around the reference's (u, v)
             double dummy;
