@@ -36,6 +36,11 @@
 #ifndef NID_CLAMP_BINS
 #define NID_CLAMP_BINS 1
 #endif
+// 1: the Jacobian phase's second pass takes its rare lanes from raremask (EXPERIMENT: 122 VGPRs under the 128-register
+// budget of the EXT kernels, i.e. four waves per SIMD); 0: it classifies again
+#ifndef NID_JAC_SECOND_MASK
+#define NID_JAC_SECOND_MASK 0
+#endif
 // 1: wave-uniform fine-level adds of the target histogram are added once per wave (hist_add); 0: one atomic per lane
 #ifndef NID_LO_AGGREGATE
 #define NID_LO_AGGREGATE 1
@@ -1512,6 +1517,18 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu((STRICT || D
       } else {
         load_tile(P, base + (unsigned)s, plane, tin);
       }
+      double ic = NAN;
+      bool rare, go;
+      if constexpr (SECOND && use_lane_masks) {
+        // the main pass has left every lane's rare samples in raremask: no FAST front, no window, no sample -- straight
+        // to the exact decisions of the lanes that need them
+        f.jr = tin.jr;
+#pragma unroll
+        for (int k = 0; k < 4; k++) f.wr[k] = tin.wr[k];
+        f.in = false; f.jin = false; f.redo = false;
+        rare = ((raremask >> r) & 1u) != 0u;
+        go = false;
+      } else {
       pixel_front<false>(P, SA, tin, f);
       // the next round's point is requested BEHIND this round's warp: x, y, z are dead by then, so the loads land in
       // the registers they come from and nothing is copied from round to round (the empty asm keeps the scheduler
@@ -1523,14 +1540,15 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu((STRICT || D
       if (!SECOND) load_tile_w(P, base + (unsigned)s, plane, tin);
       // fixed-tap sample (a convex combination of u8 taps: never negative), computed for every lane -- lanes
       // without a sample hold a harmless window
-      double ic = sample_fast_c(wc2, f.u, f.v);
+      ic = sample_fast_c(wc2, f.u, f.v);
 #ifdef NID_EXP_NO_GUARD
-      bool rare = false;
+      rare = false;
 #else
-      bool rare = f.in && fabs(ic - kGuardMid) > kGuardHalf;
+      rare = f.in && fabs(ic - kGuardMid) > kGuardHalf;
 #endif
       if (f.redo && classify_redo(P, f)) rare = true;  // (waves that meet the frame border)
-      bool go = f.in && !rare;
+      go = f.in && !rare;
+      }
       if (use_lane_masks && !SECOND) {  // r < 32
         const unsigned bit = 1u << r;
         raremask |= rare ? bit : 0u;
@@ -1872,7 +1890,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu((STRICT || D
     // Two passes like the cost phase, with the same classification on the same values (gradient_fast_interior's
     // centre sample IS sample_fast_interior's): both phases take the same decisions and use the same
     // intensity (Q7).
-    auto jac_round = [&](int sb, const TileIn &cur, TileIn &nxt, auto second_pass) {
+    auto jac_round = [&](int sb, int r, const TileIn &cur, TileIn &nxt, auto second_pass) {
       constexpr bool SECOND = decltype(second_pass)::value;
       const int s = sb + lane;
       TileIn tin;
@@ -1883,6 +1901,26 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu((STRICT || D
         for (int k = 0; k < 4; k++) tin.wr[k] = 0.0;
       } else {
         load_tile(P, base + (unsigned)s, plane, tin);
+      }
+      if constexpr (SECOND && use_lane_masks && NID_JAC_SECOND_MASK) {
+        // the cost phase's rare samples are this phase's (raremask): FAST warp for d(u,v)/d(xi), then straight to the
+        // exact decisions -- no window, no gradient, no classification for the lanes that are not rare
+        warp_fast(P, SA, tin, f);
+#pragma unroll
+        for (int k = 0; k < 4; k++) f.wr[k] = k == 0 ? fabs(tin.wr[0]) : tin.wr[k];
+        f.in = false; f.jin = false; f.redo = false;
+        if (((raremask >> r) & 1u) != 0u) {
+          double ic, gx, gy, dummy;
+          exact_decisions<EXT>(P, SA, pose_idx, tin, f, ic);
+          if (f.jin) {
+            gradient_fast_interior(f.w, f.u, f.v, gx, gy, dummy);
+            double pc, dw[4];
+            const int jc = fast_bin<true>(ic, S, pc);
+            bspline4_poly_der(pc, jc, rtab, dw);
+            jac_accumulate(f, f.zq, gx, gy, pc, jc, dw, std::true_type{});
+          }
+        }
+        return false;
       }
       pixel_front<false>(P, SA, tin, f);
       // the next round's point is requested BEHIND this round's warp: x, y, z are dead by then, so the loads land in
@@ -1981,14 +2019,14 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu((STRICT || D
       } else {
 #pragma clang loop unroll(disable)
         for (int sb = wave_base; sb < g.pstride; sb += NT, r++)
-          if (jac_round(sb, prej, prej, std::false_type{})) rare2 |= 1ull << min(r, 63);
+          if (jac_round(sb, r, prej, prej, std::false_type{})) rare2 |= 1ull << min(r, 63);
       }
     }
     if (rare2 != 0ull) {
       r = 0;
 #pragma clang loop unroll(disable)
       for (int sb = wave_base; sb < g.pstride; sb += NT, r++)
-        if ((rare2 >> min(r, 63)) & 1ull) jac_round(sb, prej, prej, std::true_type{});
+        if ((rare2 >> min(r, 63)) & 1ull) jac_round(sb, r, prej, prej, std::true_type{});
     }
   }
   if (!STRICT) { acc[0] = -acc[0]; acc[5] = -acc[5]; }
