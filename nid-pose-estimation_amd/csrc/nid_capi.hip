@@ -83,7 +83,6 @@ struct nid_ctx {
   int group_size = 1, ngroups = 1;
   int math_mode = NID_MATH_FAST;
   double *ctab_dev = nullptr;
-  double ctab_scale = 0.0;  // hist_scale folded into ctab_dev's value coefficients
   Slot slots[NID_SLOTS];
   // nid_run_sequence: result buffers of the launches in flight (device + pinned host), their copy stream and events
   static constexpr int kSeqRing = 16;  // launches in flight: min(kSeqRing, NID_SLOTS / batch)
@@ -189,14 +188,13 @@ void build_coef_table(int S, std::vector<double> *out) {
   }
 }
 
-// k_eval2 accumulates raw 2^52-magic bit patterns and masks the top 12 bits per copy in the fold, so no copy may
-// carry out of 52 bits: a copy receives at most ceil(pstride / copies) weights (each <= 1) per bin
-double eval_hist_scale(const Geometry &g, int nt, double *inv) {
-  const int per_copy = (g.pstride + eval_hist_copies(nt) - 1) / eval_hist_copies(nt);
-  int cb2 = 0;
-  while ((1 << cb2) < per_copy + 1) cb2++;
-  if (inv) *inv = std::ldexp(1.0, -(52 - cb2));
-  return std::ldexp(1.0, 52 - cb2);
+// k_eval2 accumulates the bit patterns of subnormal products = RN(w * 2^s) as plain 64-bit integers (fx_bits in
+// nid_kernels.hip.h): a single addend needs w * 2^s < 2^53 (s <= 52 for weights <= 1), a whole cell's bin -- at most
+// pstride weights, each <= 1, over all copies -- must stay below 2^63
+int eval_hist_shift(const Geometry &g) {
+  int bits = 0;
+  while ((1L << bits) < (long)g.pstride + 1) bits++;
+  return std::min(52, 63 - bits);
 }
 
 size_t eval_lds_bytes(const Geometry &g, int nt) {
@@ -307,8 +305,12 @@ int launch_eval2(nid_ctx *ctx, EvalParams &P, bool jac, hipStream_t stream, int 
                           P.g.pstride <= lat_rounds(nt) * nt && batch <= kMaxBatch;
   if (dbg && nt > 256 && !stamps_lat) nt = 256;
   size_t lds = eval_lds_bytes(P.g, nt);
-  P.hist_scale = eval_hist_scale(P.g, nt, &P.hist_inv_scale);
-  if (P.hist_scale != ctx->ctab_scale) return NID_ERR_STATE;  // the B-spline table on the device carries the scale
+  {
+    const int hs = eval_hist_shift(P.g);
+    P.hist_dn = std::ldexp(1.0, hs - 562);    // times kWcPre = 2^-512 on the other factor: 2^(hs - 1074)
+    P.hist_dn1 = std::ldexp(1.0, hs - 1074);  // (a subnormal constant: exact)
+    P.hist_inv_scale = std::ldexp(1.0, -hs);
+  }
   if (lds > 160 * 1024) return NID_ERR_UNSUPPORTED;
   static const char *pad_env = getenv("NID_EXP_LDS_PAD");  // occupancy experiments: pad the LDS request
   if (pad_env) lds = std::min<size_t>(160 * 1024, lds + (size_t)atoi(pad_env));
@@ -372,7 +374,7 @@ void fill_common_params(nid_ctx *ctx, double delta, EvalParams *P) {
   P->u_out = (double)ctx->g.cols - 3.0 + kBorderEps;
   P->v_out = (double)ctx->g.rows - 3.0 + kBorderEps;
   P->u_jout = (double)P->jac_cols - 3.0 + kBorderEps;
-  P->hist_scale = P->hist_inv_scale = 0.0;  // set by launch_eval2 (depends on the workgroup shape)
+  P->hist_dn = P->hist_dn1 = P->hist_inv_scale = 0.0;  // set by launch_eval2
   if (ctx->dbg_enabled) {
     P->dbg_u = ctx->dbg_u; P->dbg_v = ctx->dbg_v; P->dbg_ic = ctx->dbg_ic;
     P->dbg_wc = ctx->dbg_wc; P->dbg_jc = ctx->dbg_jc;
@@ -751,12 +753,10 @@ int nid_create_strided(const nid_config *cfg, int32_t cell_stride, nid_ctx **out
   if ((rc = dev_alloc(ctx, &ctx->Nc_dev, g.nloc))) return fail(rc);
   if ((rc = dev_alloc(ctx, &ctx->Href_dev, g.nloc))) return fail(rc);
   {
-    // the evaluation kernels read the table with hist_scale on its value coefficients (k_eval2's hist_add); every
-    // workgroup shape has 16 histogram copies, so the scale is a property of the geometry
+    // the evaluation kernels read the table with kWcPre on its value coefficients (k_eval2's hist_add, fx_bits)
     std::vector<double> coef;
     build_coef_table(g.S, &coef);
-    ctx->ctab_scale = eval_hist_scale(g, 128, nullptr);
-    for (size_t i = 0; i < coef.size(); i++) if ((i % 7) < 4) coef[i] *= ctx->ctab_scale;
+    for (size_t i = 0; i < coef.size(); i++) if ((i % 7) < 4) coef[i] *= kWcPre;
     if ((rc = dev_alloc(ctx, &ctx->ctab_dev, coef.size()))) return fail(rc);
     if (hipMemcpy(ctx->ctab_dev, coef.data(), coef.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess)
       return fail(NID_ERR_HIP);

@@ -113,14 +113,14 @@ struct EvalParams {
   int jac_cols;         // cols or cols-1
   double u_in, v_in, u_jin;  // FAST border bounds, kBorderEps inside the reference's: cols-3-eps, rows-3-eps, jac_cols-3-eps
   double u_out, v_out, u_jout;  // ... and kBorderEps outside: cols-3+eps, rows-3+eps, jac_cols-3+eps
-  double hist_scale, hist_inv_scale;
+  double hist_dn, hist_dn1, hist_inv_scale;  // 2^(s - 562), 2^(s - 1074), 2^-s: see fx_bits
   // fused Huber + 6x6 reduction
   double huber_delta;
   float huber_dsqr;
   int group_size;                  // cells per first-level group
   int batch;                       // poses in this launch (slot[0..batch-1])
   const double *ctab;              // FAST mode: per-span B-spline polynomial coefficients [S][kCoefRow], the value
-                                   // coefficients (entries 0..3 of every 7-entry row) times hist_scale
+                                   // coefficients (entries 0..3 of every 7-entry row) times kWcPre
   SlotArgs slot[kMaxBatch];        // per-pose arguments of launches of <= kMaxBatch poses (3.7 KB of kernel arguments)
   const SlotArgs *slots_ext;       // larger launches: the same records in device memory (copied in-stream); else null
   // optional per-pixel dump (image order), null when disabled
@@ -505,16 +505,25 @@ __device__ __forceinline__ unsigned long long fx_encode(double w, double scale) 
   return (unsigned long long)__double_as_longlong(t) - 0x4330000000000000ull;
 }
 
-// Hot-kernel form: the raw bit pattern of RN(w*scale + 2^52), i.e. the fixed-point value with
-// 0x433 left in the top 12 bits.  With the scale chosen so that a histogram copy can never carry
-// out of its low 52 bits (EvalParams::hist_scale), the copies are summed as integers and the top
-// 12 bits are masked off once per copy in the fold -- one VALU instruction less per atomic.
-__device__ __forceinline__ unsigned long long fx_encode_raw(double w, double scale) {
-  return (unsigned long long)__double_as_longlong(fma(w, scale, 0x1p52));
+// Hot-kernel form: the bit pattern of a SUBNORMAL product.  A non-negative double below 2^-1021 has the bit pattern
+// value / 2^-1074 (biased exponents 0 and 1 share one ulp), so with the operands pre-scaled so that the product is
+// w * 2^(s - 1074) its bits ARE round-to-nearest-even(w * 2^s) as a 64-bit integer: one v_mul_f64 per atomic, no
+// magic number in the top 12 bits -- hence no per-copy carry limit (the copies of a bin add up as plain 64-bit
+// integers, the scale only has to keep a whole cell's bin below 2^63: s = 52 for cells of up to 2047 slots) and seven
+// more fractional bits than RN(w * 2^45 + 2^52) had (round 2: one random case in ~3 000 missed the 1e-9 Jacobian
+// bound by the quantum of mid-range products in the joint bins).  f64 subnormals are never flushed and cost nothing
+// on gfx950 (tools/ubench/denorm_encode.hip checks the bits against the host's rounding and the issue rate).
+// Both factors must be NORMAL numbers (a subnormal factor would have lost bits already): the scale is split --
+// kWcPre = 2^-512 rides on the target weights (on the value polynomials of the FAST B-spline table: a power of two
+// commutes with every rounding of the Horner steps), EvalParams::hist_dn = 2^(s - 562) on the reference weights and
+// on the marginal adds.  Operands must be >= +0 (a negative product would carry the sign bit into the sum): target
+// weights that could be negative by rounding are the tiny outer ones, which take the fine-level path below.
+__device__ __forceinline__ unsigned long long fx_bits(double subnormal_product) {
+  return (unsigned long long)__double_as_longlong(subnormal_product);
 }
-constexpr unsigned kFxHiMask = 0x000FFFFFu;
+constexpr double kWcPre = 0x1p-512, kWcPreInv = 0x1p512;
 
-// Fine histogram levels for SMALL target weights.  The copies above resolve 2^-45..2^-46 per addend (hist_scale):
+// Fine histogram levels for SMALL target weights.  The copies above resolve 2^-52 per addend (fx_bits; 2^-45 in round 2):
 // exact enough for every bin's entropy term, but not for the Jacobian's weight W = -(1 + log2 p) of a bin whose
 // whole mass is made of small addends -- the reference keeps such masses in f64, takes W ~ 50..100 of
 // p ~ 1e-15..1e-30 and multiplies it with that bin's derivative sums.  A sample within 2^-9 of a knot feeds its
@@ -526,7 +535,7 @@ constexpr unsigned kFxHiMask = 0x000FFFFFu;
 // level L = min(floor((-8 - e) / 24), 4), e = its binary exponent, scaled by 2^(59 + 24 L) -- and every joint addend
 // wr[m] * w below 2^-8 of a sample whose target OR reference sample sits next to a knot to the level of THAT
 // product's exponent: at least 27 bits of every addend survive, at most 2^51 per addend and 2^62 per bin.  Weights >= 2^-8 stay in the coarse copies
-// (error of the Jacobian term there <= quantum * |dw| / w = 2.8e-14 * 3 * 256 = 2e-11).  kTinyW: the smaller
+// (error of the Jacobian term there <= quantum * |dw| / w = 2.2e-16 * 3 * 256 = 2e-13).  kTinyW: the smaller
 // outer weight of a sample (target or reference) is below it iff the sample sits within ~2.8e-3 of a knot.
 #ifndef NID_TINY_W_EXP
 #define NID_TINY_W_EXP 28
@@ -802,8 +811,7 @@ constexpr int kRedDoubles(int nt) { return (6 * (nt / 64) + 1) & ~1; }  // the s
 // Clamped target samples (ic >= 255 -> 254.999, types_six_dof_expmap.cpp:572-573) all have the SAME four target weights:
 // instead of 20 histogram adds each (15 of them fine-level adds), FAST math sums their reference weights per reference bin
 // (nb bins) and counts them (one more bin), NC copies like the histograms; the fold adds c_k * sum to the bins they feed.
-// The coarse sums have kClampCopies copies (their scale is hist_scale * kClampCopies / NC, so a copy still cannot carry
-// out of 52 bits); reference weights below 2^-8 go to fine levels of their own exponent like everywhere else (a joint bin
+// The coarse sums have kClampCopies copies (same scale as the histograms); reference weights below 2^-8 go to fine levels of their own exponent like everywhere else (a joint bin
 // fed only by clamped samples is c_k * this sum: it needs the sum to ~1e-9 relative even when it is one weight of 1e-8).
 constexpr int kClampBins(int nb) { return (nb + 2) & ~1; }
 constexpr int kClampCopies = 4;
@@ -1303,7 +1311,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu((STRICT || D
       rtab[jj * kRcpRow + e] = 1.0 / span_denominator(jj, e, S);
     }
   } else {
-    // (the host's table carries hist_scale on its value coefficients, see hist_add)
+    // (the host's table carries kWcPre on its value coefficients, see hist_add / fx_bits)
     for (int i = tid; i < S * kCoefRow; i += NT) rtab[i] = P.ctab[i];
   }
   __syncthreads();
@@ -1311,22 +1319,22 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu((STRICT || D
 
   // ---- phase 1: cost ---------------------------------------------------------------
   // One round = 64 consecutive tile slots per wave.  The histogram update of one in-frame sample:
-  // FAST math: the value polynomials of the LDS copy of the B-spline table carry hist_scale (a power of two: every
+  // FAST math: the value polynomials of the LDS copy of the B-spline table carry kWcPre (a power of two: every
   // Horner step is the unscaled step times the scale, bit for bit), so the target weights arrive scaled (`win`
-  // = wc * hist_scale, PRESCALED) and the four multiplications per sample are gone; the rare branches below get the
-  // plain weights back by the inverse scale (exact).
-  const double tiny_scaled = kTinyW * P.hist_scale;
+  // = wc * kWcPre, PRESCALED); the rare branches below get the plain weights back by the inverse scale (exact).
+  // The reference weights take hist_dn (four multiplications per sample), and every add is the bit pattern of a
+  // subnormal product (fx_bits).
+  const double tiny_scaled = kTinyW * kWcPre;
   auto hist_add = [&](int jr, int jc, const double (&wr_in)[4], const double (&win)[4], auto prescaled, bool clamped = false) {
     constexpr bool PRESCALED = decltype(prescaled)::value;
     if (clamped) {  // FAST second passes only: see kClampBins
-      const double cscale = P.hist_scale * ((double)kClampCopies / (double)NC);
       unsigned long long *hx = clampb + ((unsigned)copy & (kClampCopies - 1));
-      atomicAdd(hx + nb * kClampCopies, fx_encode_raw(1.0, cscale));
+      atomicAdd(hx + nb * kClampCopies, fx_bits(P.hist_dn1));
 #pragma unroll
       for (int m = 0; m < 4; m++) {
         const double w = m == 0 ? fabs(wr_in[0]) : wr_in[m];
         if (w >= kFineW) {
-          atomicAdd(hx + (jr + m) * kClampCopies, fx_encode_raw(w, cscale));
+          atomicAdd(hx + (jr + m) * kClampCopies, fx_bits(w * P.hist_dn1));
         } else if (w != 0.0) {
           const int lv = fine_level(w);
           atomicAdd(clamp_lo + lv * kClampBins(nb) + (unsigned)(jr + m), fx_encode(w, fine_scale(lv)));
@@ -1335,11 +1343,11 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu((STRICT || D
       clamp_flag[0] = 1u;
       return;
     }
-    // fixed-point encode: the scale is a power of two, so wcs = wc*scale is exact and
-    // fma(wr, wcs, 2^52) rounds wr*wc*scale once
+    // fixed-point encode: the scales are powers of two, so wcs = wc * kWcPre and wrs = wr * hist_dn are exact and
+    // wrs * wcs rounds wr * wc * 2^s once, to an integer (fx_bits)
     double wcs[4];
 #pragma unroll
-    for (int k = 0; k < 4; k++) wcs[k] = PRESCALED ? win[k] : win[k] * P.hist_scale;
+    for (int k = 0; k < 4; k++) wcs[k] = PRESCALED ? win[k] : win[k] * kWcPre;
     const unsigned hrow = (unsigned)(__mul24(jr, nb) + jc);
     unsigned long long *hc = hist + ((unsigned)jc * NC + (unsigned)copy);
     unsigned long long *hj = hist + (((unsigned)nb + hrow) * NC + (unsigned)copy);
@@ -1382,7 +1390,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu((STRICT || D
     if (fmin(wcs[0], wcs[3]) < tiny_scaled || ref_tiny) {
       double wc[4];
 #pragma unroll
-      for (int k = 0; k < 4; k++) wc[k] = PRESCALED ? win[k] * P.hist_inv_scale : win[k];
+      for (int k = 0; k < 4; k++) wc[k] = PRESCALED ? win[k] * kWcPreInv : win[k];
       wr[0] = fabs(wr[0]);
       if (!ref_tiny) {
         // target side only (about one sample in 90 on a smooth image: every other wave-round gets here)
@@ -1402,9 +1410,9 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu((STRICT || D
               }
             }
           } else {
-            atomicAdd(hc + k * NC, fx_encode_raw(wcs[k], 1.0));
+            atomicAdd(hc + k * NC, fx_bits(wcs[k] * P.hist_dn));
 #pragma unroll
-            for (int m = 0; m < 4; m++) atomicAdd(hj + (m * nb + k) * NC, fx_encode_raw(wr[m], wcs[k]));
+            for (int m = 0; m < 4; m++) atomicAdd(hj + (m * nb + k) * NC, fx_bits((wr[m] * P.hist_dn) * wcs[k]));
           }
         }
         return;
@@ -1419,7 +1427,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu((STRICT || D
             lo_add_marginal(lv * nbins + (unsigned)(jc + k), fx_encode(wc[k], fine_scale(lv)));
           }
         } else {
-          atomicAdd(hc + k * NC, fx_encode_raw(wcs[k], 1.0));
+          atomicAdd(hc + k * NC, fx_bits(wcs[k] * P.hist_dn));
         }
 #pragma unroll
         for (int m = 0; m < 4; m++) {
@@ -1430,7 +1438,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu((STRICT || D
               atomicAdd(hist_lo + lm * nbins + ((unsigned)nb + hrow + (unsigned)(m * nb + k)), fx_encode(pr, fine_scale(lm)));
             }
           } else {
-            atomicAdd(hj + (m * nb + k) * NC, fx_encode_raw(wr[m], wcs[k]));
+            atomicAdd(hj + (m * nb + k) * NC, fx_bits((wr[m] * P.hist_dn) * wcs[k]));
           }
         }
       }
@@ -1438,12 +1446,15 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu((STRICT || D
     }
 #endif
 #pragma unroll
-    for (int k = 0; k < 4; k++) atomicAdd(hc + k * NC, fx_encode_raw(wcs[k], 1.0));
+    for (int k = 0; k < 4; k++) atomicAdd(hc + k * NC, fx_bits(wcs[k] * P.hist_dn));
+    double wrs[4];
+#pragma unroll
+    for (int m = 0; m < 4; m++) wrs[m] = wr[m] * P.hist_dn;  // wr[0] >= 0 here (ref_tiny is false)
 #pragma unroll
     for (int m = 0; m < 4; m++)
 #pragma unroll
       for (int k = 0; k < 4; k++)
-        atomicAdd(hj + (m * nb + k) * NC, fx_encode_raw(wr[m], wcs[k]));  // wr[0] >= 0 here (ref_tiny is false)
+        atomicAdd(hj + (m * nb + k) * NC, fx_bits(wrs[m] * wcs[k]));
   };
   auto dump_pixel = [&](int s, const PixelFront &f, double ic, int jc, const double (&wc)[4]) {
     const int c = g.cell_begin + cl * g.cell_stride;
@@ -1573,7 +1584,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu((STRICT || D
       }
       if (DBG && P.dbg_u && !P.dbg_jac && pose_idx == 0 && f.jr >= 0 && rare == SECOND) {
 #pragma unroll
-        for (int k = 0; k < 4; k++) wc[k] *= P.hist_inv_scale;  // NaN stays NaN
+        for (int k = 0; k < 4; k++) wc[k] *= kWcPreInv;  // NaN stays NaN
         dump_pixel(s, f, ic, jc, wc);
       }
       if (use_lane_masks) return false;
@@ -1656,9 +1667,9 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu((STRICT || D
         const uint4 q = hv[c];
         acc_lo += q.x;
         acc_lo += q.z;
-        acc_hi += (q.y & kFxHiMask) + (q.w & kFxHiMask);
+        acc_hi += q.y + q.w;
       }
-      double sum = (double)(long long)(acc_lo + ((unsigned long long)acc_hi << 32)) * (P.hist_inv_scale * ((double)NC / (double)kClampCopies));
+      double sum = (double)(long long)(acc_lo + ((unsigned long long)acc_hi << 32)) * P.hist_inv_scale;
 #pragma unroll
       for (int lv = 0; lv < kFineLevels; lv++)
         sum = fma((double)(long long)clamp_lo[lv * kClampBins(nb) + e], fine_inv_scale(lv), sum);
@@ -1668,14 +1679,14 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu((STRICT || D
     jc_cl = fast_bin<false>(ic_cl, S, pc_cl);
     bspline4_poly<false>(pc_cl, jc_cl, rtab, cw, dd);
 #pragma unroll
-    for (int k = 0; k < 4; k++) cw[k] *= P.hist_inv_scale;  // rtab's value polynomials carry hist_scale
+    for (int k = 0; k < 4; k++) cw[k] *= kWcPreInv;  // rtab's value polynomials carry kWcPre
     __syncthreads();
   }
   double ent[2] = {0.0, 0.0};
   for (int b = tid; b < nbins; b += NT) {
     const uint4 *hv = reinterpret_cast<const uint4 *>(hist + (size_t)b * NC);
-    // low dwords and masked high dwords (20 bits each) summed apart: 32-bit adds for the high parts, one carry chain
-    // for the low parts, joined once (the same integer as the 64-bit sum of the masked values)
+    // low and high dwords summed apart: 32-bit adds for the high parts, one carry chain for the low parts, joined
+    // once (the same integer as the 64-bit sum; a whole cell's bin stays below 2^63, see fx_bits)
     unsigned long long acc_lo = 0;
     unsigned acc_hi = 0;
 #pragma unroll
@@ -1683,7 +1694,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu((STRICT || D
       const uint4 q = hv[(c + b) & (NC / 2 - 1)];
       acc_lo += q.x;
       acc_lo += q.z;
-      acc_hi += (q.y & kFxHiMask) + (q.w & kFxHiMask);
+      acc_hi += q.y + q.w;
     }
     const unsigned long long acc = acc_lo + ((unsigned long long)acc_hi << 32);
     double mass = (double)(long long)acc * P.hist_inv_scale;

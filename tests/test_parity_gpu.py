@@ -3,10 +3,12 @@ seeded inputs.  Tolerances: per-cell Href/Hc/Hj/err
 1e-11 absolute; per-cell Jacobian 1e-9 relative PER CELL (to the cell's own largest
 component; summation order differs); in-bound counts, bin indices and -- in STRICT
 math -- every per-pixel intermediate (u, v, bilinear intensity, B-spline weights)
-bit-exact.  Both math modes meet the same bounds on every input, saturated and
+bit-exact.  Both math modes are held to the same bounds on every input, saturated and
 border-aligned ones included: FAST re-decides the reference's discontinuous
 decisions (frame border, 255 clamp, zero clamp) with the reference's own arithmetic
-(exact_decisions in csrc/nid_kernels.hip.h), so there is no loose set."""
+(exact_decisions in csrc/nid_kernels.hip.h), so there is no loose set.  Where the
+reference's own Jacobian is rounding noise (constant / saturated cells) the noise is
+MEASURED on the oracle (one-ulp pose changes) and allowed for; see NOISE_K below."""
 import numpy as np
 import pytest
 
@@ -14,12 +16,17 @@ pytestmark = pytest.mark.gpu
 
 ATOL_H = 1e-11
 RTOL_J = 1e-9
-# Each cell's Jacobian is held to RTOL_J relative to ITS OWN largest component -- down to cells whose
-# whole Jacobian is J_FLOOR x the frame's largest component; smaller ones (fully saturated or constant cells: what is
-# left of them is roundoff of the frame's scale, and their weight in the 6x6 system is below 1e-8) are held to
-# RTOL_J x J_FLOOR of the frame's scale, i.e. 1e-13.  Observed on the flash pair: 1.07e-9 of its own scale for the
-# one cell at 1e-6 of the frame (absolute 6e-15 against a frame maximum of 5.9), <= 3e-10 for every other cell.
-J_FLOOR = 1e-4
+# Each cell's Jacobian is held to RTOL_J relative to ITS OWN largest component, whatever its size against
+# the rest of the frame.  What is allowed on top of that is the REFERENCE'S OWN NOISE, measured, not a chosen floor:
+# N(cell) = the largest change of the oracle's Jacobian of that cell when its input pose moves by ONE ulp in any one
+# component (14 neighbouring poses; _reference_noise).  The reference's four-term bilinear form returns a constant
+# image's value +- an ulp, its central differences are then 1e-14-level noise and the Jacobian of a constant or fully
+# saturated cell is that noise times the cell's weights (1e-13 .. 1e-12): defined by the last bits of (u, v) only.
+# A cell passes if |J - J_o| <= RTOL_J * max|J_o(cell)| + NOISE_K * N(cell) + J_EPS * frame scale; the noise is
+# evaluated lazily -- only when a cell misses the plain bound -- and the last term is f64 roundoff at the frame's scale
+# (exact zeros on one side against 1e-17 residue on the other).
+NOISE_K = 4.0
+J_EPS = 64 * 2.0 ** -53
 DELTA = float(np.sqrt(0.95))
 
 
@@ -53,7 +60,35 @@ def _saturated_cells(o, pair):
     return out
 
 
-def _compare_cells(got, ref, cnt):
+def _reference_noise(o, pose, J_ref):
+    """Per cell: max |J_o(pose') - J_o(pose)| over the 14 poses that differ from `pose` by one ulp in one component.
+    Leaves the oracle's state (pixel dumps) as after evaluate(pose, True)."""
+    pose = np.asarray(pose, dtype=np.float64)
+    noise = np.zeros(J_ref.shape[0])
+    for k in range(7):
+        for d in (np.inf, -np.inf):
+            p = pose.copy()
+            p[k] = np.nextafter(p[k], d)
+            Jp = o.evaluate(p, True)[3]
+            with np.errstate(invalid="ignore"):
+                dev = np.abs(Jp - J_ref).max(axis=1)
+            noise = np.fmax(noise, np.where(np.isfinite(dev), dev, 0.0))
+    o.evaluate(pose, True)
+    return noise
+
+
+def _jac_excess(J, J_o, m, noise=None):
+    """Per selected cell: |J - J_o| / allowed, allowed = RTOL_J * own scale + NOISE_K * noise + J_EPS * frame scale."""
+    percell = np.abs(J_o[m]).max(axis=1)
+    allowed = RTOL_J * percell + J_EPS * max(percell.max(), 1.0)
+    if noise is not None:
+        allowed = allowed + NOISE_K * noise[m]
+    return np.abs(J[m] - J_o[m]).max(axis=1) / allowed, percell
+
+
+def _compare_cells(got, ref, cnt, noise=None):
+    """`noise`: None, (oracle context, pose) or a zero-argument callable returning the reference's per-cell noise
+    (_reference_noise); evaluated only if some cell misses the plain bound."""
     Hc, Hj, err, J = got
     Hc_o, Hj_o, err_o, J_o = ref
     act = cnt >= 300
@@ -68,15 +103,17 @@ def _compare_cells(got, ref, cnt):
         assert np.array_equal(np.isfinite(J).all(axis=1)[act], fin[act])
         m = act & fin
         if m.any():
-            percell = np.abs(J_o[m]).max(axis=1)
-            # (a constant image gives exact zeros against 1e-17 residue: the frame scale is at least 1)
-            scale = np.maximum(percell, J_FLOOR * max(percell.max(), 1.0))
-            rel = np.abs(J[m] - J_o[m]).max(axis=1) / scale
-            if not np.all(rel <= RTOL_J):
+            rel, percell = _jac_excess(J, J_o, m)
+            used_noise = False
+            if not np.all(rel <= 1.0) and noise is not None:
+                rel, percell = _jac_excess(J, J_o, m, noise() if callable(noise) else _reference_noise(noise[0], noise[1], J_o))
+                used_noise = True
+            if not np.all(rel <= 1.0):
                 w = int(np.argmax(rel))
-                raise AssertionError(f"worst per-cell relative Jacobian error {rel[w]:.3e} in cell {np.where(m)[0][w]}: "
+                raise AssertionError(f"worst per-cell Jacobian error {rel[w]:.3e} x the allowed one in cell {np.where(m)[0][w]}: "
                                      f"max|J_o| {percell[w]:.3e} (frame {percell.max():.3e}), max|dJ| "
-                                     f"{np.abs(J[m][w] - J_o[m][w]).max():.3e}; cells over tolerance: {int((rel > RTOL_J).sum())}")
+                                     f"{np.abs(J[m][w] - J_o[m][w]).max():.3e}; cells over tolerance: {int((rel > 1.0).sum())}"
+                                     f"{' (reference noise allowed for)' if used_noise else ''}")
         assert np.all(np.isnan(J[~act]))
 
 
@@ -111,7 +148,7 @@ def test_small_pair_all_stages(capi, oracle, synth, pair_S, pair_S_edge, nb, whi
     for name, pose in _poses(synth, pair).items():
         got = ctx.evaluate(pose, True)
         ref = o.evaluate(pose, True)
-        _compare_cells(got, ref, cnt_o)
+        _compare_cells(got, ref, cnt_o, noise=(o, pose))
         got_c = ctx.evaluate(pose, False)
         assert np.array_equal(_bits(got_c[0][act]), _bits(got[0][act])), "cost-only and cost+Jacobian kernels disagree"
         assert np.array_equal(_bits(got_c[2][act]), _bits(got[2][act]))
@@ -204,7 +241,7 @@ def test_semantic_switches(capi, oracle, synth, pair_S, jac_bound, xform, math):
     cnt_o, _ = o.compute_href(pair.pose_init)
     assert np.array_equal(cnt, cnt_o)
     for pose in _poses(synth, pair).values():
-        _compare_cells(ctx.evaluate(pose, True), o.evaluate(pose, True), cnt_o)
+        _compare_cells(ctx.evaluate(pose, True), o.evaluate(pose, True), cnt_o, noise=(o, pose))
     if xform == "matrix":
         M = oracle.se3_to_matrix16(pair.pose_init)
         a = ctx.evaluate_matrix(M, True)
@@ -245,7 +282,7 @@ def test_config_A_cells_and_normal_equations(capi, oracle, synth, pair_A, nb, ma
     for name, pose in _poses(synth, pair).items():
         got = ctx.evaluate(pose, True)
         ref = o.evaluate(pose, True)
-        _compare_cells(got, ref, cnt_o)
+        _compare_cells(got, ref, cnt_o, noise=(o, pose))
         H, b, chi2, na = ctx.normal_equations(pose, DELTA)
         H_o, b_o, chi2_o, na_o = oracle.normal_equations(ref[2], ref[3], DELTA)
         assert na == na_o == int(act.sum())
@@ -354,7 +391,7 @@ def test_config_B_full_size(capi, oracle, synth, math):
     assert act.sum() > 900
     np.testing.assert_allclose(href[act], href_o[act], rtol=0, atol=ATOL_H)
     got = ctx.evaluate(pair.pose_init, True)
-    _compare_cells(got, o.evaluate(pair.pose_init, True), cnt_o)
+    _compare_cells(got, o.evaluate(pair.pose_init, True), cnt_o, noise=(o, pair.pose_init))
     again = ctx.evaluate(pair.pose_init, True)
     for x, y in zip(got, again):
         assert np.array_equal(_bits(x[act]), _bits(y[act]))
@@ -404,7 +441,7 @@ def test_launch_shapes(capi, oracle, synth, cfg, nb, math):
         ctx.set_launch_shape(nt, nt)
         ctx.compute_href(pair.pose_init)
         got = ctx.evaluate(pose, True)
-        _compare_cells(got, ref, cnt)
+        _compare_cells(got, ref, cnt, noise=(o, pose))
         cost_only = ctx.evaluate(pose, False)
         H, b, chi2, na = ctx.normal_equations(pose, DELTA)
         _, _, chi2_c, na_c = ctx.normal_equations(pose, DELTA, want_jac=False)
@@ -506,7 +543,7 @@ def test_edge_geometries(capi, oracle, synth, geom, math):
     for name, pose in _poses(synth, pair).items():
         got = ctx.evaluate(pose, True)
         ref = o.evaluate(pose, True)
-        _compare_cells(got, ref, cnt_o)
+        _compare_cells(got, ref, cnt_o, noise=(o, pose))
         H, b, chi2, na = ctx.normal_equations(pose, DELTA)
         assert na == int(act.sum())
         H_o, b_o, chi2_o, na_o = oracle.normal_equations(ref[2], ref[3], DELTA)
@@ -530,7 +567,7 @@ def test_extreme_bin_counts(capi, oracle, synth, pair_S_edge, nb):
         act = cnt_o >= 300
         np.testing.assert_allclose(href[act], href_o[act], rtol=0, atol=ATOL_H)
         for pose in (pair.pose_init, pair.pose_true):
-            _compare_cells(ctx.evaluate(pose, True), o.evaluate(pose, True), cnt_o)
+            _compare_cells(ctx.evaluate(pose, True), o.evaluate(pose, True), cnt_o, noise=(o, pose))
     with pytest.raises(capi.NidError):
         capi.Context(pair.rows, pair.cols, pair.cell, 17, pair.fx, pair.fy, pair.cx, pair.cy)
     with pytest.raises(capi.NidError):
@@ -713,8 +750,17 @@ def _random_case(synth, seed):
 # seeds beyond the first 64 that a 4 000-case sweep (tools/random_parity_sweep.py) found in violation before the fine
 # fixed-point levels took (i) the joint addends of a small target weight at the level of the PRODUCT's exponent
 # (372, 630: one cell 1e-6 off) and (ii) the products of a saturated reference pixel's tiny weights (1324, 1496, 2409:
-# one cell 0.7-2.6 % off).  Left after that: seed 3013, one cell at 3.9e-9 of its own scale (2e-9 absolute).
+# one cell 0.7-2.6 % off).
 SWEEP_SEEDS = [372, 630, 1324, 1496, 2409]
+# Round 2's kernel missed the 1e-9 bound on these (profiles/r03_parity_sweeps.txt has both kernels on them):
+#  * 3013 (one cell at 3.9e-9 of its own scale), 70874 (1.15e-9; 8 grey levels, 16 bins): the 2^-45 quantum of the
+#    fixed-point joint histogram on mid-range products -- the histograms now resolve 2^-52 (fx_bits in
+#    csrc/nid_kernels.hip.h: the bit pattern of a subnormal product);
+#  * 50185, 71823: constant TARGET image.  The reference's four-term bilinear form returns the constant +- an ulp, its
+#    central differences are 1e-14-level noise and its Jacobian is that noise (1.2e-13, 4.1e-13) where FAST math
+#    differences the integer taps and returns exact zeros: allowed for by the reference's MEASURED noise
+#    (_reference_noise), not by a chosen floor.
+SWEEP_SEEDS += [3013, 70874, 50185, 71823]
 
 
 @pytest.mark.gpu
@@ -736,7 +782,7 @@ def test_randomised_pairs(capi, oracle, synth, seed):
         for pose in poses:
             ref = o.evaluate(pose, True)
             got = ctx.evaluate(pose, True)
-            _compare_cells(got, ref, cnt_o)
+            _compare_cells(got, ref, cnt_o, noise=(o, pose))
             H, b, chi2, na = ctx.normal_equations(pose, DELTA)
             assert na == int(act.sum())
 
@@ -804,7 +850,7 @@ def test_many_small_cells(capi, oracle, synth):
     cnt_o, _ = o.compute_href(pair.pose_init)
     assert np.array_equal(cnt, cnt_o) and (cnt_o >= 300).sum() > 300
     got, ref = ctx.evaluate(pair.pose_true, True), o.evaluate(pair.pose_true, True)
-    _compare_cells(got, ref, cnt_o)
+    _compare_cells(got, ref, cnt_o, noise=(o, pair.pose_true))
     H, b, chi2, na = ctx.normal_equations(pair.pose_true, DELTA)
     H_o, b_o, chi2_o, na_o = oracle.normal_equations(ref[2], ref[3], DELTA)
     assert na == na_o and abs(chi2 - chi2_o) <= 1e-9 * chi2_o
@@ -833,7 +879,7 @@ def test_flash_pair_cells(capi, oracle, synth, nb, math):
         ref = o.evaluate(pose, True)
         sat = _saturated_cells(o, pair) & act
         assert sat.sum() >= 20, "the flash pair must put many active cells on the saturation clamp"
-        _compare_cells(ctx.evaluate(pose, True), ref, cnt_o)
+        _compare_cells(ctx.evaluate(pose, True), ref, cnt_o, noise=(o, pose))
         H, b, chi2, na = ctx.normal_equations(pose, DELTA)
         H_o, b_o, chi2_o, na_o = oracle.normal_equations(ref[2], ref[3], DELTA)
         assert na == na_o
@@ -919,4 +965,4 @@ def test_border_guard_band(capi, oracle, synth, shift, math):
     vis = ~np.isnan(d["u"]) & inc & (cnt_o[cell] >= 300)
     frac = np.abs(d["u"][vis] - np.rint(d["u"][vis]))
     assert np.median(frac) < 1e-6 and frac.min() > 1e-13, "samples must sit near, not on, integer coordinates"
-    _compare_cells(ctx.evaluate(pose, True), ref, cnt_o)
+    _compare_cells(ctx.evaluate(pose, True), ref, cnt_o, noise=(o, pose))

@@ -30,7 +30,7 @@ for nb in (8, 10, 16):
         ref = o.evaluate(pose, True)
         for math, shape, c in ctxs:
             try:
-                T._compare_cells(c.evaluate(pose, True), ref, cnt_o)
+                T._compare_cells(c.evaluate(pose, True), ref, cnt_o, noise=(o, pose))
             except AssertionError as e:
                 bad += 1
                 print(f"nb {nb} pose {i} (scale {scale}) {math} {shape}: {str(e)[:260]}")

@@ -29,7 +29,7 @@ for seed in range(first, first + count):
             assert np.array_equal(cnt, cnt_o) and np.array_equal(np.isnan(href), ~act)
             np.testing.assert_allclose(href[act], href_o[act], rtol=0, atol=T.ATOL_H)
             for pose, ref in zip(poses, refs):
-                T._compare_cells(ctx.evaluate(pose, True), ref, cnt_o)
+                T._compare_cells(ctx.evaluate(pose, True), ref, cnt_o, noise=(o, pose))
                 assert ctx.normal_equations(pose, T.DELTA)[3] == int(act.sum())
             ctx.close()
     except Exception as e:   # noqa: BLE001
