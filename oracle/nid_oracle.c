@@ -149,6 +149,30 @@ static double bilinear_u8(const unsigned char *im, int cols, double x, double y)
                   (1 - dx - dy + dxdy) * im[iy * cols + ix]);
 }
 
+/* The sampler the image GRADIENT uses (types_six_dof_expmap.cpp:434-435: central differences of four more bilinear
+ * samples).  The reference uses the four-term form above for them too.  Built with -DNID_ORACLE_GRADIENT_TWIN
+ * (oracle/libnid_oracle_twin.so, together with the reversed pixel order) the gradient's samples use the mathematically
+ * identical two-lerp association instead: wherever the reference's gradient is ROUNDING NOISE -- a constant or
+ * saturated patch, where the four-term form returns the constant +- an ulp and its differences are 1e-14-level
+ * noise -- the twin returns another rounding of the same zero.  |J(oracle) - J(twin)| per cell is the measured
+ * width of the reference's own result; tests allow for it instead of a chosen floor (tests/test_parity_gpu.py).
+ * The cost pass (intensities, clamps, histograms) is the reference's in both builds. */
+#ifdef NID_ORACLE_GRADIENT_TWIN
+static double bilinear_grad(const unsigned char *im, int cols, double x, double y) {
+  int ix = (int)x;
+  int iy = (int)y;
+  double dx = x - ix;
+  double dy = y - iy;
+  double i00 = im[iy * cols + ix], i01 = im[iy * cols + ix + 1];
+  double i10 = im[(iy + 1) * cols + ix], i11 = im[(iy + 1) * cols + ix + 1];
+  double top = i00 + dx * (i01 - i00);
+  double bot = i10 + dx * (i11 - i10);
+  return top + dy * (bot - top);
+}
+#else
+#define bilinear_grad bilinear_u8
+#endif
+
 /* ------------------------------------------------------------------------ */
 /* SE(3): Eigen closed forms used by se3quat.h (Eigen is un-vendored and
  * un-pinned in the reference: ulp-level parity unpinned)      */
@@ -594,8 +618,8 @@ static void cell_linearize(nid_oracle *o, const xform_t *xf, int ci, int cj, dou
       int jc = (int)floor(bin_pos_current);
       double gx, gy, Ju[6], Jv[6];
       if (u >= 0 && u + 3 <= jcols && v >= 0 && v + 3 <= o->rows) {
-        gx = (bilinear_u8(o->im1, o->cols, u + 1, v) - bilinear_u8(o->im1, o->cols, u - 1, v)) / 2;
-        gy = (bilinear_u8(o->im1, o->cols, u, v + 1) - bilinear_u8(o->im1, o->cols, u, v - 1)) / 2;
+        gx = (bilinear_grad(o->im1, o->cols, u + 1, v) - bilinear_grad(o->im1, o->cols, u - 1, v)) / 2;
+        gy = (bilinear_grad(o->im1, o->cols, u, v + 1) - bilinear_grad(o->im1, o->cols, u, v - 1)) / 2;
         Ju[0] = -x * y * invz_2 * fx;
         Ju[1] = (1 + (x * x * invz_2)) * fx;
         Ju[2] = -y * invz * fx;

@@ -86,6 +86,23 @@ def load_reversed():
     return _LIB_REV
 
 
+_LIB_TWIN = None
+
+
+def load_twin():
+    """The oracle built with the reversed pixel order AND the image gradient's bilinear samples in the two-lerp
+    association (oracle/Makefile: libnid_oracle_twin.so): the reference's arithmetic with every sum and every gradient
+    sample rounded differently.  |J(oracle) - J(twin)| per cell measures how far the reference's own Jacobian is
+    defined (constant / saturated patches: pure rounding noise)."""
+    global _LIB_TWIN
+    if _LIB_TWIN is None:
+        p = os.path.join(_HERE, "libnid_oracle_twin.so")
+        if not os.path.exists(p):
+            subprocess.check_call(["make", "-s", "-C", _HERE, "libnid_oracle_twin.so"])
+        _LIB_TWIN = load(p)
+    return _LIB_TWIN
+
+
 def _dp(a):
     return a.ctypes.data_as(c_dp) if a is not None else None
 
@@ -162,6 +179,9 @@ class Oracle:
 
     def __init__(self, rows, cols, cell, nb, fx, fy, cx, cy, jac_bound="cpu", xform="quat", lib=None):
         self.lib = lib or load()
+        self._args = (rows, cols, cell, nb, fx, fy, cx, cy, jac_bound, xform)
+        self._ref = self._tgt = self._href_pose = None
+        self._twin = None
         self.rows, self.cols, self.cell, self.nb = rows, cols, cell, nb
         self.ncell = cell * cell
         self.h = self.lib.nid_oracle_create(rows, cols, cell, nb, fx, fy, cx, cy)
@@ -184,18 +204,40 @@ class Oracle:
         p = _d(points3d).reshape(-1)
         im = np.ascontiguousarray(im0, dtype=np.uint8)
         assert p.size == 3 * self.rows * self.cols and im.size == self.rows * self.cols
+        self._ref, self._twin = (p.copy(), im.copy()), None
         self.lib.nid_oracle_set_reference(self.h, _dp(p), im.ctypes.data_as(c_u8p))
 
     def set_target(self, im1):
         im = np.ascontiguousarray(im1, dtype=np.uint8)
         assert im.size == self.rows * self.cols
+        self._tgt, self._twin = im.copy(), None
         self.lib.nid_oracle_set_target(self.h, im.ctypes.data_as(c_u8p))
 
     def compute_href(self, pose7):
         cnt = np.zeros(self.ncell, dtype=np.int32)
         href = np.zeros(self.ncell)
+        self._href_pose, self._twin = _d(pose7).copy(), None
         self.lib.nid_oracle_compute_href(self.h, _dp(_d(pose7)), _ip(cnt), _dp(href))
         return cnt, href
+
+    def twin(self):
+        """The same frame pair and reference stage on load_twin()'s build (created on first use)."""
+        if self._twin is None:
+            t = Oracle(*self._args, lib=load_twin())
+            t.set_reference(*self._ref)
+            t.set_target(self._tgt)
+            t.compute_href(self._href_pose)
+            self._twin = t
+        return self._twin
+
+    def jacobian_noise(self, pose7, J_ref=None):
+        """Per cell: max |J - J_twin| at `pose7` -- how far the reference's own Jacobian is defined (see load_twin)."""
+        if J_ref is None:
+            J_ref = self.evaluate(pose7, True)[3]
+        Jt = self.twin().evaluate(pose7, True)[3]
+        with np.errstate(invalid="ignore"):
+            dev = np.abs(Jt - J_ref).max(axis=1)
+        return np.where(np.isfinite(dev), dev, 0.0)
 
     def evaluate(self, pose7, want_jac=True):
         Hc = np.zeros(self.ncell)

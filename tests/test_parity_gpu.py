@@ -18,13 +18,14 @@ ATOL_H = 1e-11
 RTOL_J = 1e-9
 # Each cell's Jacobian is held to RTOL_J relative to ITS OWN largest component, whatever its size against
 # the rest of the frame.  What is allowed on top of that is the REFERENCE'S OWN NOISE, measured, not a chosen floor:
-# N(cell) = the largest change of the oracle's Jacobian of that cell when its input pose moves by ONE ulp in any one
-# component (14 neighbouring poses; _reference_noise).  The reference's four-term bilinear form returns a constant
-# image's value +- an ulp, its central differences are then 1e-14-level noise and the Jacobian of a constant or fully
-# saturated cell is that noise times the cell's weights (1e-13 .. 1e-12): defined by the last bits of (u, v) only.
-# A cell passes if |J - J_o| <= RTOL_J * max|J_o(cell)| + NOISE_K * N(cell) + J_EPS * frame scale; the noise is
-# evaluated lazily -- only when a cell misses the plain bound -- and the last term is f64 roundoff at the frame's scale
-# (exact zeros on one side against 1e-17 residue on the other).
+# N(cell) = |J_o - J_twin|, the twin being the same oracle source built with the pixels of a cell visited in the
+# opposite order and the image gradient's bilinear samples in the two-lerp association (oracle/Makefile:
+# libnid_oracle_twin.so): the reference's arithmetic, every sum and every gradient sample rounded differently.  The
+# reference's four-term bilinear form returns a constant image's value +- an ulp, its central differences are then
+# 1e-14-level noise, and the Jacobian of a constant or fully saturated cell is that noise times the cell's weights
+# (1e-13 .. 1e-12).  A cell passes if |J - J_o| <= RTOL_J * max|J_o(cell)| + NOISE_K * N(cell) + J_EPS * frame scale;
+# the twin is evaluated lazily -- only when a cell misses the plain bound -- and the last term is f64 roundoff at the
+# frame's scale (exact zeros on one side against 1e-17 residue on the other).
 NOISE_K = 4.0
 J_EPS = 64 * 2.0 ** -53
 DELTA = float(np.sqrt(0.95))
@@ -61,20 +62,8 @@ def _saturated_cells(o, pair):
 
 
 def _reference_noise(o, pose, J_ref):
-    """Per cell: max |J_o(pose') - J_o(pose)| over the 14 poses that differ from `pose` by one ulp in one component.
-    Leaves the oracle's state (pixel dumps) as after evaluate(pose, True)."""
-    pose = np.asarray(pose, dtype=np.float64)
-    noise = np.zeros(J_ref.shape[0])
-    for k in range(7):
-        for d in (np.inf, -np.inf):
-            p = pose.copy()
-            p[k] = np.nextafter(p[k], d)
-            Jp = o.evaluate(p, True)[3]
-            with np.errstate(invalid="ignore"):
-                dev = np.abs(Jp - J_ref).max(axis=1)
-            noise = np.fmax(noise, np.where(np.isfinite(dev), dev, 0.0))
-    o.evaluate(pose, True)
-    return noise
+    """Per cell: |J_o - J_twin| (oracle.jacobian_noise)."""
+    return o.jacobian_noise(pose, J_ref)
 
 
 def _jac_excess(J, J_o, m, noise=None):

@@ -1,0 +1,93 @@
+#!/usr/bin/env python3
+"""tools/diag_quantum.py SEED POSE_INDEX CELL [QBITS...]: what the fixed-point quantum of the histogram adds does to one
+cell's Jacobian -- no GPU needed.  The cell's Jacobian is recomputed in long double from the ORACLE's per-pixel dumps
+(i) with exact histograms and (ii) with every coarse addend rounded to a multiple of 2^-q the way k_eval2's hist_add
+does (samples next to a knot -- smaller outer weight below 2^-28, or tiny reference weights -- keep their small
+weights exactly: the fine levels), for each q given (default 45 52 60)."""
+import importlib, os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+synth = importlib.import_module("nid-pose-estimation_amd.synth")
+from oracle import oracle_py as O
+import test_parity_gpu as T
+seed, k, c = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
+qs = [int(x) for x in sys.argv[4:]] or [45, 52, 60]
+pair, nb, poses = T._random_case(synth, 1000 + seed)
+pose = poses[k]
+LD = np.longdouble
+o = O.from_pair(pair, nb)
+cnt_o, href_o = o.compute_href(pair.pose_init)
+ref = o.evaluate(pose, True)
+d, j = o.dump_pixels(), o.dump_jac()
+G, rb, cb = pair.cell, pair.rows // pair.cell, pair.cols // pair.cell
+rr, cc = np.divmod(np.arange(pair.rows * pair.cols), pair.cols)
+cell = np.where((rr < G * rb) & (cc < G * cb), (rr // rb) * G + cc // cb, -1)
+ids = np.where(cell == c)[0]
+Nc = LD(cnt_o[c]); S = nb - 3
+TINY, FINE = 2.0 ** -28, 2.0 ** -8
+M = synth.pose7_to_matrix(pose)
+z0 = pair.depth_m.reshape(-1)
+x0 = z0 * (cc - pair.cx) / pair.fx; y0 = z0 * (rr - pair.cy) / pair.fy
+Xw = (pair.T_wc0 @ np.stack([x0, y0, z0, np.ones_like(z0)]))[:3]
+Xc = M[:3, :3] @ Xw + M[:3, 3:4]
+href = LD(href_o[c])
+
+
+def quant(x, q):
+    if q is None:
+        return LD(x)
+    return LD(np.rint(np.float64(x) * 2.0 ** q)) / LD(2.0) ** q   # x * 2^q < 2^53: exact scaling, RN-even
+
+
+def jac(q):
+    hc = np.zeros(nb, dtype=LD); hj = np.zeros((nb, nb), dtype=LD)
+    for i in ids:
+        if d["jc"][i] < 0: continue
+        jc, jr = d["jc"][i], d["jr"][i]
+        wc, wr = d["wc"][i], d["wr"][i]
+        wrp = wr[wr > 0]
+        tiny = min(wc[0], wc[3]) < TINY or (wrp.size and min(wr[0], wr[3]) < TINY and min(wr[0], wr[3]) != 0.0)
+        for kk in range(4):
+            fine_c = tiny and wc[kk] < FINE
+            hc[jc + kk] += LD(wc[kk]) if fine_c else quant(wc[kk], q)
+            for m in range(4):
+                pr = np.float64(wr[m]) * np.float64(wc[kk])
+                fine = tiny and (wc[kk] < FINE or wr[m] < FINE)
+                hj[jr + m, jc + kk] += LD(pr) if (fine or q is None) else quant(pr, q)
+    pc_, pj_ = hc / Nc, hj / Nc
+    sig = LD(1e-30)
+    def ent_w(p):
+        w = np.zeros_like(p); e = LD(0)
+        it = np.nditer(p, flags=["multi_index"])
+        for x in it:
+            x = LD(x)
+            if not (x < sig):
+                l = np.log2(x); w[it.multi_index] = -(1 + l); e -= x * l
+        return e, w
+    Hc, Wc = ent_w(pc_); Hj, Wj = ent_w(pj_)
+    acc = np.zeros(6, dtype=LD)
+    for i in ids:
+        if j["jc"][i] < 0: continue
+        jc, jr = j["jc"][i], d["jr"][i]
+        dw = j["dw"][i].astype(LD)
+        t = sum(Wc[jc + m] * dw[m] for m in range(4))
+        s = sum(LD(d["wr"][i, kk]) * sum(Wj[jr + kk, jc + m] * dw[m] for m in range(4)) for kk in range(4))
+        cf = s * (Hc + href) - t * Hj
+        x, y, z = (LD(v) for v in Xc[:, i]); a, b, iz = x / z, y / z, 1 / z
+        Ju = LD(pair.fx) * np.array([-a * b, 1 + a * a, -b, iz, 0, -a * iz], dtype=LD)
+        Jv = LD(pair.fy) * np.array([-(1 + b * b), a * b, a, 0, iz, -b * iz], dtype=LD)
+        acc += cf * (LD(j["gx"][i]) * Ju + LD(j["gy"][i]) * Jv)
+    return np.array(acc * (LD(S) / 255) / Nc / (Hj * Hj), dtype=np.float64)
+
+
+J0 = jac(None)
+print(f"seed {seed} pose {k} cell {c}: nb {nb} N_c {int(Nc)}  max|J| {np.abs(J0).max():.3e}   |oracle - exact| {np.abs(ref[3][c] - J0).max():.3e}")
+for q in qs:
+    Jq = jac(q)
+    print(f"  quantum 2^-{q}: |J_q - exact| max {np.abs(Jq - J0).max():.3e}  = {np.abs(Jq - J0).max() / np.abs(J0).max():.3e} of the cell's scale")
+if os.environ.get("DIAG_BINS"):
+    # per-pixel weights of the Jacobian samples
+    for i in ids:
+        if j["jc"][i] < 0: continue
+        print("  jac sample: jr", d["jr"][i], "jc", j["jc"][i], "wr", d["wr"][i], "wc", d["wc"][i], "dw", j["dw"][i])
