@@ -101,6 +101,13 @@ int nid_set_launch_shape(nid_ctx *ctx, int jac_threads, int cost_threads);
  * staged, the Jacobian phase fed from registers) whenever its rounds cover a cell; on != 0 forces the loop form the
  * other shapes use.  Same bits either way (tests/test_parity_gpu.py::test_latency_form_equals_loop_form). */
 int nid_set_loop_form(nid_ctx *ctx, int on);
+/* DIRECT results (default on): a launch of ONE pose whose result the host waits for (nid_launch + nid_wait,
+ * nid_normal_equations, nid_evaluate, nid_run_chain, the first pose of nid_launch_chain) lets every cell's workgroup
+ * write its 32-double block straight to pinned host memory and the HOST adds the blocks up, in the order the in-launch
+ * reduction uses: the same bits, without that reduction's device-scope round trips behind the last cell.  on == 0:
+ * always the in-launch reduction.  Timed and diagnostic launches always use the in-launch reduction.
+ * NID_ERR_STATE while a launch is pending. */
+int nid_set_direct_results(nid_ctx *ctx, int on);
 /* both at once (0 = the defaults above) */
 int nid_set_block_threads(nid_ctx *ctx, int threads);
 

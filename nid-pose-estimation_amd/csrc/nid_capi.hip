@@ -35,6 +35,11 @@ struct Slot {
   double *cellout_host_devptr = nullptr;
   double *reduced_host = nullptr;  // pinned, mapped: [32 doubles][u64 sequence word]
   double *reduced_host_devptr = nullptr;
+  double *quad_host = nullptr;     // pinned, mapped, created on first use: [nloc][kDirectRec] per-cell records of a DIRECT launch (wait_direct)
+  double *quad_host_devptr = nullptr;
+  bool direct = false;             // the launch in flight is a DIRECT one: the host forms and sums the cells' quadratic forms
+  bool direct_jac = false;         // ... it carries Jacobians
+  double direct_delta = 0.0;       // ... its Huber delta
   unsigned long long seq = 0;      // sequence number of the last launch into this slot
   hipEvent_t done = nullptr, e0 = nullptr, e1 = nullptr;  // e0 / e1: timing events, created on first use
   bool pending = false;
@@ -52,6 +57,7 @@ struct nid_ctx {
   int xform = NID_XFORM_QUAT;
   int jac_threads = 0, cost_threads = 0;  // nid_set_launch_shape: 0 = default (128) / automatic (pick_threads)
   bool loop_form = false;                  // nid_set_loop_form (diagnostics)
+  bool direct_results = true;              // nid_set_direct_results: single-pose launches whose result the host waits for are DIRECT
   // own_stream: setup + blocking calls; aux_stream: odd slots of the pipelined path, so that
   // launch N+1 overlaps the reduction tail and the launch gap of launch N (separate
   // per-slot buffers make that safe).  An external stream (nid_set_stream) disables it.
@@ -396,7 +402,167 @@ void fill_slot_args(const Pose &pose, Slot &S, double *out_reduced, unsigned lon
   A->host_seq = host_seq;
   A->launch_seq = S.seq;
   A->cellout_host = 0;
-  A->pad_ = 0;
+  A->host_quad = 0;
+}
+
+// ---- DIRECT launches ---------------------------------------------------------------------------------------------
+// One pose, the host is waiting for the result (a Gauss-Newton / LM loop is a chain of such launches).  Every cell's
+// workgroup writes its record -- err, J[6], an active flag: 64 bytes -- straight to pinned host memory and the HOST
+// forms the Huber-weighted quadratic forms (RobustKernelHuber::robustify robust_kernel_impl.cpp:77-91 with the float
+// dsqr, constructQuadraticForm base_unary_edge.hpp:56-63: the kernel's operations in the kernel's order, all IEEE) and
+// adds them up in the order the in-launch reduction uses (sum_blocks_w0 twice: per group the even-numbered cells in
+// ascending order plus the odd-numbered ones, then the groups likewise), so the 6x6 system has the same bits either
+// way.  The launch has no ticket, no device-scope round trip and no fence; for the host it is over when the last
+// cell's 64 bytes have crossed PCIe.  No word is ordered against any other: the host pre-fills the records with a
+// sentinel no arithmetic produces and polls every word; a consumed record is reset on the spot.  (Round 2 measured 5 us
+// of reduction tail behind the last workgroup of a single-pose launch: seven dependent device-scope round trips; a
+// first version of this path that shipped the cells' finished 32-double blocks spent 4.5 us reading 64 KB of freshly
+// written host memory behind the last arrival.)
+void fill_sentinel(double *p, size_t n) {
+  unsigned long long *q = reinterpret_cast<unsigned long long *>(p);
+  for (size_t i = 0; i < n; i++) q[i] = kHostSentinel;
+}
+
+int ensure_quad_host(nid_ctx *ctx, Slot &S) {
+  if (S.quad_host) return NID_OK;
+  const size_t n = (size_t)ctx->g.nloc * kDirectRec;
+  if (hipHostMalloc(reinterpret_cast<void **>(&S.quad_host), n * sizeof(double), hipHostMallocMapped) != hipSuccess) {
+    S.quad_host = nullptr;
+    return NID_ERR_NOMEM;
+  }
+  fill_sentinel(S.quad_host, n);
+  NID_HIP(ctx, hipHostGetDevicePointer(reinterpret_cast<void **>(&S.quad_host_devptr), S.quad_host, 0));
+  return NID_OK;
+}
+
+// may this launch be DIRECT?  (timed and diagnostic launches keep the in-launch reduction: they may be re-issued into
+// the same buffers before the host has looked)
+bool direct_ok(const nid_ctx *ctx) {
+  return ctx->direct_results && !ctx->timing && !ctx->dbg_enabled && !ctx->dbg_stamps;
+}
+
+// true when all `n` words at p have arrived
+inline bool words_arrived(const double *p, int n) {
+  const volatile unsigned long long *q = reinterpret_cast<const volatile unsigned long long *>(p);
+  for (int i = 0; i < n; i++)
+    if (q[i] == kHostSentinel) return false;
+  return true;
+}
+
+// NID_DIRECT_TRACE=1 (experiments): per wait, microseconds from entering wait_direct to the first cell's arrival, to
+// the last moment the host had to WAIT for a cell, and to the end (the difference of the last two = the host's own
+// backlog behind the last arrival); averages printed every 2000 waits
+struct DirectTrace { double first = 0, last_wait = 0, end = 0; long n = 0; };
+static DirectTrace g_dtrace;
+
+// spin until `arrived()`; after a long while let a device error surface through the runtime, then give up
+template <typename F>
+int spin_until(nid_ctx *ctx, F arrived, unsigned long &spins, bool &synced, bool &waited) {
+  while (!arrived()) {
+    waited = true;
+    if (++spins > 50000000ul) {
+      if (synced) { ctx->last_error = "a cell's results never arrived"; return NID_ERR_HIP; }
+      NID_HIP(ctx, hipSetDevice(ctx->cfg.device));
+      NID_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      NID_HIP(ctx, hipStreamSynchronize(ctx->aux_stream));
+      synced = true;
+      spins = 0;
+    }
+  }
+  return NID_OK;
+}
+
+// one cell's 32-double block from its record, exactly as k_eval2's tail forms it (residual_and_huber + the quadratic form)
+inline void quad_from_record(const double *rec, bool jac, double delta, float dsqr, double *q /*[29]*/) {
+  if (rec[kDirectRec - 1] == 0.0) {  // level-1 edge: an all-zero block
+    for (int v = 0; v < 29; v++) q[v] = 0.0;
+    return;
+  }
+  const double err = rec[0];
+  const double e2 = err * err;
+  double rho0 = e2, rho1 = 1.0;
+  if (!(e2 <= dsqr)) {
+    const double sqrte = std::sqrt(e2);
+    rho0 = 2 * sqrte * delta - dsqr;
+    rho1 = delta / sqrte;
+  }
+  q[0] = rho0;
+  q[28] = 1.0;
+  if (!jac) {
+    for (int v = 1; v < 28; v++) q[v] = 0.0;
+    return;
+  }
+  const double *J = rec + 1;
+  for (int n = 0; n < 6; n++) q[1 + n] = 0.0 - (rho1 * J[n]) * err;
+  int idx = 7;
+  for (int a = 0; a < 6; a++)
+    for (int b = a; b < 6; b++) q[idx++] = (J[a] * rho1) * J[b];
+}
+
+#ifndef NID_DIRECT_AHEAD
+#define NID_DIRECT_AHEAD 24
+#endif
+constexpr int kDirectAhead = NID_DIRECT_AHEAD;
+
+int wait_direct(nid_ctx *ctx, Slot &S) {
+  const int nloc = ctx->g.nloc, gs = ctx->group_size;
+  const float dsqr = (float)(S.direct_delta * S.direct_delta);  // RobustKernelHuber::setDelta (robust_kernel_impl.h:84)
+  double top[2][32] = {}, grp[2][32], q[32];
+  unsigned long spins = 0;
+  bool synced = false;
+  static const bool trace = getenv("NID_DIRECT_TRACE") != nullptr;
+  const auto t0 = std::chrono::steady_clock::now();
+  auto t_first = t0, t_lastwait = t0;
+  bool got_first = false;
+  for (int g0 = 0, gq = 0; g0 < nloc; g0 += gs, gq++) {
+    const int gcount = std::min(gs, nloc - g0);
+    std::memset(grp, 0, sizeof(grp));
+    for (int i = 0; i < gcount; i++) {
+      double *rec = S.quad_host + (size_t)(g0 + i) * kDirectRec;
+      // the cells arrive within about a microsecond of each other and every record is a line the device has just
+      // written, i.e. a miss to memory: ask for the lines ahead while this one is worked on
+      if (g0 + i + kDirectAhead < nloc) __builtin_prefetch(rec + (size_t)kDirectAhead * kDirectRec, 0, 3);
+      bool waited = false;
+      int rc = spin_until(ctx, [&] { return words_arrived(rec, kDirectRec); }, spins, synced, waited);
+      if (rc) return rc;
+      if (trace) {
+        if (!got_first) { t_first = std::chrono::steady_clock::now(); got_first = true; }
+        if (waited) t_lastwait = std::chrono::steady_clock::now();
+      }
+      __atomic_thread_fence(__ATOMIC_ACQUIRE);  // (the words were read as volatile; keep the plain reads below behind them)
+      quad_from_record(rec, S.direct_jac, S.direct_delta, dsqr, q);
+      fill_sentinel(rec, kDirectRec);
+      double *acc = grp[i & 1];
+      for (int v = 0; v < 29; v++) acc[v] += q[v];
+    }
+    double *t = top[gq & 1];
+    for (int v = 0; v < 29; v++) t[v] += grp[0][v] + grp[1][v];
+  }
+  for (int v = 0; v < kReducedLen; v++) S.reduced_host[v] = v < 29 ? top[0][v] + top[1][v] : 0.0;
+  if (trace) {
+    const auto t1 = std::chrono::steady_clock::now();
+    auto us = [&](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::micro>(t - t0).count(); };
+    g_dtrace.first += us(t_first); g_dtrace.last_wait += us(t_lastwait); g_dtrace.end += us(t1);
+    if (++g_dtrace.n % 2000 == 0) {
+      fprintf(stderr, "[direct trace] %ld waits: first cell %.2f us, last wait %.2f us, end %.2f us after entering the wait\n", g_dtrace.n,
+              g_dtrace.first / g_dtrace.n, g_dtrace.last_wait / g_dtrace.n, g_dtrace.end / g_dtrace.n);
+      g_dtrace = DirectTrace();
+    }
+  }
+  return NID_OK;
+}
+
+// the per-cell calls: every cell's kCellOut outputs, word by word
+int wait_direct_cellout(nid_ctx *ctx, Slot &S) {
+  unsigned long spins = 0;
+  bool synced = false, waited = false;
+  for (int cl = 0; cl < ctx->g.nloc; cl++) {
+    const double *co = S.cellout_host + (size_t)cl * kCellOut;
+    int rc = spin_until(ctx, [&] { return words_arrived(co, kCellOut); }, spins, synced, waited);
+    if (rc) return rc;
+  }
+  __atomic_thread_fence(__ATOMIC_ACQUIRE);
+  return NID_OK;
 }
 
 void fill_eval_params(nid_ctx *ctx, const Pose &pose, Slot &S, double delta, double *out_reduced,
@@ -439,6 +605,16 @@ int launch_slot(nid_ctx *ctx, int slot, const Pose &pose, int want_jac, double d
       S.external_target ? nullptr : reinterpret_cast<unsigned long long *>(S.reduced_host_devptr + kReducedLen);
   EvalParams P{};
   fill_eval_params(ctx, pose, S, delta, target, host_seq, &P);
+  S.direct = false;
+  if (!S.external_target && direct_ok(ctx)) {
+    rc = ensure_quad_host(ctx, S);
+    if (rc) return rc;
+    P.slot[0].quad = S.quad_host_devptr;
+    P.slot[0].host_quad = 1;
+    S.direct = true;
+    S.direct_jac = want_jac != 0;
+    S.direct_delta = delta;
+  }
   if (ctx->dbg_enabled) {
     const size_t N = (size_t)ctx->g.rows * ctx->g.cols;
     NID_HIP(ctx, hipMemsetAsync(ctx->dbg_u, 0xFF, N * 8, ctx->stream));
@@ -494,15 +670,25 @@ int launch_batch(nid_ctx *ctx, int first_slot, int n, const Pose *poses, int wan
     recs = ctx->ext_host[ring];
     P.slots_ext = ctx->ext_dev[ring];
   }
+  const bool direct = n == 1 && !reduced_dev_base && !relaunch_ok && direct_ok(ctx);
+  if (direct) { rc = ensure_quad_host(ctx, ctx->slots[first_slot]); if (rc) return rc; }
   for (int k = 0; k < n; k++) {
     Slot &S = ctx->slots[first_slot + k];
     S.seq++;
+    S.direct = false;
     S.external_target = reduced_dev_base != nullptr;
     if (S.external_target)  // caller-owned device buffer: pose k's block at base + k*32 (multi-GPU all-reduce)
       fill_slot_args(poses[k], S, reduced_dev_base + (size_t)k * kReducedLen, nullptr, &recs[k]);
     else
       fill_slot_args(poses[k], S, S.reduced_host_devptr,
                      reinterpret_cast<unsigned long long *>(S.reduced_host_devptr + kReducedLen), &recs[k]);
+    if (direct) {
+      recs[k].quad = S.quad_host_devptr;
+      recs[k].host_quad = 1;
+      S.direct = true;
+      S.direct_jac = want_jac != 0;
+      S.direct_delta = delta;
+    }
   }
   if (ring >= 0)
     NID_HIP(ctx, hipMemcpyAsync(ctx->ext_dev[ring], recs, (size_t)n * sizeof(SlotArgs), hipMemcpyHostToDevice, st));
@@ -567,6 +753,11 @@ int evaluate_common(nid_ctx *ctx, const Pose &pose, int want_jac, double *Ht, do
                    reinterpret_cast<unsigned long long *>(S.reduced_host_devptr + kReducedLen), &P);
   P.slot[0].cellout = S.cellout_host_devptr;
   P.slot[0].cellout_host = 1;
+  const bool direct = direct_ok(ctx);
+  if (direct) {  // the per-cell outputs straight to the host, word by word, and nothing else (wait_direct_cellout)
+    fill_sentinel(S.cellout_host, (size_t)ctx->g.nloc * kCellOut);
+    P.slot[0].host_quad = 2;
+  }
   if (ctx->dbg_enabled) {
     const size_t N = (size_t)ctx->g.rows * ctx->g.cols;
     NID_HIP(ctx, hipMemsetAsync(ctx->dbg_u, 0xFF, N * 8, ctx->stream));
@@ -577,7 +768,7 @@ int evaluate_common(nid_ctx *ctx, const Pose &pose, int want_jac, double *Ht, do
   }
   rc = launch_eval(ctx, P, want_jac != 0, ctx->stream);
   if (rc) return rc;
-  rc = wait_host_seq(ctx, S);
+  rc = direct ? wait_direct_cellout(ctx, S) : wait_host_seq(ctx, S);
   if (rc) return rc;
   if (ctx->dbg_enabled) NID_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the dump is read back by the runtime
   for (int cl = 0; cl < ctx->g.nloc; cl++) {
@@ -830,6 +1021,7 @@ int nid_destroy(nid_ctx *ctx) {
   for (int s = 0; s < NID_SLOTS; s++) {
     Slot &S = ctx->slots[s];
     if (S.cellout_host) (void)hipHostFree(S.cellout_host);
+    if (S.quad_host) (void)hipHostFree(S.quad_host);
     if (S.done) (void)hipEventDestroy(S.done);
     if (S.e0) (void)hipEventDestroy(S.e0);
     if (S.e1) (void)hipEventDestroy(S.e1);
@@ -1269,11 +1461,13 @@ int nid_wait(nid_ctx *ctx, int slot, double *H36, double *b6, double *chi2, int3
     S.pending = false;
     return NID_OK;
   }
-  // the last workgroup stores the 32 results, then the sequence word (system-scope release)
+  // the last workgroup stores the 32 results, then the sequence word (system-scope release); DIRECT launches: the
+  // host collects and sums the cells' blocks
   {
-    int rc = wait_host_seq(ctx, S);
+    int rc = S.direct ? wait_direct(ctx, S) : wait_host_seq(ctx, S);
     if (rc) return rc;
   }
+  S.direct = false;
   S.pending = false;
   return nid_unpack_reduced(S.reduced_host, H36, b6, chi2, n_active);
 }
@@ -1354,6 +1548,13 @@ void nid_bspline4_host(double u, int bin_num, double *B4, double *D4) {
 }
 
 double nid_div_small_host(double x, double d) { return nid::div_small(x, d); }
+
+int nid_set_direct_results(nid_ctx *ctx, int on) {
+  if (!ctx) return NID_ERR_INVALID_ARG;
+  for (int s = 0; s < NID_SLOTS; s++) if (ctx->slots[s].pending) return NID_ERR_STATE;
+  ctx->direct_results = on != 0;
+  return NID_OK;
+}
 
 int nid_set_loop_form(nid_ctx *ctx, int on) {
   if (!ctx) return NID_ERR_INVALID_ARG;

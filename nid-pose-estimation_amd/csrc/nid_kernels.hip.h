@@ -100,8 +100,12 @@ struct SlotArgs {
   unsigned long long *host_seq;    // pinned host word that receives launch_seq (or null)
   unsigned long long launch_seq;
   int cellout_host;                // cellout is mapped pinned host memory (the blocking per-cell calls): publish it at system scope
-  int pad_;
+  int host_quad;                   // DIRECT launch (one pose, the host is waiting for it): no in-launch reduction.  1: `quad` is
+                                   // mapped pinned host memory, [nloc][kDirectRec]: every cell's workgroup writes its record
+                                   // (err, J[6], active) straight there and the HOST forms and sums the quadratic forms;
+                                   // 2: only the per-cell outputs, to `cellout` (mapped pinned host memory too)
 };
+constexpr int kDirectRec = 8;  // doubles per cell of a DIRECT launch: err | J[6] (zeros: cost-only) | 1.0 active / 0.0 inactive
 
 struct EvalParams {
   Geometry g;
@@ -802,6 +806,16 @@ __device__ __forceinline__ double load_sc1(const double *p) {
       reinterpret_cast<const unsigned long long *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
 }
 
+// Per-cell results of a DIRECT launch in host memory: plain system-scope stores (fine-grained host memory is uncached on the device: they
+// go out over PCIe as they are issued; the host polls every WORD against a sentinel, so nothing has to be ordered)
+__device__ __forceinline__ void store_sys(double *p, double v) {
+  __hip_atomic_store(reinterpret_cast<unsigned long long *>(p), (unsigned long long)__double_as_longlong(v),
+                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// The bit pattern the host fills a DIRECT launch's result words with before the launch (a signalling-NaN payload no
+// arithmetic produces: NaN results are the canonical quiet NaN); a word that still holds it has not arrived.
+constexpr unsigned long long kHostSentinel = 0x7FF4DEADBEEF5A5Aull;
+
 constexpr int kRedDoubles(int nt) { return (6 * (nt / 64) + 1) & ~1; }  // the six Jacobian sums of every wave
 // 128- / 256-thread shapes: the six sums go through a [6][kXposeStride] array of doubles that reuses the histogram area
 // (rows padded by 8 doubles so that the six row groups of a read do not share banks); 0 = the DPP form everywhere
@@ -1278,6 +1292,11 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu((STRICT || D
   double *quad = SA.quad + (size_t)cl * kQuad;
   if (n_c < 300 || isnan(href)) {  // level-1 edge: never evaluated (computeH.cu:271-275)
     if (tid >= 64) return;
+    if (SA.host_quad) {  // DIRECT launch: see the cost-only tail
+      if (tid < kCellOut && SA.cellout_host) store_sys(out + tid, (tid == kCellOut - 1) ? (double)n_c : NAN);
+      if (tid < kDirectRec && SA.host_quad == 1) store_sys(SA.quad + (size_t)cl * kDirectRec + tid, 0.0);
+      return;
+    }
     if (tid < kCellOut) out[tid] = (tid == kCellOut - 1) ? (double)n_c : NAN;
     if (tid < kQuad) store_sc1(quad + tid, 0.0);
     finish_and_reduce_w0(P, SA, cl, tid);
@@ -1752,6 +1771,24 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu((STRICT || D
   };
   if (!JAC) {
     if (tid >= 64) return;  // the cell's tail is wave 0's business: the other waves free their slots now
+    if (SA.host_quad) {
+      // DIRECT launch (one pose, the host is waiting for it): the cell's record (err, J[6], active) -- or, for the
+      // per-cell calls, its outputs -- goes straight to pinned host memory, word by word, and the HOST forms the
+      // Huber-weighted quadratic forms (the device's operations in the device's order: IEEE mul / sub / sqrt / div give
+      // the same bits) and adds them up in the order sum_blocks_w0 uses.  No ticket, no device-scope round trip, no
+      // fence: the launch is over for the host when the last cell's 64 bytes have crossed PCIe (round 2: 5 us of
+      // reduction tail behind the last cell).
+      err = wave_uniform((2 * Hj - href - Hc) / Hj);  // types_six_dof_expmap.h:227
+      if (tid < kCellOut && SA.cellout_host) {
+        const double o = tid == 0 ? Hc : (tid == 1 ? Hj : (tid == 2 ? err : (tid == kCellOut - 1 ? (double)n_c : NAN)));
+        store_sys(out + tid, o);  // (cost-only: the Jacobian slots hold NaN)
+      }
+      if (tid < kDirectRec && SA.host_quad == 1)
+        store_sys(SA.quad + (size_t)cl * kDirectRec + tid, tid == 0 ? err : (tid == kDirectRec - 1 ? 1.0 : 0.0));
+      NID_STAMP(6);
+      NID_STAMP(7);
+      return;
+    }
     residual_and_huber();
     if (tid == 0) { out[0] = Hc; out[1] = Hj; out[2] = err; out[kCellOut - 1] = (double)n_c; }
     if (tid < kQuad) store_sc1(quad + tid, tid == 0 ? rho0 : (tid == 28 ? 1.0 : 0.0));
@@ -2100,13 +2137,25 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu((STRICT || D
     }
   }
   NID_STAMP(5, acc[0], acc[2], acc[3], acc[5]);
-  residual_and_huber();
   {
     const double kappa = (double)S / 255.0;  // d_mi_i (:393), 1/N_c (:488,494), 1/Hj^2 (:521)
     const double scale = (kappa / (double)n_c) * (1.0 / (Hj * Hj));
     double J[6];
 #pragma unroll
     for (int n = 0; n < 6; n++) J[n] = acc[n] * scale;
+    if (SA.host_quad) {  // DIRECT launch: see the cost-only tail
+      err = wave_uniform((2 * Hj - href - Hc) / Hj);
+      double o = tid == 0 ? Hc : (tid == 1 ? Hj : (tid == 2 ? err : (double)n_c));   // per-cell outputs
+      double r = tid == 0 ? err : 1.0;                                                // the cell's record
+#pragma unroll
+      for (int n = 0; n < 6; n++) { if (tid == 3 + n) o = J[n]; if (tid == 1 + n) r = J[n]; }
+      if (tid < kCellOut && SA.cellout_host) store_sys(out + tid, o);
+      if (tid < kDirectRec && SA.host_quad == 1) store_sys(SA.quad + (size_t)cl * kDirectRec + tid, r);
+      NID_STAMP(6);
+      NID_STAMP(7);
+      return;
+    }
+    residual_and_huber();
     if (tid == 0) {
       out[0] = Hc; out[1] = Hj; out[2] = err;
 #pragma unroll

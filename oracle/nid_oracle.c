@@ -149,15 +149,19 @@ static double bilinear_u8(const unsigned char *im, int cols, double x, double y)
                   (1 - dx - dy + dxdy) * im[iy * cols + ix]);
 }
 
-/* The sampler the image GRADIENT uses (types_six_dof_expmap.cpp:434-435: central differences of four more bilinear
- * samples).  The reference uses the four-term form above for them too.  Built with -DNID_ORACLE_GRADIENT_TWIN
- * (oracle/libnid_oracle_twin.so, together with the reversed pixel order) the gradient's samples use the mathematically
- * identical two-lerp association instead: wherever the reference's gradient is ROUNDING NOISE -- a constant or
- * saturated patch, where the four-term form returns the constant +- an ulp and its differences are 1e-14-level
- * noise -- the twin returns another rounding of the same zero.  |J(oracle) - J(twin)| per cell is the measured
- * width of the reference's own result; tests allow for it instead of a chosen floor (tests/test_parity_gpu.py).
- * The cost pass (intensities, clamps, histograms) is the reference's in both builds. */
-#ifdef NID_ORACLE_GRADIENT_TWIN
+/* The reference's own rounding noise, made measurable.  Built with -DNID_ORACLE_TWIN (oracle/libnid_oracle_twin.so,
+ * together with the reversed pixel order) every bilinear sample -- the centre sample of the cost pass
+ * (types_six_dof_expmap.cpp:567) and the four samples of the image gradient (:434-435) -- uses the mathematically
+ * identical two-lerp association instead of the reference's four-term form.  Wherever the reference's result is
+ * ROUNDING NOISE the twin returns another rounding of the same quantity: a constant or saturated patch, where the
+ * four-term form returns the constant +- an ulp and its central differences are 1e-14-level noise; a lone sample whose
+ * constant intensity sits on a knot of the B-spline, where that ulp decides between an exactly symmetric (zero)
+ * derivative and 1e-13.  |J(oracle) - J(twin)| per cell is the measured width of the reference's own Jacobian; tests
+ * allow for it instead of a chosen floor (tests/test_parity_gpu.py).  The reference's DECISIONS are not re-rounded: a
+ * centre sample keeps the reference's value when either form puts it at a clamp (ic >= 255 -> 254.999, ic < 0 -> 0,
+ * :572-575), so the histograms' discontinuities -- which the HIP path reproduces exactly -- stay where they are and
+ * saturated cells get no allowance from it. */
+#ifdef NID_ORACLE_TWIN
 static double bilinear_grad(const unsigned char *im, int cols, double x, double y) {
   int ix = (int)x;
   int iy = (int)y;
@@ -544,6 +548,12 @@ static void cell_compute_h(nid_oracle *o, const xform_t *xf, int ci, int cj) {
       o->du[id] = u; o->dv[id] = v;
       if (u >= 0 && u + 3 <= o->cols && v >= 0 && v + 3 <= o->rows) {
         o->ic[id] = bilinear_u8(o->im1, o->cols, u, v);
+#ifdef NID_ORACLE_TWIN
+        {
+          double il = bilinear_grad(o->im1, o->cols, u, v);
+          if (o->ic[id] < 255 && o->ic[id] >= 0 && il < 255 && il >= 0) o->ic[id] = il;
+        }
+#endif
       } else {
         continue;
       }

@@ -90,9 +90,9 @@ _LIB_TWIN = None
 
 
 def load_twin():
-    """The oracle built with the reversed pixel order AND the image gradient's bilinear samples in the two-lerp
-    association (oracle/Makefile: libnid_oracle_twin.so): the reference's arithmetic with every sum and every gradient
-    sample rounded differently.  |J(oracle) - J(twin)| per cell measures how far the reference's own Jacobian is
+    """The oracle built with the reversed pixel order AND every bilinear sample in the two-lerp association
+    (oracle/Makefile: libnid_oracle_twin.so; clamp decisions stay on the reference's values): the reference's
+    arithmetic with every sum and every image sample rounded differently.  |J(oracle) - J(twin)| per cell measures how far the reference's own Jacobian is
     defined (constant / saturated patches: pure rounding noise)."""
     global _LIB_TWIN
     if _LIB_TWIN is None:

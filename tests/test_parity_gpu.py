@@ -19,8 +19,9 @@ RTOL_J = 1e-9
 # Each cell's Jacobian is held to RTOL_J relative to ITS OWN largest component, whatever its size against
 # the rest of the frame.  What is allowed on top of that is the REFERENCE'S OWN NOISE, measured, not a chosen floor:
 # N(cell) = |J_o - J_twin|, the twin being the same oracle source built with the pixels of a cell visited in the
-# opposite order and the image gradient's bilinear samples in the two-lerp association (oracle/Makefile:
-# libnid_oracle_twin.so): the reference's arithmetic, every sum and every gradient sample rounded differently.  The
+# opposite order and every bilinear sample in the two-lerp association (oracle/Makefile: libnid_oracle_twin.so; a
+# sample at a clamp keeps the reference's value, so saturated cells get no allowance): the reference's arithmetic,
+# every sum and every image sample rounded differently.  The
 # reference's four-term bilinear form returns a constant image's value +- an ulp, its central differences are then
 # 1e-14-level noise, and the Jacobian of a constant or fully saturated cell is that noise times the cell's weights
 # (1e-13 .. 1e-12).  A cell passes if |J - J_o| <= RTOL_J * max|J_o(cell)| + NOISE_K * N(cell) + J_EPS * frame scale;
@@ -955,3 +956,60 @@ def test_border_guard_band(capi, oracle, synth, shift, math):
     frac = np.abs(d["u"][vis] - np.rint(d["u"][vis]))
     assert np.median(frac) < 1e-6 and frac.min() > 1e-13, "samples must sit near, not on, integer coordinates"
     _compare_cells(ctx.evaluate(pose, True), ref, cnt_o, noise=(o, pose))
+
+
+def _same_bits(a, b):
+    """Bit for bit, except that a NaN is a NaN (an all-out-of-frame cell has J = NaN on every path; the sign and
+    payload of a NaN born on the host differ from one born on the device)."""
+    a, b = np.atleast_1d(np.asarray(a, dtype=np.float64)), np.atleast_1d(np.asarray(b, dtype=np.float64))
+    na, nb_ = np.isnan(a), np.isnan(b)
+    return a.shape == b.shape and np.array_equal(na, nb_) and np.array_equal(_bits(a[~na]), _bits(b[~nb_]))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("math", MODES)
+@pytest.mark.parametrize("cfg", ["S", "A", "edge", "many"])
+def test_direct_results_equal_in_launch_reduction(capi, synth, pair_S_edge, cfg, math):
+    """DIRECT launches (nid_set_direct_results, the default for a single pose the host waits for): every cell's
+    record (err, J[6], active) goes straight to pinned host memory, the host forms the Huber-weighted quadratic forms
+    and adds them up in the in-launch reduction's order -- the 6x6 system, chi2, the active count and the per-cell
+    outputs must be the SAME BITS as with the in-launch reduction, for cost + Jacobian and cost-only launches, through
+    every single-pose entry point, repeatedly (the host resets the sentinel words of a consumed record), and
+    interleaved with batched launches."""
+    if cfg == "edge":
+        pair = pair_S_edge
+    elif cfg == "many":
+        pair = synth.make_pair("S", rows=480, cols=640, cell=20)     # 400 cells, 20 groups of 20
+    else:
+        pair = synth.make_pair(cfg)
+    nb = 8
+    ctx = capi.from_pair(pair, nb, math=_mode(capi, math))
+    ctx.compute_href(pair.pose_init)
+    poses = list(_poses(synth, pair).values())
+    for shape in (0, 512):
+        ctx.set_launch_shape(shape, shape)
+        for want_jac in (True, False):
+            ctx.set_direct_results(False)
+            ref = [ctx.normal_equations(p, DELTA, want_jac=want_jac) for p in poses]
+            ref_cells = [ctx.evaluate(p, want_jac) for p in poses]
+            ctx.set_direct_results(True)
+            for rep in range(3):
+                for p, r, rc in zip(poses, ref, ref_cells):
+                    got = ctx.normal_equations(p, DELTA, want_jac=want_jac)
+                    assert _same_bits(got[0], r[0]) and _same_bits(got[1], r[1])
+                    assert _same_bits(got[2], r[2]) and got[3] == r[3]
+                    gc = ctx.evaluate(p, want_jac)
+                    for k in range(4 if want_jac else 3):
+                        assert _same_bits(gc[k], rc[k]), f"per-cell output {k} differs"
+                    # launch + wait on another slot, a batch in between
+                    ctx.launch(5, p, DELTA, want_jac=want_jac)
+                    ctx.launch_batch(16, poses, DELTA, want_jac=want_jac)
+                    g5 = ctx.wait(5)
+                    assert _same_bits(g5[0], r[0]) and _same_bits(g5[2], r[2])
+                    for k, rk in enumerate(ref):
+                        gk = ctx.wait(16 + k)
+                        assert _same_bits(gk[0], rk[0]) and _same_bits(gk[2], rk[2])
+            blocks, _ = ctx.run_chain(poses, DELTA, want_jac=want_jac)
+            for blk, r in zip(blocks, ref):
+                assert _same_bits(blk[0], r[2]) and blk[28] == r[3]
+    ctx.close()
