@@ -108,6 +108,25 @@ int nid_set_loop_form(nid_ctx *ctx, int on);
  * always the in-launch reduction.  Timed and diagnostic launches always use the in-launch reduction.
  * NID_ERR_STATE while a launch is pending. */
 int nid_set_direct_results(nid_ctx *ctx, int on);
+/* The RESIDENT evaluator (default off): DIRECT single-pose launches of a context in FAST math whose cost + Jacobian
+ * shape is 512 threads (nid_set_launch_shape) and whose cells fit that shape's latency form (at most 1536 slots) are
+ * not launched at all -- a kernel started once per frame pair keeps one workgroup per cell on the device; the host writes the pose
+ * into a mailbox in device memory (through the PCIe BAR), every workgroup evaluates its cell and writes its record to
+ * pinned host memory, and waits for the next request.  Same bits as the launched form; ~4 us less per dependent
+ * evaluation (no runtime call, no packet, no dispatch of the grid).  The kernel is bounded: it leaves on an exit word
+ * (every call that changes the frame pair, the options or the shapes, and nid_destroy, retire it), when the host has
+ * not used it for 50 ms (the next request restarts it), and by itself after 200 ms without a request; a request that
+ * finds it gone is re-issued as an ordinary launch.  One request in flight at a time; further single-pose launches
+ * meanwhile are ordinary launches.  While it runs, its workgroups hold two waves per SIMD with up to 256 registers
+ * each on every CU they sit on: every ordinary evaluation launch of the context retires it first (its request in
+ * flight, if any, is collected before), so mixing the two costs a restart each time -- it pays for chains of
+ * single-pose evaluations, which is what a Gauss-Newton / LM loop is.  A process-wide device synchronisation (hipDeviceSynchronize,
+ * hipFree outside this library) waits until the kernel leaves -- at most its 200 ms.
+ * NID_ERR_UNSUPPORTED if the platform does not let the CPU address the device's fine-grained memory;
+ * NID_ERR_STATE while a launch is pending. */
+int nid_set_resident(nid_ctx *ctx, int on);
+/* requests served by the resident kernel, requests re-issued as ordinary launches, kernel starts */
+int nid_resident_stats(const nid_ctx *ctx, int64_t *served, int64_t *fallbacks, int64_t *starts);
 /* both at once (0 = the defaults above) */
 int nid_set_block_threads(nid_ctx *ctx, int threads);
 

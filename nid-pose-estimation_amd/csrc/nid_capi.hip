@@ -8,6 +8,9 @@
 // is [evaluation kernel -> reduction kernel -> small D2H].
 #include <hip/hip_runtime.h>
 
+#include <setjmp.h>
+#include <signal.h>
+
 #include <algorithm>
 #include <chrono>
 #include <cmath>
@@ -38,6 +41,8 @@ struct Slot {
   double *quad_host = nullptr;     // pinned, mapped, created on first use: [nloc][kDirectRec] per-cell records of a DIRECT launch (wait_direct)
   double *quad_host_devptr = nullptr;
   bool direct = false;             // the launch in flight is a DIRECT one: the host forms and sums the cells' quadratic forms
+  bool resident = false;           // ... it is a request to the resident kernel (its records arrive in ctx->res.rec_host)
+  bool collected = false;          // its result is in reduced_host already (resident_quiesce): nid_wait only hands it over
   bool direct_jac = false;         // ... it carries Jacobians
   double direct_delta = 0.0;       // ... its Huber delta
   unsigned long long seq = 0;      // sequence number of the last launch into this slot
@@ -58,6 +63,24 @@ struct nid_ctx {
   int jac_threads = 0, cost_threads = 0;  // nid_set_launch_shape: 0 = default (128) / automatic (pick_threads)
   bool loop_form = false;                  // nid_set_loop_form (diagnostics)
   bool direct_results = true;              // nid_set_direct_results: single-pose launches whose result the host waits for are DIRECT
+  // the RESIDENT evaluator (nid_set_resident; k_resident in nid_kernels.hip.h)
+  struct Resident {
+    bool enabled = false;          // asked for
+    bool running = false;          // the kernel is on the device
+    int probed = 0;                // 0: not yet, 1: the mailbox is CPU-addressable, -1: it is not (resident launches unavailable)
+    int nt = 0;                    // workgroup shape of the running kernel
+    ResidentCtl *ctl = nullptr;    // fine-grained device memory, written by the CPU through the PCIe BAR
+    hipStream_t stream = nullptr;
+    unsigned long long seq = 0;
+    std::chrono::steady_clock::time_point last_post{};
+    double *rec_host = nullptr, *rec_devptr = nullptr;  // [nloc][kDirectRec], pinned + mapped
+    int pending_slot = -1;         // the slot whose request is in flight (one at a time)
+    // the request in flight, for the fallback (a kernel that had left: re-issued as an ordinary DIRECT launch)
+    Pose pose{};
+    bool jac = false, want_cellout = false;
+    long served = 0, fallbacks = 0, starts = 0;
+  } res;
+  std::vector<double> direct_rho1;  // wait_direct: the cells' Huber weights between its two passes
   // own_stream: setup + blocking calls; aux_stream: odd slots of the pipelined path, so that
   // launch N+1 overlaps the reduction tail and the launch gap of launch N (separate
   // per-slot buffers make that safe).  An external stream (nid_set_stream) disables it.
@@ -103,6 +126,9 @@ struct nid_ctx {
 };
 
 namespace {
+
+void resident_retire(nid_ctx *ctx);  // every call that changes what a resident kernel has cached, or frees memory, retires it first
+int resident_quiesce(nid_ctx *ctx);  // ... and every ordinary evaluation launch (the resident workgroups hold most of every CU)
 
 #define NID_HIP(ctx, expr)                                                            \
   do {                                                                                \
@@ -203,6 +229,13 @@ int eval_hist_shift(const Geometry &g) {
   return std::min(52, 63 - bits);
 }
 
+void set_hist_params(EvalParams &P) {
+  const int hs = eval_hist_shift(P.g);
+  P.hist_dn = std::ldexp(1.0, hs - 562);    // times kWcPre = 2^-512 on the other factor: 2^(hs - 1074)
+  P.hist_dn1 = std::ldexp(1.0, hs - 1074);  // (a subnormal constant: exact)
+  P.hist_inv_scale = std::ldexp(1.0, -hs);
+}
+
 size_t eval_lds_bytes(const Geometry &g, int nt) {
   const int nbins = g.nb * g.nb + g.nb;
   // copies + fine levels (the Jacobian block sum of the throughput shapes reuses the area: at least kXposeDoubles); tab + term
@@ -298,6 +331,7 @@ int pick_threads(const nid_ctx *ctx, bool jac, int batch) {
 }
 
 int launch_eval2(nid_ctx *ctx, EvalParams &P, bool jac, hipStream_t stream, int batch) {
+  { int rc = resident_quiesce(ctx); if (rc) return rc; }
   P.batch = batch;
   // Workgroup shape of the throughput path: 128 threads.  Measured on MI355X (16 poses per launch, two launches in
   // flight): 640x480 / 8 bins 237k (256 threads) -> 260k (128) evaluations/s, 1280x960 63.8k -> 70.5k; one-wave
@@ -311,12 +345,7 @@ int launch_eval2(nid_ctx *ctx, EvalParams &P, bool jac, hipStream_t stream, int 
                           P.g.pstride <= lat_rounds(nt) * nt && batch <= kMaxBatch;
   if (dbg && nt > 256 && !stamps_lat) nt = 256;
   size_t lds = eval_lds_bytes(P.g, nt);
-  {
-    const int hs = eval_hist_shift(P.g);
-    P.hist_dn = std::ldexp(1.0, hs - 562);    // times kWcPre = 2^-512 on the other factor: 2^(hs - 1074)
-    P.hist_dn1 = std::ldexp(1.0, hs - 1074);  // (a subnormal constant: exact)
-    P.hist_inv_scale = std::ldexp(1.0, -hs);
-  }
+  set_hist_params(P);
   if (lds > 160 * 1024) return NID_ERR_UNSUPPORTED;
   static const char *pad_env = getenv("NID_EXP_LDS_PAD");  // occupancy experiments: pad the LDS request
   if (pad_env) lds = std::min<size_t>(160 * 1024, lds + (size_t)atoi(pad_env));
@@ -425,7 +454,7 @@ void fill_sentinel(double *p, size_t n) {
 
 int ensure_quad_host(nid_ctx *ctx, Slot &S) {
   if (S.quad_host) return NID_OK;
-  const size_t n = (size_t)ctx->g.nloc * kDirectRec;
+  const size_t n = (size_t)2 * ctx->g.nloc * kDirectRec;
   if (hipHostMalloc(reinterpret_cast<void **>(&S.quad_host), n * sizeof(double), hipHostMallocMapped) != hipSuccess) {
     S.quad_host = nullptr;
     return NID_ERR_NOMEM;
@@ -472,96 +501,184 @@ int spin_until(nid_ctx *ctx, F arrived, unsigned long &spins, bool &synced, bool
   return NID_OK;
 }
 
-// one cell's 32-double block from its record, exactly as k_eval2's tail forms it (residual_and_huber + the quadratic form)
-inline void quad_from_record(const double *rec, bool jac, double delta, float dsqr, double *q /*[29]*/) {
-  if (rec[kDirectRec - 1] == 0.0) {  // level-1 edge: an all-zero block
-    for (int v = 0; v < 29; v++) q[v] = 0.0;
-    return;
-  }
-  const double err = rec[0];
-  const double e2 = err * err;
-  double rho0 = e2, rho1 = 1.0;
+// One cell's quadratic form, from its record, ADDED to acc[0..28] -- exactly the 32-double block k_eval2's tail forms
+// (residual_and_huber + constructQuadraticForm: the same IEEE operations on the same values) and the same addition
+// sum_blocks_w0 performs.  Terms that are +0.0 by construction (an inactive cell's block, the b and H entries of a
+// cost-only block) are not added: an accumulator that starts at +0.0 never holds -0.0, so x + 0.0 is x, bit for bit.
+inline void huber_weights(double err, double delta, float dsqr, double &rho0, double &rho1) {
+  const double e2 = err * err;  // robust_kernel_impl.cpp:77-91 (float dsqr)
+  rho0 = e2; rho1 = 1.0;
   if (!(e2 <= dsqr)) {
     const double sqrte = std::sqrt(e2);
     rho0 = 2 * sqrte * delta - dsqr;
     rho1 = delta / sqrte;
   }
-  q[0] = rho0;
-  q[28] = 1.0;
-  if (!jac) {
-    for (int v = 1; v < 28; v++) q[v] = 0.0;
-    return;
-  }
-  const double *J = rec + 1;
-  for (int n = 0; n < 6; n++) q[1 + n] = 0.0 - (rho1 * J[n]) * err;
+}
+
+// first half, from the record's early words (err, active flag): chi2 and the count; returns rho1 (0 for a level-1 edge)
+inline double add_record_cost(const double *rec, double delta, float dsqr, double *acc) {
+  if (rec[1] == 0.0) return 0.0;  // level-1 edge
+  double rho0, rho1;
+  huber_weights(rec[0], delta, dsqr, rho0, rho1);
+  acc[0] += rho0;
+  acc[28] += 1.0;
+  return rho1;
+}
+// second half, from the Jacobian words: b and the upper triangle of H
+inline void add_record_jac(const double *J, double err, double rho1, double *acc) {
+  for (int n = 0; n < 6; n++) acc[1 + n] += 0.0 - (rho1 * J[n]) * err;
   int idx = 7;
   for (int a = 0; a < 6; a++)
-    for (int b = a; b < 6; b++) q[idx++] = (J[a] * rho1) * J[b];
+    for (int b = a; b < 6; b++, idx++) acc[idx] += (J[a] * rho1) * J[b];
 }
 
 #ifndef NID_DIRECT_AHEAD
 #define NID_DIRECT_AHEAD 24
 #endif
 constexpr int kDirectAhead = NID_DIRECT_AHEAD;
+constexpr std::chrono::milliseconds kResidentPatience(2);      // a resident request unanswered for this long: fallback
+constexpr std::chrono::milliseconds kResidentHostIdle(50);     // the host retires a kernel it has not used for this long ...
+constexpr long long kResidentIdleTicks = 20000000;             // ... the kernel leaves by itself after 200 ms (100 MHz ticks)
+
+int resident_fallback(nid_ctx *ctx, Slot &S);
 
 int wait_direct(nid_ctx *ctx, Slot &S) {
   const int nloc = ctx->g.nloc, gs = ctx->group_size;
   const float dsqr = (float)(S.direct_delta * S.direct_delta);  // RobustKernelHuber::setDelta (robust_kernel_impl.h:84)
-  double top[2][32] = {}, grp[2][32], q[32];
-  unsigned long spins = 0;
-  bool synced = false;
+  const bool jac = S.direct_jac;
   static const bool trace = getenv("NID_DIRECT_TRACE") != nullptr;
   const auto t0 = std::chrono::steady_clock::now();
-  auto t_first = t0, t_lastwait = t0;
-  bool got_first = false;
-  for (int g0 = 0, gq = 0; g0 < nloc; g0 += gs, gq++) {
-    const int gcount = std::min(gs, nloc - g0);
-    std::memset(grp, 0, sizeof(grp));
-    for (int i = 0; i < gcount; i++) {
-      double *rec = S.quad_host + (size_t)(g0 + i) * kDirectRec;
-      // the cells arrive within about a microsecond of each other and every record is a line the device has just
-      // written, i.e. a miss to memory: ask for the lines ahead while this one is worked on
-      if (g0 + i + kDirectAhead < nloc) __builtin_prefetch(rec + (size_t)kDirectAhead * kDirectRec, 0, 3);
-      bool waited = false;
-      int rc = spin_until(ctx, [&] { return words_arrived(rec, kDirectRec); }, spins, synced, waited);
-      if (rc) return rc;
-      if (trace) {
-        if (!got_first) { t_first = std::chrono::steady_clock::now(); got_first = true; }
-        if (waited) t_lastwait = std::chrono::steady_clock::now();
+  std::vector<double> &hub = ctx->direct_rho1;  // per cell: rho1, err, active
+  if (jac && hub.size() < (size_t)3 * nloc) hub.resize((size_t)3 * nloc);
+  for (;;) {  // (a second round only after a resident kernel had to be replaced by an ordinary launch)
+    double *base = S.resident ? ctx->res.rec_host : S.quad_host;
+    // Two cursors over the cells, each in cell order.  c1: residual records (a cost + Jacobian kernel sends them
+    // BEFORE its Jacobian phase, so this work -- a square root and a division per cell -- is done while the device is
+    // still busy) -> Huber weights, chi2 (entry 0), count (entry 28).  c2 <= c1: Jacobian records -> b, H (entries
+    // 1..27).  Every entry has its own chain of additions, in sum_blocks_w0's order, whichever cursor performs it:
+    // per group the even-numbered cells in ascending order plus the odd-numbered ones, then the groups likewise.
+    double top[2][32] = {}, grp[2][32] = {}, g00[2] = {0.0, 0.0}, g28[2] = {0.0, 0.0};
+    int c1 = 0, c2 = jac ? 0 : nloc;
+    unsigned long spins = 0, patience = 0;
+    bool synced = false, again = false;
+    auto t_first = t0, t_lastwait = t0;
+    bool got_first = false, waited = false;
+    while (c1 < nloc || c2 < nloc) {
+      if (c1 < nloc) {
+        double *rec = base + (size_t)c1 * kDirectRec;
+        if (words_arrived(rec, kDirectRec)) {
+          // every record is a line the device has just written, i.e. a miss to memory: ask for the lines ahead
+          if (c1 + kDirectAhead < nloc) __builtin_prefetch(rec + (size_t)kDirectAhead * kDirectRec, 0, 3);
+          __atomic_thread_fence(__ATOMIC_ACQUIRE);  // (the words were read as volatile; keep the plain reads below behind them)
+          const int i = c1 % gs, gq = c1 / gs;
+          double acc[32];
+          acc[0] = g00[i & 1]; acc[28] = g28[i & 1];
+          const double r1 = add_record_cost(rec, S.direct_delta, dsqr, acc);
+          g00[i & 1] = acc[0]; g28[i & 1] = acc[28];
+          if (jac) { double *w = &hub[3 * (size_t)c1]; w[0] = r1; w[1] = rec[0]; w[2] = rec[1]; }
+          fill_sentinel(rec, kDirectRec);
+          c1++;
+          if (i == gs - 1 || c1 == nloc) {  // the group is complete
+            top[gq & 1][0] += g00[0] + g00[1];
+            top[gq & 1][28] += g28[0] + g28[1];
+            g00[0] = g00[1] = g28[0] = g28[1] = 0.0;
+          }
+          if (trace && !jac) {
+            if (!got_first) { t_first = std::chrono::steady_clock::now(); got_first = true; }
+            if (waited) t_lastwait = std::chrono::steady_clock::now();
+          }
+          waited = false;
+          continue;
+        }
       }
-      __atomic_thread_fence(__ATOMIC_ACQUIRE);  // (the words were read as volatile; keep the plain reads below behind them)
-      quad_from_record(rec, S.direct_jac, S.direct_delta, dsqr, q);
-      fill_sentinel(rec, kDirectRec);
-      double *acc = grp[i & 1];
-      for (int v = 0; v < 29; v++) acc[v] += q[v];
+      if (c2 < c1) {
+        double *rec = base + (size_t)(nloc + c2) * kDirectRec;
+        if (words_arrived(rec, kDirectRec)) {
+          if (c2 + kDirectAhead < nloc) __builtin_prefetch(rec + (size_t)kDirectAhead * kDirectRec, 0, 3);
+          __atomic_thread_fence(__ATOMIC_ACQUIRE);
+          const int i = c2 % gs, gq = c2 / gs;
+          const double *w = &hub[3 * (size_t)c2];
+          if (w[2] != 0.0) add_record_jac(rec, w[1], w[0], grp[i & 1]);
+          fill_sentinel(rec, kDirectRec);
+          c2++;
+          if (i == gs - 1 || c2 == nloc) {
+            double *t = top[gq & 1];
+            for (int v = 1; v < 28; v++) t[v] += grp[0][v] + grp[1][v];
+            std::memset(grp, 0, sizeof(grp));
+          }
+          if (trace) {
+            if (!got_first) { t_first = std::chrono::steady_clock::now(); got_first = true; }
+            if (waited) t_lastwait = std::chrono::steady_clock::now();
+          }
+          waited = false;
+          continue;
+        }
+      }
+      // nothing to do yet
+      waited = true;
+      if (S.resident) {
+        // a resident kernel answers within microseconds; one that has left (its idle limit, a device-wide wait
+        // elsewhere) never will: after kResidentPatience the request is re-issued as an ordinary DIRECT launch
+        if ((++patience & 1023ul) == 0 && std::chrono::steady_clock::now() - t0 > kResidentPatience) {
+          int rc = resident_fallback(ctx, S);
+          if (rc) return rc;
+          again = true;
+          break;
+        }
+      } else if (++spins > 50000000ul) {  // let a device error surface through the runtime, then give up
+        if (synced) { ctx->last_error = "a cell's results never arrived"; return NID_ERR_HIP; }
+        NID_HIP(ctx, hipSetDevice(ctx->cfg.device));
+        NID_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        NID_HIP(ctx, hipStreamSynchronize(ctx->aux_stream));
+        synced = true;
+        spins = 0;
+      }
     }
-    double *t = top[gq & 1];
-    for (int v = 0; v < 29; v++) t[v] += grp[0][v] + grp[1][v];
-  }
-  for (int v = 0; v < kReducedLen; v++) S.reduced_host[v] = v < 29 ? top[0][v] + top[1][v] : 0.0;
-  if (trace) {
-    const auto t1 = std::chrono::steady_clock::now();
-    auto us = [&](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::micro>(t - t0).count(); };
-    g_dtrace.first += us(t_first); g_dtrace.last_wait += us(t_lastwait); g_dtrace.end += us(t1);
-    if (++g_dtrace.n % 2000 == 0) {
-      fprintf(stderr, "[direct trace] %ld waits: first cell %.2f us, last wait %.2f us, end %.2f us after entering the wait\n", g_dtrace.n,
-              g_dtrace.first / g_dtrace.n, g_dtrace.last_wait / g_dtrace.n, g_dtrace.end / g_dtrace.n);
-      g_dtrace = DirectTrace();
+    if (again) continue;
+    for (int v = 0; v < kReducedLen; v++) S.reduced_host[v] = v < 29 ? top[0][v] + top[1][v] : 0.0;
+    if (trace) {
+      const auto t1 = std::chrono::steady_clock::now();
+      auto us = [&](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::micro>(t - t0).count(); };
+      g_dtrace.first += us(t_first); g_dtrace.last_wait += us(t_lastwait); g_dtrace.end += us(t1);
+      if (++g_dtrace.n % 2000 == 0) {
+        fprintf(stderr, "[direct trace] %ld waits: first %s record %.2f us, last wait %.2f us, end %.2f us after entering the wait\n", g_dtrace.n,
+                jac ? "Jacobian" : "residual", g_dtrace.first / g_dtrace.n, g_dtrace.last_wait / g_dtrace.n, g_dtrace.end / g_dtrace.n);
+        g_dtrace = DirectTrace();
+      }
     }
+    break;
   }
+  if (S.resident) { ctx->res.pending_slot = -1; ctx->res.served++; S.resident = false; }
   return NID_OK;
 }
 
 // the per-cell calls: every cell's kCellOut outputs, word by word
 int wait_direct_cellout(nid_ctx *ctx, Slot &S) {
-  unsigned long spins = 0;
-  bool synced = false, waited = false;
-  for (int cl = 0; cl < ctx->g.nloc; cl++) {
-    const double *co = S.cellout_host + (size_t)cl * kCellOut;
-    int rc = spin_until(ctx, [&] { return words_arrived(co, kCellOut); }, spins, synced, waited);
-    if (rc) return rc;
+  const auto t0 = std::chrono::steady_clock::now();
+  for (;;) {
+    unsigned long spins = 0;
+    bool synced = false, waited = false, again = false;
+    for (int cl = 0; cl < ctx->g.nloc && !again; cl++) {
+      const double *co = S.cellout_host + (size_t)cl * kCellOut;
+      if (S.resident) {
+        unsigned long n = 0;
+        while (!words_arrived(co, kCellOut)) {
+          if ((++n & 1023ul) == 0 && std::chrono::steady_clock::now() - t0 > kResidentPatience) {
+            int rc = resident_fallback(ctx, S);
+            if (rc) return rc;
+            again = true;
+            break;
+          }
+        }
+      } else {
+        int rc = spin_until(ctx, [&] { return words_arrived(co, kCellOut); }, spins, synced, waited);
+        if (rc) return rc;
+      }
+    }
+    if (!again) break;
   }
   __atomic_thread_fence(__ATOMIC_ACQUIRE);
+  if (S.resident) { ctx->res.pending_slot = -1; ctx->res.served++; S.resident = false; }
   return NID_OK;
 }
 
@@ -587,6 +704,197 @@ int timing_events(nid_ctx *ctx, Slot &S) {
   return NID_OK;
 }
 
+// ---- the RESIDENT evaluator (k_resident) ----------------------------------------------------------------------------
+// Host side: the mailbox lives in fine-grained DEVICE memory that the CPU writes through the PCIe BAR (pose record and
+// flags, a store fence, the doorbell word, a store fence); results come back by the DIRECT protocol into res.rec_host
+// (and slot 0's cellout_host for the per-cell calls).  One request in flight at a time.  The kernel is started on its
+// own stream at the first request, retired (exit word + stream synchronisation: microseconds, every workgroup polls the
+// word) by every call that changes what it has cached or frees device memory, and by the next request after
+// kResidentHostIdle without one; a kernel that is gone nevertheless (its own idle limit) is noticed by the unanswered
+// request, which is then re-issued as an ordinary DIRECT launch (resident_fallback).
+static sigjmp_buf g_res_probe;
+static void res_probe_fault(int) { siglongjmp(g_res_probe, 1); }
+
+int resident_probe(nid_ctx *ctx) {
+  nid_ctx::Resident &R = ctx->res;
+  if (R.probed) return R.probed > 0 ? NID_OK : NID_ERR_UNSUPPORTED;
+  R.probed = -1;
+  void *p = nullptr;
+  if (hipExtMallocWithFlags(&p, 4096, hipDeviceMallocFinegrained) != hipSuccess) { (void)hipGetLastError(); return NID_ERR_UNSUPPORTED; }
+  if (hipMemset(p, 0, 4096) != hipSuccess || hipStreamSynchronize(nullptr) != hipSuccess) { (void)hipFree(p); return NID_ERR_UNSUPPORTED; }
+  // can the CPU store to it?  (a platform without a large BAR faults: that is the answer "no")
+  struct sigaction sa = {}, old_segv, old_bus;
+  sa.sa_handler = res_probe_fault;
+  sigaction(SIGSEGV, &sa, &old_segv);
+  sigaction(SIGBUS, &sa, &old_bus);
+  bool ok = false;
+  if (sigsetjmp(g_res_probe, 1) == 0) {
+    volatile unsigned *w = reinterpret_cast<volatile unsigned *>(p) + 1000;
+    *w = 0x5A5Au;
+    ok = (*w == 0x5A5Au);
+    *w = 0u;
+  }
+  sigaction(SIGSEGV, &old_segv, nullptr);
+  sigaction(SIGBUS, &old_bus, nullptr);
+  if (!ok) { (void)hipFree(p); return NID_ERR_UNSUPPORTED; }
+  R.ctl = static_cast<ResidentCtl *>(p);
+  if (hipStreamCreateWithFlags(&R.stream, hipStreamNonBlocking) != hipSuccess) { (void)hipFree(p); R.ctl = nullptr; return NID_ERR_HIP; }
+  const size_t n = (size_t)2 * ctx->g.nloc * kDirectRec;
+  if (hipHostMalloc(reinterpret_cast<void **>(&R.rec_host), n * sizeof(double), hipHostMallocMapped) != hipSuccess) return NID_ERR_NOMEM;
+  fill_sentinel(R.rec_host, n);
+  NID_HIP(ctx, hipHostGetDevicePointer(reinterpret_cast<void **>(&R.rec_devptr), R.rec_host, 0));
+  R.probed = 1;
+  return NID_OK;
+}
+
+inline void store_fence() { __builtin_ia32_sfence(); }
+
+void resident_retire(nid_ctx *ctx) {
+  nid_ctx::Resident &R = ctx->res;
+  if (!R.running) return;
+  (void)hipSetDevice(ctx->cfg.device);
+  volatile unsigned long long *w = R.ctl->w;
+  w[7] = kResExitWord;
+  store_fence();
+  (void)hipStreamSynchronize(R.stream);  // every workgroup polls the word: microseconds
+  w[7] = R.seq << 8;                     // (a word no request carries: the next kernel starts from it)
+  store_fence();
+  R.running = false;
+}
+
+template <int NT, int NB>
+int resident_launch_t(nid_ctx *ctx, const EvalParams &P, size_t lds, unsigned grid) {
+  constexpr int LAT = NT == 512 ? 3 : 2;
+  nid_ctx::Resident &R = ctx->res;
+  // every workgroup must be ON the device for a request to be answered: check before launching
+  int per_cu = 0, cus = 0;
+  NID_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_resident<NT, NB, LAT>, NT, lds));
+  NID_HIP(ctx, hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->cfg.device));
+  if ((long)per_cu * cus < (long)grid) return NID_ERR_UNSUPPORTED;
+  long long idle_ticks = kResidentIdleTicks;
+  if (const char *e = getenv("NID_RESIDENT_IDLE_US")) idle_ticks = std::max(1L, atol(e)) * 100;  // tests: a kernel that leaves early
+  // the mailbox word the kernel starts from (whatever is there now is not a request)
+  volatile unsigned long long *w = R.ctl->w;
+  w[7] = R.seq << 8;
+  store_fence();
+  hipLaunchKernelGGL((k_resident<NT, NB, LAT>), dim3(grid), dim3(NT), lds, R.stream, P, (const ResidentCtl *)R.ctl, R.seq << 8,
+                     idle_ticks, ctx->xform);
+  NID_HIP(ctx, hipGetLastError());
+  return NID_OK;
+}
+
+int resident_start(nid_ctx *ctx, int nt) {
+  nid_ctx::Resident &R = ctx->res;
+  int rc = resident_probe(ctx);
+  if (rc) return rc;
+  EvalParams P{};
+  fill_common_params(ctx, 1.0, &P);  // (the Huber weights of a DIRECT launch are the host's business)
+  P.batch = 1;
+  set_hist_params(P);
+  SlotArgs &A = P.slot[0];
+  Slot &S0 = ctx->slots[0];
+  A.cellout = S0.cellout_host_devptr;
+  A.quad = R.rec_devptr;
+  A.gpart = nullptr; A.ticket = nullptr; A.out_reduced = nullptr; A.host_seq = nullptr;
+  A.launch_seq = 0; A.cellout_host = 0; A.host_quad = 1;
+  // eval_cell's LDS + the cell's tile entries (k_eval2's LAT branch, RES): rounds x threads x (7 doubles + 1 int)
+  const size_t lds = eval_lds_bytes(P.g, nt) + 16 + (size_t)lat_rounds(nt) * nt * (7 * 8 + 4);
+  if (lds > 160 * 1024) return NID_ERR_UNSUPPORTED;
+  const unsigned grid = (unsigned)(((P.g.nloc + 7) / 8) * 8);
+  const int nb = P.g.nb;
+  if (nt != 512) return NID_ERR_UNSUPPORTED;
+  rc = nb == 8 ? resident_launch_t<512, 8>(ctx, P, lds, grid) : (nb == 10 ? resident_launch_t<512, 10>(ctx, P, lds, grid) : resident_launch_t<512, 0>(ctx, P, lds, grid));
+  if (rc) return rc;
+  R.running = true;
+  R.nt = nt;
+  R.starts++;
+  R.last_post = std::chrono::steady_clock::now();
+  return NID_OK;
+}
+
+// may THIS single-pose launch go to the resident kernel?  (FAST math at the 512-thread latency shape -- two waves per
+// SIMD: the resident workgroup may use 256 registers per lane; at 1024 threads it would spill --, its rounds covering a
+// cell, and the shape cost + Jacobian launches of this context use anyway: the Jacobian's last bits depend on it)
+bool resident_usable(const nid_ctx *ctx) {
+  const nid_ctx::Resident &R = ctx->res;
+  if (!R.enabled || R.probed < 0 || R.pending_slot >= 0 || !direct_ok(ctx)) return false;
+  if (ctx->math_mode != NID_MATH_FAST || ctx->loop_form) return false;
+  const int nt = ctx->jac_threads;
+  if (nt != 512) return false;
+  if (ctx->cost_threads != 0 && ctx->cost_threads != nt) return false;  // (cost-only results are the same bits in every shape)
+  return ctx->g.pstride <= lat_rounds(nt) * nt;
+}
+
+// hand one request to the resident kernel (starting it if need be); NID_ERR_UNSUPPORTED: use an ordinary launch
+int resident_post(nid_ctx *ctx, int slot, const Pose &pose, bool jac, bool want_cellout) {
+  nid_ctx::Resident &R = ctx->res;
+  {  // the mailbox carries a pose7; the kernel forms the matrix from it: only poses whose matrix IS that matrix
+    Pose chk;
+    pose_from_pose7(pose.q, pose.mode, &chk);
+    if (std::memcmp(chk.M, pose.M, sizeof(chk.M)) != 0) return NID_ERR_STATE;  // (nid_evaluate_matrix: an ordinary launch)
+  }
+  const auto now = std::chrono::steady_clock::now();
+  if (R.running && (R.nt != ctx->jac_threads || now - R.last_post > kResidentHostIdle)) resident_retire(ctx);
+  if (!R.running) {
+    int rc = resident_start(ctx, ctx->jac_threads);
+    if (rc) { if (rc == NID_ERR_UNSUPPORTED) R.probed = -1; return rc; }
+  }
+  R.pose = pose; R.jac = jac; R.want_cellout = want_cellout;
+  // the mailbox line: pose7, a store fence, (number << 8 | flags), a store fence (ResidentCtl)
+  volatile unsigned long long *dst = R.ctl->w;
+  unsigned long long words[7];
+  std::memcpy(words, pose.q, sizeof(words));
+  for (int i = 0; i < 7; i++) dst[i] = words[i];
+  store_fence();
+  const unsigned flags = (jac ? kResJac : 0u) | (want_cellout ? kResCellout : kResRecord);
+  dst[7] = (++R.seq << 8) | flags;
+  store_fence();  // out of the write-combining buffer now
+  R.last_post = std::chrono::steady_clock::now();
+  R.pending_slot = slot;
+  return NID_OK;
+}
+
+// An ordinary evaluation launch is about to be enqueued.  The resident workgroups hold two waves per SIMD with ~200
+// registers each on every CU they sit on: a launch whose workgroups do not fit beside them would wait until the
+// resident kernel leaves by itself.  So it leaves now -- after the request it may be working on has been collected
+// (its slot keeps the result for nid_wait).
+int resident_quiesce(nid_ctx *ctx) {
+  nid_ctx::Resident &R = ctx->res;
+  if (!R.running) return NID_OK;
+  if (R.pending_slot >= 0) {
+    Slot &S = ctx->slots[R.pending_slot];
+    int rc = wait_direct(ctx, S);  // (the per-cell calls are blocking: never pending here)
+    if (rc) return rc;
+    S.direct = false;
+    S.collected = true;
+  }
+  resident_retire(ctx);
+  return NID_OK;
+}
+
+// the resident kernel did not answer: take it down and put the request through an ordinary DIRECT launch (into the
+// slot's own record buffer; the per-cell outputs have one buffer either way)
+int resident_fallback(nid_ctx *ctx, Slot &S) {
+  nid_ctx::Resident &R = ctx->res;
+  resident_retire(ctx);  // (if it was still there: no late writes after this)
+  R.fallbacks++;
+  fill_sentinel(R.rec_host, (size_t)2 * ctx->g.nloc * kDirectRec);
+  if (R.want_cellout) fill_sentinel(ctx->slots[0].cellout_host, (size_t)ctx->g.nloc * kCellOut);
+  int rc = ensure_quad_host(ctx, S);
+  if (rc) return rc;
+  EvalParams P{};
+  fill_common_params(ctx, 1.0, &P);
+  SlotArgs &A = P.slot[0];
+  fill_slot_args(R.pose, S, nullptr, nullptr, &A);
+  A.quad = S.quad_host_devptr;
+  A.host_quad = R.want_cellout ? 2 : 1;
+  if (R.want_cellout) { A.cellout = ctx->slots[0].cellout_host_devptr; A.cellout_host = 1; }
+  NID_HIP(ctx, hipSetDevice(ctx->cfg.device));
+  S.resident = false;  // from here on the wait is an ordinary DIRECT wait
+  R.pending_slot = -1;
+  return launch_eval(ctx, P, R.jac, ctx->stream);
+}
+
 int launch_slot(nid_ctx *ctx, int slot, const Pose &pose, int want_jac, double delta,
                 void *reduced_target) {
   int rc = check_ready(ctx);
@@ -605,15 +913,22 @@ int launch_slot(nid_ctx *ctx, int slot, const Pose &pose, int want_jac, double d
       S.external_target ? nullptr : reinterpret_cast<unsigned long long *>(S.reduced_host_devptr + kReducedLen);
   EvalParams P{};
   fill_eval_params(ctx, pose, S, delta, target, host_seq, &P);
-  S.direct = false;
+  S.direct = S.resident = false;
   if (!S.external_target && direct_ok(ctx)) {
+    S.direct = true;
+    S.direct_jac = want_jac != 0;
+    S.direct_delta = delta;
+    if (resident_usable(ctx) && resident_post(ctx, slot, pose, want_jac != 0, false) == NID_OK) {
+      S.resident = true;  // no launch at all: the resident kernel has the request
+      S.timed = false;
+      S.done_slot = slot;
+      S.pending = true;
+      return NID_OK;
+    }
     rc = ensure_quad_host(ctx, S);
     if (rc) return rc;
     P.slot[0].quad = S.quad_host_devptr;
     P.slot[0].host_quad = 1;
-    S.direct = true;
-    S.direct_jac = want_jac != 0;
-    S.direct_delta = delta;
   }
   if (ctx->dbg_enabled) {
     const size_t N = (size_t)ctx->g.rows * ctx->g.cols;
@@ -671,11 +986,23 @@ int launch_batch(nid_ctx *ctx, int first_slot, int n, const Pose *poses, int wan
     P.slots_ext = ctx->ext_dev[ring];
   }
   const bool direct = n == 1 && !reduced_dev_base && !relaunch_ok && direct_ok(ctx);
+  if (direct && !on_aux_stream && resident_usable(ctx) && resident_post(ctx, first_slot, poses[0], want_jac != 0, false) == NID_OK) {
+    Slot &S = ctx->slots[first_slot];
+    S.seq++;
+    S.external_target = false;
+    S.direct = S.resident = true;
+    S.direct_jac = want_jac != 0;
+    S.direct_delta = delta;
+    S.timed = false;
+    S.done_slot = first_slot;
+    S.pending = true;
+    return NID_OK;
+  }
   if (direct) { rc = ensure_quad_host(ctx, ctx->slots[first_slot]); if (rc) return rc; }
   for (int k = 0; k < n; k++) {
     Slot &S = ctx->slots[first_slot + k];
     S.seq++;
-    S.direct = false;
+    S.direct = S.resident = false;
     S.external_target = reduced_dev_base != nullptr;
     if (S.external_target)  // caller-owned device buffer: pose k's block at base + k*32 (multi-GPU all-reduce)
       fill_slot_args(poses[k], S, reduced_dev_base + (size_t)k * kReducedLen, nullptr, &recs[k]);
@@ -754,9 +1081,11 @@ int evaluate_common(nid_ctx *ctx, const Pose &pose, int want_jac, double *Ht, do
   P.slot[0].cellout = S.cellout_host_devptr;
   P.slot[0].cellout_host = 1;
   const bool direct = direct_ok(ctx);
+  S.resident = false;
   if (direct) {  // the per-cell outputs straight to the host, word by word, and nothing else (wait_direct_cellout)
     fill_sentinel(S.cellout_host, (size_t)ctx->g.nloc * kCellOut);
     P.slot[0].host_quad = 2;
+    if (resident_usable(ctx) && resident_post(ctx, 0, pose, want_jac != 0, true) == NID_OK) S.resident = true;
   }
   if (ctx->dbg_enabled) {
     const size_t N = (size_t)ctx->g.rows * ctx->g.cols;
@@ -766,8 +1095,10 @@ int evaluate_common(nid_ctx *ctx, const Pose &pose, int want_jac, double *Ht, do
     NID_HIP(ctx, hipMemsetAsync(ctx->dbg_wc, 0xFF, N * 32, ctx->stream));
     NID_HIP(ctx, hipMemsetAsync(ctx->dbg_jc, 0xFF, N * 4, ctx->stream));
   }
-  rc = launch_eval(ctx, P, want_jac != 0, ctx->stream);
-  if (rc) return rc;
+  if (!S.resident) {
+    rc = launch_eval(ctx, P, want_jac != 0, ctx->stream);
+    if (rc) return rc;
+  }
   rc = direct ? wait_direct_cellout(ctx, S) : wait_host_seq(ctx, S);
   if (rc) return rc;
   if (ctx->dbg_enabled) NID_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the dump is read back by the runtime
@@ -786,6 +1117,7 @@ int href_common(nid_ctx *ctx, const Pose &pose, int32_t *bs_counter, double *Hre
                 int32_t *bs_index) {
   if (!ctx) return NID_ERR_INVALID_ARG;
   if (!ctx->have_ref) { ctx->last_error = "reference not set"; return NID_ERR_STATE; }
+  resident_retire(ctx);
   hipLaunchKernelGGL((k_href<256>), dim3(ctx->g.nloc), dim3(256), 0, ctx->stream, ctx->g, pose, ctx->t,
                      ctx->Nc_dev, ctx->Href_dev, ctx->hist_scale, ctx->hist_inv_scale);
   NID_HIP(ctx, hipGetLastError());
@@ -824,6 +1156,7 @@ int upload_tiles(nid_ctx *ctx, const double *depth_m, const double *points3d, co
                  const double *Twc) {
   const Geometry &g = ctx->g;
   const size_t N = (size_t)g.rows * g.cols;
+  resident_retire(ctx);
   NID_HIP(ctx, hipMemcpyAsync(ctx->im0_dev, im0, N, hipMemcpyHostToDevice, ctx->stream));
   const double *depth_dev = nullptr, *points_dev = nullptr;
   if (depth_m) {
@@ -1000,6 +1333,10 @@ int nid_create_strided(const nid_config *cfg, int32_t cell_stride, nid_ctx **out
 int nid_destroy(nid_ctx *ctx) {
   if (!ctx) return NID_OK;
   (void)hipSetDevice(ctx->cfg.device);
+  resident_retire(ctx);
+  if (ctx->res.stream) (void)hipStreamDestroy(ctx->res.stream);
+  if (ctx->res.ctl) (void)hipFree(ctx->res.ctl);
+  if (ctx->res.rec_host) (void)hipHostFree(ctx->res.rec_host);
   if (ctx->own_stream) (void)hipStreamSynchronize(ctx->own_stream);
   (void)hipFree(ctx->t.X); (void)hipFree(ctx->t.Y); (void)hipFree(ctx->t.Z); (void)hipFree(ctx->t.W);
   (void)hipFree(ctx->t.JR); (void)hipFree(ctx->t.I0);
@@ -1040,6 +1377,7 @@ int nid_destroy(nid_ctx *ctx) {
 int nid_set_options(nid_ctx *ctx, int jac_bound_mode, int xform_mode) {
   if (!ctx || jac_bound_mode < 0 || jac_bound_mode > 1 || xform_mode < 0 || xform_mode > 1)
     return NID_ERR_INVALID_ARG;
+  resident_retire(ctx);
   ctx->jac_bound = jac_bound_mode;
   ctx->xform = xform_mode;
   return NID_OK;
@@ -1047,6 +1385,7 @@ int nid_set_options(nid_ctx *ctx, int jac_bound_mode, int xform_mode) {
 
 int nid_set_math_mode(nid_ctx *ctx, int mode) {
   if (!ctx || (mode != NID_MATH_STRICT && mode != NID_MATH_FAST)) return NID_ERR_INVALID_ARG;
+  resident_retire(ctx);
   ctx->math_mode = mode;
   return NID_OK;
 }
@@ -1080,6 +1419,7 @@ static bool valid_threads(int t) { return t == 0 || t == 128 || t == 256 || t ==
 int nid_set_launch_shape(nid_ctx *ctx, int jac_threads, int cost_threads) {
   if (!ctx) return NID_ERR_INVALID_ARG;
   if (!valid_threads(jac_threads) || !valid_threads(cost_threads)) return NID_ERR_UNSUPPORTED;
+  if (jac_threads != ctx->jac_threads) resident_retire(ctx);
   ctx->jac_threads = jac_threads;
   ctx->cost_threads = cost_threads;
   return NID_OK;
@@ -1149,6 +1489,7 @@ int nid_backproject(const double *depth_m, const double *T_wc0, double fx, doubl
 int nid_set_target_u8(nid_ctx *ctx, const uint8_t *im1) {
   if (!ctx || !im1) return NID_ERR_INVALID_ARG;
   NID_HIP(ctx, hipSetDevice(ctx->cfg.device));
+  resident_retire(ctx);
   const size_t N = (size_t)ctx->g.rows * ctx->g.cols;
   NID_HIP(ctx, hipMemcpyAsync(ctx->im1_dev, im1, N, hipMemcpyHostToDevice, ctx->stream));
   {
@@ -1216,6 +1557,7 @@ int nid_plain_nid(nid_ctx *ctx, const double *pose7, int bins, double *Href, dou
   if (!ctx || !pose7 || bins < 1 || bins > kMaxPlainBins) return NID_ERR_INVALID_ARG;
   if (!ctx->have_ref || !ctx->have_target) { ctx->last_error = "reference / target not set"; return NID_ERR_STATE; }
   NID_HIP(ctx, hipSetDevice(ctx->cfg.device));
+  resident_retire(ctx);  // (hipFree below waits for the whole device)
   Pose p; pose_from_pose7(pose7, NID_XFORM_MATRIX, &p);  // T_cw1 * pw as a 4x4 product (:353-354)
   const int nloc = ctx->g.nloc;
   double *out_dev = nullptr;
@@ -1250,6 +1592,7 @@ int nid_set_href_state(nid_ctx *ctx, const int32_t *bs_counter, const double *Hr
   if (!ctx || !bs_counter || !Href || !bs_value) return NID_ERR_INVALID_ARG;
   if (!ctx->have_ref) return NID_ERR_STATE;
   NID_HIP(ctx, hipSetDevice(ctx->cfg.device));
+  resident_retire(ctx);
   const Geometry &g = ctx->g;
   const size_t plane = (size_t)g.nloc * g.pstride;
   std::vector<double> W(4 * plane, 0.0);
@@ -1346,6 +1689,7 @@ namespace {
 // result buffers (device + pinned host), events and the copy stream of the pipelined loop, for launches of `batch` poses
 int ensure_seq_ring(nid_ctx *ctx, int batch) {
   if (ctx->seq_cap >= (size_t)batch) return NID_OK;
+  resident_retire(ctx);  // (hipFree waits for the whole device)
   for (int r = 0; r < nid_ctx::kSeqRing; r++) {
     (void)hipFree(ctx->seq_dev[r]); ctx->seq_dev[r] = nullptr;
     if (ctx->seq_host[r]) (void)hipHostFree(ctx->seq_host[r]);
@@ -1462,8 +1806,10 @@ int nid_wait(nid_ctx *ctx, int slot, double *H36, double *b6, double *chi2, int3
     return NID_OK;
   }
   // the last workgroup stores the 32 results, then the sequence word (system-scope release); DIRECT launches: the
-  // host collects and sums the cells' blocks
-  {
+  // host collects the cells' records and sums their quadratic forms
+  if (S.collected) {
+    S.collected = false;
+  } else {
     int rc = S.direct ? wait_direct(ctx, S) : wait_host_seq(ctx, S);
     if (rc) return rc;
   }
@@ -1491,6 +1837,7 @@ int nid_slot_buffers(nid_ctx *ctx, int slot, void **reduced_dev, void **cellout_
 int nid_debug_enable_pixel_dump(nid_ctx *ctx, int enable) {
   if (!ctx) return NID_ERR_INVALID_ARG;
   NID_HIP(ctx, hipSetDevice(ctx->cfg.device));
+  resident_retire(ctx);
   if (enable && !ctx->dbg_u) {
     const size_t N = (size_t)ctx->g.rows * ctx->g.cols;
     int rc;
@@ -1521,6 +1868,7 @@ int nid_debug_get_pixel_dump(nid_ctx *ctx, double *u, double *v, double *ic, int
 int nid_debug_enable_stamps(nid_ctx *ctx, int enable) {
   if (!ctx) return NID_ERR_INVALID_ARG;
   NID_HIP(ctx, hipSetDevice(ctx->cfg.device));
+  resident_retire(ctx);
   if (enable && !ctx->dbg_stamps) {
     int rc = dev_alloc(ctx, &ctx->dbg_stamps, (size_t)ctx->g.nloc * 10);
     if (rc) return rc;
@@ -1556,8 +1904,32 @@ int nid_set_direct_results(nid_ctx *ctx, int on) {
   return NID_OK;
 }
 
+int nid_set_resident(nid_ctx *ctx, int on) {
+  if (!ctx) return NID_ERR_INVALID_ARG;
+  for (int s = 0; s < NID_SLOTS; s++) if (ctx->slots[s].pending) return NID_ERR_STATE;
+  NID_HIP(ctx, hipSetDevice(ctx->cfg.device));
+  if (!on) {
+    resident_retire(ctx);
+    ctx->res.enabled = false;
+    return NID_OK;
+  }
+  int rc = resident_probe(ctx);
+  if (rc) { ctx->last_error = "resident evaluator: the device's fine-grained memory is not CPU-addressable here"; return rc; }
+  ctx->res.enabled = true;
+  return NID_OK;
+}
+
+int nid_resident_stats(const nid_ctx *ctx, int64_t *served, int64_t *fallbacks, int64_t *starts) {
+  if (!ctx) return NID_ERR_INVALID_ARG;
+  if (served) *served = ctx->res.served;
+  if (fallbacks) *fallbacks = ctx->res.fallbacks;
+  if (starts) *starts = ctx->res.starts;
+  return NID_OK;
+}
+
 int nid_set_loop_form(nid_ctx *ctx, int on) {
   if (!ctx) return NID_ERR_INVALID_ARG;
+  if (on) resident_retire(ctx);
   ctx->loop_form = on != 0;
   return NID_OK;
 }

@@ -101,11 +101,15 @@ struct SlotArgs {
   unsigned long long launch_seq;
   int cellout_host;                // cellout is mapped pinned host memory (the blocking per-cell calls): publish it at system scope
   int host_quad;                   // DIRECT launch (one pose, the host is waiting for it): no in-launch reduction.  1: `quad` is
-                                   // mapped pinned host memory, [nloc][kDirectRec]: every cell's workgroup writes its record
-                                   // (err, J[6], active) straight there and the HOST forms and sums the quadratic forms;
-                                   // 2: only the per-cell outputs, to `cellout` (mapped pinned host memory too)
+                                   // mapped pinned host memory, [2][nloc][kDirectRec]: every cell's workgroup writes its two
+                                   // records (residual, Jacobian) straight there and the HOST forms and sums the quadratic
+                                   // forms; 2: only the per-cell outputs, to `cellout` (mapped pinned host memory too)
 };
-constexpr int kDirectRec = 8;  // doubles per cell of a DIRECT launch: err | J[6] (zeros: cost-only) | 1.0 active / 0.0 inactive
+// A cell's records of a DIRECT launch, one 64-byte line each, every line written by ONE store instruction (a line
+// written in two instalments sat in a write combiner for ~30 us):
+//   residual record [cl]:        err | 1.0 active / 0.0 level-1 edge | 0 x 6   -- sent when the cost phase is over
+//   Jacobian record [nloc + cl]: J[6] | 0 | 0                                   -- cost + Jacobian launches only
+constexpr int kDirectRec = 8;
 
 struct EvalParams {
   Geometry g;
@@ -1237,10 +1241,21 @@ struct LatPix {
 // the main pass touches no global memory at all.  One workgroup per CU leaves 128+ VGPRs per lane for that.
 // Same operations on the same values in the same per-lane order as the loop form: bit-identical results (tested).
 // BIG: cells of more than 32 * NT slots (more rounds per wave than a lane's 32-bit gomask has bits).
-template <int NT, bool JAC, bool STRICT, int NB, bool DBG, bool EXT = false, int LAT = 0, bool BIG = false>
-__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu((STRICT || DBG || LAT || NT >= 512) ? 4 : (EXT ? NID_EXT_WAVES : NID_FAST_WAVES)))) void k_eval2(EvalParams P) {
+// what the resident kernel keeps of its cell from one request to the next
+struct ResCell {
+  int n_c;
+  double href;
+  bool fresh;  // first request of this kernel: the histograms have not been zeroed yet
+};
+
+// The body of the evaluation kernels: one cell at one pose by one workgroup.  RES: called from the resident kernel
+// (k_resident) -- the B-spline table is in LDS already, the cell's count and reference entropy are in registers, and
+// the histograms were zeroed behind the previous request (by the waves that had nothing left to do).
+template <int NT, bool JAC, bool STRICT, int NB, bool DBG, bool EXT, int LAT, bool BIG, bool RES>
+__device__ __forceinline__ void eval_cell(const EvalParams &P, const SlotArgs &SA, const int cl, const int pose_idx, unsigned char *smem,
+                                          const ResCell rc = ResCell{0, 0.0, true}) {
   static_assert(LAT == 0 || (!STRICT && !EXT), "the latency form exists for FAST math launches of <= kMaxBatch poses (DBG: phase stamps only)");
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x;
   constexpr int NC = eval_hist_copies(NT);
   const Geometry &g = P.g;
   const int nb = NB > 0 ? NB : g.nb;
@@ -1259,42 +1274,18 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu((STRICT || D
   double *rclamp = reinterpret_cast<double *>(clamp_lo + kFineLevels * kClampBins(nb));  // [kClampBins(nb)] folded sums, then the flag
   unsigned *clamp_flag = reinterpret_cast<unsigned *>(rclamp + kClampBins(nb));
 
-  // XCD-aware block -> (cell, pose) map: workgroups are dealt round-robin over the 8 XCDs, so
-  // id % 8 fixes the XCD; all `batch` poses of a cell get the same id % 8 and consecutive slots
-  // of that XCD's stream, i.e. they run together on one XCD and share the cell's tile rows in its
-  // L2 (measured on the 1280x960 config: HBM/MALL traffic per launch 1.13 GB -> see DESIGN.md).
-  // Speed only: nothing depends on the placement.
-  const int tid = threadIdx.x;
-  const int bid = blockIdx.x;
-  const int q = bid >> 3;
-  const int pose_idx = q % P.batch;
-  const int cl = (q / P.batch) * 8 + (bid & 7);
-  if (cl >= g.nloc) return;  // padding of the last group of 8 cells
-  SlotArgs sa_ext;
-  if (EXT) {
-    static_assert(sizeof(SlotArgs) % 4 == 0, "SlotArgs is copied dword by dword");
-    // The record array is written before the launch (in-stream copy) and never during it: read it through the CONSTANT
-    // address space, i.e. with a handful of scalar loads (s_load_dwordx16 ...) instead of one vector load and one
-    // v_readfirstlane per dword (84 instructions at the head of every wave).  pose_idx is uniform (from blockIdx).
-    typedef const unsigned __attribute__((address_space(4))) *ConstDwords;
-    ConstDwords src = (ConstDwords)(reinterpret_cast<uintptr_t>(P.slots_ext + pose_idx));
-    unsigned *dst = reinterpret_cast<unsigned *>(&sa_ext);
-    // FAST math transforms with the matrix; the quaternion (the first kPoseQuatDwords of the record) is only
-    // needed by exact_decisions, which fetches it itself: 14 scalar registers less across the pixel loops
-    static_assert(offsetof(SlotArgs, pose) == 0 && offsetof(Pose, q) == 0 && offsetof(Pose, M) == 4 * kPoseQuatDwords, "record layout");
-#pragma unroll
-    for (unsigned i = STRICT ? 0u : kPoseQuatDwords; i < sizeof(SlotArgs) / 4; i++) dst[i] = src[i];
-  }
-  const SlotArgs &SA = EXT ? sa_ext : P.slot[pose_idx];
-  const int n_c = P.Nc[cl];
-  const double href = P.Href[cl];
+  const int n_c = RES ? rc.n_c : P.Nc[cl];
+  const double href = RES ? rc.href : P.Href[cl];
   double *out = SA.cellout + (size_t)cl * kCellOut;
   double *quad = SA.quad + (size_t)cl * kQuad;
   if (n_c < 300 || isnan(href)) {  // level-1 edge: never evaluated (computeH.cu:271-275)
     if (tid >= 64) return;
     if (SA.host_quad) {  // DIRECT launch: see the cost-only tail
       if (tid < kCellOut && SA.cellout_host) store_sys(out + tid, (tid == kCellOut - 1) ? (double)n_c : NAN);
-      if (tid < kDirectRec && SA.host_quad == 1) store_sys(SA.quad + (size_t)cl * kDirectRec + tid, 0.0);
+      if (tid < kDirectRec && SA.host_quad == 1) {  // both records: the host does not know yet that the cell is a level-1 edge
+        store_sys(SA.quad + (size_t)cl * kDirectRec + tid, 0.0);
+        if (JAC) store_sys(SA.quad + ((size_t)P.g.nloc + cl) * kDirectRec + tid, 0.0);
+      }
       return;
     }
     if (tid < kCellOut) out[tid] = (tid == kCellOut - 1) ? (double)n_c : NAN;
@@ -1312,19 +1303,24 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu((STRICT || D
   const int lane = tid & 63;
   TileIn pre, prej;  // loop form of the FAST pixel loops: the next round's point and bin index (see cost_round)
   (void)pre; (void)prej;
-  {  // the copies and the fine levels behind them, 16 bytes per store (nbins is even, hist is 16-byte aligned)
+  // the copies and the fine levels behind them, 16 bytes per store (nbins is even, hist is 16-byte aligned); threads
+  // first .. NT-1 share the work
+  auto zero_histograms = [&](int first) {
     uint4 *h4 = reinterpret_cast<uint4 *>(hist);
     const int n4 = (nbins * (NC + kFineLevels) + kClampBins(nb) * (kClampCopies + kFineLevels)) / 2;  // ... and the clamped samples' bins
-    if (tid == 0) { clamp_flag[0] = 0u; clamp_flag[1] = 0u; }
-    if (NB > 0) {
+    if (tid == first) { clamp_flag[0] = 0u; clamp_flag[1] = 0u; }
+    if (NB > 0 && first == 0) {
 #pragma unroll
       for (int i = 0; i < (n4 + NT - 1) / NT; i++)
         if (i * NT + tid < n4) h4[i * NT + tid] = make_uint4(0u, 0u, 0u, 0u);
     } else {
-      for (int i = tid; i < n4; i += NT) h4[i] = make_uint4(0u, 0u, 0u, 0u);
+      for (int i = tid - first; i < n4; i += NT - first) h4[i] = make_uint4(0u, 0u, 0u, 0u);
     }
-  }
-  if (STRICT) {
+  };
+  if (!RES || rc.fresh) zero_histograms(0);
+  if (RES) {
+    // (the resident kernel has loaded the table once)
+  } else if (STRICT) {
     if (tid < S * 6) {
       const int jj = tid / 6, e = tid % 6;
       rtab[jj * kRcpRow + e] = 1.0 / span_denominator(jj, e, S);
@@ -1333,7 +1329,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu((STRICT || D
     // (the host's table carries kWcPre on its value coefficients, see hist_add / fx_bits)
     for (int i = tid; i < S * kCoefRow; i += NT) rtab[i] = P.ctab[i];
   }
-  __syncthreads();
+  if (!RES || rc.fresh) __syncthreads();  // (a later resident request: the waves have met at the kernel's own barriers since)
   NID_STAMP(1);
 
   // ---- phase 1: cost ---------------------------------------------------------------
@@ -1616,9 +1612,31 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu((STRICT || D
       PixelFront fr[LAT];
       WinC wcn[LAT];
       WinJ wjn[LAT];
+      // RES: the cell's tile entries stay in LDS from the kernel's first request on (every thread re-reads what it
+      // wrote itself: [round][field][thread] doubles, then the bin indices) -- an LDS read instead of an L2 round trip
+      // at the head of every request
+      double *tcache = reinterpret_cast<double *>((reinterpret_cast<uintptr_t>(clamp_flag + 2) + 15) & ~(uintptr_t)15);
+      int *jcache = reinterpret_cast<int *>(tcache + LAT * 7 * NT);
 #pragma unroll
       for (int q = 0; q < LAT; q++)
-        if (wave_base + q * NT < g.pstride) load_tile(P, base + (unsigned)(wave_base + q * NT + lane), plane, tin[q]);
+        if (wave_base + q * NT < g.pstride) {
+          if (RES && !rc.fresh) {
+            const double *tc = tcache + q * 7 * NT + tid;
+            tin[q].x = tc[0]; tin[q].y = tc[NT]; tin[q].z = tc[2 * NT];
+#pragma unroll
+            for (int k = 0; k < 4; k++) tin[q].wr[k] = tc[(3 + k) * NT];
+            tin[q].jr = jcache[q * NT + tid];
+          } else {
+            load_tile(P, base + (unsigned)(wave_base + q * NT + lane), plane, tin[q]);
+            if (RES) {
+              double *tc = tcache + q * 7 * NT + tid;
+              tc[0] = tin[q].x; tc[NT] = tin[q].y; tc[2 * NT] = tin[q].z;
+#pragma unroll
+              for (int k = 0; k < 4; k++) tc[(3 + k) * NT] = tin[q].wr[k];
+              jcache[q * NT + tid] = tin[q].jr;
+            }
+          }
+        }
 #pragma unroll
       for (int q = 0; q < LAT; q++)
         if (wave_base + q * NT < g.pstride) {
@@ -1770,7 +1788,10 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu((STRICT || D
     rho1 = wave_uniform(rho1);
   };
   if (!JAC) {
-    if (tid >= 64) return;  // the cell's tail is wave 0's business: the other waves free their slots now
+    if (tid >= 64) {  // the cell's tail is wave 0's business: the other waves free their slots now
+      if (RES) zero_histograms(64);  // ... in the resident kernel after clearing the histograms for the next request
+      return;
+    }
     if (SA.host_quad) {
       // DIRECT launch (one pose, the host is waiting for it): the cell's record (err, J[6], active) -- or, for the
       // per-cell calls, its outputs -- goes straight to pinned host memory, word by word, and the HOST forms the
@@ -1784,7 +1805,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu((STRICT || D
         store_sys(out + tid, o);  // (cost-only: the Jacobian slots hold NaN)
       }
       if (tid < kDirectRec && SA.host_quad == 1)
-        store_sys(SA.quad + (size_t)cl * kDirectRec + tid, tid == 0 ? err : (tid == kDirectRec - 1 ? 1.0 : 0.0));
+        store_sys(SA.quad + (size_t)cl * kDirectRec + tid, tid == 0 ? err : (tid == 1 ? 1.0 : 0.0));
       NID_STAMP(6);
       NID_STAMP(7);
       return;
@@ -1797,6 +1818,12 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu((STRICT || D
     NID_STAMP(7);
     return;
   }
+
+  // DIRECT launch: the residual goes to the host NOW -- while the Jacobian phase runs here, the host works out the
+  // cells' Huber weights (a square root and a division each) and their chi2 sum; what is left to it behind the
+  // Jacobians' arrival is multiplications and additions (wait_direct in nid_capi.hip)
+  if (SA.host_quad == 1 && tid < kDirectRec)
+    store_sys(SA.quad + (size_t)cl * kDirectRec + tid, tid == 0 ? (2 * Hj - href - Hc) / Hj : (tid == 1 ? 1.0 : 0.0));
 
   // ---- phase 2: Jacobian (recompute, see header comment) -------------------------------
   const double cA = wave_uniform(Hc + href), cB = wave_uniform(Hj);
@@ -2117,7 +2144,10 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu((STRICT || D
       for (int k = 0; k < 6; k++) red[(tid >> 6) * 6 + k] = acc[k];
     }
     __syncthreads();
-    if (tid >= 64) return;
+    if (tid >= 64) {
+      if (RES) zero_histograms(64);  // (see the cost-only tail; the histograms are dead since the fold)
+      return;
+    }
     if constexpr (NW <= 4) {
 #pragma unroll
       for (int k = 0; k < 6; k++) {
@@ -2146,11 +2176,11 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu((STRICT || D
     if (SA.host_quad) {  // DIRECT launch: see the cost-only tail
       err = wave_uniform((2 * Hj - href - Hc) / Hj);
       double o = tid == 0 ? Hc : (tid == 1 ? Hj : (tid == 2 ? err : (double)n_c));   // per-cell outputs
-      double r = tid == 0 ? err : 1.0;                                                // the cell's record
+      double r = 0.0;                                                                 // the Jacobian record (the residual went ahead)
 #pragma unroll
-      for (int n = 0; n < 6; n++) { if (tid == 3 + n) o = J[n]; if (tid == 1 + n) r = J[n]; }
+      for (int n = 0; n < 6; n++) { if (tid == 3 + n) o = J[n]; if (tid == n) r = J[n]; }
       if (tid < kCellOut && SA.cellout_host) store_sys(out + tid, o);
-      if (tid < kDirectRec && SA.host_quad == 1) store_sys(SA.quad + (size_t)cl * kDirectRec + tid, r);
+      if (tid < kDirectRec && SA.host_quad == 1) store_sys(SA.quad + ((size_t)P.g.nloc + cl) * kDirectRec + tid, r);
       NID_STAMP(6);
       NID_STAMP(7);
       return;
@@ -2185,6 +2215,174 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu((STRICT || D
   NID_STAMP(6);
   finish_and_reduce_w0(P, SA, cl, tid);
   NID_STAMP(7);
+}
+
+template <int NT, bool JAC, bool STRICT, int NB, bool DBG, bool EXT = false, int LAT = 0, bool BIG = false>
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu((STRICT || DBG || LAT || NT >= 512) ? 4 : (EXT ? NID_EXT_WAVES : NID_FAST_WAVES)))) void k_eval2(EvalParams P) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const Geometry &g = P.g;
+  // XCD-aware block -> (cell, pose) map: workgroups are dealt round-robin over the 8 XCDs, so
+  // id % 8 fixes the XCD; all `batch` poses of a cell get the same id % 8 and consecutive slots
+  // of that XCD's stream, i.e. they run together on one XCD and share the cell's tile rows in its
+  // L2 (measured on the 1280x960 config: HBM/MALL traffic per launch 1.13 GB -> see DESIGN.md).
+  // Speed only: nothing depends on the placement.
+  const int bid = blockIdx.x;
+  const int q = bid >> 3;
+  const int pose_idx = q % P.batch;
+  const int cl = (q / P.batch) * 8 + (bid & 7);
+  if (cl >= g.nloc) return;  // padding of the last group of 8 cells
+  SlotArgs sa_ext;
+  if (EXT) {
+    static_assert(sizeof(SlotArgs) % 4 == 0, "SlotArgs is copied dword by dword");
+    // The record array is written before the launch (in-stream copy) and never during it: read it through the CONSTANT
+    // address space, i.e. with a handful of scalar loads (s_load_dwordx16 ...) instead of one vector load and one
+    // v_readfirstlane per dword (84 instructions at the head of every wave).  pose_idx is uniform (from blockIdx).
+    typedef const unsigned __attribute__((address_space(4))) *ConstDwords;
+    ConstDwords src = (ConstDwords)(reinterpret_cast<uintptr_t>(P.slots_ext + pose_idx));
+    unsigned *dst = reinterpret_cast<unsigned *>(&sa_ext);
+    // FAST math transforms with the matrix; the quaternion (the first kPoseQuatDwords of the record) is only
+    // needed by exact_decisions, which fetches it itself: 14 scalar registers less across the pixel loops
+    static_assert(offsetof(SlotArgs, pose) == 0 && offsetof(Pose, q) == 0 && offsetof(Pose, M) == 4 * kPoseQuatDwords, "record layout");
+#pragma unroll
+    for (unsigned i = STRICT ? 0u : kPoseQuatDwords; i < sizeof(SlotArgs) / 4; i++) dst[i] = src[i];
+  }
+  const SlotArgs &SA = EXT ? sa_ext : P.slot[pose_idx];
+  eval_cell<NT, JAC, STRICT, NB, DBG, EXT, LAT, BIG, false>(P, SA, cl, pose_idx, smem);
+}
+
+// ---------------------------------------------------------------------------
+// The RESIDENT evaluator: the latency form of the evaluation kernel, launched ONCE per frame pair, one workgroup per
+// cell, all of them co-resident; each workgroup waits for a request -- a doorbell word in fine-grained device memory
+// that the CPU writes through the PCIe BAR, behind the request's pose record --, evaluates its cell with eval_cell and
+// writes the cell's record straight to pinned host memory (the DIRECT protocol: the host forms and sums the
+// quadratic forms), then waits again.  A Gauss-Newton / LM loop launches one pose and waits for it: the kernel launch
+// itself -- runtime call, packet, dispatch of 256 workgroups: ~6 us from the enqueue to a first result word on the
+// host, tools/ubench/mailbox_latency.hip -- is then most of what is left of an evaluation; a request to a resident
+// workgroup takes ~2 us there and back.
+// EVERY wave leaves: on the exit word, or after `idle_ticks` of s_memrealtime (100 MHz) without a request (a dead
+// host cannot keep the workgroups spinning); the host retires the kernel itself long before that (nid_capi.hip).
+// The mailbox: ONE 64-byte line -- the request's pose7 (q x y z w, t) in seven words and, in the eighth, its number and
+// flags.  The CPU writes the seven words, a store fence, the eighth word, a store fence (write-combining stores are not
+// ordered among themselves; across the fence they are), so a poll that reads a new eighth word -- the sixteen dwords
+// of the line in one request -- has the request's pose in the same registers: no second trip to memory.  The 3x4
+// matrix is formed on the device with the host's operations (pose_from_pose7 in nid_capi.hip: IEEE, no contraction:
+// the same bits).  Eighth word: (number << 8) | flags; kResExitWord: leave.
+struct ResidentCtl {
+  unsigned long long w[8];
+};
+constexpr unsigned long long kResExitWord = ~0ull;
+// (measured on A, 256 workgroups: one load at a time + 8 x 64 clocks of sleep answers first; deeper pipelines of loads
+// queue behind each other on the line's memory channel: profiles/r03_launch_cost_A.txt)
+#ifndef NID_RES_POLL_DEPTH
+#define NID_RES_POLL_DEPTH 1
+#endif
+#ifndef NID_RES_POLL_SLEEP
+#define NID_RES_POLL_SLEEP 8
+#endif
+constexpr int kResPollDepth = NID_RES_POLL_DEPTH;
+constexpr unsigned kResJac = 1u, kResRecord = 2u, kResCellout = 4u, kResLeave = 0xFFFFFFFFu;
+
+// pose_from_pose7 (nid_capi.hip) on the device: to_homogeneous_matrix (se3quat.h:270-278) = Eigen toRotationMatrix
+__device__ __forceinline__ void pose_from_pose7_dev(const double *p, int mode, Pose &out) {
+#pragma unroll
+  for (int i = 0; i < 7; i++) out.q[i] = p[i];
+  const double x = p[0], y = p[1], z = p[2], w = p[3];
+  const double tx = 2 * x, ty = 2 * y, tz = 2 * z;
+  const double twx = tx * w, twy = ty * w, twz = tz * w;
+  const double txx = tx * x, txy = ty * x, txz = tz * x;
+  const double tyy = ty * y, tyz = tz * y, tzz = tz * z;
+  double *M = out.M;
+  M[0] = 1 - (tyy + tzz); M[1] = txy - twz;       M[2] = txz + twy;        M[3] = p[4];
+  M[4] = txy + twz;       M[5] = 1 - (txx + tzz); M[6] = tyz - twx;        M[7] = p[5];
+  M[8] = txz - twy;       M[9] = tyz + twx;       M[10] = 1 - (txx + tyy); M[11] = p[6];
+  out.mode = mode;
+}
+
+__device__ __forceinline__ unsigned long long ld_sys_u64(const unsigned long long *p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ unsigned ld_sys_u32(const unsigned *p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// (One workgroup per CU: a 512-thread workgroup is two waves per SIMD, so its waves may use 256 registers -- the pose
+// arrives at run time, i.e. it is pinned in scalar registers for the whole evaluation instead of being re-read from
+// the kernel arguments where it is needed, and the scalar registers that no longer fit spill into vector lanes.)
+template <int NT, int NB, int LAT>
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT == 512 ? 2 : 4))) void k_resident(EvalParams P, const ResidentCtl *ctl, unsigned long long word0, long long idle_ticks,
+                                                                                                         int xform_mode) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  __shared__ unsigned s_req[2 + 16];  // kResLeave or 0 | (unused) | the request as it sits in the mailbox
+  const Geometry &g = P.g;
+  const int tid = threadIdx.x;
+  const int cl = (int)(blockIdx.x >> 3) * 8 + (int)(blockIdx.x & 7);  // k_eval2's map for one pose
+  if (cl >= g.nloc) return;
+  {  // the B-spline table, once (eval_cell's LDS layout)
+    const int nb = NB > 0 ? NB : g.nb;
+    const int nbins = nb * nb + nb;
+    double *rtab = reinterpret_cast<double *>(smem) + 2 * ((nbins + 1) & ~1);
+    for (int i = tid; i < (nb - 3) * kCoefRow; i += NT) rtab[i] = P.ctab[i];
+  }
+  ResCell rc{P.Nc[cl], P.Href[cl], true};
+  unsigned long long last = word0;
+  long long t_idle = __builtin_amdgcn_s_memrealtime();
+  for (;;) {
+    __syncthreads();  // every wave is back from the previous request: the request words may be rewritten
+    if (tid < 64) {   // wave 0 waits for the request
+      // One poll = the mailbox line's 16 dwords in one request (uncached device memory: ~1 us).  One load at a time
+      // would notice a request between one and two load times after it was written; with kResPollDepth loads in flight
+      // (they return in order: each turn waits for the oldest and issues a new one, then sleeps so that 256
+      // workgroups do not saturate the line's memory channel) it is noticed within about one load time.
+      const unsigned *mail = reinterpret_cast<const unsigned *>(ctl) + (tid & 15);
+      unsigned w[kResPollDepth];
+#pragma unroll
+      for (int k = 0; k < kResPollDepth; k++) w[k] = ld_sys_u32(mail);
+      unsigned got = 0u, leave = 0u;
+      unsigned long long word = last;
+      for (bool done = false; !done;) {
+#pragma unroll
+        for (int k = 0; k < kResPollDepth; k++) {
+          const unsigned v = w[k];
+          w[k] = ld_sys_u32(mail);
+          if (!done) {
+            const unsigned long long t = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)v, 15) << 32) |
+                                         (unsigned)__builtin_amdgcn_readlane((int)v, 14);
+            if (t == kResExitWord) { leave = 1u; done = true; }
+            else if (t != last) { got = v; word = t; done = true; }
+            else __builtin_amdgcn_s_sleep(NID_RES_POLL_SLEEP);
+          }
+        }
+        if (!done && __builtin_amdgcn_s_memrealtime() - t_idle > idle_ticks) { leave = 1u; done = true; }
+      }
+      if (leave) {
+        if (tid == 0) s_req[0] = kResLeave;
+      } else {
+        last = word;
+        if (tid == 0) s_req[0] = 0u;
+        if (tid < 16) s_req[2 + tid] = got;  // the request, as it sits in the mailbox
+      }
+    }
+    __syncthreads();
+    if ((unsigned)__builtin_amdgcn_readfirstlane((int)s_req[0]) == kResLeave) return;  // every wave of the workgroup, here
+    const unsigned flags = (unsigned)__builtin_amdgcn_readfirstlane((int)s_req[2 + 14]) & 0xFFu;
+    SlotArgs SA = P.slot[0];
+    {
+      double p7[7];
+#pragma unroll
+      for (int i = 0; i < 7; i++)
+        p7[i] = __hiloint2double(__builtin_amdgcn_readfirstlane((int)s_req[2 + 2 * i + 1]), __builtin_amdgcn_readfirstlane((int)s_req[2 + 2 * i]));
+      pose_from_pose7_dev(p7, xform_mode, SA.pose);
+      // (VALU results, uniform: back to scalar registers, where eval_cell expects a pose to live)
+#pragma unroll
+      for (int i = 0; i < 12; i++) SA.pose.M[i] = wave_uniform(SA.pose.M[i]);
+    }
+    SA.host_quad = (flags & kResRecord) ? 1 : 2;
+    SA.cellout_host = (flags & kResCellout) ? 1 : 0;
+    if (flags & kResJac) eval_cell<NT, true, false, NB, false, false, LAT, false, true>(P, SA, cl, 0, smem, rc);
+    else eval_cell<NT, false, false, NB, false, false, LAT, false, true>(P, SA, cl, 0, smem, rc);
+    rc.fresh = false;
+    t_idle = __builtin_amdgcn_s_memrealtime();
+  }
 }
 
 }  // namespace nid

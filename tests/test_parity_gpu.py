@@ -1013,3 +1013,85 @@ def test_direct_results_equal_in_launch_reduction(capi, synth, pair_S_edge, cfg,
             for blk, r in zip(blocks, ref):
                 assert _same_bits(blk[0], r[2]) and blk[28] == r[3]
     ctx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg", ["S", "A"])
+def test_resident_evaluator_equals_launches(capi, synth, cfg, monkeypatch, shape=512):
+    """The resident evaluator (nid_set_resident): single-pose requests are answered by a kernel that stays on the
+    device -- the SAME BITS as the launched kernels (6x6 system, chi2, count, per-cell outputs; cost + Jacobian and
+    cost-only), through every single-pose entry point; it is retired and restarted by a new target image, by an idle
+    host and by a shape change, results following the new state; a kernel that has left by itself (its idle limit,
+    shortened here) is noticed and the request is re-issued as an ordinary launch."""
+    import time
+    pair = synth.make_pair(cfg)
+    other = synth.make_pair(cfg, flash=True) if cfg == "A" else synth.make_pair("S", edge_cases=True)
+    nb = 8
+    ctx = capi.from_pair(pair, nb)
+    ctx.compute_href(pair.pose_init)
+    ctx.set_launch_shape(shape, 0)
+    poses = list(_poses(synth, pair).values())
+
+    def reference():
+        ctx.set_resident(False)
+        r = [(ctx.normal_equations(p, DELTA), ctx.normal_equations(p, DELTA, want_jac=False), ctx.evaluate(p, True)) for p in poses]
+        ctx.set_resident(True)
+        return r
+
+    def check(ref, mixed=True):
+        for p, (rj, rc, rcell) in zip(poses, ref):
+            got = ctx.normal_equations(p, DELTA)
+            assert _same_bits(got[0], rj[0]) and _same_bits(got[1], rj[1]) and _same_bits(got[2], rj[2]) and got[3] == rj[3]
+            got = ctx.normal_equations(p, DELTA, want_jac=False)
+            assert _same_bits(got[2], rc[2]) and got[3] == rc[3]
+            cells = ctx.evaluate(p, True)
+            for k in range(4):
+                assert _same_bits(cells[k], rcell[k])
+            ctx.launch(3, p, DELTA)                  # launch + wait
+            if mixed:                                # an ordinary launch meanwhile: the request is collected, the kernel retired
+                ctx.launch_batch(8, poses[:2], DELTA, want_jac=False)
+            g3 = ctx.wait(3)
+            assert _same_bits(g3[0], rj[0]) and _same_bits(g3[2], rj[2])
+            if mixed:
+                g8, g9 = ctx.wait(8), ctx.wait(9)
+                assert _same_bits(g8[2], ref[0][1][2]) and _same_bits(g9[2], ref[1][1][2])
+        blocks, _ = ctx.run_chain(poses, DELTA)
+        for blk, (rj, _, _) in zip(blocks, ref):
+            assert _same_bits(blk[0], rj[2]) and blk[28] == rj[3]
+
+    ref = reference()
+    s0 = ctx.resident_stats()
+    check(ref, mixed=False)
+    s1 = ctx.resident_stats()
+    assert s1["served"] - s0["served"] >= 5 * len(poses) and s1["fallbacks"] == s0["fallbacks"] and s1["starts"] == s0["starts"] + 1
+    # an idle host retires the kernel; the next request starts another
+    time.sleep(0.08)
+    check(ref, mixed=False)
+    assert ctx.resident_stats()["starts"] == s1["starts"] + 1 and ctx.resident_stats()["fallbacks"] == s1["fallbacks"]
+    # ordinary launches in between: every one of them retires the kernel
+    check(ref)
+    assert ctx.resident_stats()["starts"] >= s1["starts"] + 1 + len(poses) and ctx.resident_stats()["fallbacks"] == s1["fallbacks"]
+    # new target image: retired, restarted, results follow
+    ctx.set_target(other.im1)
+    ref2 = reference()
+    assert not _same_bits(ref2[0][0][2], ref[0][0][2])
+    check(ref2)
+    # another shape: the resident kernel serves the 512-thread shape only, everything else is launched as ever
+    ctx.set_launch_shape(1024, 0)
+    before = ctx.resident_stats()["served"]
+    check(reference())
+    assert ctx.resident_stats()["served"] == before
+    ctx.close()
+    # a kernel that leaves by itself after 1 ms: the unanswered request is re-issued as an ordinary launch
+    monkeypatch.setenv("NID_RESIDENT_IDLE_US", "1000")
+    ctx = capi.from_pair(pair, nb)
+    ctx.compute_href(pair.pose_init)
+    ctx.set_launch_shape(shape, 0)
+    ref = reference()
+    check(ref, mixed=False)
+    for _ in range(3):
+        time.sleep(0.01)
+        check(ref, mixed=False)
+    st = ctx.resident_stats()
+    assert st["fallbacks"] >= 3 and st["served"] > 0
+    ctx.close()
