@@ -56,6 +56,10 @@ void nid_legacy_set_device(int device);
 // threads per workgroup of the operators' launches (nid_set_launch_shape in nid_c.h); jac_threads -1 (default): 512 with
 // up to 256 cells per shard, 256 beyond
 void nid_legacy_set_launch_shape(int jac_threads, int cost_threads);
+// 1: the operators' single-pose evaluations are answered by the resident evaluator (nid_set_resident in nid_c.h:
+// a kernel that stays on the device between calls; FAST math, 512-thread shape, i.e. up to 256 cells per shard);
+// silently the launched form wherever it does not apply.  Default 0; also switched on by NID_LEGACY_RESIDENT=1.
+void nid_legacy_set_resident(int on);
 // Multi-GPU (include/nid/nid_multi.h): the operators shard the cells of the frame pair over `n` devices of THIS
 // process (entries may repeat); reduce_rccl != 0 sums the fused 6x6 blocks with RCCL instead of on the host ...
 void nid_legacy_set_devices(const int32_t *devices, int n, int reduce_rccl);

@@ -7,7 +7,7 @@
 //
 // Inputs: the config keys of config_eth_cvg.yaml (image0_id, image1_id,
 // image0_type, image1_type, dataset, im_address, depth_factor, fx, fy, cx, cy,
-// use_gpu) plus optional cell / bin_num / iterations / fused / strict_math / pyramid_levels.  Images are read from
+// use_gpu) plus optional cell / bin_num / iterations / fused / resident / strict_math / pyramid_levels.  Images are read from
 // <im_address><type>/<id>.png and <im_address>depth/<id>.png as in the reference (decoded
 // by host/nid_png.cpp on zlib; colour -> grey with the reference's imread/cvtColor channel
 // order), or the same stems with .pgm (binary PGM, 8-bit grey / 16-bit depth;
@@ -194,6 +194,9 @@ int main(int argc, char **argv) {
   pb.im0 = im0.data(); pb.im1 = im1.data(); pb.depth_u16 = d0.data(); pb.T_wc0_colmajor = T_wc0.data();
   pb.fused = fc.count("fused") ? std::atoi(fc["fused"].c_str()) : 0;
   pb.strict_math = fc.count("strict_math") ? std::atoi(fc["strict_math"].c_str()) : 0;
+  // not in the reference: "resident: 1" answers the single-pose evaluations of the optimisation from a kernel that
+  // stays on the device (nid_set_resident in include/nid/nid_c.h); best with "fused: 4"
+  if (fc.count("resident")) nid_host_set_resident(std::atoi(fc["resident"].c_str()));
   if (fc.count("devices")) {
     // not in the reference: the cells of the pair sharded over several GPUs of this node (include/nid/nid_multi.h),
     // e.g. "devices: 0,1,2,3"; "reduce_rccl: 1" sums the 6x6 blocks with RCCL instead of on the host

@@ -441,7 +441,7 @@ MULTI_SYMBOLS = [
     "nid_comm_create_local", "nid_comm_destroy", "nid_comm_ranks", "nid_multi_attach_comm", "nid_multi_comm_init",
     "nid_multi_comm_init_local", "nid_multi_comm_ranks", "nid_multi_set_exchange_hook", "nid_multi_set_reduce_mode",
     "nid_multi_set_options",
-    "nid_multi_set_math_mode", "nid_multi_set_block_threads", "nid_multi_set_launch_shape", "nid_multi_set_reference_depth",
+    "nid_multi_set_math_mode", "nid_multi_set_block_threads", "nid_multi_set_launch_shape", "nid_multi_set_resident", "nid_multi_set_reference_depth",
     "nid_multi_set_reference_points", "nid_multi_set_target_u8", "nid_multi_compute_href",
     "nid_multi_compute_href_matrix", "nid_multi_set_href_state", "nid_multi_evaluate", "nid_multi_evaluate_matrix",
     "nid_multi_normal_equations", "nid_multi_launch_batch", "nid_multi_launch_chain", "nid_multi_wait", "nid_multi_run_sequence",

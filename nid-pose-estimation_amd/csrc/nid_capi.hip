@@ -828,10 +828,16 @@ bool resident_usable(const nid_ctx *ctx) {
 // hand one request to the resident kernel (starting it if need be); NID_ERR_UNSUPPORTED: use an ordinary launch
 int resident_post(nid_ctx *ctx, int slot, const Pose &pose, bool jac, bool want_cellout) {
   nid_ctx::Resident &R = ctx->res;
-  {  // the mailbox carries a pose7; the kernel forms the matrix from it: only poses whose matrix IS that matrix
+  // the mailbox carries a pose7 and the kernel forms the matrix from it -- if the pose's matrix IS that matrix;
+  // a pose that exists only as a matrix (nid_evaluate_matrix) goes as the matrix, in two lines
+  bool as_matrix = false;
+  {
     Pose chk;
     pose_from_pose7(pose.q, pose.mode, &chk);
-    if (std::memcmp(chk.M, pose.M, sizeof(chk.M)) != 0) return NID_ERR_STATE;  // (nid_evaluate_matrix: an ordinary launch)
+    if (std::memcmp(chk.M, pose.M, sizeof(chk.M)) != 0) {
+      if (pose.mode != NID_XFORM_MATRIX) return NID_ERR_STATE;
+      as_matrix = true;
+    }
   }
   const auto now = std::chrono::steady_clock::now();
   if (R.running && (R.nt != ctx->jac_threads || now - R.last_post > kResidentHostIdle)) resident_retire(ctx);
@@ -840,15 +846,23 @@ int resident_post(nid_ctx *ctx, int slot, const Pose &pose, bool jac, bool want_
     if (rc) { if (rc == NID_ERR_UNSUPPORTED) R.probed = -1; return rc; }
   }
   R.pose = pose; R.jac = jac; R.want_cellout = want_cellout;
-  // the mailbox line: pose7, a store fence, (number << 8 | flags), a store fence (ResidentCtl)
+  // the mailbox line(s): the payload, a store fence, (number << 8 | flags), a store fence (ResidentCtl)
   volatile unsigned long long *dst = R.ctl->w;
-  unsigned long long words[7];
-  std::memcpy(words, pose.q, sizeof(words));
-  for (int i = 0; i < 7; i++) dst[i] = words[i];
+  unsigned long long words[12];
+  const unsigned flags = (jac ? kResJac : 0u) | (want_cellout ? kResCellout : kResRecord) | (as_matrix ? kResMatrix : 0u);
+  if (as_matrix) {
+    std::memcpy(words, pose.M, sizeof(words));
+    for (int i = 0; i < 7; i++) dst[i] = words[i];
+    for (int i = 0; i < 5; i++) dst[8 + i] = words[7 + i];
+  } else {
+    std::memcpy(words, pose.q, 7 * sizeof(words[0]));
+    for (int i = 0; i < 7; i++) dst[i] = words[i];
+  }
   store_fence();
-  const unsigned flags = (jac ? kResJac : 0u) | (want_cellout ? kResCellout : kResRecord);
-  dst[7] = (++R.seq << 8) | flags;
-  store_fence();  // out of the write-combining buffer now
+  const unsigned long long word = (++R.seq << 8) | flags;
+  if (as_matrix) dst[15] = word;
+  dst[7] = word;
+  store_fence();  // out of the write-combining buffers now
   R.last_post = std::chrono::steady_clock::now();
   R.pending_slot = slot;
   return NID_OK;

@@ -2267,8 +2267,10 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu((STRICT || D
 // of the line in one request -- has the request's pose in the same registers: no second trip to memory.  The 3x4
 // matrix is formed on the device with the host's operations (pose_from_pose7 in nid_capi.hip: IEEE, no contraction:
 // the same bits).  Eighth word: (number << 8) | flags; kResExitWord: leave.
+// A pose that exists only as a matrix (the legacy operators hand over a 4x4: nid_evaluate_matrix) takes a second line:
+// M[0..6] | word, M[7..11], 0, 0 | the same word; such a request has arrived when both lines carry its word.
 struct ResidentCtl {
-  unsigned long long w[8];
+  unsigned long long w[16];
 };
 constexpr unsigned long long kResExitWord = ~0ull;
 // (measured on A, 256 workgroups: one load at a time + 8 x 64 clocks of sleep answers first; deeper pipelines of loads
@@ -2280,7 +2282,7 @@ constexpr unsigned long long kResExitWord = ~0ull;
 #define NID_RES_POLL_SLEEP 8
 #endif
 constexpr int kResPollDepth = NID_RES_POLL_DEPTH;
-constexpr unsigned kResJac = 1u, kResRecord = 2u, kResCellout = 4u, kResLeave = 0xFFFFFFFFu;
+constexpr unsigned kResJac = 1u, kResRecord = 2u, kResCellout = 4u, kResMatrix = 8u, kResLeave = 0xFFFFFFFFu;
 
 // pose_from_pose7 (nid_capi.hip) on the device: to_homogeneous_matrix (se3quat.h:270-278) = Eigen toRotationMatrix
 __device__ __forceinline__ void pose_from_pose7_dev(const double *p, int mode, Pose &out) {
@@ -2312,7 +2314,7 @@ template <int NT, int NB, int LAT>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT == 512 ? 2 : 4))) void k_resident(EvalParams P, const ResidentCtl *ctl, unsigned long long word0, long long idle_ticks,
                                                                                                          int xform_mode) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  __shared__ unsigned s_req[2 + 16];  // kResLeave or 0 | (unused) | the request as it sits in the mailbox
+  __shared__ unsigned s_req[2 + 32];  // kResLeave or 0 | (unused) | the request as it sits in the mailbox
   const Geometry &g = P.g;
   const int tid = threadIdx.x;
   const int cl = (int)(blockIdx.x >> 3) * 8 + (int)(blockIdx.x & 7);  // k_eval2's map for one pose
@@ -2333,7 +2335,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT == 512 ? 
       // would notice a request between one and two load times after it was written; with kResPollDepth loads in flight
       // (they return in order: each turn waits for the oldest and issues a new one, then sleeps so that 256
       // workgroups do not saturate the line's memory channel) it is noticed within about one load time.
-      const unsigned *mail = reinterpret_cast<const unsigned *>(ctl) + (tid & 15);
+      const unsigned *mail = reinterpret_cast<const unsigned *>(ctl) + (tid & 31);
       unsigned w[kResPollDepth];
 #pragma unroll
       for (int k = 0; k < kResPollDepth; k++) w[k] = ld_sys_u32(mail);
@@ -2347,8 +2349,10 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT == 512 ? 
           if (!done) {
             const unsigned long long t = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)v, 15) << 32) |
                                          (unsigned)__builtin_amdgcn_readlane((int)v, 14);
+            const unsigned long long t1 = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)v, 31) << 32) |
+                                          (unsigned)__builtin_amdgcn_readlane((int)v, 30);
             if (t == kResExitWord) { leave = 1u; done = true; }
-            else if (t != last) { got = v; word = t; done = true; }
+            else if (t != last && (!(t & kResMatrix) || t1 == t)) { got = v; word = t; done = true; }
             else __builtin_amdgcn_s_sleep(NID_RES_POLL_SLEEP);
           }
         }
@@ -2359,7 +2363,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT == 512 ? 
       } else {
         last = word;
         if (tid == 0) s_req[0] = 0u;
-        if (tid < 16) s_req[2 + tid] = got;  // the request, as it sits in the mailbox
+        if (tid < 32) s_req[2 + tid] = got;  // the request, as it sits in the mailbox
       }
     }
     __syncthreads();
@@ -2367,11 +2371,21 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT == 512 ? 
     const unsigned flags = (unsigned)__builtin_amdgcn_readfirstlane((int)s_req[2 + 14]) & 0xFFu;
     SlotArgs SA = P.slot[0];
     {
-      double p7[7];
+      double p7[7], m5[5];
 #pragma unroll
       for (int i = 0; i < 7; i++)
         p7[i] = __hiloint2double(__builtin_amdgcn_readfirstlane((int)s_req[2 + 2 * i + 1]), __builtin_amdgcn_readfirstlane((int)s_req[2 + 2 * i]));
+#pragma unroll
+      for (int i = 0; i < 5; i++)
+        m5[i] = __hiloint2double(__builtin_amdgcn_readfirstlane((int)s_req[2 + 16 + 2 * i + 1]), __builtin_amdgcn_readfirstlane((int)s_req[2 + 16 + 2 * i]));
       pose_from_pose7_dev(p7, xform_mode, SA.pose);
+      if (flags & kResMatrix) {  // pose_from_matrix16 (nid_capi.hip): the matrix as it is, computeH.cu:152-154 semantics
+#pragma unroll
+        for (int i = 0; i < 7; i++) { SA.pose.q[i] = i == 3 ? 1.0 : 0.0; SA.pose.M[i] = p7[i]; }
+#pragma unroll
+        for (int i = 0; i < 5; i++) SA.pose.M[7 + i] = m5[i];
+        SA.pose.mode = 1;  // NID_XFORM_MATRIX
+      }
       // (VALU results, uniform: back to scalar registers, where eval_cell expects a pose to live)
 #pragma unroll
       for (int i = 0; i < 12; i++) SA.pose.M[i] = wave_uniform(SA.pose.M[i]);

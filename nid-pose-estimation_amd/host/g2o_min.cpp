@@ -485,7 +485,15 @@ OptimizationAlgorithmLevenberg::SolverResult OptimizationAlgorithmLevenberg::sol
     opt->update(_solver->x());
     _solver->restoreDiagonal();
     opt->_vertices[0]->estimate().toPose7(p7);
-    if (nid_multi_normal_equations(ctx, p7, 0, delta, nullptr, nullptr, &tempChi, &na) != NID_OK) return Fail;
+    // The FIRST trial -- the one a steady iteration accepts -- is evaluated WITH its Jacobian if asked for
+    // (setSpeculativeJacobian without speculative trials: fused 4): accepted, it IS the next outer iteration's
+    // evaluation -- one single-pose round trip per outer iteration, which is what the resident evaluator answers
+    // fastest (the chi2 of a pose is the same bits with and without the Jacobian phase).
+    const bool with_jac = _speculativeJacobian && qmax == 0;
+    double H0[36], b0[6];
+    if (nid_multi_normal_equations(ctx, p7, with_jac ? 1 : 0, delta, with_jac ? H0 : nullptr, with_jac ? b0 : nullptr, &tempChi, &na) != NID_OK)
+      return Fail;
+    const double trialChi = tempChi;
     if (!ok2) tempChi = std::numeric_limits<double>::max();
     rho = (currentChi - tempChi);
     double scale = computeScale();
@@ -499,6 +507,13 @@ OptimizationAlgorithmLevenberg::SolverResult OptimizationAlgorithmLevenberg::sol
       _ni = 2;
       currentChi = tempChi;
       opt->discardTop();
+      if (with_jac) {
+        _haveNext = true;
+        std::memcpy(_nextPose, p7, sizeof(_nextPose));
+        std::memcpy(_nextH, H0, sizeof(_nextH));
+        std::memcpy(_nextB, b0, sizeof(_nextB));
+        _nextChi = trialChi;
+      }
     } else {
       _currentLambda *= _ni;
       _ni *= 2;
@@ -506,6 +521,9 @@ OptimizationAlgorithmLevenberg::SolverResult OptimizationAlgorithmLevenberg::sol
     }
     qmax++;
   } while (rho < 0 && qmax < _maxTrialsAfterFailure);
+  if (lm_trace)
+    std::fprintf(stderr, "[lm] it %d: setup until %.1f us, J until %.1f us%s, %d sequential trials%s, end %.1f us\n", iteration, t_setup, t_jac,
+                 t_jac - t_setup < 2.0 ? " (carried over)" : "", qmax, _speculativeJacobian ? " (first with J)" : "", us_since(t_start));
   _lastRho = rho;
   _fusedChi = currentChi;
   if (qmax == _maxTrialsAfterFailure || rho == 0) return Terminate;

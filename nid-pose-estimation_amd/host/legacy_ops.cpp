@@ -44,6 +44,12 @@ int g_reduce_rccl = 0;
 // Blocking single-pose calls are latency bound: with up to 256 cells per shard (one workgroup per CU) 512-thread
 // workgroups for the Jacobian launch, 256 beyond; cost-only launches shaped per launch (profiles/r02_launch_cost_*.txt).
 int g_jac_threads = -1, g_cost_threads = 0;  // nid_legacy_set_launch_shape; -1 = by shard size
+int g_resident = -1;                         // nid_legacy_set_resident; -1 = the NID_LEGACY_RESIDENT environment variable
+bool resident_wanted() {
+  if (g_resident >= 0) return g_resident != 0;
+  const char *e = getenv("NID_LEGACY_RESIDENT");
+  return e && e[0] == '1';
+}
 
 int jac_threads_for(int cells, int shards) {
   if (g_jac_threads >= 0) return g_jac_threads;
@@ -112,6 +118,7 @@ nid_multi *get_multi(int rows, int cols, int cell, int bins, int deg, const doub
   // the operators are blocking, one pose (or one LM rejection chain) at a time: latency matters, not the
   // pipelined throughput the 128-thread default is tuned for (nid_set_launch_shape, tools/latency_sweep.py)
   nid_multi_set_launch_shape(m, jac_threads_for(cell * cell, g_world > 1 ? g_world : (int)g_devices.size()), g_cost_threads);
+  if (resident_wanted()) (void)nid_multi_set_resident(m, 1);  // (unsupported platform: the launched form)
   S.m = m; S.rows = rows; S.cols = cols; S.cell = cell; S.bins = bins;
   std::memcpy(S.intr, intr, sizeof(S.intr));
   return m;
@@ -264,6 +271,11 @@ void nid_legacy_set_jacobian_bound(int mode) {
 void nid_legacy_set_math_mode(int mode) {
   g_math_mode = mode ? NID_MATH_STRICT : NID_MATH_FAST;
   if (g_state.m) nid_multi_set_math_mode(g_state.m, g_math_mode);
+}
+
+void nid_legacy_set_resident(int on) {
+  g_resident = on ? 1 : 0;
+  if (g_state.m) (void)nid_multi_set_resident(g_state.m, g_resident);
 }
 
 void nid_legacy_set_launch_shape(int jac_threads, int cost_threads) {

@@ -17,6 +17,7 @@ static double g_last_optimize_s = 0.0;
 double nid_host_last_optimize_seconds(void) { return g_last_optimize_s; }
 
 void nid_host_set_devices(const int32_t *devices, int n, int reduce_rccl) { nid_legacy_set_devices(devices, n, reduce_rccl); }
+void nid_host_set_resident(int on) { nid_legacy_set_resident(on); }
 void nid_host_set_rank(int device, int rank, int world, const uint8_t *rccl_id128) { nid_legacy_set_rank(device, rank, world, rccl_id128); }
 
 int nid_host_run_lm(const nid_pose_problem *pb, double *pose7_inout, nid_host_lm_record *trace,
@@ -42,8 +43,8 @@ int nid_host_run_lm(const nid_pose_problem *pb, double *pose7_inout, nid_host_lm
   g2o::BlockSolver_6_X *solver_ptr = new g2o::BlockSolver_6_X(linearSolver);
   g2o::OptimizationAlgorithmLevenberg *solver = new g2o::OptimizationAlgorithmLevenberg(solver_ptr);
   solver->setFusedNormalEquations(pb->fused != 0);
-  solver->setSpeculativeTrials(pb->fused >= 2);
-  solver->setSpeculativeJacobian(pb->fused == 3);
+  solver->setSpeculativeTrials(pb->fused == 2 || pb->fused == 3);
+  solver->setSpeculativeJacobian(pb->fused >= 3);
   optimizer.setAlgorithm(solver);
   optimizer.setVerbose(true);
   optimizer.setComputeBatchStatistics(true);

@@ -14,7 +14,10 @@ typedef struct {
   int32_t jac_bound_cuda;   /* 0 = CPU-edge bound (parity target), 1 = CUDA-kernel bound */
   int32_t fused;            /* 0 = per-edge walk like the reference, 1 = fused device normal equations,
                                2 = fused + the LM rejection chain evaluated in one batched launch,
-                               3 = 2 + the first trials evaluated with their Jacobian (one launch per outer iteration) */
+                               3 = 2 + the first trials evaluated with their Jacobian (one launch per outer iteration),
+                               4 = 1 + the first trial of every outer iteration evaluated with its Jacobian: nothing but
+                                   single-pose evaluations, one per outer iteration in the steady state (the flow the
+                                   resident evaluator -- nid_legacy_set_resident -- is made for) */
   int32_t strict_math;      /* 1 = NID_MATH_STRICT, 0 = NID_MATH_FAST */
   int32_t pad_;
   double fx, fy, cx, cy, depth_factor, huber_delta;
@@ -60,6 +63,8 @@ void nid_pyr_down_depth_u16(const uint16_t *src, int rows, int cols, double dept
  * nid_host_run_pyramid_lm shards the cells of each frame pair (each pyramid level) over these devices of this
  * process (entries may repeat; reduce_rccl: sum the 6x6 blocks with RCCL instead of on the host) ... */
 void nid_host_set_devices(const int32_t *devices, int n, int reduce_rccl);
+/* nid_legacy_set_resident (include/nid/legacy_ops.h) for C callers */
+void nid_host_set_resident(int on);
 /* ... or runs as rank `rank` of `world` processes, one per GPU, summing with RCCL (id: nid_multi_comm_unique_id
  * of rank 0).  Every rank runs the same optimisation and takes the same decisions. */
 void nid_host_set_rank(int device, int rank, int world, const uint8_t *rccl_id128);

@@ -59,6 +59,8 @@ def load():
     lib.nid_legacy_set_math_mode.argtypes = [C.c_int]
     lib.nid_legacy_set_launch_shape.restype = None
     lib.nid_legacy_set_launch_shape.argtypes = [C.c_int, C.c_int]
+    lib.nid_legacy_set_resident.restype = None
+    lib.nid_legacy_set_resident.argtypes = [C.c_int]
     lib.nid_host_set_devices.restype = None
     lib.nid_host_set_devices.argtypes = [C.POINTER(C.c_int32), C.c_int, C.c_int]
     lib.nid_host_set_rank.restype = None
@@ -226,6 +228,11 @@ def png_read_u16(path):
     if rc:
         raise RuntimeError(f"nid_png_read_u16({path}) -> {rc}")
     return out
+
+
+def set_resident(on):
+    """The legacy operators' / the host LM's single-pose evaluations through the resident evaluator (nid_set_resident)."""
+    load().nid_legacy_set_resident(1 if on else 0)
 
 
 def set_launch_shape(jac_threads, cost_threads):

@@ -248,6 +248,23 @@ def test_lm_fused_path_equals_per_edge_path(hostlib, synth, pair_A):
     assert [r["lm_trials"] for r in recs_d] == [r["lm_trials"] for r in recs_b]
     assert [r["chi2"] for r in recs_d] == [r["chi2"] for r in recs_b]
     assert np.array_equal(pose_d, pose_b)
+    # fused 4: sequential trials, the first of every outer iteration with its Jacobian -- nothing but single-pose
+    # evaluations; then the same, and the reference's per-edge flow, answered by the RESIDENT evaluator (a kernel that
+    # stays on the device): the same bits again
+    pose_e, recs_e, _ = hostlib.run_lm(pair, nb, pair.pose_init, 10, fused=4)
+    assert [r["chi2"] for r in recs_e] == [r["chi2"] for r in recs_b] and np.array_equal(pose_e, pose_b)
+    hostlib.set_resident(True)
+    try:
+        pose_f, recs_f, _ = hostlib.run_lm(pair, nb, pair.pose_init, 10, fused=4)
+        assert [r["chi2"] for r in recs_f] == [r["chi2"] for r in recs_b] and np.array_equal(pose_f, pose_b)
+        pose_g, recs_g, _ = hostlib.run_lm(pair, nb, pair.pose_init, 10, fused=1)
+        assert [r["chi2"] for r in recs_g] == [r["chi2"] for r in recs_b] and np.array_equal(pose_g, pose_b)
+        pose_h, recs_h, _ = hostlib.run_lm(pair, nb, pair.pose_init, 10, fused=False)
+        assert [r["chi2"] for r in recs_h] == [r["chi2"] for r in recs_a] and np.array_equal(pose_h, pose_a)
+        pose_i, recs_i, _ = hostlib.run_lm(pair, nb, pair.pose_init, 10, fused=3)   # batched trials retire the kernel: still the same
+        assert [r["chi2"] for r in recs_i] == [r["chi2"] for r in recs_b] and np.array_equal(pose_i, pose_b)
+    finally:
+        hostlib.set_resident(False)
 
 
 def test_pyramid_lm_pose_parity(hostlib, oracle, synth, pair_A):
