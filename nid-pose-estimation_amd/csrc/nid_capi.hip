@@ -766,11 +766,19 @@ template <int NT, int NB>
 int resident_launch_t(nid_ctx *ctx, const EvalParams &P, size_t lds, unsigned grid) {
   constexpr int LAT = NT == 512 ? 3 : 2;
   nid_ctx::Resident &R = ctx->res;
-  // every workgroup must be ON the device for a request to be answered: check before launching
-  int per_cu = 0, cus = 0;
-  NID_HIP(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_resident<NT, NB, LAT>, NT, lds));
+  // every workgroup must be ON the device for a request to be answered.  A 512-thread workgroup of this kernel is two
+  // waves per SIMD with up to 256 registers each and > 100 KB of LDS: exactly one fits a CU, so the grid must not
+  // exceed the CU count.  (Not hipOccupancyMaxActiveBlocksPerMultiprocessor: the ROCm 7.0 runtime a torch process
+  // carries answers 0 for any kernel with more than 64 KB of dynamic LDS, which the device runs all the same.)
+  int cus = 0;
   NID_HIP(ctx, hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->cfg.device));
-  if ((long)per_cu * cus < (long)grid) return NID_ERR_UNSUPPORTED;
+  if ((long)cus < (long)grid) {
+    ctx->last_error = "resident evaluator: " + std::to_string(grid) + " workgroups of " + std::to_string(lds) + " B of LDS on " +
+                      std::to_string(cus) + " CUs";
+    return NID_ERR_UNSUPPORTED;
+  }
+  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_resident<NT, NB, LAT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  (void)hipGetLastError();
   long long idle_ticks = kResidentIdleTicks;
   if (const char *e = getenv("NID_RESIDENT_IDLE_US")) idle_ticks = std::max(1L, atol(e)) * 100;  // tests: a kernel that leaves early
   // the mailbox word the kernel starts from (whatever is there now is not a request)
@@ -786,7 +794,7 @@ int resident_launch_t(nid_ctx *ctx, const EvalParams &P, size_t lds, unsigned gr
 int resident_start(nid_ctx *ctx, int nt) {
   nid_ctx::Resident &R = ctx->res;
   int rc = resident_probe(ctx);
-  if (rc) return rc;
+  if (rc) { ctx->last_error = "resident evaluator: mailbox probe failed"; return rc; }
   EvalParams P{};
   fill_common_params(ctx, 1.0, &P);  // (the Huber weights of a DIRECT launch are the host's business)
   P.batch = 1;
@@ -799,10 +807,10 @@ int resident_start(nid_ctx *ctx, int nt) {
   A.launch_seq = 0; A.cellout_host = 0; A.host_quad = 1;
   // eval_cell's LDS + the cell's tile entries (k_eval2's LAT branch, RES): rounds x threads x (7 doubles + 1 int)
   const size_t lds = eval_lds_bytes(P.g, nt) + 16 + (size_t)lat_rounds(nt) * nt * (7 * 8 + 4);
-  if (lds > 160 * 1024) return NID_ERR_UNSUPPORTED;
+  if (lds > 160 * 1024) { ctx->last_error = "resident evaluator: LDS request " + std::to_string(lds); return NID_ERR_UNSUPPORTED; }
   const unsigned grid = (unsigned)(((P.g.nloc + 7) / 8) * 8);
   const int nb = P.g.nb;
-  if (nt != 512) return NID_ERR_UNSUPPORTED;
+  if (nt != 512) { ctx->last_error = "resident evaluator: shape " + std::to_string(nt); return NID_ERR_UNSUPPORTED; }
   rc = nb == 8 ? resident_launch_t<512, 8>(ctx, P, lds, grid) : (nb == 10 ? resident_launch_t<512, 10>(ctx, P, lds, grid) : resident_launch_t<512, 0>(ctx, P, lds, grid));
   if (rc) return rc;
   R.running = true;
@@ -843,7 +851,11 @@ int resident_post(nid_ctx *ctx, int slot, const Pose &pose, bool jac, bool want_
   if (R.running && (R.nt != ctx->jac_threads || now - R.last_post > kResidentHostIdle)) resident_retire(ctx);
   if (!R.running) {
     int rc = resident_start(ctx, ctx->jac_threads);
-    if (rc) { if (rc == NID_ERR_UNSUPPORTED) R.probed = -1; return rc; }
+    if (rc) {
+      if (getenv("NID_RESIDENT_DEBUG")) fprintf(stderr, "[nid resident] start failed: %d %s\n", rc, ctx->last_error.c_str());
+      if (rc == NID_ERR_UNSUPPORTED) R.probed = -1;
+      return rc;
+    }
   }
   R.pose = pose; R.jac = jac; R.want_cellout = want_cellout;
   // the mailbox line(s): the payload, a store fence, (number << 8 | flags), a store fence (ResidentCtl)
