@@ -155,11 +155,22 @@ def pose_error_vs_ref(pair, bins):
     hostlib = importlib.import_module("nid-pose-estimation_amd.hostlib")
     synth = importlib.import_module("nid-pose-estimation_amd.synth")
     runs = {}
-    for name, fused in (("hip_reference_flow", 0), ("hip_fused", 1), ("hip_fused_batched_trials", 2)):
+    flows = (("hip_reference_flow", 0, False), ("hip_fused", 1, False), ("hip_fused_batched_trials", 2, False),
+             ("hip_fused_first_trial_with_jacobian", 4, False),
+             # the same flows answered by the resident evaluator (nid_legacy_set_resident): same bits, no launches
+             ("hip_reference_flow_resident", 0, True), ("hip_fused_first_trial_with_jacobian_resident", 4, True))
+    for name, fused, resident in flows:
+        hostlib.set_resident(resident)
         hostlib.run_lm(pair, bins, pair.pose_init, 10, fused=fused)     # warm (library, clocks)
-        t0 = time.perf_counter()
-        pose, recs, _ = hostlib.run_lm(pair, bins, pair.pose_init, 10, fused=fused)
-        runs[name] = dict(pose=pose, recs=recs, wall=time.perf_counter() - t0, opt=hostlib.last_optimize_seconds())
+        best = None
+        for _ in range(3):
+            t0 = time.perf_counter()
+            pose, recs, _ = hostlib.run_lm(pair, bins, pair.pose_init, 10, fused=fused)
+            r = dict(pose=pose, recs=recs, wall=time.perf_counter() - t0, opt=hostlib.last_optimize_seconds())
+            if best is None or r["opt"] < best["opt"]:
+                best = r
+        runs[name] = best
+    hostlib.set_resident(False)
     o = oracle_py.from_pair(pair, bins, jac_bound="cpu", xform="matrix")
     o.compute_href(pair.pose_init)
     t0 = time.perf_counter()
@@ -198,11 +209,15 @@ def pose_error_vs_ref(pair, bins):
         "lm_wall_s": {k: v["wall"] for k, v in runs.items()} | {"cpu_oracle_1core": t_cpu},
         "optimize_only_s": {k: v["opt"] for k, v in runs.items()},
         # the DEPENDENT rates: what a real optimisation gets out of the path
-        "lm_outer_iterations_per_s": n_outer / spec["opt"],
+        "lm_outer_iterations_per_s": n_outer / min(v["opt"] for v in runs.values()),
+        "lm_outer_iterations_per_s_by_flow": {k: len(v["recs"]) / v["opt"] for k, v in runs.items()},
         "lm_evaluations_per_s_reference_flow": n_eval / ref["opt"],
-        "note": "lm_wall_s includes the per-pair setup (upload, back-projection, reference weights); "
-                "reference schedule = 1 Jacobian + k cost-only + 1 verbose evaluation per outer iteration; "
-                "lm_outer_iterations_per_s = outer iterations / optimize() time of the fused + batched-trials path",
+        "all_flows_same_pose_bits": bool(all(np.array_equal(v["pose"], runs["hip_fused"]["pose"]) for k, v in runs.items() if "reference_flow" not in k)),
+        "note": "lm_wall_s includes the per-pair setup (upload, back-projection, reference weights); optimize_only_s is the "
+                "optimize() call alone, which still contains the pair's first-use uploads and, for the resident flows, the "
+                "start of the resident kernel; reference schedule = 1 Jacobian + k cost-only + 1 verbose evaluation per outer "
+                "iteration; lm_outer_iterations_per_s = outer iterations / optimize() time of the fastest flow; a steady outer "
+                "iteration (first trial accepted, its Jacobian carried over) is ONE evaluation: roofline.sequential",
     }
 
 
@@ -497,17 +512,40 @@ def main():
             chain = pose_arr[np.arange(nseq) % len(poses)]
             per_pose = kctx.contract_bytes()
             seq = {}
+
+            def chain_rate(direct, resident):
+                ctx.set_direct_results(direct)
+                ctx.set_resident(resident)
+                ctx.run_chain(chain[:200], delta, want_jac=want_jac, collect=False)
+                el = min(ctx.run_chain(chain, delta, want_jac=want_jac, collect=False)[1] for _ in range(3))
+                return {"it_per_s": nseq / el, "us_per_evaluation": el / nseq * 1e6, "frac": per_pose / (el / nseq) / 1e9 / HBM_PEAK_GBS}
+
             for name, nt in (("throughput_shape_128", 128), ("latency_shape_512", 512)):
                 ctx.set_launch_shape(nt, nt)
-                ctx.run_chain(chain[:200], delta, want_jac=want_jac, collect=False)
-                _, el = ctx.run_chain(chain, delta, want_jac=want_jac, collect=False)
-                one = float(np.median([kctx.time_launches(pose_arr[[i]], delta, repeats=10, want_jac=want_jac) for i in range(8)]))
-                seq[name] = {"it_per_s": nseq / el, "us_per_evaluation": el / nseq * 1e6, "kernel_us_one_pose": one * 1e3,
-                             "frac": per_pose / (el / nseq) / 1e9 / HBM_PEAK_GBS}
+                seq[name] = chain_rate(True, False)       # the library's default: DIRECT results, launched kernels
+                seq[name]["kernel_us_one_pose"] = 1e3 * float(np.median([kctx.time_launches(pose_arr[[i]], delta, repeats=10, want_jac=want_jac) for i in range(8)]))
+                if nt == 512:
+                    seq[name]["in_launch_reduction"] = chain_rate(False, False)
+                    try:
+                        seq[name]["resident_evaluator"] = chain_rate(True, True)
+                        seq[name]["resident_evaluator"]["stats"] = ctx.resident_stats()
+                    except Exception as e:   # noqa: BLE001 -- a platform without a CPU-addressable BAR
+                        seq[name]["resident_evaluator"] = {"error": str(e)[:200]}
+                    ctx.set_resident(False)
+                    ctx.set_direct_results(True)
             ctx.set_launch_shape(args.block_threads, args.block_threads)
-            roof["sequential"] = dict(seq["latency_shape_512"], threads_per_cell=512, throughput_shape_128=seq["throughput_shape_128"],
-                                      note="nid_run_chain: one pose per launch, the host waits for each 6x6 system before it launches "
-                                           "the next (launch + kernel + result in host memory)")
+            best = seq["latency_shape_512"].get("resident_evaluator", {})
+            head = best if "it_per_s" in best else seq["latency_shape_512"]
+            roof["sequential"] = dict(it_per_s=head["it_per_s"], us_per_evaluation=head["us_per_evaluation"], frac=head["frac"],
+                                      form="resident evaluator" if head is best else "launched, DIRECT results",
+                                      threads_per_cell=512, latency_shape_512=seq["latency_shape_512"],
+                                      throughput_shape_128=seq["throughput_shape_128"],
+                                      note="nid_run_chain: one pose per evaluation, the host waits for each 6x6 system before it "
+                                           "asks for the next.  latency_shape_512: launched kernels with DIRECT results (every "
+                                           "cell's record straight to pinned host memory, summed by the host; the default), "
+                                           ".in_launch_reduction (round 2's form: two-level ticket reduction in the kernel), "
+                                           ".resident_evaluator (nid_set_resident: no launch at all, a kernel that stays on the "
+                                           "device answers requests from a mailbox); all three give the same bits")
             # the other math mode in the same run
             other = capi.MATH_FAST if args.strict else capi.MATH_STRICT
             ctx.set_math_mode(other)

@@ -43,6 +43,7 @@ struct Slot {
   bool direct = false;             // the launch in flight is a DIRECT one: the host forms and sums the cells' quadratic forms
   bool resident = false;           // ... it is a request to the resident kernel (its records arrive in ctx->res.rec_host)
   bool collected = false;          // its result is in reduced_host already (resident_quiesce): nid_wait only hands it over
+  bool quad_dirty = false;         // a DIRECT launch wrote (or may still write) into quad_host and wait_direct has not consumed it
   bool direct_jac = false;         // ... it carries Jacobians
   double direct_delta = 0.0;       // ... its Huber delta
   unsigned long long seq = 0;      // sequence number of the last launch into this slot
@@ -453,6 +454,13 @@ void fill_sentinel(double *p, size_t n) {
 }
 
 int ensure_quad_host(nid_ctx *ctx, Slot &S) {
+  if (S.quad_host && S.quad_dirty) {
+    // the previous DIRECT launch into this buffer was never collected (its wait failed): let it finish, start clean
+    NID_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    NID_HIP(ctx, hipStreamSynchronize(ctx->aux_stream));
+    fill_sentinel(S.quad_host, (size_t)2 * ctx->g.nloc * kDirectRec);
+    S.quad_dirty = false;
+  }
   if (S.quad_host) return NID_OK;
   const size_t n = (size_t)2 * ctx->g.nloc * kDirectRec;
   if (hipHostMalloc(reinterpret_cast<void **>(&S.quad_host), n * sizeof(double), hipHostMallocMapped) != hipSuccess) {
@@ -649,6 +657,7 @@ int wait_direct(nid_ctx *ctx, Slot &S) {
     break;
   }
   if (S.resident) { ctx->res.pending_slot = -1; ctx->res.served++; S.resident = false; }
+  else S.quad_dirty = false;
   return NID_OK;
 }
 
@@ -914,6 +923,7 @@ int resident_fallback(nid_ctx *ctx, Slot &S) {
   fill_slot_args(R.pose, S, nullptr, nullptr, &A);
   A.quad = S.quad_host_devptr;
   A.host_quad = R.want_cellout ? 2 : 1;
+  S.quad_dirty = !R.want_cellout;
   if (R.want_cellout) { A.cellout = ctx->slots[0].cellout_host_devptr; A.cellout_host = 1; }
   NID_HIP(ctx, hipSetDevice(ctx->cfg.device));
   S.resident = false;  // from here on the wait is an ordinary DIRECT wait
@@ -955,6 +965,7 @@ int launch_slot(nid_ctx *ctx, int slot, const Pose &pose, int want_jac, double d
     if (rc) return rc;
     P.slot[0].quad = S.quad_host_devptr;
     P.slot[0].host_quad = 1;
+    S.quad_dirty = true;
   }
   if (ctx->dbg_enabled) {
     const size_t N = (size_t)ctx->g.rows * ctx->g.cols;
@@ -983,7 +994,7 @@ int launch_slot(nid_ctx *ctx, int slot, const Pose &pose, int want_jac, double d
 // pinned result block), so the reduction tails and the launch cost overlap with other poses' work
 // and two workgroups share a CU.  Results are collected per slot with nid_wait().
 int launch_batch(nid_ctx *ctx, int first_slot, int n, const Pose *poses, int want_jac, double delta,
-                 double *reduced_dev_base = nullptr, bool on_aux_stream = false, bool relaunch_ok = false) {
+                 double *reduced_dev_base = nullptr, bool on_aux_stream = false, bool relaunch_ok = false, bool allow_direct = true) {
   int rc = check_ready(ctx);
   if (rc) return rc;
   if (n < 1 || n > kMaxBatchExt || first_slot < 0 || first_slot + n > NID_SLOTS) return NID_ERR_INVALID_ARG;
@@ -1011,7 +1022,7 @@ int launch_batch(nid_ctx *ctx, int first_slot, int n, const Pose *poses, int wan
     recs = ctx->ext_host[ring];
     P.slots_ext = ctx->ext_dev[ring];
   }
-  const bool direct = n == 1 && !reduced_dev_base && !relaunch_ok && direct_ok(ctx);
+  const bool direct = n == 1 && !reduced_dev_base && !relaunch_ok && allow_direct && direct_ok(ctx);
   if (direct && !on_aux_stream && resident_usable(ctx) && resident_post(ctx, first_slot, poses[0], want_jac != 0, false) == NID_OK) {
     Slot &S = ctx->slots[first_slot];
     S.seq++;
@@ -1038,6 +1049,7 @@ int launch_batch(nid_ctx *ctx, int first_slot, int n, const Pose *poses, int wan
     if (direct) {
       recs[k].quad = S.quad_host_devptr;
       recs[k].host_quad = 1;
+      S.quad_dirty = true;
       S.direct = true;
       S.direct_jac = want_jac != 0;
       S.direct_delta = delta;
@@ -1998,7 +2010,8 @@ int nid_time_launches(nid_ctx *ctx, int n, const double *poses7, int want_jac, d
   }
   NID_HIP(ctx, hipEventRecord(S0.e0, ctx->stream));
   for (int r = 0; r < repeats; r++) {
-    int rc = launch_batch(ctx, 0, n, p, want_jac, delta, target, false, /*relaunch_ok=*/r > 0);
+    // (never DIRECT: the launches are re-issued into the same buffers before the host has looked)
+    int rc = launch_batch(ctx, 0, n, p, want_jac, delta, target, false, /*relaunch_ok=*/r > 0, /*allow_direct=*/false);
     if (rc) return rc;
   }
   NID_HIP(ctx, hipEventRecord(S0.e1, ctx->stream));

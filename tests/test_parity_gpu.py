@@ -1012,6 +1012,12 @@ def test_direct_results_equal_in_launch_reduction(capi, synth, pair_S_edge, cfg,
             blocks, _ = ctx.run_chain(poses, DELTA, want_jac=want_jac)
             for blk, r in zip(blocks, ref):
                 assert _same_bits(blk[0], r[2]) and blk[28] == r[3]
+            # timed launches are re-issued into the same buffers before the host looks: never DIRECT, and they leave
+            # nothing behind for the next DIRECT launch of the slot to mistake for its own records
+            ctx.time_launches(np.stack(poses[:1]), DELTA, repeats=3, want_jac=want_jac)
+            for p, r in zip(poses[::-1], ref[::-1]):
+                got = ctx.normal_equations(p, DELTA, want_jac=want_jac)
+                assert _same_bits(got[0], r[0]) and _same_bits(got[2], r[2]) and got[3] == r[3]
     ctx.close()
 
 
