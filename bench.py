@@ -397,7 +397,9 @@ def main():
     last = poses[(K - 1) % len(poses)]
     H, b, chi2, na = (m if multi else ctx).normal_equations(last, delta, want_jac=want_jac)
     Hp, bp, chi2p, nap = capi.unpack_reduced(results[K - 1])
-    exact = world <= 2   # a collective may add >= 3 ranks in another order for another message size
+    # a collective may add >= 3 ranks in another order for another message size; a context pinned to a latency shape
+    # (--block-threads 512 / 1024) evaluates launches of more than 16 poses with 256 threads: other last bits of H, b
+    exact = world <= 2 and not (args.block_threads >= 512 and (Bm if multi else B) > 16)
     same = (np.array_equal(Hp, H) and chi2p == chi2) if exact else (np.allclose(Hp, H, rtol=1e-12, atol=1e-300) and abs(chi2p - chi2) <= 1e-12 * abs(chi2))
     assert ablation or same, "pipelined result differs from the synchronous evaluation"
     assert ablation or (np.isfinite(chi2) and np.all(np.isfinite(H)) and na > 0)

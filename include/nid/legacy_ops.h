@@ -18,10 +18,18 @@
 // Errors are printed to stderr and execution continues, like the reference
 // (computeH.cu:454-473) -- the signatures return void.
 //
-// Differences, all deliberate: no per-call allocation / memset / re-upload (the
+// Differences, all deliberate: no per-call allocation / memset / re-upload.  The
 // frame-pair state is cached per (rows, cols, cell_num, bin_num) and re-uploaded
-// only when the CONTENT of a caller buffer changes -- a fingerprint of its length
-// and 64 samples, not its address --, or always with NID_LEGACY_ALWAYS_UPLOAD=1); out-of-frame reference weights are NaN in the
+// when the CONTENT of a caller buffer has changed -- judged by a full 64-bit hash
+// of the buffer, which is recomputed whenever its address, its length or a quick
+// fingerprint of 64 samples changes, on every 128th call, and after
+// nid_legacy_invalidate(); the two per-cell arrays are fully hashed on every call.
+// THE CONTRACT: a new frame pair (new buffers, or CudaComputeHref) is always
+// noticed; a caller that rewrites part of im0 / points3d / im1 / bs_ref IN PLACE
+// between two CudaComputeH calls, without a CudaComputeHref in between, says so
+// with nid_legacy_invalidate(parts) -- otherwise the change may go unnoticed for
+// up to 128 calls.  NID_LEGACY_ALWAYS_UPLOAD=1 restores the reference's
+// upload-everything-every-call behaviour.  Out-of-frame reference weights are NaN in the
 // arrays handed back (as CudaComputeHref.cu:126-130 writes them) but are treated
 // as 0 inside, the CPU edge's convention; the Jacobian in-frame
 // test defaults to the CPU edge's `cols-1` (the parity target),
@@ -69,6 +77,10 @@ void nid_legacy_set_devices(const int32_t *devices, int n, int reduce_rccl);
 void nid_legacy_set_rank(int device, int rank, int world, const uint8_t *rccl_id128);
 // drop every cached context (e.g. before the caller frees its buffers)
 void nid_legacy_reset(void);
+// The caller has changed, IN PLACE, the content of the buffers named by `parts` since its last call: the next
+// CudaComputeH recomputes their full hashes (and uploads what differs) instead of trusting address + samples.
+enum { NID_LEGACY_REFERENCE = 1 /* im0, points3d */, NID_LEGACY_TARGET = 2 /* im1 */, NID_LEGACY_HREF_STATE = 4 /* bs_ref */ };
+void nid_legacy_invalidate(unsigned parts);
 // the context the legacy calls are currently using (NULL before the first call); lets a host
 // mix the legacy operators with the fused C-ABI entry points on the same device state
 nid_ctx *nid_legacy_context(void);   // shard 0

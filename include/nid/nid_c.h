@@ -95,7 +95,12 @@ int nid_set_stream(nid_ctx *ctx, void *hip_stream);
  * shape in their last bits, so every launch of a context uses the same one.  A blocking caller that evaluates
  * one pose at a time (an LM loop) wants 1024: a cell's pixels in two rounds instead of ten.
  * cost_threads: cost-only launches; 0 = chosen per launch by its size (their results are the same bits in every
- * shape).  NID_ERR_UNSUPPORTED for any other value. */
+ * shape).  NID_ERR_UNSUPPORTED for any other value.
+ * The 512 / 1024 shapes exist for launches of up to 16 poses (they are latency shapes).  A launch of MORE than 16
+ * poses on a context set to 512 / 1024 runs with 256 threads: a cost + Jacobian evaluation in such a launch
+ * (nid_launch_batch, nid_run_sequence) then differs from the same pose evaluated alone in the last bits of H and b
+ * (chi2 and the active count are the same bits in every shape).  Callers that need identical bits across both keep
+ * jac_threads at 0, 128 or 256. */
 int nid_set_launch_shape(nid_ctx *ctx, int jac_threads, int cost_threads);
 /* Diagnostics: FAST launches of the 512 / 1024 shapes run the latency form of the pixel loops (rounds unrolled and
  * staged, the Jacobian phase fed from registers) whenever its rounds cover a cell; on != 0 forces the loop form the

@@ -168,6 +168,7 @@ class Context:
         if not self.h:
             raise NidError(f"nid_multi_shard({k}): no such shard")
         self._borrowed = True
+        self._owner = multi   # keeps the Multi (and with it this shard) alive as long as the borrowed handle is
         self.rows, self.cols, self.cell_num, self.bin_num = multi.rows, multi.cols, multi.cell_num, multi.bin_num
         self.ncell = multi.ncell
         self.cell_begin, self.cell_end = 0, self.ncell

@@ -2000,6 +2000,9 @@ int nid_time_launches(nid_ctx *ctx, int n, const double *poses7, int want_jac, d
   for (int k = 0; k < n; k++) pose_from_pose7(poses7 + 7 * k, ctx->xform, &p[k]);
   Slot &S0 = ctx->slots[0];
   { int rc = timing_events(ctx, S0); if (rc) return rc; }
+  // (nid_enable_timing would make launch_batch record the slot's e0 / e1 around every repeat: off for the duration)
+  struct TimingOff { nid_ctx *c; bool was; ~TimingOff() { c->timing = was; } } timing_off{ctx, ctx->timing};
+  ctx->timing = false;
   // launches of more than kMaxBatch poses are what the pipelined loop issues: they write their result blocks to a
   // device buffer like there (nid_run_sequence); smaller ones to pinned host memory like the blocking calls
   double *target = nullptr;

@@ -7,10 +7,16 @@
 // What is resident is identified by CONTENT, not by pointer: a caller that frees and re-mallocs its buffers per
 // pair (NID_pose_estimation.cpp:229-251, 385-392) usually gets the same addresses back.
 //   * CudaComputeHref is called once per pair: it always uploads the reference (im0, points3d) afresh;
-//   * CudaComputeH compares a fingerprint of im0 / im1 / points3d / bs_ref / bs_counter / Href -- 64 samples
-//     spread over each array plus its length -- with the fingerprint of what is resident, and uploads what
-//     changed.  A new frame pair differs in essentially every sample; a caller that changes single pixels in
-//     place between calls can force the upload with NID_LEGACY_ALWAYS_UPLOAD=1 or nid_legacy_reset().
+//   * CudaComputeH keeps, per caller buffer (im0, points3d, im1, bs_ref, bs_counter, Href), a key (address, length,
+//     quick fingerprint of 64 samples, FULL 64-bit hash of the content).  Every call checks address, length and the
+//     quick fingerprint (about a microsecond for all six); the full hash is recomputed -- and decides whether the
+//     buffer is uploaded -- whenever one of those changed, on every kRehashEvery-th call, and after
+//     nid_legacy_invalidate().  The two per-cell arrays (1-2 KB) are fully hashed on every call.
+//     So: a new frame pair is always noticed (new address or new samples -> full hash -> upload); a caller that rewrites
+//     part of a buffer IN PLACE between two calls without touching a sampled element is noticed within kRehashEvery
+//     calls, or at once if it says so with nid_legacy_invalidate() -- the one thing this library asks of a caller
+//     beyond the reference's contract (the reference re-uploads everything on every call, computeH.cu:420-429: 11 MB
+//     per call).  NID_LEGACY_ALWAYS_UPLOAD=1 restores that behaviour.
 #include "nid/legacy_ops.h"
 
 #include <cmath>
@@ -28,10 +34,19 @@ struct LegacyState {
   nid_multi *m = nullptr;
   int rows = 0, cols = 0, cell = 0, bins = 0;
   double intr[4] = {0, 0, 0, 0};
-  // fingerprints of what is resident on the device(s)
-  uint64_t fp_im0 = 0, fp_points = 0, fp_im1 = 0, fp_bs_ref = 0, fp_counter = 0, fp_href = 0;
+  // keys of what is resident on the device(s)
+  struct Key {
+    const void *addr = nullptr;
+    size_t n = 0;
+    uint64_t quick = 0, full = 0;
+    bool valid = false;
+  };
+  Key k_im0, k_points, k_im1, k_bs_ref, k_counter, k_href;
   bool have_ref = false, have_target = false, have_href = false;
+  unsigned long calls = 0;      // CudaComputeH calls on this state
+  unsigned force_full = 0;      // nid_legacy_invalidate: parts whose full hash the next call recomputes
 };
+constexpr unsigned long kRehashEvery = 128;
 
 LegacyState g_state;
 std::vector<int32_t> g_devices = {0};
@@ -79,6 +94,43 @@ uint64_t fingerprint(const T *a, size_t n) {
     mix(&a[i], sizeof(T));
   }
   return h ? h : 2;
+}
+
+// the whole content, 64 bits: four interleaved multiply-xor lanes over the 8-byte words (memory-bound: ~0.1 ms/MB)
+template <typename T>
+uint64_t full_hash(const T *a, size_t n) {
+  if (!a) return 1;
+  const size_t bytes = n * sizeof(T), words = bytes / 8;
+  const unsigned char *b = reinterpret_cast<const unsigned char *>(a);
+  uint64_t h[4] = {0x9E3779B97F4A7C15ull ^ bytes, 0xC2B2AE3D27D4EB4Full, 0x165667B19E3779F9ull, 0x27D4EB2F165667C5ull};
+  size_t i = 0;
+  for (; i + 4 <= words; i += 4) {
+    uint64_t w[4];
+    std::memcpy(w, b + 8 * i, 32);
+    for (int k = 0; k < 4; k++) { h[k] = (h[k] ^ w[k]) * 0x9FB21C651E98DF25ull; h[k] ^= h[k] >> 29; }
+  }
+  for (; i < words; i++) { uint64_t w; std::memcpy(&w, b + 8 * i, 8); h[i & 3] = (h[i & 3] ^ w) * 0x9FB21C651E98DF25ull; h[i & 3] ^= h[i & 3] >> 29; }
+  for (size_t t = 8 * words; t < bytes; t++) h[0] = (h[0] ^ b[t]) * 0x100000001B3ull;
+  uint64_t r = h[0];
+  for (int k = 1; k < 4; k++) r = (r ^ h[k]) * 0xFF51AFD7ED558CCDull + k;
+  r ^= r >> 32;
+  return r ? r : 2;
+}
+
+// Does the caller's buffer still hold what is resident?  Updates the key; `force`: recompute the full hash even if
+// address, length and the quick fingerprint are unchanged.
+template <typename T>
+bool same_content(LegacyState::Key &k, const T *a, size_t n, bool force) {
+  const uint64_t q = fingerprint(a, n);
+  if (k.valid && !force && k.addr == (const void *)a && k.n == n && k.quick == q) return true;
+  const uint64_t f = full_hash(a, n);
+  const bool same = k.valid && k.n == n && k.full == f;
+  k.addr = a; k.n = n; k.quick = q; k.full = f; k.valid = true;
+  return same;
+}
+template <typename T>
+void remember(LegacyState::Key &k, const T *a, size_t n) {
+  k.addr = a; k.n = n; k.quick = fingerprint(a, n); k.full = full_hash(a, n); k.valid = true;
 }
 
 void report(const char *where, int rc, nid_multi *m) {
@@ -135,15 +187,18 @@ int upload_reference(LegacyState &S, const double *im0, const double *points3d) 
   if (!to_u8(im0, N, &im)) return NID_ERR_UNSUPPORTED;
   int rc = nid_multi_set_reference_points(S.m, points3d, im.data());
   if (rc != NID_OK) return rc;
-  S.fp_im0 = fingerprint(im0, N); S.fp_points = fingerprint(points3d, 3 * N);
+  remember(S.k_im0, im0, N); remember(S.k_points, points3d, 3 * N);
   S.have_ref = true; S.have_href = false;
   g_uploads++;
   return NID_OK;
 }
 
-int ensure_reference(LegacyState &S, const double *im0, const double *points3d) {
+int ensure_reference(LegacyState &S, const double *im0, const double *points3d, bool force) {
   const size_t N = (size_t)S.rows * S.cols;
-  if (S.have_ref && !always_upload() && S.fp_im0 == fingerprint(im0, N) && S.fp_points == fingerprint(points3d, 3 * N)) return NID_OK;
+  if (S.have_ref && !always_upload()) {
+    const bool a = same_content(S.k_im0, im0, N, force), b = same_content(S.k_points, points3d, 3 * N, force);
+    if (a && b) return NID_OK;
+  }
   return upload_reference(S, im0, points3d);
 }
 
@@ -188,9 +243,9 @@ void CudaComputeHref(double *im0, double *points3d, double *pose, double *camera
   if (bs_index) for (size_t i = 0; i < N; i++) bs_index[i] = idx[i];
   // the device already holds these weights (CPU-edge convention: 0 instead of NaN)
   S.have_href = true;
-  S.fp_bs_ref = fingerprint(bs_value, bs_value ? 4 * N : 0);
-  S.fp_counter = fingerprint(bs_counter, (size_t)ncell);
-  S.fp_href = fingerprint(Href, (size_t)ncell);
+  remember(S.k_bs_ref, bs_value, bs_value ? 4 * N : 0);
+  remember(S.k_counter, bs_counter, (size_t)ncell);
+  remember(S.k_href, Href, (size_t)ncell);
 }
 
 namespace {
@@ -233,27 +288,40 @@ nid_multi *ensure_state(double *im0, double *im1, double *points3d, int *bs_coun
   LegacyState &S = g_state;
   const size_t N = (size_t)rows * cols;
   const int ncell = cell_num * cell_num;
-  int rc = ensure_reference(S, im0, points3d);
+  // the full hashes: whenever a key's cheap part changed (same_content), every kRehashEvery-th call, after an invalidate
+  S.calls++;
+  const bool periodic = S.calls % kRehashEvery == 0;
+  const unsigned force = S.force_full;
+  S.force_full = 0;
+  int rc = ensure_reference(S, im0, points3d, periodic || (force & NID_LEGACY_REFERENCE));
   if (rc != NID_OK) { report("CudaComputeH(reference upload)", rc, m); return nullptr; }
-  const uint64_t fp1 = fingerprint(im1, N);
-  if (!S.have_target || always_upload() || S.fp_im1 != fp1) {
+  if (!S.have_target || always_upload() || !same_content(S.k_im1, im1, N, periodic || (force & NID_LEGACY_TARGET))) {
     std::vector<uint8_t> im;
     if (!to_u8(im1, N, &im)) { report("CudaComputeH(im1 is not u8-valued)", NID_ERR_UNSUPPORTED, m); return nullptr; }
     rc = nid_multi_set_target_u8(m, im.data());
     if (rc != NID_OK) { report("CudaComputeH(target upload)", rc, m); return nullptr; }
-    S.fp_im1 = fp1; S.have_target = true;
+    remember(S.k_im1, im1, N);
+    S.have_target = true;
     g_uploads++;
   }
   // Href is only READ by the reference with calculate_der (computeH.cu:428-429); the kernels also need it to know
   // which cells are active.  A NULL Href gives zeros (cost-only outputs do not depend on it) and the first call
-  // that brings one replaces them: Href is part of the key.
-  const uint64_t fpb = fingerprint(bs_ref, 4 * N), fpc = fingerprint(bs_counter, (size_t)ncell), fph = fingerprint(Href, (size_t)ncell);
-  if (!S.have_href || always_upload() || S.fp_bs_ref != fpb || S.fp_counter != fpc || (Href && S.fp_href != fph)) {
+  // that brings one replaces them: Href is part of the key.  The per-cell arrays are small: full hashes every call.
+  const bool fh = periodic || (force & NID_LEGACY_HREF_STATE);
+  bool same = S.have_href && !always_upload();
+  if (same) {
+    const bool a = same_content(S.k_bs_ref, bs_ref, 4 * N, fh), b = same_content(S.k_counter, bs_counter, (size_t)ncell, true);
+    const bool c = !Href || same_content(S.k_href, Href, (size_t)ncell, true);
+    same = a && b && c;
+  }
+  if (!same) {
     std::vector<double> href(ncell, 0.0);
     if (Href) for (int c = 0; c < ncell; c++) href[c] = Href[c];
     rc = nid_multi_set_href_state(m, bs_counter, href.data(), bs_ref, bs_index_ref);
     if (rc != NID_OK) { report("CudaComputeH(href state upload)", rc, m); return nullptr; }
-    S.fp_bs_ref = fpb; S.fp_counter = fpc; S.fp_href = Href ? fph : 1; S.have_href = true;
+    remember(S.k_bs_ref, bs_ref, 4 * N); remember(S.k_counter, bs_counter, (size_t)ncell);
+    if (Href) remember(S.k_href, Href, (size_t)ncell); else S.k_href = LegacyState::Key();
+    S.have_href = true;
     g_uploads++;
   }
   return m;
@@ -312,6 +380,8 @@ void nid_legacy_set_rank(int device, int rank, int world, const uint8_t *rccl_id
   if (rccl_id128) std::memcpy(g_id, rccl_id128, sizeof(g_id));
   g_reduce_rccl = g_world > 1 ? 1 : 0;
 }
+
+void nid_legacy_invalidate(unsigned parts) { g_state.force_full |= parts; }
 
 void nid_legacy_reset(void) {
   if (g_state.m) nid_multi_destroy(g_state.m);

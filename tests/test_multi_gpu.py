@@ -260,4 +260,38 @@ def test_legacy_operators_follow_buffer_contents(hostlib, oracle, synth, pair_S,
         Hc_o2, Hj_o2, _, _ = o.evaluate(pair.pose_true, False)
         np.testing.assert_allclose(Ht2[act], Hc_o2[act], rtol=0, atol=1e-11)
         assert not np.allclose(Ht2[act], Ht[act])
+    # A change IN PLACE that touches none of the 64 sampled elements of the quick fingerprint (one pixel in the middle of
+    # a cell): declared with nid_legacy_invalidate it is followed at once; undeclared, within 128 calls -- the full hash
+    # is recomputed on every 128th call (include/nid/legacy_ops.h, "THE CONTRACT").
+    pair = pair_S
+    lib.nid_legacy_invalidate.argtypes = [hostlib.C.c_uint]
+    samples = {int(k * (N - 1) // 63) for k in range(64)}
+    cellpx = (pair.rows // pair.cell // 2) * pair.cols + pair.cols // pair.cell // 2      # inside cell 0
+    assert cellpx not in samples
+
+    def evaluate():
+        a, b = np.zeros(ncell), np.zeros(ncell)
+        lib.nid_legacy_call_CudaComputeH(0, dp(im0), dp(im1), dp(pts), ip(cnt), dp(bsv), ip(bsi), dp(M), dp(intr),
+                                         nb, 3, pair.cell, pair.rows, pair.cols, dp(href), dp(a), dp(b), dp(der))
+        return a
+
+    base = evaluate()
+    u0 = lib.nid_legacy_upload_count()
+    im1[cellpx] = 255.0 - im1[cellpx]
+    lib.nid_legacy_invalidate(2)                      # NID_LEGACY_TARGET
+    changed = evaluate()
+    assert lib.nid_legacy_upload_count() == u0 + 1 and changed[0] != base[0] and np.array_equal(changed[1:], base[1:])
+    im1[cellpx] = 255.0 - im1[cellpx]                 # back, undeclared this time
+    seen_after = None
+    for k in range(130):
+        if np.array_equal(evaluate(), base):
+            seen_after = k
+            break
+    assert seen_after is not None and seen_after <= 128 and lib.nid_legacy_upload_count() == u0 + 2
+    # the small per-cell arrays are fully hashed on every call: a changed count is followed at once
+    cnt_keep = cnt.copy()
+    cnt[0] = 0
+    assert np.isnan(evaluate()[0])
+    cnt[:] = cnt_keep
+    assert np.array_equal(evaluate(), base)
     lib.nid_legacy_reset()

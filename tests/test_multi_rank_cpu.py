@@ -26,10 +26,11 @@ def _free_port():
 
 def _worker(rank, world, port, q):
     sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    parallel = importlib.import_module("nid-pose-estimation_amd.parallel")
+    import parallel_helpers as parallel   # tests/parallel_helpers.py: numpy / torch.distributed helpers of this test
     synth = importlib.import_module("nid-pose-estimation_amd.synth")
     from oracle import oracle_py
     pair = synth.make_pair("S")
@@ -83,7 +84,7 @@ def test_two_rank_cell_sharding_allreduce():
 
 
 def test_cell_ranges_partition():
-    parallel = importlib.import_module("nid-pose-estimation_amd.parallel")
+    import parallel_helpers as parallel   # tests/parallel_helpers.py: numpy / torch.distributed helpers of this test
     for ncell in (16, 256, 1024, 250):
         for world in (1, 2, 3, 4, 8):
             rs = parallel.all_ranges(world, ncell)
@@ -96,7 +97,7 @@ def test_cell_ranges_partition():
 
 
 def test_pack_unpack_roundtrip(capi):
-    parallel = importlib.import_module("nid-pose-estimation_amd.parallel")
+    import parallel_helpers as parallel   # tests/parallel_helpers.py: numpy / torch.distributed helpers of this test
     rng = np.random.default_rng(0)
     A = rng.normal(size=(6, 6)); H = A + A.T; b = rng.normal(size=6)
     r = parallel.pack_reduced_np(H, b, 1.25, 7)
@@ -107,7 +108,7 @@ def test_pack_unpack_roundtrip(capi):
 
 
 def test_interleaved_cell_sets_partition():
-    parallel = importlib.import_module("nid-pose-estimation_amd.parallel")
+    import parallel_helpers as parallel   # tests/parallel_helpers.py: numpy / torch.distributed helpers of this test
     for ncell in (16, 256, 1024, 250):
         for world in (1, 2, 3, 4, 8):
             sets = [parallel.cell_set(r, world, ncell, interleaved=True) for r in range(world)]
