@@ -221,6 +221,34 @@ def pose_error_vs_ref(pair, bins):
     }
 
 
+def call_with_deadline(fn, seconds):
+    """fn() in a worker thread; (result, error string) -- error "deadline" if it has not returned after `seconds`
+    (the thread is a daemon: a native call that never returns does not keep the process alive)."""
+    box = {}
+
+    def work():
+        try:
+            box["r"] = fn()
+        except Exception as e:   # noqa: BLE001
+            box["e"] = str(e) or type(e).__name__
+
+    th = threading.Thread(target=work, daemon=True)
+    th.start()
+    th.join(seconds)
+    if th.is_alive():
+        return None, "deadline"
+    return box.get("r"), box.get("e")
+
+
+def give_up(result_out, rank, world, what):
+    """A rank that cannot go on (a collective that never returned): ONE JSON line on rank 0's stdout -- or this rank's
+    stderr -- and exit code 3, without waiting for anything: no barrier, no destructor, no re-exec."""
+    line = json.dumps({"error": what, "n_gpus": world, "rank": rank, "metric": "NID GN iterations/sec (640x480 dense pair)",
+                       "value": None})
+    print(line, file=(result_out if rank == 0 else sys.stderr), flush=True)
+    os._exit(3)
+
+
 def profile_numbers(config, bins, poses_per_launch):
     """HBM bytes per launch and instruction mix per wave of the evaluation kernel from the committed rocprofv3 PMC
     passes (profiles/traffic.json, profiles/issue_model.json, written by tools/); None where that configuration /
@@ -308,12 +336,18 @@ def main():
             if rccl:
                 ids = [my_id if rank == 0 else None]
                 dist.broadcast_object_list(ids, src=0)
-                why = ""
-                try:
-                    m.comm_init(ids[0])
+                # ncclCommInitRank may fail -- or never return (a rank that is missing, a fabric that is down): it runs
+                # under a deadline, and a rank whose deadline passes ends the job with an error line instead of hanging
+                # until the driver's timeout with no record
+                deadline = float(os.environ.get("NID_BENCH_COMM_DEADLINE", "60"))
+                _, why = call_with_deadline(lambda: m.comm_init(ids[0]), deadline)
+                if why == "deadline":
+                    give_up(result_out, rank, world, f"ncclCommInitRank did not return within {deadline:.0f} s on rank {rank}")
+                why = why or ""
+                if not why:
                     rccl_ranks_seen = m.comm_ranks()
-                except Exception as e:   # noqa: BLE001 -- ncclCommInitRank said no (it may also never return: not catchable)
-                    why = str(e)
+                    if rccl_ranks_seen != world:
+                        why = f"communicator of {rccl_ranks_seen} ranks, expected {world}"
                 flag = torch.tensor([0.0 if why else 1.0], dtype=torch.float64)
                 dist.all_reduce(flag, op=dist.ReduceOp.MIN)
                 if flag.item() == 0.0:   # same decision on every rank
@@ -403,6 +437,16 @@ def main():
     same = (np.array_equal(Hp, H) and chi2p == chi2) if exact else (np.allclose(Hp, H, rtol=1e-12, atol=1e-300) and abs(chi2p - chi2) <= 1e-12 * abs(chi2))
     assert ablation or same, "pipelined result differs from the synchronous evaluation"
     assert ablation or (np.isfinite(chi2) and np.all(np.isfinite(H)) and na > 0)
+    if not multi and not ablation:
+        # the N = 1 leg IS the single-context path; the multi-GPU layer with one shard must give the same bits (what the
+        # N > 1 legs build on)
+        m1 = capi.multi_from_pair(pair, args.bins, devices=[local_rank], math=math_mode)
+        if args.block_threads:
+            m1.set_block_threads(args.block_threads)
+        m1.compute_href(pair.pose_init)
+        H1, b1, chi1, na1 = m1.normal_equations(last, delta, want_jac=want_jac)
+        assert np.array_equal(H1, H) and np.array_equal(b1, b) and chi1 == chi2 and na1 == na, "one shard of the multi-GPU layer differs from the single context"
+        m1.close()
     if args.cost_only and rank == 0:
         print("[bench] --cost-only: cost evaluations without the Jacobian phase; not the BASELINE metric", file=sys.stderr)
 
@@ -424,6 +468,21 @@ def main():
             n_s = int(n_s * args.sustained_seconds / el) // (Bm * G) * (Bm * G)   # the first estimate was latency-bound
         sustained_multi = {"it_per_s": n_s / el, "ms_per_step": el / n_s * 1e3, "steps": n_s, "seconds": el}
 
+    # N > 1: what one exchange of the pipelined loop costs by itself (G launches x Bm poses of 32 doubles), so that a
+    # flat scaling curve can be attributed: kernel time per rank (below) vs exchange time per group
+    exchange_ms = None
+    if world > 1:
+        barrier()
+        if rccl:
+            exchange_ms = m.time_exchange(G * Bm, repeats=20)
+        else:
+            buf = torch.zeros(G * Bm * capi.NID_REDUCED_LEN, dtype=torch.float64)
+            dist.all_reduce(buf)
+            t0 = time.perf_counter()
+            for _ in range(20):
+                dist.all_reduce(buf)
+            exchange_ms = (time.perf_counter() - t0) / 20 * 1e3
+
     # ---- side measurements on this rank's shard (rank 0 reports) -----------------------------------------------
     kctx = ctx if ctx is not None else capi.Context.borrow(m, 0)
     Bk = B if not multi else Bm
@@ -435,6 +494,11 @@ def main():
         idx = [(i * Bk + k) % len(poses) for k in range(Bk)]
         ev_ms.append(kctx.time_launches(pose_arr[idx], delta, repeats=10, want_jac=want_jac))
     eval_ms = float(np.median(ev_ms[4:]))
+    per_rank_kernel_ms = None
+    if dist is not None:
+        t = [torch.zeros(1, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(t, torch.tensor([eval_ms], dtype=torch.float64))
+        per_rank_kernel_ms = [float(x.item()) for x in t]
 
     out = None
     if rank == 0:
@@ -616,8 +680,14 @@ def main():
             },
             "roofline": roof,
         }
-        if rccl_ranks_seen is not None:
-            out["rccl_ranks_seen"] = rccl_ranks_seen
+        if multi:
+            out["rccl_ranks_seen"] = rccl_ranks_seen if rccl_ranks_seen is not None else 0   # 0: the exchange does not use RCCL
+        if world > 1:
+            out["multi_gpu"] = {"per_rank_kernel_ms": per_rank_kernel_ms, "poses_per_launch": Bm, "launches_per_exchange": G,
+                                "exchange_ms_per_group": exchange_ms, "exchange_bytes_per_group": G * Bm * capi.NID_REDUCED_LEN * 8,
+                                "kernel_ms_per_group": max(per_rank_kernel_ms) * G,
+                                "note": "one group = launches_per_exchange launches of poses_per_launch poses on every rank's cells + "
+                                        "ONE exchange; the exchange runs on a comm stream beside the next group's launches"}
         if rccl_fallback is not None:
             out["rccl_unavailable"] = rccl_fallback
         out["check"] = {"chi2": chi2, "n_active": int(na), "H00": float(H[0, 0]), "b0": float(b[0])}

@@ -88,6 +88,9 @@ int nid_multi_comm_init(nid_multi *m, const uint8_t id[NID_RCCL_ID_BYTES]);
 /* ... or over the shards of this process (devices must be distinct) */
 int nid_multi_comm_init_local(nid_multi *m);
 int nid_multi_comm_ranks(const nid_multi *m, int32_t *nranks); /* ncclCommCount of the live communicator */
+/* measurement: `repeats` exchanges of `blocks` 32-double blocks back to back on the comm stream(s), milliseconds per
+ * exchange (0 without a live communicator: host sum / hook).  Collective: every rank of the job calls it. */
+int nid_multi_time_exchange(nid_multi *m, int blocks, int repeats, float *ms_per_exchange);
 /* Another transport instead of RCCL for a multi-process job (MPI, gloo, a test harness): after the shards of this
  * process have been summed on the host, `fn` must replace data[0..count) by its sum over all processes (0 = ok).
  * Collective like RCCL: every rank gets the same calls in the same order.  Selects NID_REDUCE_HOOK. */

@@ -440,7 +440,7 @@ MULTI_SYMBOLS = [
     "nid_multi_cell_range", "nid_multi_create", "nid_multi_create_rank", "nid_multi_create_partitioned", "nid_multi_destroy", "nid_multi_last_error",
     "nid_multi_shards", "nid_multi_shard", "nid_multi_world", "nid_multi_comm_unique_id", "nid_comm_create_rank",
     "nid_comm_create_local", "nid_comm_destroy", "nid_comm_ranks", "nid_multi_attach_comm", "nid_multi_comm_init",
-    "nid_multi_comm_init_local", "nid_multi_comm_ranks", "nid_multi_set_exchange_hook", "nid_multi_set_reduce_mode",
+    "nid_multi_comm_init_local", "nid_multi_comm_ranks", "nid_multi_time_exchange", "nid_multi_set_exchange_hook", "nid_multi_set_reduce_mode",
     "nid_multi_set_options",
     "nid_multi_set_math_mode", "nid_multi_set_block_threads", "nid_multi_set_launch_shape", "nid_multi_set_resident", "nid_multi_set_reference_depth",
     "nid_multi_set_reference_points", "nid_multi_set_target_u8", "nid_multi_compute_href",
@@ -469,6 +469,7 @@ def _load_multi():
     lib.nid_multi_comm_init.argtypes = [vp, c_u8p]
     lib.nid_multi_comm_init_local.argtypes = [vp]
     lib.nid_multi_comm_ranks.argtypes = [vp, c_ip]
+    lib.nid_multi_time_exchange.argtypes = [vp, C.c_int, C.c_int, c_fp]
     lib.nid_multi_set_reduce_mode.argtypes = [vp, C.c_int]
     lib.nid_multi_set_exchange_hook.argtypes = [vp, EXCHANGE_FN, vp]
     lib.nid_multi_set_options.argtypes = [vp, C.c_int, C.c_int]
@@ -559,6 +560,11 @@ class Multi:
 
     def comm_init_local(self):
         self._check(self.lib.nid_multi_comm_init_local(self.h), "nid_multi_comm_init_local")
+
+    def time_exchange(self, blocks, repeats=20):
+        ms = C.c_float(0)
+        self._check(self.lib.nid_multi_time_exchange(self.h, int(blocks), int(repeats), C.byref(ms)), "nid_multi_time_exchange")
+        return float(ms.value)
 
     def comm_ranks(self):
         n = C.c_int32(0)

@@ -423,6 +423,10 @@ def test_bench_multi_rank_code_path_on_one_gpu(tmp_path):
         line = [l for l in two.stdout.strip().splitlines() if l.startswith("{")][-1]
         r2 = json.loads(line)
         assert r2["n_gpus"] == world and r2["scaling"] == "strong"
+        # what a flat scaling curve would be attributed with: every rank's kernel time, the exchange by itself
+        mg = r2["multi_gpu"]
+        assert len(mg["per_rank_kernel_ms"]) == world and all(t > 0 for t in mg["per_rank_kernel_ms"]) and mg["exchange_ms_per_group"] > 0
+        assert r2["rccl_ranks_seen"] == 0   # (--backend gloo: the exchange does not go through RCCL)
         if extra[1] == "20":     # same last pose as the 1-rank run: the exchanged sums must agree
             assert r2["check"]["n_active"] == r1["check"]["n_active"]
             for k in ("chi2", "H00", "b0"):

@@ -4,6 +4,7 @@
 that librccl loads, that the all-reduce is ordered behind the kernel on the shard's stream and that the result
 comes home.  More than one rank per device is refused by RCCL itself; the 2/4/8-GPU runs are the driver's."""
 import importlib
+import os
 
 import numpy as np
 import pytest
@@ -295,3 +296,22 @@ def test_legacy_operators_follow_buffer_contents(hostlib, oracle, synth, pair_S,
     cnt[:] = cnt_keep
     assert np.array_equal(evaluate(), base)
     lib.nid_legacy_reset()
+
+
+def test_bench_two_ranks_with_an_rccl_that_never_returns(tmp_path):
+    """bench.py --gpus 2 with NID_RCCL_LIBRARY pointing at a librccl whose ncclCommInitRank never returns (a missing
+    rank, a fabric that is down): instead of hanging until the driver's timeout with no record, the ranks' deadline
+    ends the job with ONE JSON error line on stdout and a non-zero exit code.  (Both ranks share the one GPU of the box:
+    nothing gets as far as a collective.)"""
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    stub = str(tmp_path / "librccl_stub.so")
+    subprocess.check_call(["gcc", "-shared", "-fPIC", "-O1", "-o", stub, os.path.join(root, "tests", "cpp", "rccl_stub.c")])
+    env = dict(os.environ, NID_RCCL_LIBRARY=stub, NID_BENCH_COMM_DEADLINE="5", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29671", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5", "--quick",
+           "--no-cpu-baseline", "--preheat-seconds", "0"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=240, env=env, cwd=root)
+    assert r.returncode != 0, "a job whose communicator never comes up must not report success"
+    lines = [json.loads(l) for l in r.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1 and "ncclCommInitRank did not return" in lines[0]["error"] and lines[0]["value"] is None, r.stdout + r.stderr[-2000:]
