@@ -550,6 +550,13 @@ constexpr double kWcPre = 0x1p-512, kWcPreInv = 0x1p512;
 #endif
 constexpr double kTinyW = 1.0 / (double)(1ull << NID_TINY_W_EXP);
 constexpr double kFineW = 0x1p-8;
+// An addend below this is dropped: a bin is looked at only if its mass reaches kSigma * N_c >= 3e-28 (types_six_dof_expmap.h:281,
+// the 300-pixel activity threshold), and 19 200 such addends -- the largest cell -- are 1e-9 of the smallest mass that
+// counts.  What falls below it: the outermost weight of a sample an ulp away from a knot (a saturated target sample the
+// reference's bilinear sum leaves at 255 - 3e-14: weight 1e-47) and its products -- half the samples of a flash pair's hot
+// spot, each of which used to cost five single-copy fine-level atomics on the same few addresses.  (Also: a negative
+// weight by rounding, which the integer encodes cannot take.)
+constexpr double kNegligibleW = 0x1p-136;
 constexpr int kFineLevels = 5;
 __device__ __forceinline__ int fine_level(double w) {
   const int e = __builtin_amdgcn_frexp_exp(w);  // w = m * 2^e, m in [0.5, 1): e <= -8 for w < 2^-8
@@ -832,7 +839,12 @@ constexpr int kRedDoubles(int nt) { return (6 * (nt / 64) + 1) & ~1; }  // the s
 // The coarse sums have kClampCopies copies (same scale as the histograms); reference weights below 2^-8 go to fine levels of their own exponent like everywhere else (a joint bin
 // fed only by clamped samples is c_k * this sum: it needs the sum to ~1e-9 relative even when it is one weight of 1e-8).
 constexpr int kClampBins(int nb) { return (nb + 2) & ~1; }
-constexpr int kClampCopies = 4;
+// (more copies would thin out the same-address conflicts of a saturated patch, but the workgroup's LDS request sits at the
+// 15 360 bytes ten workgroups per CU allow: 8 or 16 copies cost the plain pair 4 %, profiles/r03_ablations_A.txt)
+#ifndef NID_CLAMP_COPIES
+#define NID_CLAMP_COPIES 4
+#endif
+constexpr int kClampCopies = NID_CLAMP_COPIES;
 constexpr int kXposeStride(int nt) { return nt + 8; }
 constexpr int kXposeDoubles(int nt) { return (nt <= 256 && NID_XPOSE_SUM) ? 6 * kXposeStride(nt) : 0; }
 constexpr int kQuad = 32;  // per-cell block: rho0 | b[6] | H upper[21] | 1.0 | 0 0 0
@@ -1168,11 +1180,25 @@ __device__ __forceinline__ void exact_decisions(const EvalParams &P, const SlotA
   if (in) {
     // the whole window around the REFERENCE's (u, v) -- which may truncate to the pixel next to FAST's
     f.w.wx = (int)u - 1; f.w.wy = (int)v - 1;
+#ifdef NID_EXP_SECOND_NO_WINDOW
+    f.w.r0 = f.w.r1 = f.w.r2 = f.w.r3 = make_uint2(0x00ff00ffu, 0x00ff00ffu);
+#else
     load_window(P, f.w);
+#endif
     ic = bilinear_rows(win_rows(f.w, v), f.w.wx, u);
     if (ic < 0) ic = 0.0;                              // :574-575
-    const double uj = g.fx * (qx / qz) + g.cx;         // linearizeOplus' own projection (:407-422, Q6)
-    const double vj = g.fy * (qy / qz) + g.cy;
+    // linearizeOplus' own projection fx*(x/z)+cx (:407-422, Q6) differs from u by a rounding: it can decide a border
+    // test differently only within an ulp of the border -- two more divisions, taken only by samples that close
+    double uj = u, vj = v;
+#ifdef NID_EXP_NO_NEARJ
+    if (true ||
+#else
+    if (
+#endif
+        fabs(u) < kBorderEps || fabs(v) < kBorderEps || fabs(u + 3 - (double)P.jac_cols) < kBorderEps || fabs(v + 3 - (double)g.rows) < kBorderEps) {
+      uj = g.fx * (qx / qz) + g.cx;
+      vj = g.fy * (qy / qz) + g.cy;
+    }
     jin = (uj >= 0 && uj + 3 <= P.jac_cols && vj >= 0 && vj + 3 <= g.rows);
   }
   f.in = in; f.jin = jin; f.u = u; f.v = v;
@@ -1274,13 +1300,16 @@ __device__ __forceinline__ void eval_cell(const EvalParams &P, const SlotArgs &S
   double *rclamp = reinterpret_cast<double *>(clamp_lo + kFineLevels * kClampBins(nb));  // [kClampBins(nb)] folded sums, then the flag
   unsigned *clamp_flag = reinterpret_cast<unsigned *>(rclamp + kClampBins(nb));
 
+  // DIRECT launches are launches of ONE pose: the kernels for more than kMaxBatch poses (EXT: the throughput path) are
+  // compiled without that code (five registers of the hot kernel)
+  const bool direct_launch = !EXT && SA.host_quad != 0;
   const int n_c = RES ? rc.n_c : P.Nc[cl];
   const double href = RES ? rc.href : P.Href[cl];
   double *out = SA.cellout + (size_t)cl * kCellOut;
   double *quad = SA.quad + (size_t)cl * kQuad;
   if (n_c < 300 || isnan(href)) {  // level-1 edge: never evaluated (computeH.cu:271-275)
     if (tid >= 64) return;
-    if (SA.host_quad) {  // DIRECT launch: see the cost-only tail
+    if (direct_launch) {  // see the cost-only tail
       if (tid < kCellOut && SA.cellout_host) store_sys(out + tid, (tid == kCellOut - 1) ? (double)n_c : NAN);
       if (tid < kDirectRec && SA.host_quad == 1) {  // both records: the host does not know yet that the cell is a level-1 edge
         store_sys(SA.quad + (size_t)cl * kDirectRec + tid, 0.0);
@@ -1344,13 +1373,22 @@ __device__ __forceinline__ void eval_cell(const EvalParams &P, const SlotArgs &S
     constexpr bool PRESCALED = decltype(prescaled)::value;
     if (clamped) {  // FAST second passes only: see kClampBins
       unsigned long long *hx = clampb + ((unsigned)copy & (kClampCopies - 1));
+#ifdef NID_EXP_CLAMP_COUNT_PER_LANE
       atomicAdd(hx + nb * kClampCopies, fx_bits(P.hist_dn1));
+#else
+      {
+        // the count: every clamped lane of the wave would add the same number to the same bin -- one lane adds the lot
+        const unsigned long long act = __builtin_amdgcn_ballot_w64(true);
+        if ((unsigned)__builtin_ctzll(act) == (unsigned)(tid & 63))
+          atomicAdd(hx + nb * kClampCopies, (unsigned long long)__builtin_popcountll(act) * fx_bits(P.hist_dn1));
+      }
+#endif
 #pragma unroll
       for (int m = 0; m < 4; m++) {
         const double w = m == 0 ? fabs(wr_in[0]) : wr_in[m];
         if (w >= kFineW) {
           atomicAdd(hx + (jr + m) * kClampCopies, fx_bits(w * P.hist_dn1));
-        } else if (w != 0.0) {
+        } else if (w > kNegligibleW) {
           const int lv = fine_level(w);
           atomicAdd(clamp_lo + lv * kClampBins(nb) + (unsigned)(jr + m), fx_encode(w, fine_scale(lv)));
         }
@@ -1412,13 +1450,13 @@ __device__ __forceinline__ void eval_cell(const EvalParams &P, const SlotArgs &S
 #pragma unroll
         for (int k = 0; k < 4; k++) {
           if (wc[k] < kFineW) {
-            if (wc[k] != 0.0) {
+            if (wc[k] > kNegligibleW) {
               const int lv = fine_level(fabs(wc[k]));
               lo_add_marginal(lv * nbins + (unsigned)(jc + k), fx_encode(wc[k], fine_scale(lv)));
 #pragma unroll
               for (int m = 0; m < 4; m++) {
                 const double pr = wr[m] * wc[k];  // the reference's own product, rounded once like there
-                if (pr != 0.0) {
+                if (pr > kNegligibleW) {
                   const int lm = fine_level(fabs(pr));
                   atomicAdd(hist_lo + lm * nbins + ((unsigned)nb + hrow + (unsigned)(m * nb + k)), fx_encode(pr, fine_scale(lm)));
                 }
@@ -1437,7 +1475,7 @@ __device__ __forceinline__ void eval_cell(const EvalParams &P, const SlotArgs &S
       for (int k = 0; k < 4; k++) {
         const bool small_c = wc[k] < kFineW;
         if (small_c) {
-          if (wc[k] != 0.0) {
+          if (wc[k] > kNegligibleW) {
             const int lv = fine_level(fabs(wc[k]));
             lo_add_marginal(lv * nbins + (unsigned)(jc + k), fx_encode(wc[k], fine_scale(lv)));
           }
@@ -1448,7 +1486,7 @@ __device__ __forceinline__ void eval_cell(const EvalParams &P, const SlotArgs &S
         for (int m = 0; m < 4; m++) {
           if (small_c || wr[m] < kFineW) {
             const double pr = wr[m] * wc[k];
-            if (pr != 0.0) {
+            if (pr > kNegligibleW) {
               const int lm = fine_level(fabs(pr));
               atomicAdd(hist_lo + lm * nbins + ((unsigned)nb + hrow + (unsigned)(m * nb + k)), fx_encode(pr, fine_scale(lm)));
             }
@@ -1488,6 +1526,7 @@ __device__ __forceinline__ void eval_cell(const EvalParams &P, const SlotArgs &S
   // the sums stay run-to-run reproducible), and integer histogram adds do not care about the order.
   // rounds: bit min(r, 63) of a wave-uniform mask; a cell of more than 64 rounds per wave shares the last bit.
   unsigned long long rare_rounds = 0ull;
+
   // Loop form, cost + Jacobian: bit r of a lane's gomask = "the main pass of the cost phase took this lane's sample of
   // round r".  The Jacobian phase redoes the identical warp and sample, so its main pass takes exactly those samples
   // (minus the ones outside linearizeOplus' narrower frame) and revisits exactly the cost phase's rare rounds: five f64
@@ -1593,6 +1632,9 @@ __device__ __forceinline__ void eval_cell(const EvalParams &P, const SlotArgs &S
         double pc;
         jc = fast_bin<SECOND || kMainPassClamps>(ic, S, pc);
         bspline4_poly<false, JAC && !SECOND>(pc, jc, rtab, wc, dw);
+#ifdef NID_EXP_SECOND_NO_ADD
+        if (!SECOND)
+#endif
         hist_add(f.jr, jc, SECOND ? f.wr : tin.wr, wc, std::true_type{}, SECOND && NID_CLAMP_BINS && ic == 254.999);
       } else {
         ic = NAN;
@@ -1679,6 +1721,9 @@ __device__ __forceinline__ void eval_cell(const EvalParams &P, const SlotArgs &S
         if (cost_round(sb, r, pre, pre, std::false_type{})) rare_rounds |= 1ull << min(r, 63);
       if (use_lane_masks) rare_rounds = wave_or_u32(raremask);
     }
+#ifdef NID_EXP_DROP_RARE_COST
+    rare_rounds = 0ull;
+#endif
     if (rare_rounds != 0ull) {
       r = 0;
 #pragma clang loop unroll(disable)
@@ -1792,7 +1837,7 @@ __device__ __forceinline__ void eval_cell(const EvalParams &P, const SlotArgs &S
       if (RES) zero_histograms(64);  // ... in the resident kernel after clearing the histograms for the next request
       return;
     }
-    if (SA.host_quad) {
+    if (direct_launch) {
       // DIRECT launch (one pose, the host is waiting for it): the cell's record (err, J[6], active) -- or, for the
       // per-cell calls, its outputs -- goes straight to pinned host memory, word by word, and the HOST forms the
       // Huber-weighted quadratic forms (the device's operations in the device's order: IEEE mul / sub / sqrt / div give
@@ -1822,7 +1867,7 @@ __device__ __forceinline__ void eval_cell(const EvalParams &P, const SlotArgs &S
   // DIRECT launch: the residual goes to the host NOW -- while the Jacobian phase runs here, the host works out the
   // cells' Huber weights (a square root and a division each) and their chi2 sum; what is left to it behind the
   // Jacobians' arrival is multiplications and additions (wait_direct in nid_capi.hip)
-  if (SA.host_quad == 1 && tid < kDirectRec)
+  if (direct_launch && SA.host_quad == 1 && tid < kDirectRec)
     store_sys(SA.quad + (size_t)cl * kDirectRec + tid, tid == 0 ? (2 * Hj - href - Hc) / Hj : (tid == 1 ? 1.0 : 0.0));
 
   // ---- phase 2: Jacobian (recompute, see header comment) -------------------------------
@@ -2022,6 +2067,18 @@ __device__ __forceinline__ void eval_cell(const EvalParams &P, const SlotArgs &S
       bool go = f.jin && !exact;
       if (SECOND) {
         go = false;
+        // A rare sample whose twelve gradient taps are all equal (the inside of a saturated or black patch: most rare
+        // samples of a flash pair) has the gradient (0, 0): whatever the exact decisions say, it adds exact zeros to
+        // the six sums -- skipped.  (Only if the reference's window is this window: (u, v) away from integer
+        // coordinates by more than FAST arithmetic's error, or its truncation could pick the neighbouring pixel.)
+#ifndef NID_EXP_NO_FLAT
+        if (exact) {
+          const unsigned t0 = wj.r1.x;
+          const bool flat = (t0 == wj.r1.y) & (t0 == wj.r2.x) & (t0 == wj.r2.y) & (t0 == wj.c0) & (t0 == wj.c3) & ((t0 >> 16) == (t0 & 0xFFFFu));
+          const double fu = f.u - floor(f.u), fv = f.v - floor(f.v);
+          if (flat && fu > kBorderEps && fu < 1.0 - kBorderEps && fv > kBorderEps && fv < 1.0 - kBorderEps) exact = false;
+        }
+#endif
         if (exact) {
           exact_decisions<EXT>(P, SA, pose_idx, tin, f, ic);
           go = f.jin;
@@ -2088,6 +2145,9 @@ __device__ __forceinline__ void eval_cell(const EvalParams &P, const SlotArgs &S
       if constexpr (use_gomask) {
         // the cost phase's decisions (gomask) instead of a second classification; the rounds with rare samples are
         // the cost phase's too (same classification on the same values)
+        // (tried and dropped, profiles/r03_ablations_A.txt: skipping the rounds in which the cost phase's main pass took
+        // no sample of the wave -- the branch cost the plain pair 3 % --; a per-lane mask from the cost phase's second
+        // pass that spares this phase's second pass the rounds whose rare samples all sit in flat windows: +-0)
 #pragma clang loop unroll(disable)
         for (int sb = wave_base; sb < g.pstride; sb += NT, r++) jac_round_masked(sb, r, prej, prej);
         rare2 = rare_rounds;
@@ -2097,6 +2157,9 @@ __device__ __forceinline__ void eval_cell(const EvalParams &P, const SlotArgs &S
           if (jac_round(sb, r, prej, prej, std::false_type{})) rare2 |= 1ull << min(r, 63);
       }
     }
+#ifdef NID_EXP_DROP_RARE_JAC
+    rare2 = 0ull;
+#endif
     if (rare2 != 0ull) {
       r = 0;
 #pragma clang loop unroll(disable)
@@ -2173,7 +2236,7 @@ __device__ __forceinline__ void eval_cell(const EvalParams &P, const SlotArgs &S
     double J[6];
 #pragma unroll
     for (int n = 0; n < 6; n++) J[n] = acc[n] * scale;
-    if (SA.host_quad) {  // DIRECT launch: see the cost-only tail
+    if (direct_launch) {  // see the cost-only tail
       err = wave_uniform((2 * Hj - href - Hc) / Hj);
       double o = tid == 0 ? Hc : (tid == 1 ? Hj : (tid == 2 ? err : (double)n_c));   // per-cell outputs
       double r = 0.0;                                                                 // the Jacobian record (the residual went ahead)
@@ -2217,8 +2280,15 @@ __device__ __forceinline__ void eval_cell(const EvalParams &P, const SlotArgs &S
   NID_STAMP(7);
 }
 
+#ifndef NID_EXT_VGPRS
+#define NID_EXT_VGPRS 0
+#endif
 template <int NT, bool JAC, bool STRICT, int NB, bool DBG, bool EXT = false, int LAT = 0, bool BIG = false>
-__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu((STRICT || DBG || LAT || NT >= 512) ? 4 : (EXT ? NID_EXT_WAVES : NID_FAST_WAVES)))) void k_eval2(EvalParams P) {
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu((STRICT || DBG || LAT || NT >= 512) ? 4 : (EXT ? NID_EXT_WAVES : NID_FAST_WAVES))))
+#if NID_EXT_VGPRS
+__attribute__((amdgpu_num_vgpr((EXT && !STRICT && !DBG && LAT == 0 && NT <= 256) ? NID_EXT_VGPRS : 0)))
+#endif
+void k_eval2(EvalParams P) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const Geometry &g = P.g;
   // XCD-aware block -> (cell, pose) map: workgroups are dealt round-robin over the 8 XCDs, so
