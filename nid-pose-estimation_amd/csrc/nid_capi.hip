@@ -1041,8 +1041,10 @@ int launch_batch(nid_ctx *ctx, int first_slot, int n, const Pose *poses, int wan
     S.seq++;
     S.direct = S.resident = false;
     S.external_target = reduced_dev_base != nullptr;
-    if (S.external_target)  // caller-owned device buffer: pose k's block at base + k*32 (multi-GPU all-reduce)
+    if (S.external_target) {  // caller-owned device buffer: pose k's block at base + k*32 (the pipelined loops, multi-GPU all-reduce)
       fill_slot_args(poses[k], S, reduced_dev_base + (size_t)k * kReducedLen, nullptr, &recs[k]);
+      if (n > kMaxBatch) recs[k].cellout = nullptr;  // nobody reads the per-cell outputs of such a launch
+    }
     else
       fill_slot_args(poses[k], S, S.reduced_host_devptr,
                      reinterpret_cast<unsigned long long *>(S.reduced_host_devptr + kReducedLen), &recs[k]);

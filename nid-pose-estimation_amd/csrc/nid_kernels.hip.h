@@ -1306,6 +1306,11 @@ __device__ __forceinline__ void eval_cell(const EvalParams &P, const SlotArgs &S
   const int n_c = RES ? rc.n_c : P.Nc[cl];
   const double href = RES ? rc.href : P.Href[cl];
   double *out = SA.cellout + (size_t)cl * kCellOut;
+#ifdef NID_EXP_ALWAYS_CELLOUT
+  const bool want_cellout = true;
+#else
+  const bool want_cellout = SA.cellout != nullptr;  // (the pipelined loops hand over none: ten stores per cell and pose nobody reads)
+#endif
   double *quad = SA.quad + (size_t)cl * kQuad;
   if (n_c < 300 || isnan(href)) {  // level-1 edge: never evaluated (computeH.cu:271-275)
     if (tid >= 64) return;
@@ -1317,7 +1322,7 @@ __device__ __forceinline__ void eval_cell(const EvalParams &P, const SlotArgs &S
       }
       return;
     }
-    if (tid < kCellOut) out[tid] = (tid == kCellOut - 1) ? (double)n_c : NAN;
+    if (tid < kCellOut && want_cellout) out[tid] = (tid == kCellOut - 1) ? (double)n_c : NAN;
     if (tid < kQuad) store_sc1(quad + tid, 0.0);
     finish_and_reduce_w0(P, SA, cl, tid);
     return;
@@ -1856,7 +1861,7 @@ __device__ __forceinline__ void eval_cell(const EvalParams &P, const SlotArgs &S
       return;
     }
     residual_and_huber();
-    if (tid == 0) { out[0] = Hc; out[1] = Hj; out[2] = err; out[kCellOut - 1] = (double)n_c; }
+    if (tid == 0 && want_cellout) { out[0] = Hc; out[1] = Hj; out[2] = err; out[kCellOut - 1] = (double)n_c; }
     if (tid < kQuad) store_sc1(quad + tid, tid == 0 ? rho0 : (tid == 28 ? 1.0 : 0.0));
     NID_STAMP(6);
     finish_and_reduce_w0(P, SA, cl, tid);
@@ -2249,7 +2254,7 @@ __device__ __forceinline__ void eval_cell(const EvalParams &P, const SlotArgs &S
       return;
     }
     residual_and_huber();
-    if (tid == 0) {
+    if (tid == 0 && want_cellout) {
       out[0] = Hc; out[1] = Hj; out[2] = err;
 #pragma unroll
       for (int n = 0; n < 6; n++) out[3 + n] = J[n];
