@@ -137,16 +137,34 @@ double nid_oracle_bspline_der(int bin_num, int index, int order, double u) {
 
 /* ------------------------------------------------------------------------ */
 /* bilinear sampler: types_six_dof_expmap.h:310-328 ((int) truncation, Q3)   */
+/* linearizeOplus samples bil(u - 1, v) and bil(u, v - 1) (:434-435).  For u in (0, 1) the (int) truncation toward zero
+ * makes that an extrapolation from columns 0 and 1; at u == 0.0 EXACTLY it is (int)(-1.0) = -1: the reference reads
+ * im[-1], the element before the row (before the buffer in row 0) -- undefined behaviour, which this restatement
+ * reproduces (AddressSanitizer reports it; the result changes from one instance to the next).  Built with
+ * -DNID_ORACLE_MARGIN (oracle/libnid_oracle_margin.so) column -1 and row -1 hold the value the extrapolation tends to,
+ * 2 I[0] - I[1]: the continuous completion of what the reference computes next to them, and what the HIP path's image
+ * margin holds (k_im1_margins).  Tests use it to check the cells the reference leaves undefined. */
+#ifdef NID_ORACLE_MARGIN
+static double tap_at(const unsigned char *im, int cols, int r, int c) {
+  if (r >= 0 && c >= 0) return im[r * cols + c];
+  if (r >= 0) return 2.0 * im[r * cols] - im[r * cols + 1];
+  if (c >= 0) return 2.0 * im[c] - im[cols + c];
+  return 2.0 * (2.0 * im[0] - im[1]) - (2.0 * im[cols] - im[cols + 1]);
+}
+#define NID_TAP(r, c) tap_at(im, cols, (r), (c))
+#else
+#define NID_TAP(r, c) ((double)im[(r) * cols + (c)])
+#endif
 static double bilinear_u8(const unsigned char *im, int cols, double x, double y) {
   int ix = (int)x;
   int iy = (int)y;
   double dx = x - ix;
   double dy = y - iy;
   double dxdy = dx * dy;
-  return (double)(dxdy * im[(iy + 1) * cols + ix + 1] +
-                  (dy - dxdy) * im[(iy + 1) * cols + ix] +
-                  (dx - dxdy) * im[iy * cols + ix + 1] +
-                  (1 - dx - dy + dxdy) * im[iy * cols + ix]);
+  return (double)(dxdy * NID_TAP(iy + 1, ix + 1) +
+                  (dy - dxdy) * NID_TAP(iy + 1, ix) +
+                  (dx - dxdy) * NID_TAP(iy, ix + 1) +
+                  (1 - dx - dy + dxdy) * NID_TAP(iy, ix));
 }
 
 /* The reference's own rounding noise, made measurable.  Built with -DNID_ORACLE_TWIN (oracle/libnid_oracle_twin.so,
@@ -167,8 +185,8 @@ static double bilinear_grad(const unsigned char *im, int cols, double x, double 
   int iy = (int)y;
   double dx = x - ix;
   double dy = y - iy;
-  double i00 = im[iy * cols + ix], i01 = im[iy * cols + ix + 1];
-  double i10 = im[(iy + 1) * cols + ix], i11 = im[(iy + 1) * cols + ix + 1];
+  double i00 = NID_TAP(iy, ix), i01 = NID_TAP(iy, ix + 1);
+  double i10 = NID_TAP(iy + 1, ix), i11 = NID_TAP(iy + 1, ix + 1);
   double top = i00 + dx * (i01 - i00);
   double bot = i10 + dx * (i11 - i10);
   return top + dy * (bot - top);

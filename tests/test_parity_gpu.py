@@ -918,6 +918,15 @@ def test_identity_like_pose_border_ties(capi, oracle, synth, cfg, math):
     Jg[~defined & act] = 0.0
     Jo[~defined & act] = 0.0
     _compare_cells((got[0], got[1], got[2], Jg), (ref[0], ref[1], ref[2], Jo), cnt_o)
+    # ... and the cells the reference leaves undefined against the oracle built with a DEFINED margin (column -1 / row -1
+    # = 2 I[0] - I[1], the value the reference's own extrapolation tends to as u -> 0+; oracle/Makefile:
+    # libnid_oracle_margin.so): every cell, first row and column included, at the stated bounds
+    om = oracle.from_pair(pair, nb, defined_margin=True)
+    cnt_m, _ = om.compute_href(ident)
+    assert np.array_equal(cnt_m, cnt_o)
+    ref_m = om.evaluate(ident, True)
+    assert np.array_equal(_bits(ref_m[3][defined & act]), _bits(ref[3][defined & act])), "the margin only matters where the reference reads im[-1]"
+    _compare_cells(got, ref_m, cnt_o)
     ctx.enable_pixel_dump(True)
     ctx.evaluate(ident, True)
     g = ctx.pixel_dump()
