@@ -12,3 +12,9 @@ bash tools/pmc_round.sh $tag A > gpurun_out/$tag/pmc_round.log 2>&1; echo "pmc r
 python tools/latency_sweep.py A 8 > gpurun_out/$tag/launch_cost_A.txt 2> gpurun_out/$tag/launch_cost_A.err; echo "lat A rc=$?"
 python tools/latency_sweep.py B 8 > gpurun_out/$tag/launch_cost_B.txt 2> gpurun_out/$tag/launch_cost_B.err; echo "lat B rc=$?"
 python tools/batch_sweep.py > gpurun_out/$tag/batch_sweep.txt 2> gpurun_out/$tag/batch_sweep.err; echo "batch rc=$?"
+python tools/direct_latency.py A 8 > gpurun_out/$tag/direct_latency_A.txt 2> gpurun_out/$tag/direct_latency_A.err; echo "direct A rc=$?"
+python tools/direct_latency.py B 8 > gpurun_out/$tag/direct_latency_B.txt 2> gpurun_out/$tag/direct_latency_B.err; echo "direct B rc=$?"
+python tools/lm_latency.py A 8 > gpurun_out/$tag/lm_latency_A.txt 2> gpurun_out/$tag/lm_latency_A.err; echo "lm rc=$?"
+python tools/lm_trace.py 4 resident > /dev/null 2> gpurun_out/$tag/lm_trace_fused4_resident.txt; echo "lm trace rc=$?"
+python tools/flash_rate.py > gpurun_out/$tag/flash_rate.txt 2> gpurun_out/$tag/flash_rate.err; echo "flash rc=$?"
+./tools/ubench/mailbox_latency > gpurun_out/$tag/mailbox_latency.txt 2>&1; echo "mailbox rc=$?"

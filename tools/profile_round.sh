@@ -13,11 +13,11 @@ for cfg in A B; do
   O=$R/gpurun_out/${tag}_$cfg
   rm -rf $O
   export NID_ONE_STREAM=1
-  rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python3 $R/bench.py --config $cfg --steps $steps --warmup 200 --no-cpu-baseline > $R/gpurun_out/${tag}_${cfg}_bench_onestream.json 2>/dev/null
-  rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/fetch -- python3 $R/bench.py --config $cfg --steps 400 --warmup 40 --no-cpu-baseline > /dev/null 2>&1
-  rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/write -- python3 $R/bench.py --config $cfg --steps 400 --warmup 40 --no-cpu-baseline > /dev/null 2>&1
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -- python3 $R/bench.py --config $cfg --steps $steps --warmup 200 --no-cpu-baseline --quick > $R/gpurun_out/${tag}_${cfg}_bench_onestream.json 2>/dev/null
+  rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/fetch -- python3 $R/bench.py --config $cfg --steps 400 --warmup 40 --no-cpu-baseline --quick > /dev/null 2>&1
+  rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/write -- python3 $R/bench.py --config $cfg --steps 400 --warmup 40 --no-cpu-baseline --quick > /dev/null 2>&1
   unset NID_ONE_STREAM
-  rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_pipelined -- python3 $R/bench.py --config $cfg --steps $steps --warmup 200 --no-cpu-baseline > $R/gpurun_out/${tag}_${cfg}_bench_pipelined.json 2>/dev/null
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_pipelined -- python3 $R/bench.py --config $cfg --steps $steps --warmup 200 --no-cpu-baseline --quick > $R/gpurun_out/${tag}_${cfg}_bench_pipelined.json 2>/dev/null
 done
 cd $R
 find gpurun_out/${tag}_A gpurun_out/${tag}_B -name "*kernel_stats.csv" | head
