@@ -594,7 +594,12 @@ def main():
                     seq[name]["in_launch_reduction"] = chain_rate(False, False)
                     try:
                         seq[name]["resident_evaluator"] = chain_rate(True, True)
-                        seq[name]["resident_evaluator"]["stats"] = ctx.resident_stats()
+                        seq[name]["resident_evaluator"]["stats"] = st = ctx.resident_stats()
+                        if not st.get("served"):
+                            # e.g. config B: 1024 cells do not fit the chip as one resident workgroup each -- the requests
+                            # were answered by ordinary launches (nid_set_resident's documented fallback)
+                            seq[name]["resident_evaluator"] = {"unavailable": "not startable for this geometry (one resident workgroup "
+                                                               "per cell must fit the chip's CUs); launches answered", "stats": st}
                     except Exception as e:   # noqa: BLE001 -- a platform without a CPU-addressable BAR
                         seq[name]["resident_evaluator"] = {"error": str(e)[:200]}
                     ctx.set_resident(False)

@@ -1640,7 +1640,11 @@ __device__ __forceinline__ void eval_cell(const EvalParams &P, const SlotArgs &S
 #ifdef NID_EXP_SECOND_NO_ADD
         if (!SECOND)
 #endif
+#ifdef NID_EXP_NEARSAT_CLAMPED  // timing only (wrong weights): samples a few ulps below 255 through the clamped samples' bins
+        hist_add(f.jr, jc, SECOND ? f.wr : tin.wr, wc, std::true_type{}, SECOND && NID_CLAMP_BINS && ic >= 254.999);
+#else
         hist_add(f.jr, jc, SECOND ? f.wr : tin.wr, wc, std::true_type{}, SECOND && NID_CLAMP_BINS && ic == 254.999);
+#endif
       } else {
         ic = NAN;
       }
