@@ -80,6 +80,7 @@ struct nid_ctx {
     Pose pose{};
     bool jac = false, want_cellout = false;
     long served = 0, fallbacks = 0, starts = 0;
+    std::string why;               // probed < 0: which step said no
   } res;
   std::vector<double> direct_rho1;  // wait_direct: the cells' Huber weights between its two passes
   // own_stream: setup + blocking calls; aux_stream: odd slots of the pipelined path, so that
@@ -237,10 +238,13 @@ void set_hist_params(EvalParams &P) {
   P.hist_inv_scale = std::ldexp(1.0, -hs);
 }
 
-size_t eval_lds_bytes(const Geometry &g, int nt) {
+size_t eval_lds_bytes(const Geometry &g, int nt, bool resident = false) {
   const int nbins = g.nb * g.nb + g.nb;
   // copies + fine levels (the Jacobian block sum of the throughput shapes reuses the area: at least kXposeDoubles); tab + term
-  const size_t clamp_bytes = (size_t)kClampBins(g.nb) * (kClampCopies + kFineLevels + 1) * 8 + 8;  // coarse copies, fine levels, folded sums, flag
+  // clamped samples: coarse copies, fine levels, folded sums, flags; near-saturated samples: folded sums, and their bins
+  // unless the weight tables lend them their area (near_sat_aliased)
+  const size_t clamp_bytes = (size_t)kClampBins(g.nb) * (kClampCopies + kFineLevels + 1) * 8 + 8 + (size_t)(g.nb + 1) * 8 +
+                             ((near_sat_aliased(g.nb) && !resident) ? 0 : (size_t)kNearSatBinBytes(g.nb) + 8);
   const size_t hist_bytes = std::max((size_t)nbins * (eval_hist_copies(nt) + kFineLevels) * 8 + clamp_bytes, (size_t)kXposeDoubles(nt) * 8);
   return hist_bytes + 2 * (size_t)((nbins + 1) & ~1) * 8 + (size_t)g.S * kCoefRow * 8 + (size_t)kRedDoubles(nt) * 8;
 }
@@ -729,8 +733,20 @@ int resident_probe(nid_ctx *ctx) {
   if (R.probed) return R.probed > 0 ? NID_OK : NID_ERR_UNSUPPORTED;
   R.probed = -1;
   void *p = nullptr;
-  if (hipExtMallocWithFlags(&p, 4096, hipDeviceMallocFinegrained) != hipSuccess) { (void)hipGetLastError(); return NID_ERR_UNSUPPORTED; }
-  if (hipMemset(p, 0, 4096) != hipSuccess || hipStreamSynchronize(nullptr) != hipSuccess) { (void)hipFree(p); return NID_ERR_UNSUPPORTED; }
+  hipError_t e = hipExtMallocWithFlags(&p, 4096, hipDeviceMallocFinegrained);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    R.why = std::string("hipExtMallocWithFlags(hipDeviceMallocFinegrained): ") + hipGetErrorString(e);
+    return NID_ERR_UNSUPPORTED;
+  }
+  e = hipMemset(p, 0, 4096);
+  if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    (void)hipFree(p);
+    R.why = std::string("clearing the mailbox: ") + hipGetErrorString(e);
+    return NID_ERR_UNSUPPORTED;
+  }
   // can the CPU store to it?  (a platform without a large BAR faults: that is the answer "no")
   struct sigaction sa = {}, old_segv, old_bus;
   sa.sa_handler = res_probe_fault;
@@ -745,7 +761,11 @@ int resident_probe(nid_ctx *ctx) {
   }
   sigaction(SIGSEGV, &old_segv, nullptr);
   sigaction(SIGBUS, &old_bus, nullptr);
-  if (!ok) { (void)hipFree(p); return NID_ERR_UNSUPPORTED; }
+  if (!ok) {
+    (void)hipFree(p);
+    R.why = "the device's fine-grained memory is not CPU-addressable here (a store from the host faulted)";
+    return NID_ERR_UNSUPPORTED;
+  }
   R.ctl = static_cast<ResidentCtl *>(p);
   if (hipStreamCreateWithFlags(&R.stream, hipStreamNonBlocking) != hipSuccess) { (void)hipFree(p); R.ctl = nullptr; return NID_ERR_HIP; }
   const size_t n = (size_t)2 * ctx->g.nloc * kDirectRec;
@@ -815,7 +835,7 @@ int resident_start(nid_ctx *ctx, int nt) {
   A.gpart = nullptr; A.ticket = nullptr; A.out_reduced = nullptr; A.host_seq = nullptr;
   A.launch_seq = 0; A.cellout_host = 0; A.host_quad = 1;
   // eval_cell's LDS + the cell's tile entries (k_eval2's LAT branch, RES): rounds x threads x (7 doubles + 1 int)
-  const size_t lds = eval_lds_bytes(P.g, nt) + 16 + (size_t)lat_rounds(nt) * nt * (7 * 8 + 4);
+  const size_t lds = eval_lds_bytes(P.g, nt, true) + 16 + (size_t)lat_rounds(nt) * nt * (7 * 8 + 4);
   if (lds > 160 * 1024) { ctx->last_error = "resident evaluator: LDS request " + std::to_string(lds); return NID_ERR_UNSUPPORTED; }
   const unsigned grid = (unsigned)(((P.g.nloc + 7) / 8) * 8);
   const int nb = P.g.nb;
@@ -1954,7 +1974,7 @@ int nid_set_resident(nid_ctx *ctx, int on) {
     return NID_OK;
   }
   int rc = resident_probe(ctx);
-  if (rc) { ctx->last_error = "resident evaluator: the device's fine-grained memory is not CPU-addressable here"; return rc; }
+  if (rc) { ctx->last_error = "resident evaluator unavailable: " + (ctx->res.why.empty() ? std::string("mailbox setup failed") : ctx->res.why); return rc; }
   ctx->res.enabled = true;
   return NID_OK;
 }

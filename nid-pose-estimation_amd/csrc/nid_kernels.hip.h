@@ -844,7 +844,26 @@ constexpr int kClampBins(int nb) { return (nb + 2) & ~1; }
 #ifndef NID_CLAMP_COPIES
 #define NID_CLAMP_COPIES 4
 #endif
+#ifndef NID_NEAR_SAT_BINS
+#define NID_NEAR_SAT_BINS 1
+#endif
 constexpr int kClampCopies = NID_CLAMP_COPIES;
+// NEAR-SATURATED target samples: four equal taps of 255 leave the reference's four-term bilinear sum at 255 (clamped,
+// above) or an ulp or two below it (about half of a saturated patch).  Every sample at EXACTLY 255 - ulp has the same four
+// target weights, bit for bit -- FAST math sums the reference weights of those in a second set of bins and folds them in
+// with that sample's weights, like the clamped ones.  Only the exact value qualifies: the last span is an END span of the
+// clamped knot vector, its small weights are linear / quadratic in 1 - t (1e-15, 1e-30) with O(1) derivatives, and a joint
+// bin made of them alone enters the Jacobian through log2 of its mass -- a sample two ulps below 255 has TWICE that
+// weight, so it takes the general path (a window of 2^-40 below 255 instead of the one value put 0.17 on a Jacobian of
+// 6.7 in one cell of sweep seed 70874).  The Jacobian phase does not add to histograms and is unchanged.
+constexpr double kNearSatIc = 255.0 - 0x1p-45;  // the largest double below 255
+constexpr int kNearSatBinBytes(int nb) { return kClampBins(nb) * (kClampCopies + kFineLevels) * 8; }
+// the two weight tables (tab, term: (nbins + 1) & ~1 doubles each) lend the bins their area when it is large enough
+#ifdef NID_EXP_NEAR_SAT_NO_ALIAS
+__host__ __device__ constexpr bool near_sat_aliased(int) { return false; }
+#else
+__host__ __device__ constexpr bool near_sat_aliased(int nb) { return 16 * ((nb * nb + nb + 1) & ~1) >= kNearSatBinBytes(nb); }
+#endif
 constexpr int kXposeStride(int nt) { return nt + 8; }
 constexpr int kXposeDoubles(int nt) { return (nt <= 256 && NID_XPOSE_SUM) ? 6 * kXposeStride(nt) : 0; }
 constexpr int kQuad = 32;  // per-cell block: rho0 | b[6] | H upper[21] | 1.0 | 0 0 0
@@ -1297,8 +1316,18 @@ __device__ __forceinline__ void eval_cell(const EvalParams &P, const SlotArgs &S
   unsigned long long *hist_lo = hist + nbins * NC;  // [kFineLevels][nbins], single copies (see kTinyW)
   unsigned long long *clampb = hist_lo + kFineLevels * nbins;                   // [kClampBins(nb)][kClampCopies]: see kClampBins
   unsigned long long *clamp_lo = clampb + kClampBins(nb) * kClampCopies;         // [kFineLevels][kClampBins(nb)], single copies
-  double *rclamp = reinterpret_cast<double *>(clamp_lo + kFineLevels * kClampBins(nb));  // [kClampBins(nb)] folded sums, then the flag
-  unsigned *clamp_flag = reinterpret_cast<unsigned *>(rclamp + kClampBins(nb));
+  double *rclamp = reinterpret_cast<double *>(clamp_lo + kFineLevels * kClampBins(nb));  // [kClampBins(nb)] folded sums, then the flags
+  unsigned *clamp_flag = reinterpret_cast<unsigned *>(rclamp + kClampBins(nb));          // [0]: clamped samples seen, [1]: near-saturated ones
+  // ... and the same for the NEAR-SATURATED samples (see kNearSatIc): folded sums behind the flags; the bins themselves
+  // borrow the area of the two weight tables, which nobody touches before the fold (when they fit there: nb >= 5)
+  double *rns = reinterpret_cast<double *>(clamp_flag + 2);                               // [nb + 1]
+  // (not in the resident kernel, which clears the bins for the next request while wave 0 still reads the tables)
+  const bool ns_alias = !RES && near_sat_aliased(nb);
+  unsigned long long *ns_own = reinterpret_cast<unsigned long long *>(rns + ((nb + 1) | 1));  // (rns sits 8 bytes past a 16-byte boundary: an odd count ends on one)
+  unsigned long long *nsb = ns_alias ? reinterpret_cast<unsigned long long *>(tab) : ns_own;  // [kClampBins(nb)][kClampCopies]
+  unsigned long long *ns_lo = nsb + kClampBins(nb) * kClampCopies;                       // [kFineLevels][kClampBins(nb)]
+  unsigned char *lds_tail = reinterpret_cast<unsigned char *>(ns_alias ? reinterpret_cast<unsigned long long *>(rns + nb + 1)
+                                                                        : ns_own + kNearSatBinBytes(nb) / 8);
 
   // DIRECT launches are launches of ONE pose: the kernels for more than kMaxBatch poses (EXT: the throughput path) are
   // compiled without that code (five registers of the hot kernel)
@@ -1343,12 +1372,22 @@ __device__ __forceinline__ void eval_cell(const EvalParams &P, const SlotArgs &S
     uint4 *h4 = reinterpret_cast<uint4 *>(hist);
     const int n4 = (nbins * (NC + kFineLevels) + kClampBins(nb) * (kClampCopies + kFineLevels)) / 2;  // ... and the clamped samples' bins
     if (tid == first) { clamp_flag[0] = 0u; clamp_flag[1] = 0u; }
+    // the near-saturated samples' bins (elsewhere in LDS, see nsb) ride behind: the slots n4 .. n4 + nns - 1 of the same
+    // loop -- with 8 bins and 128 threads they fall into the idle threads of its last iteration
+    uint4 *n4p = reinterpret_cast<uint4 *>(nsb);
+    const int nns = (!STRICT && NID_CLAMP_BINS) ? kNearSatBinBytes(nb) / 16 : 0;
     if (NB > 0 && first == 0) {
 #pragma unroll
-      for (int i = 0; i < (n4 + NT - 1) / NT; i++)
-        if (i * NT + tid < n4) h4[i * NT + tid] = make_uint4(0u, 0u, 0u, 0u);
+      for (int i = 0; i < (n4 + nns + NT - 1) / NT; i++) {
+        const int idx = i * NT + tid;
+        if ((i + 1) * NT <= n4 || idx < n4) h4[idx] = make_uint4(0u, 0u, 0u, 0u);
+        else if (idx < n4 + nns) n4p[idx - n4] = make_uint4(0u, 0u, 0u, 0u);
+      }
     } else {
-      for (int i = tid - first; i < n4; i += NT - first) h4[i] = make_uint4(0u, 0u, 0u, 0u);
+      for (int i = tid - first; i < n4 + nns; i += NT - first) {
+        if (i < n4) h4[i] = make_uint4(0u, 0u, 0u, 0u);
+        else n4p[i - n4] = make_uint4(0u, 0u, 0u, 0u);
+      }
     }
   };
   if (!RES || rc.fresh) zero_histograms(0);
@@ -1374,16 +1413,18 @@ __device__ __forceinline__ void eval_cell(const EvalParams &P, const SlotArgs &S
   // The reference weights take hist_dn (four multiplications per sample), and every add is the bit pattern of a
   // subnormal product (fx_bits).
   const double tiny_scaled = kTinyW * kWcPre;
-  auto hist_add = [&](int jr, int jc, const double (&wr_in)[4], const double (&win)[4], auto prescaled, bool clamped = false) {
+  auto hist_add = [&](int jr, int jc, const double (&wr_in)[4], const double (&win)[4], auto prescaled, int group = 0) {
     constexpr bool PRESCALED = decltype(prescaled)::value;
-    if (clamped) {  // FAST second passes only: see kClampBins
-      unsigned long long *hx = clampb + ((unsigned)copy & (kClampCopies - 1));
+    if (group != 0) {  // FAST second passes only: 1 = clamped (kClampBins), 2 = near-saturated (kNearSatIc)
+      unsigned long long *hx = (group == 2 ? nsb : clampb) + ((unsigned)copy & (kClampCopies - 1));
+      unsigned long long *hlo = group == 2 ? ns_lo : clamp_lo;
 #ifdef NID_EXP_CLAMP_COUNT_PER_LANE
       atomicAdd(hx + nb * kClampCopies, fx_bits(P.hist_dn1));
 #else
       {
-        // the count: every clamped lane of the wave would add the same number to the same bin -- one lane adds the lot
-        const unsigned long long act = __builtin_amdgcn_ballot_w64(true);
+        // the count: every lane of the wave in this group would add the same number to the same bin -- one lane adds the lot
+        const unsigned long long in2 = __builtin_amdgcn_ballot_w64(group == 2);
+        const unsigned long long act = group == 2 ? in2 : (__builtin_amdgcn_ballot_w64(true) & ~in2);
         if ((unsigned)__builtin_ctzll(act) == (unsigned)(tid & 63))
           atomicAdd(hx + nb * kClampCopies, (unsigned long long)__builtin_popcountll(act) * fx_bits(P.hist_dn1));
       }
@@ -1395,10 +1436,10 @@ __device__ __forceinline__ void eval_cell(const EvalParams &P, const SlotArgs &S
           atomicAdd(hx + (jr + m) * kClampCopies, fx_bits(w * P.hist_dn1));
         } else if (w > kNegligibleW) {
           const int lv = fine_level(w);
-          atomicAdd(clamp_lo + lv * kClampBins(nb) + (unsigned)(jr + m), fx_encode(w, fine_scale(lv)));
+          atomicAdd(hlo + lv * kClampBins(nb) + (unsigned)(jr + m), fx_encode(w, fine_scale(lv)));
         }
       }
-      clamp_flag[0] = 1u;
+      clamp_flag[group - 1] = 1u;
       return;
     }
     // fixed-point encode: the scales are powers of two, so wcs = wc * kWcPre and wrs = wr * hist_dn are exact and
@@ -1640,11 +1681,9 @@ __device__ __forceinline__ void eval_cell(const EvalParams &P, const SlotArgs &S
 #ifdef NID_EXP_SECOND_NO_ADD
         if (!SECOND)
 #endif
-#ifdef NID_EXP_NEARSAT_CLAMPED  // timing only (wrong weights): samples a few ulps below 255 through the clamped samples' bins
-        hist_add(f.jr, jc, SECOND ? f.wr : tin.wr, wc, std::true_type{}, SECOND && NID_CLAMP_BINS && ic >= 254.999);
-#else
-        hist_add(f.jr, jc, SECOND ? f.wr : tin.wr, wc, std::true_type{}, SECOND && NID_CLAMP_BINS && ic == 254.999);
-#endif
+        // (second pass: `ic` is the reference's own sample, evaluated exactly and clamped like there)
+        hist_add(f.jr, jc, SECOND ? f.wr : tin.wr, wc, std::true_type{},
+                 (SECOND && NID_CLAMP_BINS) ? (ic == 254.999 ? 1 : ((NID_NEAR_SAT_BINS && ic == kNearSatIc) ? 2 : 0)) : 0);
       } else {
         ic = NAN;
       }
@@ -1666,7 +1705,7 @@ __device__ __forceinline__ void eval_cell(const EvalParams &P, const SlotArgs &S
       // RES: the cell's tile entries stay in LDS from the kernel's first request on (every thread re-reads what it
       // wrote itself: [round][field][thread] doubles, then the bin indices) -- an LDS read instead of an L2 round trip
       // at the head of every request
-      double *tcache = reinterpret_cast<double *>((reinterpret_cast<uintptr_t>(clamp_flag + 2) + 15) & ~(uintptr_t)15);
+      double *tcache = reinterpret_cast<double *>((reinterpret_cast<uintptr_t>(lds_tail) + 15) & ~(uintptr_t)15);
       int *jcache = reinterpret_cast<int *>(tcache + LAT * 7 * NT);
 #pragma unroll
       for (int q = 0; q < LAT; q++)
@@ -1745,12 +1784,20 @@ __device__ __forceinline__ void eval_cell(const EvalParams &P, const SlotArgs &S
 
   // ---- fold the copies, probabilities, entropies, weight tables ----------------------
   // clamped samples first (flash data only: the flag is workgroup-uniform): their sums per reference bin and their count
-  const bool any_clamped = !STRICT && NID_CLAMP_BINS && clamp_flag[0] != 0u;
+  const unsigned long long sat_flags = *reinterpret_cast<const unsigned long long *>(clamp_flag);  // (one LDS read)
+  const bool any_sat = !STRICT && NID_CLAMP_BINS && sat_flags != 0ull;
+  const bool any_clamped = any_sat && (unsigned)sat_flags != 0u, any_ns = any_sat && (unsigned)(sat_flags >> 32) != 0u;
   double cw[4] = {0.0, 0.0, 0.0, 0.0};  // their four target weights, as the sample path computes them
-  int jc_cl = 0;
-  if (any_clamped) {
-    for (int e = tid; e <= nb; e += NT) {
-      const uint4 *hv = reinterpret_cast<const uint4 *>(clampb + (size_t)e * kClampCopies);
+  double nw[4] = {0.0, 0.0, 0.0, 0.0};  // ... and the near-saturated samples'
+  int jc_cl = 0, jc_ns = 0;
+  if (any_sat) {
+    // (both groups, 2 * (nb + 1) sums; a group without samples holds zeros.  The near-saturated bins may sit in the
+    // weight tables' area: the barrier below separates these reads from the fold's table writes)
+    for (int e2 = tid; e2 < 2 * (nb + 1); e2 += NT) {
+      const bool ns = e2 > nb;
+      const int e = ns ? e2 - (nb + 1) : e2;
+      const unsigned long long *gb = ns ? nsb : clampb, *gl = ns ? ns_lo : clamp_lo;
+      const uint4 *hv = reinterpret_cast<const uint4 *>(gb + (size_t)e * kClampCopies);
       unsigned long long acc_lo = 0;
       unsigned acc_hi = 0;
 #pragma unroll
@@ -1763,14 +1810,17 @@ __device__ __forceinline__ void eval_cell(const EvalParams &P, const SlotArgs &S
       double sum = (double)(long long)(acc_lo + ((unsigned long long)acc_hi << 32)) * P.hist_inv_scale;
 #pragma unroll
       for (int lv = 0; lv < kFineLevels; lv++)
-        sum = fma((double)(long long)clamp_lo[lv * kClampBins(nb) + e], fine_inv_scale(lv), sum);
-      rclamp[e] = sum;
+        sum = fma((double)(long long)gl[lv * kClampBins(nb) + e], fine_inv_scale(lv), sum);
+      (ns ? rns : rclamp)[e] = sum;
     }
     double ic_cl = 254.999, pc_cl, dd[4];
     jc_cl = fast_bin<false>(ic_cl, S, pc_cl);
     bspline4_poly<false>(pc_cl, jc_cl, rtab, cw, dd);
+    double ic_ns = kNearSatIc, pc_ns;
+    jc_ns = fast_bin<false>(ic_ns, S, pc_ns);
+    bspline4_poly<false>(pc_ns, jc_ns, rtab, nw, dd);
 #pragma unroll
-    for (int k = 0; k < 4; k++) cw[k] *= kWcPreInv;  // rtab's value polynomials carry kWcPre
+    for (int k = 0; k < 4; k++) { cw[k] *= kWcPreInv; nw[k] *= kWcPreInv; }  // rtab's value polynomials carry kWcPre
     __syncthreads();
   }
   double ent[2] = {0.0, 0.0};
@@ -1800,6 +1850,14 @@ __device__ __forceinline__ void eval_cell(const EvalParams &P, const SlotArgs &S
       if (k >= 0 && k < 4) {
         const double ck = k == 0 ? cw[0] : (k == 1 ? cw[1] : (k == 2 ? cw[2] : cw[3]));
         mass = fma(ck, b < nb ? rclamp[nb] : rclamp[(b - nb) / nb], mass);
+      }
+    }
+    if (any_ns) {
+      const int col = b < nb ? b : (b - nb) % nb;
+      const int k = col - jc_ns;
+      if (k >= 0 && k < 4) {
+        const double nk = k == 0 ? nw[0] : (k == 1 ? nw[1] : (k == 2 ? nw[2] : nw[3]));
+        mass = fma(nk, b < nb ? rns[nb] : rns[(b - nb) / nb], mass);
       }
     }
     const double p = mass / (double)n_c;  // Q1: N_c of the initial pose

@@ -19,6 +19,18 @@ seq = poses[np.arange(4000) % 16]
 ctx.run_sequence(seq, delta, batch=16, collect=False)   # clocks up
 print(f"config {cfg}, {bins} bins, {pair.cell ** 2} cells: us per dependent evaluation (nid_run_chain, best of 5 runs of 2000)")
 print("threads | J in-launch | J direct | J resident | cost in-launch | cost direct | cost resident | evaluate() in-launch | direct | resident (python loop)")
+resident_why = ""
+
+
+def set_resident(on):
+    """nid_set_resident, tolerating a platform (or geometry) without it: the column then shows launches"""
+    global resident_why
+    try:
+        ctx.set_resident(on)
+    except capi.NidError as e:
+        resident_why = str(e)
+
+
 for nt in (128, 256, 512, 1024):
     ctx.set_launch_shape(nt, nt)
     row = []
@@ -26,17 +38,17 @@ for nt in (128, 256, 512, 1024):
     for jac in (True, False):
         for direct, resident in modes:
             ctx.set_direct_results(direct)
-            ctx.set_resident(resident and nt >= 512)
+            set_resident(resident and nt >= 512)
             ctx.run_chain(seq[:200], delta, want_jac=jac, collect=False)
             row.append(min(ctx.run_chain(seq[:2000], delta, want_jac=jac, collect=False)[1] for _ in range(5)) / 2000 * 1e6)
     ev = []
     for direct, resident in modes:
         ctx.set_direct_results(direct)
-        ctx.set_resident(resident and nt >= 512)
+        set_resident(resident and nt >= 512)
         t0 = time.perf_counter()
         for i in range(300):
             ctx.evaluate(poses[i % 16], True)
         ev.append((time.perf_counter() - t0) / 300 * 1e6)
     ctx.set_resident(False)
     print(f"{nt:7d} | {row[0]:11.1f} | {row[1]:8.1f} | {row[2]:10.1f} | {row[3]:14.1f} | {row[4]:11.1f} | {row[5]:13.1f} | {ev[0]:20.1f} | {ev[1]:6.1f} | {ev[2]:8.1f}")
-print("resident evaluator:", ctx.resident_stats())
+print("resident evaluator:", ctx.resident_stats(), resident_why)
