@@ -127,7 +127,11 @@ int nid_set_direct_results(nid_ctx *ctx, int on);
  * flight, if any, is collected before), so mixing the two costs a restart each time -- it pays for chains of
  * single-pose evaluations, which is what a Gauss-Newton / LM loop is.  A process-wide device synchronisation (hipDeviceSynchronize,
  * hipFree outside this library) waits until the kernel leaves -- at most its 200 ms.
- * NID_ERR_UNSUPPORTED if the platform does not let the CPU address the device's fine-grained memory;
+ * One workgroup per cell has to be ON the device at once: a context of more cells than the device has CUs (1024 cells
+ * on 256 CUs: BASELINE configs[1] at 1280x960) is answered by ordinary launches -- the first request finds that out,
+ * nid_resident_stats keeps saying served == 0, and later nid_set_resident(ctx, 1) calls return NID_ERR_UNSUPPORTED with
+ * the reason in nid_last_error.
+ * NID_ERR_UNSUPPORTED also if the platform does not let the CPU address the device's fine-grained memory;
  * NID_ERR_STATE while a launch is pending. */
 int nid_set_resident(nid_ctx *ctx, int on);
 /* requests served by the resident kernel, requests re-issued as ordinary launches, kernel starts */

@@ -882,7 +882,7 @@ int resident_post(nid_ctx *ctx, int slot, const Pose &pose, bool jac, bool want_
     int rc = resident_start(ctx, ctx->jac_threads);
     if (rc) {
       if (getenv("NID_RESIDENT_DEBUG")) fprintf(stderr, "[nid resident] start failed: %d %s\n", rc, ctx->last_error.c_str());
-      if (rc == NID_ERR_UNSUPPORTED) R.probed = -1;
+      if (rc == NID_ERR_UNSUPPORTED) { R.probed = -1; R.why = ctx->last_error; }  // (this geometry never fits: later nid_set_resident(1) calls say so)
       return rc;
     }
   }

@@ -849,7 +849,7 @@ constexpr int kClampBins(int nb) { return (nb + 2) & ~1; }
 #endif
 constexpr int kClampCopies = NID_CLAMP_COPIES;
 // NEAR-SATURATED target samples: four equal taps of 255 leave the reference's four-term bilinear sum at 255 (clamped,
-// above) or an ulp or two below it (about half of a saturated patch).  Every sample at EXACTLY 255 - ulp has the same four
+// above) or an ulp or two below it (one sample in seventeen of a saturated patch at the bench's poses).  Every sample at EXACTLY 255 - ulp has the same four
 // target weights, bit for bit -- FAST math sums the reference weights of those in a second set of bins and folds them in
 // with that sample's weights, like the clamped ones.  Only the exact value qualifies: the last span is an END span of the
 // clamped knot vector, its small weights are linear / quadratic in 1 - t (1e-15, 1e-30) with O(1) derivatives, and a joint

@@ -11,7 +11,8 @@
 //     quick fingerprint of 64 samples, FULL 64-bit hash of the content).  Every call checks address, length and the
 //     quick fingerprint (about a microsecond for all six); the full hash is recomputed -- and decides whether the
 //     buffer is uploaded -- whenever one of those changed, on every kRehashEvery-th call, and after
-//     nid_legacy_invalidate().  The two per-cell arrays (1-2 KB) are fully hashed on every call.
+//     nid_legacy_invalidate().  The two per-cell arrays (1-2 KB) are fully hashed on every call; the two images'
+//     full hashes are taken over their u8 conversion (check_image: the same content at an eighth of the bytes).
 //     So: a new frame pair is always noticed (new address or new samples -> full hash -> upload); a caller that rewrites
 //     part of a buffer IN PLACE between two calls without touching a sampled element is noticed within kRehashEvery
 //     calls, or at once if it says so with nid_legacy_invalidate() -- the one thing this library asks of a caller
@@ -96,23 +97,26 @@ uint64_t fingerprint(const T *a, size_t n) {
   return h ? h : 2;
 }
 
-// the whole content, 64 bits: four interleaved multiply-xor lanes over the 8-byte words (memory-bound: ~0.1 ms/MB)
+// the whole content, 64 bits: eight interleaved multiply-xor lanes over the 8-byte words (eight independent dependency
+// chains keep the multiplier busy: memory-bound, ~0.05 ms/MB on one core)
 template <typename T>
 uint64_t full_hash(const T *a, size_t n) {
   if (!a) return 1;
   const size_t bytes = n * sizeof(T), words = bytes / 8;
   const unsigned char *b = reinterpret_cast<const unsigned char *>(a);
-  uint64_t h[4] = {0x9E3779B97F4A7C15ull ^ bytes, 0xC2B2AE3D27D4EB4Full, 0x165667B19E3779F9ull, 0x27D4EB2F165667C5ull};
+  constexpr int L = 8;
+  uint64_t h[L] = {0x9E3779B97F4A7C15ull ^ bytes, 0xC2B2AE3D27D4EB4Full, 0x165667B19E3779F9ull, 0x27D4EB2F165667C5ull,
+                   0x85EBCA77C2B2AE63ull, 0xD6E8FEB86659FD93ull, 0xA0761D6478BD642Full, 0xE7037ED1A0B428DBull};
   size_t i = 0;
-  for (; i + 4 <= words; i += 4) {
-    uint64_t w[4];
-    std::memcpy(w, b + 8 * i, 32);
-    for (int k = 0; k < 4; k++) { h[k] = (h[k] ^ w[k]) * 0x9FB21C651E98DF25ull; h[k] ^= h[k] >> 29; }
+  for (; i + L <= words; i += L) {
+    uint64_t w[L];
+    std::memcpy(w, b + 8 * i, 8 * L);
+    for (int k = 0; k < L; k++) { h[k] = (h[k] ^ w[k]) * 0x9FB21C651E98DF25ull; h[k] ^= h[k] >> 29; }
   }
-  for (; i < words; i++) { uint64_t w; std::memcpy(&w, b + 8 * i, 8); h[i & 3] = (h[i & 3] ^ w) * 0x9FB21C651E98DF25ull; h[i & 3] ^= h[i & 3] >> 29; }
+  for (; i < words; i++) { uint64_t w; std::memcpy(&w, b + 8 * i, 8); h[i % L] = (h[i % L] ^ w) * 0x9FB21C651E98DF25ull; h[i % L] ^= h[i % L] >> 29; }
   for (size_t t = 8 * words; t < bytes; t++) h[0] = (h[0] ^ b[t]) * 0x100000001B3ull;
   uint64_t r = h[0];
-  for (int k = 1; k < 4; k++) r = (r ^ h[k]) * 0xFF51AFD7ED558CCDull + k;
+  for (int k = 1; k < L; k++) r = (r ^ h[k]) * 0xFF51AFD7ED558CCDull + k;
   r ^= r >> 32;
   return r ? r : 2;
 }
@@ -131,6 +135,23 @@ bool same_content(LegacyState::Key &k, const T *a, size_t n, bool force) {
 template <typename T>
 void remember(LegacyState::Key &k, const T *a, size_t n) {
   k.addr = a; k.n = n; k.quick = fingerprint(a, n); k.full = full_hash(a, n); k.valid = true;
+}
+
+bool to_u8(const double *im, size_t n, std::vector<uint8_t> *out);
+// An f64 image carrying u8 values (NID_pose_estimation.cpp:245-251): its key's full hash is that of the CONVERTED image
+// -- the conversion checks every value (an integer in [0, 255] or the call fails), so the u8 image determines the
+// buffer's content, at an eighth of the bytes; and the conversion is needed for the upload anyway.  `have`: something is
+// resident to compare with.  On return *same says whether the resident image can stay; u8 holds the converted image
+// whenever the full check ran (empty: address, length and quick fingerprint were unchanged and no full check was due).
+int check_image(LegacyState::Key &k, const double *im, size_t n, bool force, bool have, std::vector<uint8_t> *u8, bool *same) {
+  const uint64_t q = fingerprint(im, n);
+  u8->clear();
+  if (have && k.valid && !force && k.addr == (const void *)im && k.n == n && k.quick == q) { *same = true; return NID_OK; }
+  if (!to_u8(im, n, u8)) return NID_ERR_UNSUPPORTED;
+  const uint64_t f = full_hash(u8->data(), n);
+  *same = have && k.valid && k.n == n && k.full == f;
+  k.addr = im; k.n = n; k.quick = q; k.full = f; k.valid = true;
+  return NID_OK;
 }
 
 void report(const char *where, int rc, nid_multi *m) {
@@ -181,13 +202,19 @@ bool to_u8(const double *im, size_t n, std::vector<uint8_t> *out) {
   return nid_set_reference_image_f64(im, (int64_t)n, out->data()) == NID_OK;
 }
 
-int upload_reference(LegacyState &S, const double *im0, const double *points3d) {
+// (`im`: im0 converted already, with its key up to date -- or empty: converted and keyed here)
+int upload_reference(LegacyState &S, const double *im0, const double *points3d, std::vector<uint8_t> *im, bool points_keyed) {
   const size_t N = (size_t)S.rows * S.cols;
-  std::vector<uint8_t> im;
-  if (!to_u8(im0, N, &im)) return NID_ERR_UNSUPPORTED;
-  int rc = nid_multi_set_reference_points(S.m, points3d, im.data());
+  std::vector<uint8_t> local;
+  if (!im || im->empty()) {
+    bool dummy;
+    int rc = check_image(S.k_im0, im0, N, true, false, &local, &dummy);
+    if (rc != NID_OK) return rc;
+    im = &local;
+  }
+  int rc = nid_multi_set_reference_points(S.m, points3d, im->data());
   if (rc != NID_OK) return rc;
-  remember(S.k_im0, im0, N); remember(S.k_points, points3d, 3 * N);
+  if (!points_keyed) remember(S.k_points, points3d, 3 * N);
   S.have_ref = true; S.have_href = false;
   g_uploads++;
   return NID_OK;
@@ -195,11 +222,17 @@ int upload_reference(LegacyState &S, const double *im0, const double *points3d) 
 
 int ensure_reference(LegacyState &S, const double *im0, const double *points3d, bool force) {
   const size_t N = (size_t)S.rows * S.cols;
+  std::vector<uint8_t> im;
+  bool points_keyed = false;
   if (S.have_ref && !always_upload()) {
-    const bool a = same_content(S.k_im0, im0, N, force), b = same_content(S.k_points, points3d, 3 * N, force);
+    bool a = false;
+    int rc = check_image(S.k_im0, im0, N, force, true, &im, &a);
+    if (rc != NID_OK) return rc;
+    const bool b = same_content(S.k_points, points3d, 3 * N, force);
+    points_keyed = true;
     if (a && b) return NID_OK;
   }
-  return upload_reference(S, im0, points3d);
+  return upload_reference(S, im0, points3d, &im, points_keyed);
 }
 
 }  // namespace
@@ -217,7 +250,7 @@ void CudaComputeHref(double *im0, double *points3d, double *pose, double *camera
   nid_multi *m = get_multi(rows, cols, cell_num, bin_num, bs_degree, camera_intrincis);
   if (!m) return;
   LegacyState &S = g_state;
-  int rc = upload_reference(S, im0, points3d);  // once per frame pair: always fresh
+  int rc = upload_reference(S, im0, points3d, nullptr, false);  // once per frame pair: always fresh
   if (rc != NID_OK) { report("CudaComputeHref(reference upload)", rc, m); return; }
   S.have_target = false;                        // a new pair: the next CudaComputeH re-checks its target
   const size_t N = (size_t)rows * cols;
@@ -295,14 +328,18 @@ nid_multi *ensure_state(double *im0, double *im1, double *points3d, int *bs_coun
   S.force_full = 0;
   int rc = ensure_reference(S, im0, points3d, periodic || (force & NID_LEGACY_REFERENCE));
   if (rc != NID_OK) { report("CudaComputeH(reference upload)", rc, m); return nullptr; }
-  if (!S.have_target || always_upload() || !same_content(S.k_im1, im1, N, periodic || (force & NID_LEGACY_TARGET))) {
+  {
     std::vector<uint8_t> im;
-    if (!to_u8(im1, N, &im)) { report("CudaComputeH(im1 is not u8-valued)", NID_ERR_UNSUPPORTED, m); return nullptr; }
-    rc = nid_multi_set_target_u8(m, im.data());
-    if (rc != NID_OK) { report("CudaComputeH(target upload)", rc, m); return nullptr; }
-    remember(S.k_im1, im1, N);
-    S.have_target = true;
-    g_uploads++;
+    bool same = false;
+    const bool have = S.have_target && !always_upload();
+    rc = check_image(S.k_im1, im1, N, periodic || (force & NID_LEGACY_TARGET), have, &im, &same);
+    if (rc != NID_OK) { report("CudaComputeH(im1 is not u8-valued)", rc, m); return nullptr; }
+    if (!same) {
+      rc = nid_multi_set_target_u8(m, im.data());
+      if (rc != NID_OK) { report("CudaComputeH(target upload)", rc, m); return nullptr; }
+      S.have_target = true;
+      g_uploads++;
+    }
   }
   // Href is only READ by the reference with calculate_der (computeH.cu:428-429); the kernels also need it to know
   // which cells are active.  A NULL Href gives zeros (cost-only outputs do not depend on it) and the first call

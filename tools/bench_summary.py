@@ -8,7 +8,7 @@ print("value", round(d["value"]), "it/s; sustained", round(r.get("sustained", {}
 if "sequential" in r:
     s = r["sequential"]
     print("sequential:", s["form"], round(s["us_per_evaluation"], 2), "us;",
-          {k: round(v["us_per_evaluation"], 2) for k, v in (("launched DIRECT", s["latency_shape_512"]), ("in-launch", s["latency_shape_512"].get("in_launch_reduction", {"us_per_evaluation": 0})),
+          {k: round(v.get("us_per_evaluation", float("nan")), 2) for k, v in (("launched DIRECT", s["latency_shape_512"]), ("in-launch", s["latency_shape_512"].get("in_launch_reduction", {"us_per_evaluation": 0})),
                                                          ("resident", s["latency_shape_512"].get("resident_evaluator", {"us_per_evaluation": 0})), ("128 threads", s["throughput_shape_128"]))})
     print("  resident stats", s["latency_shape_512"].get("resident_evaluator", {}).get("stats"))
 for k in ("cold", "other_math_mode", "flash_pair"):

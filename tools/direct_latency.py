@@ -28,7 +28,7 @@ def set_resident(on):
     try:
         ctx.set_resident(on)
     except capi.NidError as e:
-        resident_why = str(e)
+        resident_why = resident_why or str(e)   # (the first refusal says why)
 
 
 for nt in (128, 256, 512, 1024):
