@@ -544,8 +544,17 @@ inline void add_record_jac(const double *J, double err, double rho1, double *acc
     for (int b = a; b < 6; b++, idx++) acc[idx] += (J[a] * rho1) * J[b];
 }
 
+// the same sums with AVX-512 (nid_hostsum.cpp: host-only C++ next to this file; the same operations lane by lane)
+extern "C" __attribute__((visibility("hidden"))) int nid_hostsum_have_avx512(void);
+extern "C" __attribute__((visibility("hidden"))) void nid_hostsum_jac_avx512(const double *rec, double err, double rho1, double *acc);
+extern "C" __attribute__((visibility("hidden"))) int nid_hostsum_take_jac_avx512(double *rec, unsigned long long sentinel, int active, double err,
+                                                                                  double rho1, double *acc);
+
 #ifndef NID_DIRECT_AHEAD
 #define NID_DIRECT_AHEAD 24
+#endif
+#ifndef NID_DIRECT_HINT
+#define NID_DIRECT_HINT 3
 #endif
 constexpr int kDirectAhead = NID_DIRECT_AHEAD;
 constexpr std::chrono::milliseconds kResidentPatience(2);      // a resident request unanswered for this long: fallback
@@ -559,6 +568,7 @@ int wait_direct(nid_ctx *ctx, Slot &S) {
   const float dsqr = (float)(S.direct_delta * S.direct_delta);  // RobustKernelHuber::setDelta (robust_kernel_impl.h:84)
   const bool jac = S.direct_jac;
   static const bool trace = getenv("NID_DIRECT_TRACE") != nullptr;
+  static const bool vec512 = nid_hostsum_have_avx512() != 0 && getenv("NID_DIRECT_SCALAR") == nullptr;
   const auto t0 = std::chrono::steady_clock::now();
   std::vector<double> &hub = ctx->direct_rho1;  // per cell: rho1, err, active
   if (jac && hub.size() < (size_t)3 * nloc) hub.resize((size_t)3 * nloc);
@@ -569,7 +579,8 @@ int wait_direct(nid_ctx *ctx, Slot &S) {
     // still busy) -> Huber weights, chi2 (entry 0), count (entry 28).  c2 <= c1: Jacobian records -> b, H (entries
     // 1..27).  Every entry has its own chain of additions, in sum_blocks_w0's order, whichever cursor performs it:
     // per group the even-numbered cells in ascending order plus the odd-numbered ones, then the groups likewise.
-    double top[2][32] = {}, grp[2][32] = {}, g00[2] = {0.0, 0.0}, g28[2] = {0.0, 0.0};
+    alignas(64) double top[2][32] = {}, grp[2][32] = {};
+    double g00[2] = {0.0, 0.0}, g28[2] = {0.0, 0.0};
     int c1 = 0, c2 = jac ? 0 : nloc;
     unsigned long spins = 0, patience = 0;
     bool synced = false, again = false;
@@ -580,7 +591,7 @@ int wait_direct(nid_ctx *ctx, Slot &S) {
         double *rec = base + (size_t)c1 * kDirectRec;
         if (words_arrived(rec, kDirectRec)) {
           // every record is a line the device has just written, i.e. a miss to memory: ask for the lines ahead
-          if (c1 + kDirectAhead < nloc) __builtin_prefetch(rec + (size_t)kDirectAhead * kDirectRec, 0, 3);
+          if (c1 + kDirectAhead < nloc) __builtin_prefetch(rec + (size_t)kDirectAhead * kDirectRec, 0, NID_DIRECT_HINT);
           __atomic_thread_fence(__ATOMIC_ACQUIRE);  // (the words were read as volatile; keep the plain reads below behind them)
           const int i = c1 % gs, gq = c1 / gs;
           double acc[32];
@@ -605,13 +616,22 @@ int wait_direct(nid_ctx *ctx, Slot &S) {
       }
       if (c2 < c1) {
         double *rec = base + (size_t)(nloc + c2) * kDirectRec;
-        if (words_arrived(rec, kDirectRec)) {
-          if (c2 + kDirectAhead < nloc) __builtin_prefetch(rec + (size_t)kDirectAhead * kDirectRec, 0, 3);
-          __atomic_thread_fence(__ATOMIC_ACQUIRE);
-          const int i = c2 % gs, gq = c2 / gs;
-          const double *w = &hub[3 * (size_t)c2];
-          if (w[2] != 0.0) add_record_jac(rec, w[1], w[0], grp[i & 1]);
-          fill_sentinel(rec, kDirectRec);
+        const int i = c2 % gs, gq = c2 / gs;
+        const double *w = &hub[3 * (size_t)c2];
+        bool took;
+        if (vec512) {  // arrival test, sums and re-arming on one load of the line (nid_hostsum.cpp)
+          took = nid_hostsum_take_jac_avx512(rec, kHostSentinel, w[2] != 0.0, w[1], w[0], grp[i & 1]) != 0;
+          if (took && c2 + kDirectAhead < nloc) __builtin_prefetch(rec + (size_t)kDirectAhead * kDirectRec, 0, NID_DIRECT_HINT);
+        } else {
+          took = words_arrived(rec, kDirectRec);
+          if (took) {
+            if (c2 + kDirectAhead < nloc) __builtin_prefetch(rec + (size_t)kDirectAhead * kDirectRec, 0, NID_DIRECT_HINT);
+            __atomic_thread_fence(__ATOMIC_ACQUIRE);
+            if (w[2] != 0.0) add_record_jac(rec, w[1], w[0], grp[i & 1]);
+            fill_sentinel(rec, kDirectRec);
+          }
+        }
+        if (took) {
           c2++;
           if (i == gs - 1 || c2 == nloc) {
             double *t = top[gq & 1];

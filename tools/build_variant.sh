@@ -7,7 +7,7 @@ root=$(cd "$(dirname "$0")/.." && pwd)
 mkdir -p $root/exp /tmp/nidv_$name
 cd /tmp/nidv_$name
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -ffp-contract=off -ldl "$@" -I$root/include -I$root/nid-pose-estimation_amd/csrc \
-  -o /tmp/nidv_$name/libnid_$name.so $root/nid-pose-estimation_amd/csrc/nid_capi.hip --save-temps=obj 2>&1 | grep -E "error" -A5 || true
+  -o /tmp/nidv_$name/libnid_$name.so $root/nid-pose-estimation_amd/csrc/nid_capi.hip $root/nid-pose-estimation_amd/csrc/nid_hostsum.cpp --save-temps=obj 2>&1 | grep -E "error" -A5 || true
 python3 - "$name" <<'PY'
 import re, glob, sys
 f = glob.glob('/tmp/nidv_%s/*gfx950*.s' % sys.argv[1])

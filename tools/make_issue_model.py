@@ -24,6 +24,6 @@ out[f"{cfg}:{bins}"] = {
     "wave_cycles": c["SQ_WAVE_CYCLES"] / w, "wait_any_frac": c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"],
     "wait_inst_frac": c["SQ_WAIT_INST_ANY"] / c["SQ_WAVE_CYCLES"], "active_inst_frac": c["SQ_ACTIVE_INST_ANY"] / c["SQ_WAVE_CYCLES"],
     "source": f"{os.path.relpath(table, ROOT)} (rocprofv3 --pmc SQ_* passes over tools/pmc_run.py, {ppl} poses per launch, "
-              "128-thread workgroups, FAST math; committed as profiles/r02_A_pmc_counters.txt)"}
+              "128-thread workgroups, FAST math; committed as profiles/r0N_A_pmc_counters.txt of the same round)"}
 json.dump(out, open(path, "w"), indent=1)
 print(json.dumps(out[f"{cfg}:{bins}"], indent=1))
