@@ -370,6 +370,29 @@ __device__ __forceinline__ void bspline4_poly(double u, int jc, const double *ct
   }
 }
 
+// The four VALUES with an error relative to each weight at BOTH ends of the span.  Horner in t = u - jc is exact to
+// ~1e-16 ABSOLUTE: fine for a weight that vanishes at the span's left end (its constant coefficient is an exact 0), not
+// for one that vanishes at the right end -- 3 (1 - t) at 1 - t = 4e-16 (a target sample an ulp below 255 on the last span)
+// came out 15 % off, and a bin made of such weights alone enters the Jacobian through log2 of its mass (2.3e-3 of a
+// one-sample cell's Jacobian: sweep seed 344412).  The clamped knot vector is symmetric: the basis on span jc at t is the
+// basis on span S - 1 - jc at s = 1 - t in reverse order, and s = (jc + 1) - u is exact next to the knot -- so the right
+// half of a span is evaluated from its mirror image's row.  Used where small weights are looked at one by one: the rare
+// branch of hist_add and the constant weights of the clamped / near-saturated samples.
+__device__ __forceinline__ void bspline4_vals_both_ends(double u, int jc, int S, const double *ctab, double B[4]) {
+  const double t = u - (double)jc;
+  const bool right = t > 0.5;
+  const double x = right ? (double)(jc + 1) - u : t;
+  const double *c = ctab + __mul24(right ? S - 1 - jc : jc, kCoefRow);
+  double v[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const double *ck = c + 7 * k;
+    v[k] = fma(fma(fma(ck[3], x, ck[2]), x, ck[1]), x, ck[0]);
+  }
+#pragma unroll
+  for (int k = 0; k < 4; k++) B[k] = right ? v[3 - k] : v[k];
+}
+
 // derivative-only form of bspline4_poly (Jacobian phase of k_eval2).  The u == 0 quirk (Q5: all
 // four derivatives identically 0) is applied by the caller, once, on the pixel's coefficient.
 __device__ __forceinline__ void bspline4_poly_der(double u, int jc, const double *ctab, double D[4]) {
@@ -544,9 +567,16 @@ constexpr double kWcPre = 0x1p-512, kWcPreInv = 0x1p512;
 // wr[m] * w below 2^-8 of a sample whose target OR reference sample sits next to a knot to the level of THAT
 // product's exponent: at least 27 bits of every addend survive, at most 2^51 per addend and 2^62 per bin.  Weights >= 2^-8 stay in the coarse copies
 // (error of the Jacobian term there <= quantum * |dw| / w = 2.2e-16 * 3 * 256 = 2e-13).  kTinyW: the smaller
-// outer weight of a sample (target or reference) is below it iff the sample sits within ~2.8e-3 of a knot.
+// outer weight of a sample (target or reference) -- always the CUBIC one, c * d^3 in the distance d to the knot, on end
+// spans too -- is below it iff the sample sits within ~5.6e-4 of a knot.  What a sample OUTSIDE that distance loses in
+// the coarse copies is bounded by quantum * |dw| / w ~ quantum * 3 / d for its cubic weight, quantum * 2 / d for a
+// quadratic and quantum / d for a linear end-span weight: 2^-52 / 5.6e-4 = 4e-13 per addend.  Round 2 had 2^-45 / 2.8e-3 =
+// 1e-11 (threshold 2^-28: chosen for THAT quantum); with the 2^-52 encode the threshold moved to 2^-35 -- a fifth of the
+// samples take the rare branch of hist_add (one wave-round in eight instead of one in two on a smooth image): -1.1 %
+// kernel time on the plain pair, -1.9 % on the flash pair; 2^-40 would give another 0.2 / 0.7 %.  The per-case Jacobian
+// errors of a 3 000-case sweep are the same to three digits at 2^-28, 2^-35 and 2^-40 (profiles/r03_ablations_A.txt).
 #ifndef NID_TINY_W_EXP
-#define NID_TINY_W_EXP 28
+#define NID_TINY_W_EXP 35
 #endif
 constexpr double kTinyW = 1.0 / (double)(1ull << NID_TINY_W_EXP);
 constexpr double kFineW = 0x1p-8;
@@ -1226,9 +1256,19 @@ __device__ __forceinline__ void exact_decisions(const EvalParams &P, const SlotA
 // FAST: clamped centre sample -> bin position -> span; returns jc, pc.  CLAMP = false: the caller knows
 // ic < 255 (the main passes only take samples inside the clamp guard |ic - 127.5| <= kGuardHalf; the clamp's
 // compare and two selects then cost nothing)
-template <bool CLAMP = true>
+// EXACT (the second passes, whose `ic` is the reference's own sample): the bin position with the reference's own
+// rounding, (ic * S) / 255 (types_six_dof_expmap.cpp:574) -- a sample an ulp below 255 sits 1 - t = one or two ulps of
+// S below the last knot, the end span's linear weight 3 (1 - t) is that distance, and a bin made of such weights alone
+// enters the Jacobian through log2 of its mass: ic * (S / 255) is the neighbouring double for some S (S = 2: twice the
+// weight, W off by 1 of 59 -- 2.3e-3 of a one-sample cell's Jacobian, sweep seed 344412).  The main passes only take
+// samples at least 1e-4 away from 0 and 255 (the clamp guard): there an ulp of S is 1e-10 of 1 - t and below.
+template <bool CLAMP = true, bool EXACT = false>
 __device__ __forceinline__ int fast_bin(double &ic, int S, double &pc) {
   if (CLAMP) { if (ic >= 255) ic = 254.999; }
+  if (EXACT) {
+    pc = ic * (double)S / 255.0;
+    return min((int)pc, S - 1);  // (a quotient that rounds up to S itself: t = 1 on the last span)
+  }
   pc = ic * ((double)S / 255.0);
   return (int)pc;
 }
@@ -1413,7 +1453,7 @@ __device__ __forceinline__ void eval_cell(const EvalParams &P, const SlotArgs &S
   // The reference weights take hist_dn (four multiplications per sample), and every add is the bit pattern of a
   // subnormal product (fx_bits).
   const double tiny_scaled = kTinyW * kWcPre;
-  auto hist_add = [&](int jr, int jc, const double (&wr_in)[4], const double (&win)[4], auto prescaled, int group = 0) {
+  auto hist_add = [&](int jr, int jc, const double (&wr_in)[4], const double (&win)[4], auto prescaled, double pcv, int group = 0) {
     constexpr bool PRESCALED = decltype(prescaled)::value;
     if (group != 0) {  // FAST second passes only: 1 = clamped (kClampBins), 2 = near-saturated (kNearSatIc)
       unsigned long long *hx = (group == 2 ? nsb : clampb) + ((unsigned)copy & (kClampCopies - 1));
@@ -1488,11 +1528,20 @@ __device__ __forceinline__ void eval_cell(const EvalParams &P, const SlotArgs &S
     const bool ref_tiny = wr_in[0] < 0.0;
     if (fmin(wcs[0], wcs[3]) < tiny_scaled || ref_tiny) {
       double wc[4];
+      if (!STRICT && PRESCALED) {
+        // FAST: the weights once more, each with an error relative to ITSELF (bspline4_vals_both_ends; the same values
+        // for a sample in the left half of its span)
+        double wv[4];
+        bspline4_vals_both_ends(pcv, jc, S, rtab, wv);
 #pragma unroll
-      for (int k = 0; k < 4; k++) wc[k] = PRESCALED ? win[k] * kWcPreInv : win[k];
+        for (int k = 0; k < 4; k++) { wcs[k] = wv[k]; wc[k] = wv[k] * kWcPreInv; }
+      } else {
+#pragma unroll
+        for (int k = 0; k < 4; k++) wc[k] = PRESCALED ? win[k] * kWcPreInv : win[k];
+      }
       wr[0] = fabs(wr[0]);
       if (!ref_tiny) {
-        // target side only (about one sample in 90 on a smooth image: every other wave-round gets here)
+        // target side only (about one sample in 450 on a smooth image: one wave-round in eight gets here)
 #pragma unroll
         for (int k = 0; k < 4; k++) {
           if (wc[k] < kFineW) {
@@ -1607,7 +1656,7 @@ __device__ __forceinline__ void eval_cell(const EvalParams &P, const SlotArgs &S
       int jc = -1;
       if (f.in) {
         jc = pixel_sample<true, false>(f, nb, S, rtab, ic, wc, dw);
-        hist_add(f.jr, jc, f.wr, wc, std::false_type{});
+        hist_add(f.jr, jc, f.wr, wc, std::false_type{}, 0.0);
       }
       if (DBG && P.dbg_u && !P.dbg_jac && pose_idx == 0 && f.jr >= 0) dump_pixel(s, f, ic, jc, wc);
     }
@@ -1676,13 +1725,13 @@ __device__ __forceinline__ void eval_cell(const EvalParams &P, const SlotArgs &S
       int jc = -1;
       if (go) {
         double pc;
-        jc = fast_bin<SECOND || kMainPassClamps>(ic, S, pc);
+        jc = fast_bin<SECOND || kMainPassClamps, SECOND>(ic, S, pc);
         bspline4_poly<false, JAC && !SECOND>(pc, jc, rtab, wc, dw);
 #ifdef NID_EXP_SECOND_NO_ADD
         if (!SECOND)
 #endif
         // (second pass: `ic` is the reference's own sample, evaluated exactly and clamped like there)
-        hist_add(f.jr, jc, SECOND ? f.wr : tin.wr, wc, std::true_type{},
+        hist_add(f.jr, jc, SECOND ? f.wr : tin.wr, wc, std::true_type{}, pc,
                  (SECOND && NID_CLAMP_BINS) ? (ic == 254.999 ? 1 : ((NID_NEAR_SAT_BINS && ic == kNearSatIc) ? 2 : 0)) : 0);
       } else {
         ic = NAN;
@@ -1749,7 +1798,7 @@ __device__ __forceinline__ void eval_cell(const EvalParams &P, const SlotArgs &S
           if (f.in && !rare) {
             jc = fast_bin<kMainPassClamps>(ic, S, pc);
             bspline4_poly<false>(pc, jc, rtab, wc, dw);
-            hist_add(f.jr, jc, f.wr, wc, std::true_type{});
+            hist_add(f.jr, jc, f.wr, wc, std::true_type{}, pc);
           }
           if (__builtin_amdgcn_ballot_w64(rare) != 0ull) rare_rounds |= 1ull << q;
           if (JAC) {
@@ -1813,12 +1862,12 @@ __device__ __forceinline__ void eval_cell(const EvalParams &P, const SlotArgs &S
         sum = fma((double)(long long)gl[lv * kClampBins(nb) + e], fine_inv_scale(lv), sum);
       (ns ? rns : rclamp)[e] = sum;
     }
-    double ic_cl = 254.999, pc_cl, dd[4];
-    jc_cl = fast_bin<false>(ic_cl, S, pc_cl);
-    bspline4_poly<false>(pc_cl, jc_cl, rtab, cw, dd);
+    double ic_cl = 254.999, pc_cl;
+    jc_cl = fast_bin<false, true>(ic_cl, S, pc_cl);  // (as the second pass places a sample)
+    bspline4_vals_both_ends(pc_cl, jc_cl, S, rtab, cw);
     double ic_ns = kNearSatIc, pc_ns;
-    jc_ns = fast_bin<false>(ic_ns, S, pc_ns);
-    bspline4_poly<false>(pc_ns, jc_ns, rtab, nw, dd);
+    jc_ns = fast_bin<false, true>(ic_ns, S, pc_ns);
+    bspline4_vals_both_ends(pc_ns, jc_ns, S, rtab, nw);
 #pragma unroll
     for (int k = 0; k < 4; k++) { cw[k] *= kWcPreInv; nw[k] *= kWcPreInv; }  // rtab's value polynomials carry kWcPre
     __syncthreads();
@@ -2102,7 +2151,7 @@ __device__ __forceinline__ void eval_cell(const EvalParams &P, const SlotArgs &S
           if (f.jin) {
             gradient_fast_interior(f.w, f.u, f.v, gx, gy, dummy);
             double pc, dw[4];
-            const int jc = fast_bin<true>(ic, S, pc);
+            const int jc = fast_bin<true, true>(ic, S, pc);
             bspline4_poly_der(pc, jc, rtab, dw);
             jac_accumulate(f, f.zq, gx, gy, pc, jc, dw, std::true_type{});
           }
@@ -2157,7 +2206,7 @@ __device__ __forceinline__ void eval_cell(const EvalParams &P, const SlotArgs &S
       }
       if (go) {
         double pc, dw[4];
-        const int jc = fast_bin<SECOND || kMainPassClamps>(ic, S, pc);
+        const int jc = fast_bin<SECOND || kMainPassClamps, SECOND>(ic, S, pc);
         bspline4_poly_der(pc, jc, rtab, dw);
         jac_accumulate(f, f.zq, gx, gy, pc, jc, dw, std::integral_constant<bool, SECOND || kMainPassClamps>{});
         if (DBG && P.dbg_u && P.dbg_jac && pose_idx == 0) {
