@@ -583,8 +583,8 @@ constexpr double kFineW = 0x1p-8;
 // An addend below this is dropped: a bin is looked at only if its mass reaches kSigma * N_c >= 3e-28 (types_six_dof_expmap.h:281,
 // the 300-pixel activity threshold), and 19 200 such addends -- the largest cell -- are 1e-9 of the smallest mass that
 // counts.  What falls below it: the outermost weight of a sample an ulp away from a knot (a saturated target sample the
-// reference's bilinear sum leaves at 255 - 3e-14: weight 1e-47) and its products -- half the samples of a flash pair's hot
-// spot, each of which used to cost five single-copy fine-level atomics on the same few addresses.  (Also: a negative
+// reference's bilinear sum leaves at 255 - 3e-14: weight 1e-47) and its products -- one in seventeen of the saturated samples
+// of a flash pair's hot spot, each of which used to cost five single-copy fine-level atomics on the same few addresses.  (Also: a negative
 // weight by rounding, which the integer encodes cannot take.)
 constexpr double kNegligibleW = 0x1p-136;
 constexpr int kFineLevels = 5;
