@@ -1038,6 +1038,32 @@ def test_direct_results_equal_in_launch_reduction(capi, synth, pair_S_edge, cfg,
 
 
 @pytest.mark.gpu
+def test_resident_evaluator_needs_one_workgroup_per_cell_on_the_chip(capi, synth):
+    """A context of more cells than the device has CUs (400 here; BASELINE configs[1] at 1280x960 has 1024): nid_set_resident
+    is accepted, the first request finds that one resident workgroup per cell does not fit and ordinary launches answer --
+    same bits, served stays 0 -- and later nid_set_resident(1) calls are refused with the reason."""
+    pair = synth.make_pair("S", rows=480, cols=640, cell=20)     # 400 cells
+    ctx = capi.from_pair(pair, 8)
+    cnt, _ = ctx.compute_href(pair.pose_init)
+    assert (cnt >= 300).sum() > 256
+    ctx.set_launch_shape(512, 0)
+    poses = list(_poses(synth, pair).values())[:3]
+    ref = [ctx.normal_equations(p, DELTA) for p in poses]
+    ctx.set_resident(True)
+    for p, r in zip(poses, ref):
+        got = ctx.normal_equations(p, DELTA)
+        assert _same_bits(got[0], r[0]) and _same_bits(got[1], r[1]) and _same_bits(got[2], r[2]) and got[3] == r[3]
+    st = ctx.resident_stats()
+    assert st["served"] == 0 and st["starts"] == 0
+    with pytest.raises(capi.NidError, match="workgroups"):
+        ctx.set_resident(True)
+    ctx.set_resident(False)   # (always accepted)
+    got = ctx.normal_equations(poses[0], DELTA)
+    assert _same_bits(got[2], ref[0][2])
+    ctx.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("cfg", ["S", "A"])
 def test_resident_evaluator_equals_launches(capi, synth, cfg, monkeypatch, shape=512):
     """The resident evaluator (nid_set_resident): single-pose requests are answered by a kernel that stays on the

@@ -18,3 +18,4 @@ python tools/lm_latency.py A 8 > gpurun_out/$tag/lm_latency_A.txt 2> gpurun_out/
 python tools/lm_trace.py 4 resident > /dev/null 2> gpurun_out/$tag/lm_trace_fused4_resident.txt; echo "lm trace rc=$?"
 python tools/flash_rate.py > gpurun_out/$tag/flash_rate.txt 2> gpurun_out/$tag/flash_rate.err; echo "flash rc=$?"
 ./tools/ubench/mailbox_latency > gpurun_out/$tag/mailbox_latency.txt 2>&1; echo "mailbox rc=$?"
+NID_DIRECT_TRACE=1 python tools/direct_trace.py > gpurun_out/$tag/direct_trace.txt 2>&1; echo "direct trace rc=$?"

@@ -1,3 +1,6 @@
+"""tools/resident_probe_B.py: what nid_set_resident does on a context of more cells than the chip has CUs (config B, 1024
+cells): the call is accepted, the first request finds that one workgroup per cell cannot be resident, launches answer
+(served == 0), and later nid_set_resident(1) calls say why."""
 import importlib, sys, numpy as np
 sys.path.insert(0, '.')
 capi = importlib.import_module("nid-pose-estimation_amd.capi")
@@ -11,5 +14,6 @@ try:
     print("set_resident ok")
     print(ctx.run_chain(np.stack([pair.pose_init] * 10), float(np.sqrt(0.95)), want_jac=True, collect=False)[1])
     print(ctx.resident_stats())
+    ctx.set_resident(True)
 except Exception as e:
     print("first error:", e)
