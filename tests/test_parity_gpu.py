@@ -760,8 +760,20 @@ SWEEP_SEEDS += [3013, 70874, 50185, 71823]
 SWEEP_SEEDS += [344412]
 
 
+# KNOWN OPEN CASE (found 45 000 sweep cases in, at the end of round 3; STRICT and FAST alike, every kernel since round 1):
+# seed 407031, pose 2, cell 6 -- 3.0e-8 of the cell's Jacobian scale (30 x the bound).  A saturated target sample an ulp
+# below 255 (end-span weight 2.7e-15, derivative 3) shares the joint bin (7, 7) with ONE ordinary product of 9.0e-13 (a
+# reference weight of 1.3e-8 times a target weight of 7e-5, neither small enough for the fine levels): the 2^-52 quantum of
+# the coarse copies is 5.6e-5 of that bin's mass, i.e. 8e-5 on its W, which the saturated sample multiplies by its O(1)
+# derivative.  tools/diag_quantum.py 407031 2 6 52 reproduces the GPU's deviation to four digits from the oracle's own
+# per-pixel values with a 2^-52 quantum (DIAG_ATTR=1 names the bin).  Removing it needs a second limb for the coarse
+# products that land in the end spans' linear-weight columns -- a per-sample cost in the main pass that was not paid for a
+# 1-in-45 000 case at 3e-8; the case stays here as an expected failure so that it is looked at again.
+KNOWN_OPEN_SEEDS = [407031]
+
+
 @pytest.mark.gpu
-@pytest.mark.parametrize("seed", list(range(64)) + SWEEP_SEEDS)
+@pytest.mark.parametrize("seed", list(range(64)) + SWEEP_SEEDS + [pytest.param(s_, marks=pytest.mark.xfail(strict=True, reason="2^-52 quantum on a one-addend joint bin shared with an end-span sample, see KNOWN_OPEN_SEEDS")) for s_ in KNOWN_OPEN_SEEDS])
 def test_randomised_pairs(capi, oracle, synth, seed):
     """Randomised parity (fixed seeds): geometry, bins, images (noise, few grey levels on bin boundaries,
     constant, saturated blobs), depth holes, small and large pose perturbations -- both math modes against

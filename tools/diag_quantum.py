@@ -91,3 +91,29 @@ if os.environ.get("DIAG_BINS"):
     for i in ids:
         if j["jc"][i] < 0: continue
         print("  jac sample: jr", d["jr"][i], "jc", j["jc"][i], "wr", d["wr"][i], "wc", d["wc"][i], "dw", j["dw"][i])
+if os.environ.get("DIAG_ATTR"):
+    # which bins carry the difference: masses exact vs quantised, and each bin's share of the Jacobian change
+    def hists(q):
+        hc = np.zeros(nb, dtype=LD); hj = np.zeros((nb, nb), dtype=LD)
+        for i in ids:
+            if d["jc"][i] < 0: continue
+            jc, jr = d["jc"][i], d["jr"][i]
+            wc, wr = d["wc"][i], d["wr"][i]
+            wrp = wr[wr > 0]
+            tiny = min(wc[0], wc[3]) < TINY or (wrp.size and min(wr[0], wr[3]) < TINY and min(wr[0], wr[3]) != 0.0)
+            for kk in range(4):
+                fine_c = tiny and wc[kk] < FINE
+                hc[jc + kk] += LD(wc[kk]) if fine_c else quant(wc[kk], q)
+                for m in range(4):
+                    pr = np.float64(wr[m]) * np.float64(wc[kk])
+                    fine = tiny and (wc[kk] < FINE or wr[m] < FINE)
+                    hj[jr + m, jc + kk] += LD(pr) if (fine or q is None) else quant(pr, q)
+        return hc, hj
+    hc0, hj0 = hists(None); hcq, hjq = hists(qs[0])
+    rel = np.where(hj0 > 0, np.abs(hjq - hj0) / np.where(hj0 > 0, hj0, 1), 0)
+    order = np.dstack(np.unravel_index(np.argsort(-rel.ravel()), rel.shape))[0][:8]
+    for r_, c_ in order:
+        print(f"  joint bin ({r_},{c_}): mass {float(hj0[r_, c_]):.4e}  relative change {float(rel[r_, c_]):.3e}")
+    relc = np.where(hc0 > 0, np.abs(hcq - hc0) / np.where(hc0 > 0, hc0, 1), 0)
+    for b in np.argsort(-relc)[:4]:
+        print(f"  marginal bin {b}: mass {float(hc0[b]):.4e}  relative change {float(relc[b]):.3e}")
