@@ -10,6 +10,15 @@
 // Plain C++ (host only): built into libnid_hip.so next to nid_capi.hip.
 #include <immintrin.h>
 
+// Every product and sum below is an operation of its own: a compiler that fuses the multiplication into the addition
+// (fp-contract, on by default in GNU mode once the target has FMA) would give other bits than the scalar loop and the
+// device.  The library is built with -ffp-contract=off; this file says so itself as well.
+#if defined(__clang__)
+#pragma clang fp contract(off)
+#elif defined(__GNUC__)
+#pragma GCC optimize("fp-contract=off")
+#endif
+
 namespace {
 
 struct Tables {

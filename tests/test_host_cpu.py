@@ -237,3 +237,23 @@ def test_driver_refuses_cpu_mode(tmp_path):
                    "dataset: eth_cvg\nim_address: /nonexistent/\ndepth_factor: 5000.0\nfx: 1\nfy: 1\ncx: 0\ncy: 0\nuse_gpu: 0\n")
     r = subprocess.run([exe, str(cfg)], capture_output=True, text=True)
     assert r.returncode == 2 and "use_gpu" in r.stderr
+
+
+@pytest.mark.parametrize("compiler", ["g++", "/opt/rocm/lib/llvm/bin/clang++"])
+def test_direct_results_avx512_sums_equal_the_scalar_loop(tmp_path, compiler):
+    """csrc/nid_hostsum.cpp (the host's part of a DIRECT launch on a CPU with AVX-512: one load per record -- arrival
+    test, the 27 products of the normal equations, re-arming) against the scalar loop of csrc/nid_capi.hip, bit for bit
+    on 200 000 random records (zeros, signed zeros, 600 binades of magnitudes, inactive cells, records with a word still
+    missing); built WITHOUT -ffp-contract=off on purpose: the file must not depend on the library's build flags.
+    No GPU involved; tests/test_parity_gpu.py::test_direct_results_equal_in_launch_reduction is the end-to-end check."""
+    import shutil
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if not (shutil.which(compiler) or os.path.exists(compiler)):
+        pytest.skip(f"{compiler} not available")
+    exe = str(tmp_path / "hostsum_check")
+    subprocess.check_call([compiler, "-O2", "-std=c++17", "-o", exe, os.path.join(root, "tests", "cpp", "hostsum_check.cpp"),
+                           os.path.join(root, "nid-pose-estimation_amd", "csrc", "nid_hostsum.cpp")])
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    if r.returncode == 2:
+        pytest.skip("no AVX-512 on this CPU: the library takes the scalar loop here")
+    assert r.returncode == 0, r.stdout[-2000:]
