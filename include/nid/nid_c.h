@@ -248,6 +248,10 @@ int nid_debug_get_pixel_dump(nid_ctx *ctx, double *u, double *v, double *ic, int
  * s_memrealtime (100 MHz) at kernel start and end of the same wave */
 int nid_debug_enable_stamps(nid_ctx *ctx, int enable);
 int nid_debug_get_stamps(nid_ctx *ctx, int64_t *stamps);
+/* diagnostic: how many (cell, pose) evaluations of this context ran the REPAIR pass of the histogram fold (a bin of an
+ * end span's linear-weight column rebuilt in the fine fixed-point levels: kLinFlagW in csrc/nid_kernels.hip.h) since
+ * creation or the last reset.  Waits for the device. */
+int nid_debug_repair_count(nid_ctx *ctx, int64_t *count, int reset);
 /* host evaluation of the closed-form B-spline used by the kernels */
 void nid_bspline4_host(double u, int bin_num, double *B4, double *D4);
 /* host evaluation of the FAST-mode per-span polynomial B-spline table */

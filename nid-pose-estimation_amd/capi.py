@@ -46,7 +46,7 @@ SYMBOLS = [
     "nid_normal_equations", "nid_launch", "nid_launch_batch", "nid_launch_chain", "nid_launch_batch_to", "nid_run_sequence", "nid_run_chain", "nid_set_loop_form", "nid_set_direct_results", "nid_set_resident", "nid_resident_stats", "nid_wait", "nid_slot_buffers", "nid_launch_to",
     "nid_unpack_reduced", "nid_debug_enable_pixel_dump", "nid_debug_get_pixel_dump",
     "nid_debug_enable_stamps", "nid_debug_get_stamps", "nid_bspline4_host", "nid_bspline4_poly_host", "nid_log2_fast_host", "nid_div_small_host", "nid_last_kernel_ms", "nid_enable_timing", "nid_time_launches",
-    "nid_contract_bytes",
+    "nid_contract_bytes", "nid_debug_repair_count",
 ]
 
 _lib = None
@@ -119,6 +119,7 @@ def load():
     lib.nid_set_resident.argtypes = [vp, C.c_int]
     lib.nid_resident_stats.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     lib.nid_time_launches.argtypes = [vp, C.c_int, c_dp, C.c_int, C.c_double, C.c_int, c_fp]
+    lib.nid_debug_repair_count.argtypes = [vp, C.POINTER(C.c_int64), C.c_int]
     lib.nid_contract_bytes.restype = C.c_int64
     lib.nid_contract_bytes.argtypes = [vp]
     _lib = lib
@@ -360,6 +361,12 @@ class Context:
 
     def contract_bytes(self):
         return int(self.lib.nid_contract_bytes(self.h))
+
+    def repair_count(self, reset=False):
+        """(cell, pose) evaluations that ran the fold's repair pass (kLinFlagW in csrc/nid_kernels.hip.h)."""
+        n = C.c_int64(0)
+        self._check(self.lib.nid_debug_repair_count(self.h, C.byref(n), 1 if reset else 0), "nid_debug_repair_count")
+        return int(n.value)
 
     # ---- debug ----------------------------------------------------------------
     def enable_pixel_dump(self, on=True):

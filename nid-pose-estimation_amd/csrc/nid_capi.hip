@@ -22,7 +22,8 @@
 #include <vector>
 
 #include "nid/nid_c.h"
-#include "nid_kernels.hip.h"
+#define NID_SETUP_KERNELS 1  // k_tile, k_im1_margins, k_backproject_plain: this translation unit's
+#include "nid_eval_launch.h"
 
 using namespace nid;
 
@@ -106,6 +107,7 @@ struct nid_ctx {
   double *dbg_u = nullptr, *dbg_v = nullptr, *dbg_ic = nullptr, *dbg_wc = nullptr;
   int *dbg_jc = nullptr;
   long long *dbg_stamps = nullptr;
+  unsigned long long *repair_count_dev = nullptr;  // EvalParams::repair_count (nid_debug_repair_count)
   bool dbg_enabled = false;
   int dbg_jac = 0;
   bool timing = false;
@@ -243,62 +245,13 @@ size_t eval_lds_bytes(const Geometry &g, int nt, bool resident = false) {
   // copies + fine levels (the Jacobian block sum of the throughput shapes reuses the area: at least kXposeDoubles); tab + term
   // clamped samples: coarse copies, fine levels, folded sums, flags; near-saturated samples: folded sums, and their bins
   // unless the weight tables lend them their area (near_sat_aliased)
-  const size_t clamp_bytes = (size_t)kClampBins(g.nb) * (kClampCopies + kFineLevels + 1) * 8 + 8 + (size_t)(g.nb + 1) * 8 +
+  const size_t clamp_bytes = (size_t)kClampBins(g.nb) * (kClampCopies + kFineLevels + 1) * 8 + (size_t)kFlagWords * 4 + (size_t)(g.nb + 1) * 8 +
                              ((near_sat_aliased(g.nb) && !resident) ? 0 : (size_t)kNearSatBinBytes(g.nb) + 8);
   const size_t hist_bytes = std::max((size_t)nbins * (eval_hist_copies(nt) + kFineLevels) * 8 + clamp_bytes, (size_t)kXposeDoubles(nt) * 8);
   return hist_bytes + 2 * (size_t)((nbins + 1) & ~1) * 8 + (size_t)g.S * kCoefRow * 8 + (size_t)kRedDoubles(nt) * 8;
 }
 
-// k_eval2 (occupancy-organised, runtime pixel loop): one workgroup shape for every cell size.
-// EXTOK: instantiate the variants for launches of more than kMaxBatch poses too (throughput shapes only).
-template <int NT, int NB, bool DBG, bool EXTOK = true>
-void launch_eval2_v(const EvalParams &P, bool jac, bool strict, size_t lds, hipStream_t s, int batch) {
-  const dim3 grid((unsigned)(((P.g.nloc + 7) / 8) * 8 * batch)), block(NT);
-  if constexpr (EXTOK && !DBG) {
-    if (P.slots_ext) {  // more than kMaxBatch poses: per-pose records in device memory
-      if (strict) {
-        if (jac) hipLaunchKernelGGL((k_eval2<NT, true, true, NB, false, true>), grid, block, lds, s, P);
-        else hipLaunchKernelGGL((k_eval2<NT, false, true, NB, false, true>), grid, block, lds, s, P);
-      } else {
-        if (jac) hipLaunchKernelGGL((k_eval2<NT, true, false, NB, false, true>), grid, block, lds, s, P);
-        else hipLaunchKernelGGL((k_eval2<NT, false, false, NB, false, true>), grid, block, lds, s, P);
-      }
-      return;
-    }
-  }
-  if (strict) {
-    if (jac) hipLaunchKernelGGL((k_eval2<NT, true, true, NB, DBG>), grid, block, lds, s, P);
-    else hipLaunchKernelGGL((k_eval2<NT, false, true, NB, DBG>), grid, block, lds, s, P);
-  } else {
-    if (jac) hipLaunchKernelGGL((k_eval2<NT, true, false, NB, DBG>), grid, block, lds, s, P);
-    else hipLaunchKernelGGL((k_eval2<NT, false, false, NB, DBG>), grid, block, lds, s, P);
-  }
-}
-
-// The latency form of the FAST pixel loops (k_eval2's LAT parameter): 512- / 1024-thread workgroups whose LAT rounds
-// cover the cell.  Register budget 128 per lane = the residency the loop form has at these shapes (2 / 1 workgroups
-// per CU), so it is used whenever it applies.
-template <int NT, int NB>
-void launch_eval2_lat(const EvalParams &P, bool jac, size_t lds, hipStream_t s, int batch) {
-  constexpr int LAT = NT == 512 ? 3 : 2;
-  const dim3 grid((unsigned)(((P.g.nloc + 7) / 8) * 8 * batch)), block(NT);
-  if (jac) hipLaunchKernelGGL((k_eval2<NT, true, false, NB, false, false, LAT>), grid, block, lds, s, P);
-  else hipLaunchKernelGGL((k_eval2<NT, false, false, NB, false, false, LAT>), grid, block, lds, s, P);
-}
-template <int NT>
-void launch_eval2_lat_nb(const EvalParams &P, bool jac, size_t lds, hipStream_t s, int batch) {
-  if (P.g.nb == 8) launch_eval2_lat<NT, 8>(P, jac, lds, s, batch);
-  else if (P.g.nb == 10) launch_eval2_lat<NT, 10>(P, jac, lds, s, batch);
-  else launch_eval2_lat<NT, 0>(P, jac, lds, s, batch);
-}
 constexpr int lat_rounds(int nt) { return nt == 512 ? 3 : (nt == 1024 ? 2 : 0); }
-
-template <int NT, bool EXTOK>
-void launch_eval2_nb(const EvalParams &P, bool jac, bool strict, size_t lds, hipStream_t s, int batch) {
-  if (P.g.nb == 8) launch_eval2_v<NT, 8, false, EXTOK>(P, jac, strict, lds, s, batch);
-  else if (P.g.nb == 10) launch_eval2_v<NT, 10, false, EXTOK>(P, jac, strict, lds, s, batch);
-  else launch_eval2_v<NT, 0, false, EXTOK>(P, jac, strict, lds, s, batch);
-}
 
 // Threads per workgroup (one workgroup per cell and pose) of a launch.
 //  * Cost + Jacobian launches use the context's shape (nid_set_launch_shape; default 128): the six Jacobian sums
@@ -307,22 +260,6 @@ void launch_eval2_nb(const EvalParams &P, bool jac, bool strict, size_t lds, hip
 //    histograms, entropy sums in a fixed order --, so unless the context pins their shape they take the one that
 //    fills the chip: ~8 waves per SIMD at most, i.e. 1024 threads for a single pose of 256 cells (a cell's
 //    1200 pixels in two rounds instead of ten), 128 from 16 poses on.  Measured: tools/latency_sweep.py.
-// Cells of more than 32 * NT slots (test geometries: a single cell of 6 144 / 19 200 pixels): the FAST kernels' BIG
-// instantiation (k_eval2), generic bin count only.
-template <int NT>
-void launch_eval2_big(const EvalParams &P, bool jac, size_t lds, hipStream_t s, int batch) {
-  const dim3 grid((unsigned)(((P.g.nloc + 7) / 8) * 8 * batch)), block(NT);
-  if constexpr (NT <= 256) {
-    if (P.slots_ext) {
-      if (jac) hipLaunchKernelGGL((k_eval2<NT, true, false, 0, false, true, 0, true>), grid, block, lds, s, P);
-      else hipLaunchKernelGGL((k_eval2<NT, false, false, 0, false, true, 0, true>), grid, block, lds, s, P);
-      return;
-    }
-  }
-  if (jac) hipLaunchKernelGGL((k_eval2<NT, true, false, 0, false, false, 0, true>), grid, block, lds, s, P);
-  else hipLaunchKernelGGL((k_eval2<NT, false, false, 0, false, false, 0, true>), grid, block, lds, s, P);
-}
-
 int pick_threads(const nid_ctx *ctx, bool jac, int batch) {
   int nt = jac ? ctx->jac_threads : ctx->cost_threads;
   if (nt == 0) {
@@ -355,37 +292,25 @@ int launch_eval2(nid_ctx *ctx, EvalParams &P, bool jac, hipStream_t stream, int 
   static const char *pad_env = getenv("NID_EXP_LDS_PAD");  // occupancy experiments: pad the LDS request
   if (pad_env) lds = std::min<size_t>(160 * 1024, lds + (size_t)atoi(pad_env));
   const bool strict = ctx->math_mode == NID_MATH_STRICT;
-  if (stamps_lat) {
-    const dim3 grid((unsigned)(((P.g.nloc + 7) / 8) * 8 * batch));
-    if (nt == 512) {
-      if (jac) hipLaunchKernelGGL((k_eval2<512, true, false, 0, true, false, 3>), grid, dim3(512), lds, stream, P);
-      else hipLaunchKernelGGL((k_eval2<512, false, false, 0, true, false, 3>), grid, dim3(512), lds, stream, P);
-    } else {
-      if (jac) hipLaunchKernelGGL((k_eval2<1024, true, false, 0, true, false, 2>), grid, dim3(1024), lds, stream, P);
-      else hipLaunchKernelGGL((k_eval2<1024, false, false, 0, true, false, 2>), grid, dim3(1024), lds, stream, P);
-    }
-  } else if (dbg) {  // diagnostics keep the workgroup shape: the Jacobian sums depend on it in their last bits
-    if (nt == 128) launch_eval2_v<128, 0, true>(P, jac, strict, lds, stream, batch);
-    else launch_eval2_v<256, 0, true>(P, jac, strict, lds, stream, batch);
-  } else if (!strict && P.g.pstride > 32 * nt) {
-    if (nt == 128) launch_eval2_big<128>(P, jac, lds, stream, batch);
-    else if (nt == 256) launch_eval2_big<256>(P, jac, lds, stream, batch);
-    else if (nt == 512) launch_eval2_big<512>(P, jac, lds, stream, batch);
-    else launch_eval2_big<1024>(P, jac, lds, stream, batch);
-  } else if (nt == 128) {
-    launch_eval2_nb<128, true>(P, jac, strict, lds, stream, batch);
-  } else if (nt == 256) {
-    launch_eval2_nb<256, true>(P, jac, strict, lds, stream, batch);
-  } else {
+  // The kernels live in one translation unit per workgroup shape and kind (nid_eval_launch.h).  Families: the latency
+  // form (512 / 1024 threads, FAST math, <= kMaxBatch poses, LAT rounds cover the cell) with or without phase stamps;
+  // diagnostics (128 / 256 threads: they keep the workgroup shape, the Jacobian sums depend on it in their last bits);
+  // cells of more than 32 * NT slots (test geometries: a single cell of 6 144 / 19 200 pixels: the FAST kernels' BIG
+  // instantiation, generic bin count only); everything else the loop form.
+  int family = kFamLoop;
+  if (stamps_lat) family = kFamStampsLat;
+  else if (dbg) family = kFamDbg;
+  else if (!strict && P.g.pstride > 32 * nt) family = kFamBig;
+  else if (nt >= 512) {
     static const bool no_lat = getenv("NID_NO_LAT") != nullptr;  // experiments: the loop form at the latency shapes
-    const bool lat = !strict && !no_lat && !ctx->loop_form && P.g.pstride <= lat_rounds(nt) * nt;
-    if (nt == 512) {
-      if (lat) launch_eval2_lat_nb<512>(P, jac, lds, stream, batch);
-      else launch_eval2_nb<512, false>(P, jac, strict, lds, stream, batch);
-    } else {
-      if (lat) launch_eval2_lat_nb<1024>(P, jac, lds, stream, batch);
-      else launch_eval2_nb<1024, false>(P, jac, strict, lds, stream, batch);
-    }
+    if (!strict && !no_lat && !ctx->loop_form && P.g.pstride <= lat_rounds(nt) * nt) family = kFamLat;
+  }
+  if (family == kFamLat && batch > kMaxBatch) return NID_ERR_INVALID_ARG;
+  switch (nt) {
+    case 128: (jac ? launch_eval_128_jac : launch_eval_128_cost)(P, family, strict, lds, stream, batch); break;
+    case 256: (jac ? launch_eval_256_jac : launch_eval_256_cost)(P, family, strict, lds, stream, batch); break;
+    case 512: (jac ? launch_eval_512_jac : launch_eval_512_cost)(P, family, strict, lds, stream, batch); break;
+    default: (jac ? launch_eval_1024_jac : launch_eval_1024_cost)(P, family, strict, lds, stream, batch); break;
   }
   NID_HIP(ctx, hipGetLastError());
   return NID_OK;
@@ -424,6 +349,7 @@ void fill_common_params(nid_ctx *ctx, double delta, EvalParams *P) {
     P->dbg_jc = nullptr;
   }
   P->dbg_stamps = ctx->dbg_stamps;
+  P->repair_count = ctx->repair_count_dev;
 }
 
 void fill_slot_args(const Pose &pose, Slot &S, double *out_reduced, unsigned long long *host_seq, SlotArgs *A) {
@@ -811,9 +737,7 @@ void resident_retire(nid_ctx *ctx) {
   R.running = false;
 }
 
-template <int NT, int NB>
-int resident_launch_t(nid_ctx *ctx, const EvalParams &P, size_t lds, unsigned grid) {
-  constexpr int LAT = NT == 512 ? 3 : 2;
+int resident_launch(nid_ctx *ctx, const EvalParams &P, size_t lds, unsigned grid) {
   nid_ctx::Resident &R = ctx->res;
   // every workgroup must be ON the device for a request to be answered.  A 512-thread workgroup of this kernel is two
   // waves per SIMD with up to 256 registers each and > 100 KB of LDS: exactly one fits a CU, so the grid must not
@@ -826,16 +750,13 @@ int resident_launch_t(nid_ctx *ctx, const EvalParams &P, size_t lds, unsigned gr
                       std::to_string(cus) + " CUs";
     return NID_ERR_UNSUPPORTED;
   }
-  (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_resident<NT, NB, LAT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  (void)hipGetLastError();
   long long idle_ticks = kResidentIdleTicks;
   if (const char *e = getenv("NID_RESIDENT_IDLE_US")) idle_ticks = std::max(1L, atol(e)) * 100;  // tests: a kernel that leaves early
   // the mailbox word the kernel starts from (whatever is there now is not a request)
   volatile unsigned long long *w = R.ctl->w;
   w[7] = R.seq << 8;
   store_fence();
-  hipLaunchKernelGGL((k_resident<NT, NB, LAT>), dim3(grid), dim3(NT), lds, R.stream, P, (const ResidentCtl *)R.ctl, R.seq << 8,
-                     idle_ticks, ctx->xform);
+  launch_resident_512(P, lds, grid, R.stream, (const ResidentCtl *)R.ctl, R.seq << 8, idle_ticks, ctx->xform);
   NID_HIP(ctx, hipGetLastError());
   return NID_OK;
 }
@@ -860,7 +781,7 @@ int resident_start(nid_ctx *ctx, int nt) {
   const unsigned grid = (unsigned)(((P.g.nloc + 7) / 8) * 8);
   const int nb = P.g.nb;
   if (nt != 512) { ctx->last_error = "resident evaluator: shape " + std::to_string(nt); return NID_ERR_UNSUPPORTED; }
-  rc = nb == 8 ? resident_launch_t<512, 8>(ctx, P, lds, grid) : (nb == 10 ? resident_launch_t<512, 10>(ctx, P, lds, grid) : resident_launch_t<512, 0>(ctx, P, lds, grid));
+  rc = resident_launch(ctx, P, lds, grid);
   if (rc) return rc;
   R.running = true;
   R.nt = nt;
@@ -1356,6 +1277,8 @@ int nid_create_strided(const nid_config *cfg, int32_t cell_stride, nid_ctx **out
   if ((rc = dev_alloc(ctx, &ctx->Twc_dev, 16))) return fail(rc);
   if ((rc = dev_alloc(ctx, &ctx->Nc_dev, g.nloc))) return fail(rc);
   if ((rc = dev_alloc(ctx, &ctx->Href_dev, g.nloc))) return fail(rc);
+  if ((rc = dev_alloc(ctx, &ctx->repair_count_dev, 1))) return fail(rc);
+  if (hipMemset(ctx->repair_count_dev, 0, sizeof(unsigned long long)) != hipSuccess) return fail(NID_ERR_HIP);
   {
     // the evaluation kernels read the table with kWcPre on its value coefficients (k_eval2's hist_add, fx_bits)
     std::vector<double> coef;
@@ -1422,7 +1345,7 @@ int nid_destroy(nid_ctx *ctx) {
   (void)hipFree(ctx->t.JR); (void)hipFree(ctx->t.I0);
   (void)hipFree(ctx->im1_dev); (void)hipFree(ctx->im1s_dev); (void)hipFree(ctx->im0_dev); (void)hipFree(ctx->depth_dev);
   (void)hipFree(ctx->points_dev); (void)hipFree(ctx->Twc_dev);
-  (void)hipFree(ctx->Nc_dev); (void)hipFree(ctx->Href_dev); (void)hipFree(ctx->ctab_dev);
+  (void)hipFree(ctx->Nc_dev); (void)hipFree(ctx->Href_dev); (void)hipFree(ctx->ctab_dev); (void)hipFree(ctx->repair_count_dev);
   (void)hipFree(ctx->dbg_u); (void)hipFree(ctx->dbg_v); (void)hipFree(ctx->dbg_ic);
   (void)hipFree(ctx->dbg_wc); (void)hipFree(ctx->dbg_jc); (void)hipFree(ctx->dbg_stamps);
   for (int r = 0; r < nid_ctx::kSeqRing; r++) {
@@ -1942,6 +1865,18 @@ int nid_debug_get_pixel_dump(nid_ctx *ctx, double *u, double *v, double *ic, int
   if (ic) NID_HIP(ctx, hipMemcpy(ic, ctx->dbg_ic, N * 8, hipMemcpyDeviceToHost));
   if (jc) NID_HIP(ctx, hipMemcpy(jc, ctx->dbg_jc, N * 4, hipMemcpyDeviceToHost));
   if (wc4) NID_HIP(ctx, hipMemcpy(wc4, ctx->dbg_wc, N * 32, hipMemcpyDeviceToHost));
+  return NID_OK;
+}
+
+int nid_debug_repair_count(nid_ctx *ctx, int64_t *count, int reset) {
+  if (!ctx || !count) return NID_ERR_INVALID_ARG;
+  NID_HIP(ctx, hipSetDevice(ctx->cfg.device));
+  resident_retire(ctx);
+  NID_HIP(ctx, hipDeviceSynchronize());
+  unsigned long long v = 0;
+  NID_HIP(ctx, hipMemcpy(&v, ctx->repair_count_dev, sizeof(v), hipMemcpyDeviceToHost));
+  *count = (int64_t)v;
+  if (reset) NID_HIP(ctx, hipMemset(ctx->repair_count_dev, 0, sizeof(v)));
   return NID_OK;
 }
 

@@ -135,6 +135,7 @@ struct EvalParams {
   double *dbg_u, *dbg_v, *dbg_ic, *dbg_wc;
   int *dbg_jc;
   int dbg_jac;  // 0: the dump describes the cost phase (u, v, ic, jc, wc[4]); 1: the Jacobian phase (gx, gy, pc, jc, dw[4])
+  unsigned long long *repair_count;  // cells and poses that ran the repair pass (kLinFlagW), or null
   // optional phase stamps (s_memtime) of wave 0 of every workgroup: [nloc][10] (8 phase stamps + s_memrealtime at start/end); diagnostic runs only
   long long *dbg_stamps;
 };
@@ -588,6 +589,25 @@ constexpr double kFineW = 0x1p-8;
 // weight by rounding, which the integer encodes cannot take.)
 constexpr double kNegligibleW = 0x1p-136;
 constexpr int kFineLevels = 5;
+// REPAIR of the end spans' LINEAR-weight columns (round 4; sweep seed 407031).  On the two end spans of the clamped knot
+// vector one basis function is linear in the distance to the end knot (weight 3 t, derivative 3: target column 1 on the
+// first span, column nb - 2 on the last), so a sample an ulp away from the knot carries an O(1) derivative on a weight of
+// 1e-15: the Jacobian then needs W = -(1 + log2 p) of every bin that weight lands in, i.e. the bin's WHOLE mass, to
+// ~1e-9 relative -- also the part of it that ordinary samples added through the coarse copies, whose 2^-52 quantum is an
+// ABSOLUTE resolution (one product of 9e-13 = 1.3e-8 * 7e-5, neither factor small enough for the fine levels, is 1.2e-4
+// off in relative terms: 3e-8 of that cell's Jacobian).  No per-sample work in the main pass pays for that:
+//  * the rare branches of the histogram update FLAG the bins (joint row / marginal, column 1 or nb - 2) that receive a
+//    linear end-span weight below kLinFlagW (one LDS atomic OR inside code that is rare already; the near-saturated and
+//    clamped groups flag theirs in the fold);
+//  * the fold looks at the flagged bins only: one that holds coarse addends and less than kRepairMass in all is to be
+//    REPAIRED -- the cost phase's pixel loops run once more (hist_add<REPAIR>), every addend that went to the coarse
+//    copies of such a bin now goes to the fine level of its own exponent (27+ bits of every addend, still integer adds),
+//    and the bin is folded again from its fine levels alone.
+// What an unflagged or heavier bin loses is bounded by n * 2^-53 * 3 / kLinFlagW resp. n * 2^-53 / kRepairMass per unit of
+// the flagged samples' reference weight: 1e-11 * n.  Cells that need a repair: one in ~45 000 random cases, and cells on
+// the rim of a saturated patch (counted: EvalParams::repair_count, nid_debug_repair_count).
+constexpr double kLinFlagW = 0x1p-16;
+constexpr double kRepairMass = 0x1p-12;
 __device__ __forceinline__ int fine_level(double w) {
   const int e = __builtin_amdgcn_frexp_exp(w);  // w = m * 2^e, m in [0.5, 1): e <= -8 for w < 2^-8
   const int x = min(max(-8 - e, 0), 119);
@@ -604,6 +624,7 @@ __device__ __forceinline__ double fine_inv_scale(int level) {
 // Setup: back-projection + tiling.  Calculate3DpointKernel (CudaPoints3d.cu:5-32)
 // == Get3dPointAndIntensity (NID_pose_estimation.cpp:401-432) folded into the
 // cell-major tile writer.  One thread per tile slot.
+#ifdef NID_SETUP_KERNELS  // (plain kernels: defined in ONE translation unit, nid_capi.hip)
 __global__ void k_tile(Geometry g, const double *__restrict__ depth,
                        const double *__restrict__ points_in, const uint8_t *__restrict__ im0,
                        const double *__restrict__ Twc /*col-major 16*/, Tiles t,
@@ -688,6 +709,8 @@ __global__ void k_backproject_plain(Geometry g, const double *__restrict__ depth
   }
   pts[3 * id] = X; pts[3 * id + 1] = Y; pts[3 * id + 2] = Z;
 }
+
+#endif  // NID_SETUP_KERNELS
 
 // ---------------------------------------------------------------------------
 // Setup: reference stage at the initial pose -- computeHref
@@ -857,18 +880,20 @@ __device__ __forceinline__ void store_sys(double *p, double v) {
 // arithmetic produces: NaN results are the canonical quiet NaN); a word that still holds it has not arrived.
 constexpr unsigned long long kHostSentinel = 0x7FF4DEADBEEF5A5Aull;
 
-constexpr int kRedDoubles(int nt) { return (6 * (nt / 64) + 1) & ~1; }  // the six Jacobian sums of every wave
 // 128- / 256-thread shapes: the six sums go through a [6][kXposeStride] array of doubles that reuses the histogram area
 // (rows padded by 8 doubles so that the six row groups of a read do not share banks); 0 = the DPP form everywhere
 #ifndef NID_XPOSE_SUM
 #define NID_XPOSE_SUM 1
 #endif
+// the six Jacobian sums of every wave (DPP form: the 512- / 1024-thread shapes; the others need no such scratch)
+constexpr int kRedDoubles(int nt) { return (nt <= 256 && NID_XPOSE_SUM) ? 0 : ((6 * (nt / 64) + 1) & ~1); }
 // Clamped target samples (ic >= 255 -> 254.999, types_six_dof_expmap.cpp:572-573) all have the SAME four target weights:
 // instead of 20 histogram adds each (15 of them fine-level adds), FAST math sums their reference weights per reference bin
 // (nb bins) and counts them (one more bin), NC copies like the histograms; the fold adds c_k * sum to the bins they feed.
 // The coarse sums have kClampCopies copies (same scale as the histograms); reference weights below 2^-8 go to fine levels of their own exponent like everywhere else (a joint bin
 // fed only by clamped samples is c_k * this sum: it needs the sum to ~1e-9 relative even when it is one weight of 1e-8).
 constexpr int kClampBins(int nb) { return (nb + 2) & ~1; }
+constexpr int kFlagWords = 6;  // clamp_flag[2] | lin_flag[2] | repair_set[2] (eval_cell): 24 bytes, 16-byte aligned start
 // (more copies would thin out the same-address conflicts of a saturated patch, but the workgroup's LDS request sits at the
 // 15 360 bytes ten workgroups per CU allow: 8 or 16 copies cost the plain pair 4 %, profiles/r03_ablations_A.txt)
 #ifndef NID_CLAMP_COPIES
@@ -1358,9 +1383,11 @@ __device__ __forceinline__ void eval_cell(const EvalParams &P, const SlotArgs &S
   unsigned long long *clamp_lo = clampb + kClampBins(nb) * kClampCopies;         // [kFineLevels][kClampBins(nb)], single copies
   double *rclamp = reinterpret_cast<double *>(clamp_lo + kFineLevels * kClampBins(nb));  // [kClampBins(nb)] folded sums, then the flags
   unsigned *clamp_flag = reinterpret_cast<unsigned *>(rclamp + kClampBins(nb));          // [0]: clamped samples seen, [1]: near-saturated ones
+  unsigned *lin_flag = clamp_flag + 2;  // [0]: target column 1, [1]: column nb - 2 -- bit a: joint row a, bit 16: the marginal bin (kLinFlagW)
+  unsigned *repair_set = clamp_flag + 4;  // the bins of those two columns that the fold wants repaired (same bits)
   // ... and the same for the NEAR-SATURATED samples (see kNearSatIc): folded sums behind the flags; the bins themselves
   // borrow the area of the two weight tables, which nobody touches before the fold (when they fit there: nb >= 5)
-  double *rns = reinterpret_cast<double *>(clamp_flag + 2);                               // [nb + 1]
+  double *rns = reinterpret_cast<double *>(clamp_flag + kFlagWords);                      // [nb + 1]
   // (not in the resident kernel, which clears the bins for the next request while wave 0 still reads the tables)
   const bool ns_alias = !RES && near_sat_aliased(nb);
   unsigned long long *ns_own = reinterpret_cast<unsigned long long *>(rns + ((nb + 1) | 1));  // (rns sits 8 bytes past a 16-byte boundary: an odd count ends on one)
@@ -1411,7 +1438,10 @@ __device__ __forceinline__ void eval_cell(const EvalParams &P, const SlotArgs &S
   auto zero_histograms = [&](int first) {
     uint4 *h4 = reinterpret_cast<uint4 *>(hist);
     const int n4 = (nbins * (NC + kFineLevels) + kClampBins(nb) * (kClampCopies + kFineLevels)) / 2;  // ... and the clamped samples' bins
-    if (tid == first) { clamp_flag[0] = 0u; clamp_flag[1] = 0u; }
+    if (tid == first) {
+#pragma unroll
+      for (int i = 0; i < kFlagWords; i++) clamp_flag[i] = 0u;
+    }
     // the near-saturated samples' bins (elsewhere in LDS, see nsb) ride behind: the slots n4 .. n4 + nns - 1 of the same
     // loop -- with 8 bins and 128 threads they fall into the idle threads of its last iteration
     uint4 *n4p = reinterpret_cast<uint4 *>(nsb);
@@ -1453,9 +1483,14 @@ __device__ __forceinline__ void eval_cell(const EvalParams &P, const SlotArgs &S
   // The reference weights take hist_dn (four multiplications per sample), and every add is the bit pattern of a
   // subnormal product (fx_bits).
   const double tiny_scaled = kTinyW * kWcPre;
-  auto hist_add = [&](int jr, int jc, const double (&wr_in)[4], const double (&win)[4], auto prescaled, double pcv, int group = 0) {
+  // REPAIR (see kLinFlagW): the same routing of every addend, but nothing is added except what NORMAL mode sent to the
+  // COARSE copies of a bin in the repair set -- to the fine level of its own exponent
+  unsigned rep_col1 = 0u, rep_colz = 0u;  // repair_set[0], [1] (wave-uniform; loaded before the repair pass)
+  auto hist_add = [&](int jr, int jc, const double (&wr_in)[4], const double (&win)[4], auto prescaled, double pcv, int group, auto repair_tag) {
     constexpr bool PRESCALED = decltype(prescaled)::value;
+    constexpr bool REPAIR = decltype(repair_tag)::value;
     if (group != 0) {  // FAST second passes only: 1 = clamped (kClampBins), 2 = near-saturated (kNearSatIc)
+      if (REPAIR) return;  // (their sums are exact relative to themselves: coarse copies for weights >= 2^-8 only)
       unsigned long long *hx = (group == 2 ? nsb : clampb) + ((unsigned)copy & (kClampCopies - 1));
       unsigned long long *hlo = group == 2 ? ns_lo : clamp_lo;
 #ifdef NID_EXP_CLAMP_COUNT_PER_LANE
@@ -1491,6 +1526,36 @@ __device__ __forceinline__ void eval_cell(const EvalParams &P, const SlotArgs &S
     unsigned long long *hc = hist + ((unsigned)jc * NC + (unsigned)copy);
     unsigned long long *hj = hist + (((unsigned)nb + hrow) * NC + (unsigned)copy);
     double wr[4] = {wr_in[0], wr_in[1], wr_in[2], wr_in[3]};
+    // a COARSE add to the marginal bin jc + k / to the joint bin (jr + m, jc + k); REPAIR: to the fine levels, if the bin
+    // is in the repair set (`w`, `pr`: the plain weight / the reference's own product, rounded once like there)
+    auto rep_set = [&](int col) -> unsigned { return col == 1 ? rep_col1 : (col == nb - 2 ? rep_colz : 0u); };
+    auto add_c = [&](int k, double wcs_k, double w) {
+      if (!REPAIR) { atomicAdd(hc + k * NC, fx_bits(wcs_k * P.hist_dn)); return; }
+      if (((rep_set(jc + k) >> 16) & 1u) && w > kNegligibleW) {
+        const int lv = fine_level(w);
+        atomicAdd(hist_lo + lv * nbins + (unsigned)(jc + k), fx_encode(w, fine_scale(lv)));
+      }
+    };
+    auto add_j = [&](int m, int k, double wr_m, double wcs_k, double w) {
+      if (!REPAIR) { atomicAdd(hj + (m * nb + k) * NC, fx_bits((wr_m * P.hist_dn) * wcs_k)); return; }
+      if ((rep_set(jc + k) >> (jr + m)) & 1u) {
+        const double pr = wr_m * w;
+        if (pr > kNegligibleW) {
+          const int lm = fine_level(pr);
+          atomicAdd(hist_lo + lm * nbins + ((unsigned)nb + hrow + (unsigned)(m * nb + k)), fx_encode(pr, fine_scale(lm)));
+        }
+      }
+    };
+    // NORMAL mode, rare branches: a LINEAR end-span weight below kLinFlagW flags the bins it lands in (kLinFlagW)
+    auto flag_linear = [&](int k, double w, const double (&wrm)[4]) {
+      const bool last = k == 2 && jc == S - 1;
+      if (w < kLinFlagW && ((k == 1 && jc == 0) || last)) {
+        unsigned bits = 1u << 16;
+#pragma unroll
+        for (int m = 0; m < 4; m++) bits |= (wrm[m] * w > kNegligibleW) ? (1u << (jr + m)) : 0u;
+        atomicOr(lin_flag + (last ? 1 : 0), bits);
+      }
+    };
     // A fine-level add of the TARGET histogram.  The fine levels are single copies; the lanes of a saturated (clamped:
     // one constant intensity) or black region all add the SAME value to the SAME bin -- a 64-way serialised LDS atomic
     // per weight and round (the flash pair ran 1.8x slower than the plain pair mostly for this).  If every active
@@ -1545,7 +1610,7 @@ __device__ __forceinline__ void eval_cell(const EvalParams &P, const SlotArgs &S
 #pragma unroll
         for (int k = 0; k < 4; k++) {
           if (wc[k] < kFineW) {
-            if (wc[k] > kNegligibleW) {
+            if (!REPAIR && wc[k] > kNegligibleW) {
               const int lv = fine_level(fabs(wc[k]));
               lo_add_marginal(lv * nbins + (unsigned)(jc + k), fx_encode(wc[k], fine_scale(lv)));
 #pragma unroll
@@ -1556,11 +1621,12 @@ __device__ __forceinline__ void eval_cell(const EvalParams &P, const SlotArgs &S
                   atomicAdd(hist_lo + lm * nbins + ((unsigned)nb + hrow + (unsigned)(m * nb + k)), fx_encode(pr, fine_scale(lm)));
                 }
               }
+              flag_linear(k, wc[k], wr);
             }
           } else {
-            atomicAdd(hc + k * NC, fx_bits(wcs[k] * P.hist_dn));
+            add_c(k, wcs[k], wc[k]);
 #pragma unroll
-            for (int m = 0; m < 4; m++) atomicAdd(hj + (m * nb + k) * NC, fx_bits((wr[m] * P.hist_dn) * wcs[k]));
+            for (int m = 0; m < 4; m++) add_j(m, k, wr[m], wcs[k], wc[k]);
           }
         }
         return;
@@ -1570,29 +1636,41 @@ __device__ __forceinline__ void eval_cell(const EvalParams &P, const SlotArgs &S
       for (int k = 0; k < 4; k++) {
         const bool small_c = wc[k] < kFineW;
         if (small_c) {
-          if (wc[k] > kNegligibleW) {
+          if (!REPAIR && wc[k] > kNegligibleW) {
             const int lv = fine_level(fabs(wc[k]));
             lo_add_marginal(lv * nbins + (unsigned)(jc + k), fx_encode(wc[k], fine_scale(lv)));
+            flag_linear(k, wc[k], wr);
           }
         } else {
-          atomicAdd(hc + k * NC, fx_bits(wcs[k] * P.hist_dn));
+          add_c(k, wcs[k], wc[k]);
         }
 #pragma unroll
         for (int m = 0; m < 4; m++) {
           if (small_c || wr[m] < kFineW) {
             const double pr = wr[m] * wc[k];
-            if (pr > kNegligibleW) {
+            if (!REPAIR && pr > kNegligibleW) {
               const int lm = fine_level(fabs(pr));
               atomicAdd(hist_lo + lm * nbins + ((unsigned)nb + hrow + (unsigned)(m * nb + k)), fx_encode(pr, fine_scale(lm)));
             }
           } else {
-            atomicAdd(hj + (m * nb + k) * NC, fx_bits((wr[m] * P.hist_dn) * wcs[k]));
+            add_j(m, k, wr[m], wcs[k], wc[k]);
           }
         }
       }
       return;
     }
 #endif
+    if constexpr (REPAIR) {  // an ordinary sample: all twenty addends went to the coarse copies
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        if (rep_set(jc + k) == 0u) continue;
+        const double w = wcs[k] * kWcPreInv;
+        add_c(k, wcs[k], w);
+#pragma unroll
+        for (int m = 0; m < 4; m++) add_j(m, k, wr[m], wcs[k], w);
+      }
+      return;
+    }
 #pragma unroll
     for (int k = 0; k < 4; k++) atomicAdd(hc + k * NC, fx_bits(wcs[k] * P.hist_dn));
     double wrs[4];
@@ -1643,7 +1721,9 @@ __device__ __forceinline__ void eval_cell(const EvalParams &P, const SlotArgs &S
   constexpr bool use_gomask = JAC && use_lane_masks;
   LatPix lat[LAT > 0 ? LAT : 1];  // LAT + JAC: the cost phase's hand-over to the Jacobian phase
   (void)lat;
-  if constexpr (STRICT) {
+  // STRICT: the cost phase's pixel loop (REPAIR: once more, see kLinFlagW)
+  auto strict_cost_loop = [&](auto repair_tag) {
+    constexpr bool REPAIR = decltype(repair_tag)::value;
 #pragma clang loop unroll(disable)
     for (int sb = wave_base; sb < g.pstride; sb += NT) {
       const int s = sb + lane;
@@ -1656,16 +1736,20 @@ __device__ __forceinline__ void eval_cell(const EvalParams &P, const SlotArgs &S
       int jc = -1;
       if (f.in) {
         jc = pixel_sample<true, false>(f, nb, S, rtab, ic, wc, dw);
-        hist_add(f.jr, jc, f.wr, wc, std::false_type{}, 0.0);
+        hist_add(f.jr, jc, f.wr, wc, std::false_type{}, 0.0, 0, repair_tag);
       }
-      if (DBG && P.dbg_u && !P.dbg_jac && pose_idx == 0 && f.jr >= 0) dump_pixel(s, f, ic, jc, wc);
+      if (!REPAIR && DBG && P.dbg_u && !P.dbg_jac && pose_idx == 0 && f.jr >= 0) dump_pixel(s, f, ic, jc, wc);
     }
-  } else {
-    // Main pass of the loop form: the NEXT round's point and bin index (7 registers) are fetched while this round is
-    // worked on, and this round's reference weights are fetched behind its window loads: a round then exposes ONE
-    // memory round trip (the window) instead of two.  Both phases; the Jacobian phase ends at 95 of its 96 VGPRs.
-    // Measured: 1030 -> 1008 us per 256-pose launch (profiles/r02_ablations_A.txt).
-    auto cost_round = [&](int sb, int r, const TileIn &cur, TileIn &nxt, auto second_pass) -> bool {
+  };
+  // FAST: one round of the cost phase's pixel loops (main or second pass; REPAIR: once more, see kLinFlagW).
+  // Main pass of the loop form: the NEXT round's point and bin index (7 registers) are fetched while this round is
+  // worked on, and this round's reference weights are fetched behind its window loads: a round then exposes ONE
+  // memory round trip (the window) instead of two.  Both phases; the Jacobian phase ends at 95 of its 96 VGPRs.
+  // Measured: 1030 -> 1008 us per 256-pose launch (profiles/r02_ablations_A.txt).
+  auto cost_round = [&](int sb, int r, const TileIn &cur, TileIn &nxt, auto second_pass) -> bool {
+    if constexpr (STRICT) {
+      return false;
+    } else {
       constexpr bool SECOND = decltype(second_pass)::value;
       const int s = sb + lane;
       TileIn tin;
@@ -1701,11 +1785,7 @@ __device__ __forceinline__ void eval_cell(const EvalParams &P, const SlotArgs &S
       // fixed-tap sample (a convex combination of u8 taps: never negative), computed for every lane -- lanes
       // without a sample hold a harmless window
       ic = sample_fast_c(wc2, f.u, f.v);
-#ifdef NID_EXP_NO_GUARD
-      rare = false;
-#else
       rare = f.in && fabs(ic - kGuardMid) > kGuardHalf;
-#endif
       if (f.redo && classify_redo(P, f)) rare = true;  // (waves that meet the frame border)
       go = f.in && !rare;
       }
@@ -1727,12 +1807,9 @@ __device__ __forceinline__ void eval_cell(const EvalParams &P, const SlotArgs &S
         double pc;
         jc = fast_bin<SECOND || kMainPassClamps, SECOND>(ic, S, pc);
         bspline4_poly<false, JAC && !SECOND>(pc, jc, rtab, wc, dw);
-#ifdef NID_EXP_SECOND_NO_ADD
-        if (!SECOND)
-#endif
         // (second pass: `ic` is the reference's own sample, evaluated exactly and clamped like there)
         hist_add(f.jr, jc, SECOND ? f.wr : tin.wr, wc, std::true_type{}, pc,
-                 (SECOND && NID_CLAMP_BINS) ? (ic == 254.999 ? 1 : ((NID_NEAR_SAT_BINS && ic == kNearSatIc) ? 2 : 0)) : 0);
+                 (SECOND && NID_CLAMP_BINS) ? (ic == 254.999 ? 1 : ((NID_NEAR_SAT_BINS && ic == kNearSatIc) ? 2 : 0)) : 0, std::false_type{});
       } else {
         ic = NAN;
       }
@@ -1743,7 +1820,40 @@ __device__ __forceinline__ void eval_cell(const EvalParams &P, const SlotArgs &S
       }
       if (use_lane_masks) return false;
       return !SECOND && __builtin_amdgcn_ballot_w64(rare) != 0ull;
-    };
+    }
+  };
+  // FAST, REPAIR (see kLinFlagW; rare, so ONE pass and no prefetch): every sample once more with the arithmetic of the
+  // pass that took it -- the same classification on the same values -- and hist_add in REPAIR mode
+  auto repair_round = [&](int sb) {
+    if constexpr (!STRICT) {
+      TileIn tin;
+      PixelFront f;
+      load_tile(P, base + (unsigned)(sb + lane), plane, tin);
+      pixel_front<false>(P, SA, tin, f);
+      WinC wc2;
+      load_win_centre(P, f.w.wx, f.w.wy, wc2);
+      double ic = sample_fast_c(wc2, f.u, f.v);
+      bool rare = f.in && fabs(ic - kGuardMid) > kGuardHalf;
+      if (f.redo && classify_redo(P, f)) rare = true;
+      bool go = f.in && !rare;
+      if (rare) {
+        exact_decisions<EXT>(P, SA, pose_idx, tin, f, ic);
+        go = f.in;
+      }
+      if (go) {
+        double pc, wc[4], dw[4];
+        int jc;
+        if (rare) jc = fast_bin<true, true>(ic, S, pc);
+        else jc = fast_bin<kMainPassClamps, false>(ic, S, pc);
+        bspline4_poly<false, false>(pc, jc, rtab, wc, dw);
+        hist_add(f.jr, jc, tin.wr, wc, std::true_type{}, pc,
+                 (rare && NID_CLAMP_BINS) ? (ic == 254.999 ? 1 : ((NID_NEAR_SAT_BINS && ic == kNearSatIc) ? 2 : 0)) : 0, std::true_type{});
+      }
+    }
+  };
+  if constexpr (STRICT) {
+    strict_cost_loop(std::false_type{});
+  } else {
     int r = 0;
     if constexpr (LAT > 0) {
       // staged main pass (see the template comment); the host launches this form only if LAT rounds cover the cell
@@ -1798,7 +1908,7 @@ __device__ __forceinline__ void eval_cell(const EvalParams &P, const SlotArgs &S
           if (f.in && !rare) {
             jc = fast_bin<kMainPassClamps>(ic, S, pc);
             bspline4_poly<false>(pc, jc, rtab, wc, dw);
-            hist_add(f.jr, jc, f.wr, wc, std::true_type{}, pc);
+            hist_add(f.jr, jc, f.wr, wc, std::true_type{}, pc, 0, std::false_type{});
           }
           if (__builtin_amdgcn_ballot_w64(rare) != 0ull) rare_rounds |= 1ull << q;
           if (JAC) {
@@ -1818,9 +1928,6 @@ __device__ __forceinline__ void eval_cell(const EvalParams &P, const SlotArgs &S
         if (cost_round(sb, r, pre, pre, std::false_type{})) rare_rounds |= 1ull << min(r, 63);
       if (use_lane_masks) rare_rounds = wave_or_u32(raremask);
     }
-#ifdef NID_EXP_DROP_RARE_COST
-    rare_rounds = 0ull;
-#endif
     if (rare_rounds != 0ull) {
       r = 0;
 #pragma clang loop unroll(disable)
@@ -1833,13 +1940,21 @@ __device__ __forceinline__ void eval_cell(const EvalParams &P, const SlotArgs &S
 
   // ---- fold the copies, probabilities, entropies, weight tables ----------------------
   // clamped samples first (flash data only: the flag is workgroup-uniform): their sums per reference bin and their count
-  const unsigned long long sat_flags = *reinterpret_cast<const unsigned long long *>(clamp_flag);  // (one LDS read)
-  const bool any_sat = !STRICT && NID_CLAMP_BINS && sat_flags != 0ull;
-  const bool any_clamped = any_sat && (unsigned)sat_flags != 0u, any_ns = any_sat && (unsigned)(sat_flags >> 32) != 0u;
+  uint4 flagw = *reinterpret_cast<const uint4 *>(clamp_flag);  // (one LDS read: clamped | near-saturated | lin_flag[2])
+  const bool any_sat = !STRICT && NID_CLAMP_BINS && (flagw.x | flagw.y) != 0u;
+  const bool any_clamped = any_sat && flagw.x != 0u, any_ns = any_sat && flagw.y != 0u;
   double cw[4] = {0.0, 0.0, 0.0, 0.0};  // their four target weights, as the sample path computes them
   double nw[4] = {0.0, 0.0, 0.0, 0.0};  // ... and the near-saturated samples'
   int jc_cl = 0, jc_ns = 0;
   if (any_sat) {
+    double ic_cl = 254.999, pc_cl;
+    jc_cl = fast_bin<false, true>(ic_cl, S, pc_cl);  // (as the second pass places a sample)
+    bspline4_vals_both_ends(pc_cl, jc_cl, S, rtab, cw);
+    double ic_ns = kNearSatIc, pc_ns;
+    jc_ns = fast_bin<false, true>(ic_ns, S, pc_ns);
+    bspline4_vals_both_ends(pc_ns, jc_ns, S, rtab, nw);
+#pragma unroll
+    for (int k = 0; k < 4; k++) { cw[k] *= kWcPreInv; nw[k] *= kWcPreInv; }  // rtab's value polynomials carry kWcPre
     // (both groups, 2 * (nb + 1) sums; a group without samples holds zeros.  The near-saturated bins may sit in the
     // weight tables' area: the barrier below separates these reads from the fold's table writes)
     for (int e2 = tid; e2 < 2 * (nb + 1); e2 += NT) {
@@ -1861,32 +1976,36 @@ __device__ __forceinline__ void eval_cell(const EvalParams &P, const SlotArgs &S
       for (int lv = 0; lv < kFineLevels; lv++)
         sum = fma((double)(long long)gl[lv * kClampBins(nb) + e], fine_inv_scale(lv), sum);
       (ns ? rns : rclamp)[e] = sum;
+      // the groups' LINEAR end-span weight (last span, column nb - 2; the near-saturated samples': 3 ulps of S) flags the
+      // bins it lands in like a sample of the rare branches does (flag_linear in hist_add; e == nb: the marginal bin)
+      const double wlin = ns ? nw[2] : cw[2];
+      if (sum != 0.0 && wlin < kLinFlagW && wlin > kNegligibleW && (ns ? jc_ns : jc_cl) == S - 1)
+        atomicOr(lin_flag + 1, e < nb ? (1u << e) : (1u << 16));
     }
-    double ic_cl = 254.999, pc_cl;
-    jc_cl = fast_bin<false, true>(ic_cl, S, pc_cl);  // (as the second pass places a sample)
-    bspline4_vals_both_ends(pc_cl, jc_cl, S, rtab, cw);
-    double ic_ns = kNearSatIc, pc_ns;
-    jc_ns = fast_bin<false, true>(ic_ns, S, pc_ns);
-    bspline4_vals_both_ends(pc_ns, jc_ns, S, rtab, nw);
-#pragma unroll
-    for (int k = 0; k < 4; k++) { cw[k] *= kWcPreInv; nw[k] *= kWcPreInv; }  // rtab's value polynomials carry kWcPre
     __syncthreads();
+    flagw = *reinterpret_cast<const uint4 *>(clamp_flag);
   }
-  double ent[2] = {0.0, 0.0};
-  for (int b = tid; b < nbins; b += NT) {
-    const uint4 *hv = reinterpret_cast<const uint4 *>(hist + (size_t)b * NC);
-    // low and high dwords summed apart: 32-bit adds for the high parts, one carry chain for the low parts, joined
-    // once (the same integer as the 64-bit sum; a whole cell's bin stays below 2^63, see fx_bits)
-    unsigned long long acc_lo = 0;
-    unsigned acc_hi = 0;
+  const unsigned lin_col1 = (unsigned)__builtin_amdgcn_readfirstlane((int)flagw.z), lin_colz = (unsigned)__builtin_amdgcn_readfirstlane((int)flagw.w);
+  // One bin: its mass from the copies (COARSE = false: without them, after a repair), the fine levels and the two
+  // groups; p = mass / N_c, W = -(1 + log2 p), p log2 p into the tables.  Returns the copies' integer sum.
+  auto fold_bin = [&](int b, auto coarse_tag, double &mass_out) -> unsigned long long {
+    constexpr bool COARSE = decltype(coarse_tag)::value;
+    unsigned long long acc = 0ull;
+    if (COARSE) {
+      const uint4 *hv = reinterpret_cast<const uint4 *>(hist + (size_t)b * NC);
+      // low and high dwords summed apart: 32-bit adds for the high parts, one carry chain for the low parts, joined
+      // once (the same integer as the 64-bit sum; a whole cell's bin stays below 2^63, see fx_bits)
+      unsigned long long acc_lo = 0;
+      unsigned acc_hi = 0;
 #pragma unroll
-    for (int c = 0; c < NC / 2; c++) {
-      const uint4 q = hv[(c + b) & (NC / 2 - 1)];
-      acc_lo += q.x;
-      acc_lo += q.z;
-      acc_hi += q.y + q.w;
+      for (int c = 0; c < NC / 2; c++) {
+        const uint4 q = hv[(c + b) & (NC / 2 - 1)];
+        acc_lo += q.x;
+        acc_lo += q.z;
+        acc_hi += q.y + q.w;
+      }
+      acc = acc_lo + ((unsigned long long)acc_hi << 32);
     }
-    const unsigned long long acc = acc_lo + ((unsigned long long)acc_hi << 32);
     double mass = (double)(long long)acc * P.hist_inv_scale;
 #pragma unroll
     for (int lv = 0; lv < kFineLevels; lv++) {  // small target weights (kTinyW); all zero leaves `mass` bit for bit
@@ -1918,8 +2037,62 @@ __device__ __forceinline__ void eval_cell(const EvalParams &P, const SlotArgs &S
     }
     tab[b] = w;
     term[b] = pl;
+    mass_out = mass;
+    return acc;
+  };
+  // which bit of lin_flag / repair_set a bin is, and in which of the two words (-1: not in a linear-weight column)
+  auto lin_word = [&](int b, int &bit) -> int {
+    const int col = b < nb ? b : (b - nb) % nb;
+    bit = b < nb ? 16 : (b - nb) / nb;
+    return col == 1 ? 0 : (col == nb - 2 ? 1 : -1);
+  };
+  double ent[2] = {0.0, 0.0};
+  for (int b = tid; b < nbins; b += NT) {
+    double mass;
+    const unsigned long long acc = fold_bin(b, std::true_type{}, mass);
+    if (__builtin_expect((lin_col1 | lin_colz) != 0u, 0)) {  // (workgroup-uniform, rare: some bin received a tiny linear end-span weight)
+      // A flagged bin with less than kRepairMass is repaired -- if the COLUMN has coarse addends at all: a joint product
+      // may have rounded to zero in the copies (1e-8 * 1e-9 against the 2^-52 quantum), a marginal weight of a coarse
+      // sample never does (>= kTinyW), so the marginal bin's copies say whether any sample went that way (bit 31)
+      int bit;
+      const int wsel = lin_word(b, bit);
+      if (wsel >= 0) {
+        unsigned bits = ((((wsel == 0 ? lin_col1 : lin_colz) >> bit) & 1u) && mass < kRepairMass) ? (1u << bit) : 0u;
+        if (b < nb && acc != 0ull) bits |= 1u << 31;
+        if (bits) atomicOr(repair_set + wsel, bits);
+      }
+    }
   }
   __syncthreads();
+  if (__builtin_expect((lin_col1 | lin_colz) != 0u, 0)) {
+    const uint2 rs = *reinterpret_cast<const uint2 *>(repair_set);
+    rep_col1 = (unsigned)__builtin_amdgcn_readfirstlane((int)rs.x);
+    rep_colz = (unsigned)__builtin_amdgcn_readfirstlane((int)rs.y);
+    rep_col1 = (rep_col1 >> 31) ? (rep_col1 & 0x1FFFFu) : 0u;
+    rep_colz = (rep_colz >> 31) ? (rep_colz & 0x1FFFFu) : 0u;
+    if (__builtin_expect((rep_col1 | rep_colz) != 0u, 0)) {
+      // REPAIR (see kLinFlagW): the pixel loops once more; what they sent to the coarse copies of a bin in the repair
+      // set goes to its fine levels now, and the bin is folded again without the copies.  Same lane -> sample
+      // assignment, integer adds: run-to-run reproducible like everything else.
+      if (tid == 0 && P.repair_count) atomicAdd(P.repair_count, 1ull);  // (diagnostics: nid_debug_repair_count)
+      if constexpr (STRICT) {
+        strict_cost_loop(std::true_type{});
+      } else {
+#pragma clang loop unroll(disable)
+        for (int sb = wave_base; sb < g.pstride; sb += NT) repair_round(sb);
+      }
+      __syncthreads();
+      for (int b = tid; b < nbins; b += NT) {
+        int bit;
+        const int wsel = lin_word(b, bit);
+        if (wsel >= 0 && (((wsel == 0 ? rep_col1 : rep_colz) >> bit) & 1u)) {
+          double mass;
+          fold_bin(b, std::false_type{}, mass);
+        }
+      }
+      __syncthreads();
+    }
+  }
   // Entropies: every wave sums the bins' terms itself, in ONE order whatever the workgroup shape is (lane l takes
   // the joint bins l, l + 64, ...; then the DPP tree), so that Hc, Hj, err and chi2 of a pose are the same bits
   // for 128-, 256-, 512- and 1024-thread workgroups: cost-only launches may pick their shape by batch size.

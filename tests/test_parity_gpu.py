@@ -29,7 +29,17 @@ RTOL_J = 1e-9
 # frame's scale (exact zeros on one side against 1e-17 residue on the other).
 NOISE_K = 4.0
 J_EPS = 64 * 2.0 ** -53
+# The allowance is BOUNDED (round 4): a cell may call on it only while the measured noise is small -- at most NOISE_CAP_REL
+# of the cell's own Jacobian scale, or below NOISE_CAP_ABS outright (the Jacobian of a constant / saturated cell IS
+# noise: 1e-13-level numbers, 100 % of "their own scale").  A larger difference between the oracle and its twin is a
+# sample that changed its bin between the two roundings -- a discontinuity, not noise -- and buys nothing.
+NOISE_CAP_REL = 1e-6
+NOISE_CAP_ABS = 1e-11
 DELTA = float(np.sqrt(0.95))
+# Every cell that passed ONLY on the noise term, for the terminal summary (tests/conftest.py) and
+# gpurun_out/noise_term_cells.txt: (test id, cell, |dJ| / own scale, noise / own scale).
+NOISE_PASSES = []
+# tests that assert the hard bound WITHOUT the noise term on textured data call _compare_cells(..., noise=None)
 
 
 def _bits(a):
@@ -68,11 +78,13 @@ def _reference_noise(o, pose, J_ref):
 
 
 def _jac_excess(J, J_o, m, noise=None):
-    """Per selected cell: |J - J_o| / allowed, allowed = RTOL_J * own scale + NOISE_K * noise + J_EPS * frame scale."""
+    """Per selected cell: |J - J_o| / allowed, allowed = RTOL_J * own scale + NOISE_K * noise + J_EPS * frame scale
+    (the noise term only within its cap: NOISE_CAP_REL / NOISE_CAP_ABS)."""
     percell = np.abs(J_o[m]).max(axis=1)
     allowed = RTOL_J * percell + J_EPS * max(percell.max(), 1.0)
     if noise is not None:
-        allowed = allowed + NOISE_K * noise[m]
+        n = noise[m]
+        allowed = allowed + NOISE_K * np.where((n <= NOISE_CAP_REL * percell) | (n <= NOISE_CAP_ABS), n, 0.0)
     return np.abs(J[m] - J_o[m]).max(axis=1) / allowed, percell
 
 
@@ -96,8 +108,15 @@ def _compare_cells(got, ref, cnt, noise=None):
             rel, percell = _jac_excess(J, J_o, m)
             used_noise = False
             if not np.all(rel <= 1.0) and noise is not None:
-                rel, percell = _jac_excess(J, J_o, m, noise() if callable(noise) else _reference_noise(noise[0], noise[1], J_o))
+                plain = rel
+                nz = noise() if callable(noise) else _reference_noise(noise[0], noise[1], J_o)
+                rel, percell = _jac_excess(J, J_o, m, nz)
                 used_noise = True
+                import os
+                tid = os.environ.get("PYTEST_CURRENT_TEST", "?").split(" ")[0]
+                for w in np.where((plain > 1.0) & (rel <= 1.0))[0]:
+                    own = max(percell[w], 1e-300)
+                    NOISE_PASSES.append((tid, int(np.where(m)[0][w]), float(np.abs(J[m][w] - J_o[m][w]).max() / own), float(nz[m][w] / own)))
             if not np.all(rel <= 1.0):
                 w = int(np.argmax(rel))
                 raise AssertionError(f"worst per-cell Jacobian error {rel[w]:.3e} x the allowed one in cell {np.where(m)[0][w]}: "
@@ -272,7 +291,7 @@ def test_config_A_cells_and_normal_equations(capi, oracle, synth, pair_A, nb, ma
     for name, pose in _poses(synth, pair).items():
         got = ctx.evaluate(pose, True)
         ref = o.evaluate(pose, True)
-        _compare_cells(got, ref, cnt_o, noise=(o, pose))
+        _compare_cells(got, ref, cnt_o, noise=None)  # textured data: the hard 1e-9 bound, no noise term
         H, b, chi2, na = ctx.normal_equations(pose, DELTA)
         H_o, b_o, chi2_o, na_o = oracle.normal_equations(ref[2], ref[3], DELTA)
         assert na == na_o == int(act.sum())
@@ -381,7 +400,7 @@ def test_config_B_full_size(capi, oracle, synth, math):
     assert act.sum() > 900
     np.testing.assert_allclose(href[act], href_o[act], rtol=0, atol=ATOL_H)
     got = ctx.evaluate(pair.pose_init, True)
-    _compare_cells(got, o.evaluate(pair.pose_init, True), cnt_o, noise=(o, pair.pose_init))
+    _compare_cells(got, o.evaluate(pair.pose_init, True), cnt_o, noise=None)  # textured data: the hard 1e-9 bound, no noise term
     again = ctx.evaluate(pair.pose_init, True)
     for x, y in zip(got, again):
         assert np.array_equal(_bits(x[act]), _bits(y[act]))
@@ -431,7 +450,7 @@ def test_launch_shapes(capi, oracle, synth, cfg, nb, math):
         ctx.set_launch_shape(nt, nt)
         ctx.compute_href(pair.pose_init)
         got = ctx.evaluate(pose, True)
-        _compare_cells(got, ref, cnt, noise=(o, pose))
+        _compare_cells(got, ref, cnt, noise=None)  # textured data: the hard 1e-9 bound, no noise term
         cost_only = ctx.evaluate(pose, False)
         H, b, chi2, na = ctx.normal_equations(pose, DELTA)
         _, _, chi2_c, na_c = ctx.normal_equations(pose, DELTA, want_jac=False)
@@ -760,20 +779,19 @@ SWEEP_SEEDS += [3013, 70874, 50185, 71823]
 SWEEP_SEEDS += [344412]
 
 
-# KNOWN OPEN CASE (found 45 000 sweep cases in, at the end of round 3; STRICT and FAST alike, every kernel since round 1):
-# seed 407031, pose 2, cell 6 -- 3.0e-8 of the cell's Jacobian scale (30 x the bound).  A saturated target sample an ulp
-# below 255 (end-span weight 2.7e-15, derivative 3) shares the joint bin (7, 7) with ONE ordinary product of 9.0e-13 (a
-# reference weight of 1.3e-8 times a target weight of 7e-5, neither small enough for the fine levels): the 2^-52 quantum of
-# the coarse copies is 5.6e-5 of that bin's mass, i.e. 8e-5 on its W, which the saturated sample multiplies by its O(1)
-# derivative.  tools/diag_quantum.py 407031 2 6 52 reproduces the GPU's deviation to four digits from the oracle's own
-# per-pixel values with a 2^-52 quantum (DIAG_ATTR=1 names the bin).  Removing it needs a second limb for the coarse
-# products that land in the end spans' linear-weight columns -- a per-sample cost in the main pass that was not paid for a
-# 1-in-45 000 case at 3e-8; the case stays here as an expected failure so that it is looked at again.
-KNOWN_OPEN_SEEDS = [407031]
+# Round 3's one open case (found 45 000 sweep cases in; STRICT and FAST alike, every kernel since round 1): seed 407031,
+# pose 2, cell 6 -- 3.0e-8 of the cell's Jacobian scale.  A saturated target sample an ulp below 255 (end-span LINEAR
+# weight 2.7e-15, derivative 3) shares the joint bin (7, 7) with ONE ordinary product of 9.0e-13 (a reference weight of
+# 1.3e-8 times a target weight of 7e-5, neither small enough for the fine levels): the 2^-52 quantum of the coarse copies
+# is 5.6e-5 of that bin's mass, i.e. 8e-5 on its W, which the saturated sample multiplies by its O(1) derivative
+# (tools/diag_quantum.py 407031 2 6 52 reproduces it on the CPU; DIAG_REPAIR=1 models the remedy).  Round 4: the rare
+# branches flag the bins that receive such a weight, the fold repairs a flagged bin of small mass -- one more pass of
+# the cost phase's pixel loops with its coarse addends sent to the fine levels (kLinFlagW in csrc/nid_kernels.hip.h).
+SWEEP_SEEDS += [407031]
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("seed", list(range(64)) + SWEEP_SEEDS + [pytest.param(s_, marks=pytest.mark.xfail(strict=True, reason="2^-52 quantum on a one-addend joint bin shared with an end-span sample, see KNOWN_OPEN_SEEDS")) for s_ in KNOWN_OPEN_SEEDS])
+@pytest.mark.parametrize("seed", list(range(64)) + SWEEP_SEEDS)
 def test_randomised_pairs(capi, oracle, synth, seed):
     """Randomised parity (fixed seeds): geometry, bins, images (noise, few grey levels on bin boundaries,
     constant, saturated blobs), depth holes, small and large pose perturbations -- both math modes against
@@ -888,7 +906,7 @@ def test_flash_pair_cells(capi, oracle, synth, nb, math):
         ref = o.evaluate(pose, True)
         sat = _saturated_cells(o, pair) & act
         assert sat.sum() >= 20, "the flash pair must put many active cells on the saturation clamp"
-        _compare_cells(ctx.evaluate(pose, True), ref, cnt_o, noise=(o, pose))
+        _compare_cells(ctx.evaluate(pose, True), ref, cnt_o, noise=None)  # textured data: the hard 1e-9 bound, no noise term
         H, b, chi2, na = ctx.normal_equations(pose, DELTA)
         H_o, b_o, chi2_o, na_o = oracle.normal_equations(ref[2], ref[3], DELTA)
         assert na == na_o

@@ -25,7 +25,7 @@ rr, cc = np.divmod(np.arange(pair.rows * pair.cols), pair.cols)
 cell = np.where((rr < G * rb) & (cc < G * cb), (rr // rb) * G + cc // cb, -1)
 ids = np.where(cell == c)[0]
 Nc = LD(cnt_o[c]); S = nb - 3
-TINY, FINE = 2.0 ** -28, 2.0 ** -8
+TINY, FINE = 2.0 ** -35, 2.0 ** -8
 M = synth.pose7_to_matrix(pose)
 z0 = pair.depth_m.reshape(-1)
 x0 = z0 * (cc - pair.cx) / pair.fx; y0 = z0 * (rr - pair.cy) / pair.fy
@@ -40,21 +40,64 @@ def quant(x, q):
     return LD(np.rint(np.float64(x) * 2.0 ** q)) / LD(2.0) ** q   # x * 2^q < 2^53: exact scaling, RN-even
 
 
+REPAIR = os.environ.get("DIAG_REPAIR")  # model of the round-4 repair pass (hist_add REPAIR in csrc/nid_kernels.hip.h)
+LIN_FLAG, REPAIR_MASS = 2.0 ** -16, 2.0 ** -12
+
+
+def fine_quant(x):
+    """a fine-level add: level = floor((-8 - e) / 24) capped at 4, scale 2^(59 + 24 level), round to nearest"""
+    if x <= 0: return LD(0)
+    e = int(np.frexp(np.float64(x))[1])
+    lv = min(max(-8 - e, 0), 119) // 24
+    sc = 59 + 24 * lv
+    return LD(np.rint(np.float64(x) * 2.0 ** sc)) / LD(2.0) ** sc
+
+
 def jac(q):
     hc = np.zeros(nb, dtype=LD); hj = np.zeros((nb, nb), dtype=LD)
+    coarse_j = np.zeros((nb, nb), dtype=bool); coarse_c = np.zeros(nb, dtype=bool)
+    flag_j = np.zeros((nb, nb), dtype=bool); flag_c = np.zeros(nb, dtype=bool)
+    def tiny_of(i):
+        wc, wr = d["wc"][i], d["wr"][i]
+        wrp = wr[wr > 0]
+        return min(wc[0], wc[3]) < TINY or (wrp.size and min(wr[0], wr[3]) < TINY and min(wr[0], wr[3]) != 0.0)
     for i in ids:
         if d["jc"][i] < 0: continue
         jc, jr = d["jc"][i], d["jr"][i]
         wc, wr = d["wc"][i], d["wr"][i]
-        wrp = wr[wr > 0]
-        tiny = min(wc[0], wc[3]) < TINY or (wrp.size and min(wr[0], wr[3]) < TINY and min(wr[0], wr[3]) != 0.0)
+        tiny = tiny_of(i)
         for kk in range(4):
             fine_c = tiny and wc[kk] < FINE
+            lin = (jc == 0 and kk == 1) or (jc == S - 1 and kk == 2)
+            if fine_c and lin and 0 < wc[kk] < LIN_FLAG:
+                flag_c[jc + kk] = True
+                for m in range(4):
+                    if wr[m] * wc[kk] > 0: flag_j[jr + m, jc + kk] = True
             hc[jc + kk] += LD(wc[kk]) if fine_c else quant(wc[kk], q)
+            if not fine_c: coarse_c[jc + kk] = True
             for m in range(4):
                 pr = np.float64(wr[m]) * np.float64(wc[kk])
                 fine = tiny and (wc[kk] < FINE or wr[m] < FINE)
                 hj[jr + m, jc + kk] += LD(pr) if (fine or q is None) else quant(pr, q)
+                if not fine and pr != 0: coarse_j[jr + m, jc + kk] = True
+    if REPAIR and q is not None:
+        rep_j = flag_j & coarse_c[None, :] & (hj < REPAIR_MASS); rep_c = flag_c & coarse_c & (hc < REPAIR_MASS)
+        if rep_j.any() or rep_c.any():
+            print(f"    repair pass: joint bins {list(zip(*np.where(rep_j)))} marginal {list(np.where(rep_c)[0])}")
+            hj[rep_j] = 0; hc[rep_c] = 0
+            for i in ids:
+                if d["jc"][i] < 0: continue
+                jc, jr = d["jc"][i], d["jr"][i]
+                wc, wr = d["wc"][i], d["wr"][i]
+                tiny = tiny_of(i)
+                for kk in range(4):
+                    fine_c = tiny and wc[kk] < FINE
+                    if rep_c[jc + kk]: hc[jc + kk] += LD(wc[kk]) if fine_c else fine_quant(wc[kk])
+                    for m in range(4):
+                        if not rep_j[jr + m, jc + kk]: continue
+                        pr = np.float64(wr[m]) * np.float64(wc[kk])
+                        fine = tiny and (wc[kk] < FINE or wr[m] < FINE)
+                        hj[jr + m, jc + kk] += LD(pr) if fine else fine_quant(pr)
     pc_, pj_ = hc / Nc, hj / Nc
     sig = LD(1e-30)
     def ent_w(p):

@@ -19,6 +19,9 @@ for name, kw in (("plain", {}), ("flash + edge cases", dict(flash=True, edge_cas
         t0 = time.perf_counter(); ctx.run_sequence(seq, delta, batch=256, collect=False); el = time.perf_counter() - t0
         ms = float(np.median([ctx.time_launches(poses, delta, repeats=4) for _ in range(5)]))
         sat = float((pair.im1 >= 255).mean())
+        ctx.repair_count(reset=True)
+        ctx.run_sequence(poses, delta, batch=256, collect=False)
+        rep = ctx.repair_count()
         print(f"{name:20s} {mname:6s} active cells {int((cnt >= 300).sum()):3d}, saturated target pixels {100 * sat:4.1f} %: "
-              f"{len(seq) / el:9.0f} it/s, kernel {ms * 1e3:7.1f} us per 256 poses")
+              f"{len(seq) / el:9.0f} it/s, kernel {ms * 1e3:7.1f} us per 256 poses; repair passes {rep} of {256 * int((cnt >= 300).sum())} cell evaluations")
         ctx.close()
