@@ -199,6 +199,11 @@ int nid_wait(nid_ctx *ctx, int slot, double *H36, double *b6, double *chi2, int3
  * or consecutive candidates of a sampling optimiser); collect each with nid_wait() */
 int nid_launch_batch(nid_ctx *ctx, int first_slot, int n, const double *poses7, int want_jac,
                      double huber_delta);
+/* SHORT sequences: nid_launch_batch and nid_run_sequence split a sequence of <= 64 poses whose results the host
+ * collects into launches of `poses_per_launch` poses, alternating between the context's two streams when `streams` is
+ * 2 (1: one stream).  poses_per_launch = 0 (the default): the library's measured table (two or more launches of <= 16
+ * poses -- their records ride in the kernel arguments -- beside each other).  Results do not depend on the policy. */
+int nid_set_short_sequence_policy(nid_ctx *ctx, int poses_per_launch, int streams);
 /* The rejection chain of a Levenberg-Marquardt iteration in ONE call: poses 0 .. n_jac-1 are evaluated WITH the
  * Jacobian phase (the likely accepted trials: their H and b are the next iteration's linear system), the rest cost
  * only, as two concurrent launches on the context's two streams (with a caller's stream: back to back).  Slot by slot

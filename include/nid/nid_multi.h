@@ -62,6 +62,8 @@ int nid_multi_create_rank(const nid_config *cfg, int32_t device, int32_t rank, i
  * nid_multi_create_rank (world == 1: n shards in this process; world > 1: n must be 1). */
 #define NID_PARTITION_CONTIGUOUS 0
 #define NID_PARTITION_INTERLEAVED 1
+/* The cells of shard `k` of `n` under `partition`: begin, begin + stride, ... < end (no device needed). */
+int nid_multi_cell_partition(int32_t k, int32_t n, int32_t ncell, int32_t partition, int32_t *begin, int32_t *end, int32_t *stride);
 int nid_multi_create_partitioned(const nid_config *cfg, const int32_t *devices, int32_t n, int32_t rank, int32_t world,
                                  int32_t partition, nid_multi **out);
 int nid_multi_destroy(nid_multi *m);

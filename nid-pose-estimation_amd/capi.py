@@ -46,7 +46,7 @@ SYMBOLS = [
     "nid_normal_equations", "nid_launch", "nid_launch_batch", "nid_launch_chain", "nid_launch_batch_to", "nid_run_sequence", "nid_run_chain", "nid_set_loop_form", "nid_set_direct_results", "nid_set_resident", "nid_resident_stats", "nid_wait", "nid_slot_buffers", "nid_launch_to",
     "nid_unpack_reduced", "nid_debug_enable_pixel_dump", "nid_debug_get_pixel_dump",
     "nid_debug_enable_stamps", "nid_debug_get_stamps", "nid_bspline4_host", "nid_bspline4_poly_host", "nid_log2_fast_host", "nid_div_small_host", "nid_last_kernel_ms", "nid_enable_timing", "nid_time_launches",
-    "nid_contract_bytes", "nid_debug_repair_count",
+    "nid_contract_bytes", "nid_debug_repair_count", "nid_set_short_sequence_policy",
 ]
 
 _lib = None
@@ -119,7 +119,10 @@ def load():
     lib.nid_set_resident.argtypes = [vp, C.c_int]
     lib.nid_resident_stats.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     lib.nid_time_launches.argtypes = [vp, C.c_int, c_dp, C.c_int, C.c_double, C.c_int, c_fp]
-    lib.nid_debug_repair_count.argtypes = [vp, C.POINTER(C.c_int64), C.c_int]
+    if hasattr(lib, "nid_debug_repair_count"):   # (an older experiment build, NID_HIP_LIB, may lack the newest diagnostics)
+        lib.nid_debug_repair_count.argtypes = [vp, C.POINTER(C.c_int64), C.c_int]
+    if hasattr(lib, "nid_set_short_sequence_policy"):
+        lib.nid_set_short_sequence_policy.argtypes = [vp, C.c_int, C.c_int]
     lib.nid_contract_bytes.restype = C.c_int64
     lib.nid_contract_bytes.argtypes = [vp]
     _lib = lib
@@ -362,8 +365,14 @@ class Context:
     def contract_bytes(self):
         return int(self.lib.nid_contract_bytes(self.h))
 
+    def set_short_sequence_policy(self, poses_per_launch=0, streams=0):
+        """How nid_launch_batch / nid_run_sequence split a short sequence (0, 0: the library's table)."""
+        self._check(self.lib.nid_set_short_sequence_policy(self.h, int(poses_per_launch), int(streams)), "nid_set_short_sequence_policy")
+
     def repair_count(self, reset=False):
         """(cell, pose) evaluations that ran the fold's repair pass (kLinFlagW in csrc/nid_kernels.hip.h)."""
+        if not hasattr(self.lib, "nid_debug_repair_count"):
+            return -1
         n = C.c_int64(0)
         self._check(self.lib.nid_debug_repair_count(self.h, C.byref(n), 1 if reset else 0), "nid_debug_repair_count")
         return int(n.value)
@@ -444,7 +453,7 @@ PARTITION_CONTIGUOUS, PARTITION_INTERLEAVED = 0, 1
 EXCHANGE_FN = C.CFUNCTYPE(C.c_int, c_dp, C.c_int64, C.c_void_p)
 RCCL_ID_BYTES = 128
 MULTI_SYMBOLS = [
-    "nid_multi_cell_range", "nid_multi_create", "nid_multi_create_rank", "nid_multi_create_partitioned", "nid_multi_destroy", "nid_multi_last_error",
+    "nid_multi_cell_range", "nid_multi_cell_partition", "nid_multi_create", "nid_multi_create_rank", "nid_multi_create_partitioned", "nid_multi_destroy", "nid_multi_last_error",
     "nid_multi_shards", "nid_multi_shard", "nid_multi_world", "nid_multi_comm_unique_id", "nid_comm_create_rank",
     "nid_comm_create_local", "nid_comm_destroy", "nid_comm_ranks", "nid_multi_attach_comm", "nid_multi_comm_init",
     "nid_multi_comm_init_local", "nid_multi_comm_ranks", "nid_multi_time_exchange", "nid_multi_set_exchange_hook", "nid_multi_set_reduce_mode",
@@ -463,6 +472,8 @@ def _load_multi():
         return lib
     vp = C.c_void_p
     lib.nid_multi_cell_range.argtypes = [C.c_int32] * 3 + [c_ip, c_ip]
+    if hasattr(lib, "nid_multi_cell_partition"):
+        lib.nid_multi_cell_partition.argtypes = [C.c_int32] * 4 + [c_ip, c_ip, c_ip]
     lib.nid_multi_create.argtypes = [C.POINTER(NidConfig), c_ip, C.c_int32, C.POINTER(vp)]
     lib.nid_multi_create_rank.argtypes = [C.POINTER(NidConfig), C.c_int32, C.c_int32, C.c_int32, C.POINTER(vp)]
     lib.nid_multi_create_partitioned.argtypes = [C.POINTER(NidConfig), c_ip, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(vp)]
@@ -505,6 +516,17 @@ def cell_range(k, n, ncell):
     if rc != NID_OK:
         raise NidError(f"nid_multi_cell_range({k}, {n}, {ncell}): {lib.nid_status_string(rc).decode()}")
     return lo.value, hi.value
+
+
+def cell_set(k, n, ncell, partition=0):
+    """The cell ids shard k of n owns under `partition` (PARTITION_CONTIGUOUS / PARTITION_INTERLEAVED): the library's
+    own arithmetic (nid_multi_cell_partition), no device needed."""
+    lib = _load_multi()
+    b, e, st = C.c_int32(0), C.c_int32(0), C.c_int32(0)
+    rc = lib.nid_multi_cell_partition(k, n, ncell, int(partition), C.byref(b), C.byref(e), C.byref(st))
+    if rc != NID_OK:
+        raise NidError(f"nid_multi_cell_partition({k}, {n}, {ncell}, {partition}): {lib.nid_status_string(rc).decode()}")
+    return np.arange(b.value, e.value, st.value)
 
 
 def rccl_unique_id():

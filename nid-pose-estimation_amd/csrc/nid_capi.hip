@@ -65,6 +65,7 @@ struct nid_ctx {
   int jac_threads = 0, cost_threads = 0;  // nid_set_launch_shape: 0 = default (128) / automatic (pick_threads)
   bool loop_form = false;                  // nid_set_loop_form (diagnostics)
   bool direct_results = true;              // nid_set_direct_results: single-pose launches whose result the host waits for are DIRECT
+  int seq_chunk = 0, seq_streams = 0;      // nid_set_short_sequence_policy: poses per launch / streams of a SHORT sequence (0 = the measured table)
   // the RESIDENT evaluator (nid_set_resident; k_resident in nid_kernels.hip.h)
   struct Resident {
     bool enabled = false;          // asked for
@@ -1043,6 +1044,45 @@ int launch_batch(nid_ctx *ctx, int first_slot, int n, const Pose *poses, int wan
   return NID_OK;
 }
 
+// SHORT sequences (round 4): n poses whose results the host collects slot by slot, n too small to fill a pipeline --
+// the candidates of a Gauss-Newton / LM step, the driver's `--steps 20`.  One launch of n poses is not the fastest
+// form: beyond kMaxBatch poses the per-pose records travel by an in-stream copy (a second enqueue and a dependency in
+// front of the kernel), and a launch's workgroups start together and walk through their phases in step (load, atomics,
+// fold, Jacobian), so that the chip's units take turns idling.  Launches of <= kMaxBatch poses carry their records in
+// the kernel arguments, and two of them on the context's two streams run beside each other out of step.  The plan:
+// poses per launch and whether consecutive launches alternate between the streams; from the measured table
+// (profiles/r04_short_sequences.txt, tools/short_seq_sweep.py) unless nid_set_short_sequence_policy pins it.
+// Results do not depend on the plan (a pose gives the same bits alone, in any launch, on either stream: tested).
+struct SplitPlan { int chunk; bool two_streams; };
+constexpr int kShortSequence = 64;  // longer sequences are one launch (<= NID_MAX_BATCH) or the pipeline (nid_run_sequence)
+
+SplitPlan plan_split(const nid_ctx *ctx, int n, bool jac) {
+  if (n > kShortSequence) return {n, false};
+  if (ctx->seq_chunk > 0) return {std::min(ctx->seq_chunk, n), ctx->seq_streams != 1};
+  if (ctx->external_stream) return {n, false};  // one stream: nothing to run beside
+  (void)jac;
+  if (n <= 4) return {n, false};
+  // as few launches of <= kMaxBatch poses as cover n, at least two, equally filled: 20 -> 10 + 10, 40 -> 14 + 13 + 13
+  const int launches = std::max(2, (n + kMaxBatch - 1) / kMaxBatch);
+  return {(n + launches - 1) / launches, true};
+}
+
+int launch_split(nid_ctx *ctx, int first_slot, int n, const Pose *poses, int want_jac, double delta) {
+  if (!ctx) return NID_ERR_INVALID_ARG;
+  if (n < 1 || n > kMaxBatchExt || first_slot < 0 || first_slot + n > NID_SLOTS) return NID_ERR_INVALID_ARG;
+  const SplitPlan plan = plan_split(ctx, n, want_jac != 0);
+  if (plan.chunk >= n || ctx->dbg_enabled || ctx->timing) return launch_batch(ctx, first_slot, n, poses, want_jac, delta);
+  for (int k = 0; k < n; k++)  // all or nothing: no half-launched sequence
+    if (ctx->slots[first_slot + k].pending) { ctx->last_error = "slot still pending: nid_wait() it first"; return NID_ERR_STATE; }
+  int l = 0;
+  for (int i = 0; i < n; i += plan.chunk, l++) {
+    const int cnt = std::min(plan.chunk, n - i);
+    int rc = launch_batch(ctx, first_slot + i, cnt, poses + i, want_jac, delta, nullptr, plan.two_streams && (l & 1), false, /*allow_direct=*/false);
+    if (rc) return rc;
+  }
+  return NID_OK;
+}
+
 // spin on the sequence word the last workgroup of slot S's launch writes behind its results (system-scope release)
 int wait_host_seq(nid_ctx *ctx, Slot &S) {
   volatile unsigned long long *seqw = reinterpret_cast<volatile unsigned long long *>(S.reduced_host + kReducedLen);
@@ -1662,7 +1702,14 @@ int nid_launch_batch(nid_ctx *ctx, int first_slot, int n, const double *poses7, 
   if (!ctx || !poses7 || n < 1 || n > kMaxBatchExt) return NID_ERR_INVALID_ARG;
   Pose p[kMaxBatchExt];
   for (int k = 0; k < n; k++) pose_from_pose7(poses7 + 7 * k, ctx->xform, &p[k]);
-  return launch_batch(ctx, first_slot, n, p, want_jac, delta);
+  return launch_split(ctx, first_slot, n, p, want_jac, delta);  // (one launch, or a short sequence's several: plan_split)
+}
+
+int nid_set_short_sequence_policy(nid_ctx *ctx, int poses_per_launch, int streams) {
+  if (!ctx || poses_per_launch < 0 || poses_per_launch > kMaxBatchExt || streams < 0 || streams > 2) return NID_ERR_INVALID_ARG;
+  ctx->seq_chunk = poses_per_launch;
+  ctx->seq_streams = streams;
+  return NID_OK;
 }
 
 int nid_launch_chain(nid_ctx *ctx, int first_slot, int n, const double *poses7, int n_jac, double delta) {
@@ -1723,13 +1770,13 @@ int nid_run_sequence(nid_ctx *ctx, const double *poses7, int n, int batch, int w
   NID_HIP(ctx, hipSetDevice(ctx->cfg.device));
   for (int s = 0; s < NID_SLOTS; s++) if (ctx->slots[s].pending) return NID_ERR_STATE;
   if (n <= batch) {
-    // ONE launch: nothing to pipeline, latency is what counts -- the kernel writes every pose's block straight to
-    // pinned host memory and the host spins on the sequence words (no copy, no event: 128 us instead of 193 us
-    // from the enqueue to the last of 20 results)
+    // Nothing to pipeline, latency is what counts -- the kernel writes every pose's block straight to pinned host
+    // memory and the host spins on the sequence words (no copy, no event: 128 us instead of 193 us from the enqueue
+    // to the last of 20 results); a SHORT sequence goes as several launches of <= kMaxBatch poses (plan_split)
     if (n == 0) return NID_OK;
     Pose q[kMaxBatchExt];
     for (int k = 0; k < n; k++) pose_from_pose7(poses7 + 7 * (size_t)k, ctx->xform, &q[k]);
-    int rc = launch_batch(ctx, 0, n, q, want_jac, delta);
+    int rc = launch_split(ctx, 0, n, q, want_jac, delta);
     if (rc) return rc;
     for (int k = 0; k < n; k++) {
       rc = nid_wait(ctx, k, nullptr, nullptr, nullptr, nullptr);

@@ -606,6 +606,9 @@ constexpr int kFineLevels = 5;
 // What an unflagged or heavier bin loses is bounded by n * 2^-53 * 3 / kLinFlagW resp. n * 2^-53 / kRepairMass per unit of
 // the flagged samples' reference weight: 1e-11 * n.  Cells that need a repair: one in ~45 000 random cases, and cells on
 // the rim of a saturated patch (counted: EvalParams::repair_count, nid_debug_repair_count).
+#ifndef NID_REPAIR
+#define NID_REPAIR 1   // 0: experiment builds without the flags, the detection and the repair pass (tools/build_variant.py)
+#endif
 constexpr double kLinFlagW = 0x1p-16;
 constexpr double kRepairMass = 0x1p-12;
 __device__ __forceinline__ int fine_level(double w) {
@@ -1549,7 +1552,7 @@ __device__ __forceinline__ void eval_cell(const EvalParams &P, const SlotArgs &S
     // NORMAL mode, rare branches: a LINEAR end-span weight below kLinFlagW flags the bins it lands in (kLinFlagW)
     auto flag_linear = [&](int k, double w, const double (&wrm)[4]) {
       const bool last = k == 2 && jc == S - 1;
-      if (w < kLinFlagW && ((k == 1 && jc == 0) || last)) {
+      if (NID_REPAIR && w < kLinFlagW && ((k == 1 && jc == 0) || last)) {
         unsigned bits = 1u << 16;
 #pragma unroll
         for (int m = 0; m < 4; m++) bits |= (wrm[m] * w > kNegligibleW) ? (1u << (jr + m)) : 0u;
@@ -1979,13 +1982,14 @@ __device__ __forceinline__ void eval_cell(const EvalParams &P, const SlotArgs &S
       // the groups' LINEAR end-span weight (last span, column nb - 2; the near-saturated samples': 3 ulps of S) flags the
       // bins it lands in like a sample of the rare branches does (flag_linear in hist_add; e == nb: the marginal bin)
       const double wlin = ns ? nw[2] : cw[2];
-      if (sum != 0.0 && wlin < kLinFlagW && wlin > kNegligibleW && (ns ? jc_ns : jc_cl) == S - 1)
+      if (NID_REPAIR && sum != 0.0 && wlin < kLinFlagW && wlin > kNegligibleW && (ns ? jc_ns : jc_cl) == S - 1)
         atomicOr(lin_flag + 1, e < nb ? (1u << e) : (1u << 16));
     }
     __syncthreads();
     flagw = *reinterpret_cast<const uint4 *>(clamp_flag);
   }
-  const unsigned lin_col1 = (unsigned)__builtin_amdgcn_readfirstlane((int)flagw.z), lin_colz = (unsigned)__builtin_amdgcn_readfirstlane((int)flagw.w);
+  const unsigned lin_col1 = NID_REPAIR ? (unsigned)__builtin_amdgcn_readfirstlane((int)flagw.z) : 0u;
+  const unsigned lin_colz = NID_REPAIR ? (unsigned)__builtin_amdgcn_readfirstlane((int)flagw.w) : 0u;
   // One bin: its mass from the copies (COARSE = false: without them, after a repair), the fine levels and the two
   // groups; p = mass / N_c, W = -(1 + log2 p), p log2 p into the tables.  Returns the copies' integer sum.
   auto fold_bin = [&](int b, auto coarse_tag, double &mass_out) -> unsigned long long {

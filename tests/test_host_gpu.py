@@ -395,22 +395,39 @@ def test_bench_multi_rank_code_path_on_one_gpu(tmp_path):
     assert len(rc.stdout.strip().splitlines()) == 1, rc.stdout     # RCCL's own banner must not land on stdout
     rj = json.loads(rc.stdout.strip().splitlines()[-1])
     assert rj["rccl_ranks_seen"] == 1 and "RCCL" in rj["config"]["parallelism"]
-    # RCCL that cannot be loaded (here: forced to a missing file): every rank notices, they agree, and the job exchanges
-    # over the gloo control group instead of hanging in ncclCommInitRank -- the default backend, 2 ranks on this GPU
+    # RCCL that cannot be loaded (here: forced to a missing file): every rank notices, they agree -- and the job FAILS
+    # with one error record instead of hanging in ncclCommInitRank or quietly measuring over gloo (round 4: a scaling
+    # curve over the test transport must never read as the result; --backend gloo asks for it explicitly)
     nb_env = dict(env, NID_RCCL_LIBRARY="/nonexistent/librccl.so")
     fb = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                          "--master-addr", "127.0.0.1", "--master-port", "29516", bench, "--gpus", "2", "--no-cpu-baseline",
                          "--quick", "--steps", "20", "--warmup", "5"], capture_output=True, text=True, env=nb_env, timeout=900)
-    assert fb.returncode == 0, fb.stderr[-3000:]
+    assert fb.returncode != 0, fb.stdout[-2000:]
     rf = json.loads([l for l in fb.stdout.strip().splitlines() if l.startswith("{")][-1])
-    assert "rccl_unavailable" in rf and "gloo" in rf["config"]["parallelism"] and rf["n_gpus"] == 2
-    # ... and a communicator RCCL refuses (two ranks on ONE device: ncclCommInitRank fails on both): same agreement
-    dup = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                          "--master-addr", "127.0.0.1", "--master-port", "29515", bench, "--gpus", "2", "--no-cpu-baseline",
-                          "--quick", "--steps", "20", "--warmup", "5"], capture_output=True, text=True, env=env, timeout=900)
-    assert dup.returncode == 0, dup.stderr[-3000:]
-    rd = json.loads([l for l in dup.stdout.strip().splitlines() if l.startswith("{")][-1])
-    assert "ncclCommInitRank" in rd["rccl_unavailable"] and "gloo" in rd["config"]["parallelism"]
+    assert rf["value"] is None and "RCCL" in rf["error"] and rf["n_gpus"] == 2 and rf["rccl_ranks_seen"] == 0
+    # ... and a communicator RCCL refuses (two ranks on ONE device: ncclCommInitRank fails on both): same agreement.
+    # Started the way the driver starts its N = 1 leg -- plain `python bench.py --gpus 2`, no launcher: bench.py starts
+    # the two ranks itself (a child torch.distributed.run, before this process touches the GPU) and relays the record
+    # and the exit code; it can no longer run one process and print n_gpus 1.
+    env_plain = {k: v for k, v in env.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    dup = subprocess.run([sys.executable, bench, "--gpus", "2", "--no-cpu-baseline", "--quick", "--steps", "20", "--warmup", "5"],
+                         capture_output=True, text=True, env=env_plain, timeout=900)
+    assert dup.returncode != 0, dup.stdout[-2000:]
+    assert len(dup.stdout.strip().splitlines()) == 1, dup.stdout
+    rd = json.loads(dup.stdout.strip())
+    assert rd["value"] is None and "ncclCommInitRank" in rd["error"] and rd["n_gpus"] == 2
+    # the same plain invocation with the test transport asked for: a result line with n_gpus 2
+    own = subprocess.run([sys.executable, bench, "--gpus", "2", "--no-cpu-baseline", "--quick", "--steps", "20", "--warmup", "5",
+                          "--backend", "gloo"], capture_output=True, text=True, env=env_plain, timeout=900)
+    assert own.returncode == 0, own.stderr[-3000:]
+    assert len(own.stdout.strip().splitlines()) == 1, own.stdout
+    ro = json.loads(own.stdout.strip())
+    assert ro["n_gpus"] == 2 and ro["rccl_ranks_seen"] == 0 and "gloo" in ro["exchange"] and ro["value"] > 0
+    # a launcher that started another number of ranks than --gpus says is refused
+    bad = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29515", bench, "--gpus", "4", "--no-cpu-baseline",
+                          "--quick", "--steps", "20", "--warmup", "5", "--backend", "gloo"], capture_output=True, text=True, env=env, timeout=900)
+    assert bad.returncode != 0
     for port, world, extra in ((29517, 2, ["--steps", "20", "--warmup", "5"]),
                                (29518, 2, ["--steps", "300", "--warmup", "70"]),
                                (29519, 2, ["--steps", "300", "--warmup", "70", "--group", "8", "--batch", "16"]),

@@ -1,7 +1,9 @@
 """The N>1 path on CPU: world_size-2 gloo processes.  Each rank produces the
-partial 6x6 block of ITS cell range (the oracle stands in for the GPU kernel
-here -- test infrastructure), the product's sharding helpers partition, sum and
-unpack; the result must equal the unsharded reduction."""
+partial 6x6 block of ITS cells -- which cells those are comes from the PRODUCT
+(capi.cell_range / capi.cell_set = nid_multi_cell_range / nid_multi_cell_partition
+of libnid_hip.so, which need no device); the oracle stands in for the GPU kernel
+(test infrastructure), the blocks are unpacked by the product's nid_unpack_reduced;
+the result must equal the unsharded reduction."""
 import importlib
 import os
 import socket
@@ -33,12 +35,14 @@ def _worker(rank, world, port, q):
     import parallel_helpers as parallel   # tests/parallel_helpers.py: numpy / torch.distributed helpers of this test
     synth = importlib.import_module("nid-pose-estimation_amd.synth")
     from oracle import oracle_py
+    capi = importlib.import_module("nid-pose-estimation_amd.capi")
     pair = synth.make_pair("S")
     o = oracle_py.from_pair(pair, 8)
     o.compute_href(pair.pose_init)
     _, _, err, J = o.evaluate(pair.pose_init, True)
     ncell = pair.cell * pair.cell
-    lo, hi = parallel.cell_range(rank, world, ncell)
+    lo, hi = capi.cell_range(rank, world, ncell)                    # the product's partition (GPU-free)
+    assert (lo, hi) == parallel.cell_range(rank, world, ncell)      # ... which the test's numpy twin restates
     delta = float(np.sqrt(0.95))
     # this rank's partial block over its own cells only
     e_loc = np.full(ncell, np.nan); e_loc[lo:hi] = err[lo:hi]
@@ -46,7 +50,8 @@ def _worker(rank, world, port, q):
     block = torch.from_numpy(parallel.pack_reduced_np(H, b, chi2, na))
     parallel.allreduce_reduced(block)
     # the interleaved partition (NID_PARTITION_INTERLEAVED): other cell sets, the same sum
-    own = parallel.cell_set(rank, world, ncell, interleaved=True)
+    own = capi.cell_set(rank, world, ncell, capi.PARTITION_INTERLEAVED)
+    assert np.array_equal(own, parallel.cell_set(rank, world, ncell, interleaved=True))
     e_int = np.full(ncell, np.nan); e_int[own] = err[own]
     Hi, bi, chi2i, nai = oracle_py.normal_equations(e_int, J, delta)
     block_i = torch.from_numpy(parallel.pack_reduced_np(Hi, bi, chi2i, nai))
@@ -55,10 +60,10 @@ def _worker(rank, world, port, q):
     cells = torch.from_numpy(np.concatenate([err[lo:hi, None], J[lo:hi]], axis=1))
     gathered = parallel.allgather_cells(cells, world) if (hi - lo) * world == ncell else None
     Hf, bf, cf, nf = oracle_py.normal_equations(err, J, delta)
-    Hs, bs, cs, ns = parallel.unpack_reduced_np(block.numpy())
+    Hs, bs, cs, ns = capi.unpack_reduced(block.numpy())
     ok = (ns == nf and np.allclose(cs, cf, rtol=1e-13) and np.allclose(Hs, Hf, rtol=1e-12, atol=1e-13)
           and np.allclose(bs, bf, rtol=1e-12, atol=1e-13))
-    Hq, bq, cq, nq = parallel.unpack_reduced_np(block_i.numpy())
+    Hq, bq, cq, nq = capi.unpack_reduced(block_i.numpy())
     ok = ok and nq == nf and np.allclose(cq, cf, rtol=1e-13) and np.allclose(Hq, Hf, rtol=1e-12, atol=1e-13) \
         and np.allclose(bq, bf, rtol=1e-12, atol=1e-13)
     if gathered is not None:
