@@ -109,6 +109,7 @@ struct nid_ctx {
   int *dbg_jc = nullptr;
   long long *dbg_stamps = nullptr;
   unsigned long long *repair_count_dev = nullptr;  // EvalParams::repair_count (nid_debug_repair_count)
+  unsigned *repair_queue_dev[2] = {nullptr, nullptr};  // EvalParams::repair_queue of launches on `stream` / on aux_stream (k_repair)
   bool dbg_enabled = false;
   int dbg_jac = 0;
   bool timing = false;
@@ -237,7 +238,6 @@ int eval_hist_shift(const Geometry &g) {
 void set_hist_params(EvalParams &P) {
   const int hs = eval_hist_shift(P.g);
   P.hist_dn = std::ldexp(1.0, hs - 562);    // times kWcPre = 2^-512 on the other factor: 2^(hs - 1074)
-  P.hist_dn1 = std::ldexp(1.0, hs - 1074);  // (a subnormal constant: exact)
   P.hist_inv_scale = std::ldexp(1.0, -hs);
 }
 
@@ -298,6 +298,7 @@ int launch_eval2(nid_ctx *ctx, EvalParams &P, bool jac, hipStream_t stream, int 
   // diagnostics (128 / 256 threads: they keep the workgroup shape, the Jacobian sums depend on it in their last bits);
   // cells of more than 32 * NT slots (test geometries: a single cell of 6 144 / 19 200 pixels: the FAST kernels' BIG
   // instantiation, generic bin count only); everything else the loop form.
+  P.repair_queue = ctx->repair_queue_dev[(stream == ctx->aux_stream && !ctx->external_stream) ? 1 : 0];
   int family = kFamLoop;
   if (stamps_lat) family = kFamStampsLat;
   else if (dbg) family = kFamDbg;
@@ -334,13 +335,18 @@ void fill_common_params(nid_ctx *ctx, double delta, EvalParams *P) {
   P->Nc = ctx->Nc_dev;
   P->Href = ctx->Href_dev;
   P->jac_cols = (ctx->jac_bound == NID_JACBOUND_CPU) ? ctx->g.cols - 1 : ctx->g.cols;
-  P->u_in = (double)ctx->g.cols - 3.0 - kBorderEps;
-  P->v_in = (double)ctx->g.rows - 3.0 - kBorderEps;
-  P->u_jin = (double)P->jac_cols - 3.0 - kBorderEps;
-  P->u_out = (double)ctx->g.cols - 3.0 + kBorderEps;
-  P->v_out = (double)ctx->g.rows - 3.0 + kBorderEps;
-  P->u_jout = (double)P->jac_cols - 3.0 + kBorderEps;
-  P->hist_dn = P->hist_dn1 = P->hist_inv_scale = 0.0;  // set by launch_eval2
+  {
+    // FAST border bounds as ranges of the coordinates' high dwords (EvalParams::hu_lo ...): strictly inside
+    // [kBorderEps, bound - kBorderEps] at the high dword's granularity
+    auto hi = [](double x) { uint64_t b; std::memcpy(&b, &x, 8); return (unsigned)(b >> 32); };
+    const unsigned lo = hi(kBorderEps) + 1u;
+    auto span = [&](double bound) { const unsigned top = hi(bound - kBorderEps); return top > lo + 1u ? top - 1u - lo : 0u; };
+    P->hu_lo = lo;
+    P->hu_span = span((double)ctx->g.cols - 3.0);
+    P->hv_span = span((double)ctx->g.rows - 3.0);
+    P->hj_span = span((double)P->jac_cols - 3.0);
+  }
+  P->hist_dn = P->hist_inv_scale = 0.0;  // set by launch_eval2
   if (ctx->dbg_enabled) {
     P->dbg_u = ctx->dbg_u; P->dbg_v = ctx->dbg_v; P->dbg_ic = ctx->dbg_ic;
     P->dbg_wc = ctx->dbg_wc; P->dbg_jc = ctx->dbg_jc;
@@ -351,6 +357,7 @@ void fill_common_params(nid_ctx *ctx, double delta, EvalParams *P) {
   }
   P->dbg_stamps = ctx->dbg_stamps;
   P->repair_count = ctx->repair_count_dev;
+  P->repair_queue = ctx->repair_queue_dev[0];  // (launch_eval2 picks the launch stream's)
 }
 
 void fill_slot_args(const Pose &pose, Slot &S, double *out_reduced, unsigned long long *host_seq, SlotArgs *A) {
@@ -1282,6 +1289,7 @@ int nid_create_strided(const nid_config *cfg, int32_t cell_stride, nid_ctx **out
   ctx->hist_inv_scale = std::ldexp(1.0, -hs);
   // 32-bit byte offsets into the reference weights (load_tile_w): 4 x 8 B x nloc x pstride < 2^32
   if ((size_t)g.nloc * (size_t)g.pstride >= ((size_t)1 << 27)) { delete ctx; return NID_ERR_UNSUPPORTED; }
+  if (g.nloc >= (1 << 16)) { delete ctx; return NID_ERR_UNSUPPORTED; }  // a repair-queue entry is pose << 16 | cell (k_repair)
   if (const char *bt = getenv("NID_BLOCK_THREADS")) {  // tuning: both kinds of launches
     const int v = atoi(bt);
     if (v == 128 || v == 256 || v == 512 || v == 1024) ctx->jac_threads = ctx->cost_threads = v;
@@ -1319,6 +1327,11 @@ int nid_create_strided(const nid_config *cfg, int32_t cell_stride, nid_ctx **out
   if ((rc = dev_alloc(ctx, &ctx->Href_dev, g.nloc))) return fail(rc);
   if ((rc = dev_alloc(ctx, &ctx->repair_count_dev, 1))) return fail(rc);
   if (hipMemset(ctx->repair_count_dev, 0, sizeof(unsigned long long)) != hipSuccess) return fail(NID_ERR_HIP);
+  for (int q = 0; q < 2; q++) {  // one queue per launch stream: [count | exit ticket | pose << 16 | cell ...], see k_repair
+    const size_t n = 2 + (size_t)g.nloc * kMaxBatchExt;
+    if ((rc = dev_alloc(ctx, &ctx->repair_queue_dev[q], n))) return fail(rc);
+    if (hipMemset(ctx->repair_queue_dev[q], 0, n * sizeof(unsigned)) != hipSuccess) return fail(NID_ERR_HIP);
+  }
   {
     // the evaluation kernels read the table with kWcPre on its value coefficients (k_eval2's hist_add, fx_bits)
     std::vector<double> coef;
@@ -1386,6 +1399,7 @@ int nid_destroy(nid_ctx *ctx) {
   (void)hipFree(ctx->im1_dev); (void)hipFree(ctx->im1s_dev); (void)hipFree(ctx->im0_dev); (void)hipFree(ctx->depth_dev);
   (void)hipFree(ctx->points_dev); (void)hipFree(ctx->Twc_dev);
   (void)hipFree(ctx->Nc_dev); (void)hipFree(ctx->Href_dev); (void)hipFree(ctx->ctab_dev); (void)hipFree(ctx->repair_count_dev);
+  (void)hipFree(ctx->repair_queue_dev[0]); (void)hipFree(ctx->repair_queue_dev[1]);
   (void)hipFree(ctx->dbg_u); (void)hipFree(ctx->dbg_v); (void)hipFree(ctx->dbg_ic);
   (void)hipFree(ctx->dbg_wc); (void)hipFree(ctx->dbg_jc); (void)hipFree(ctx->dbg_stamps);
   for (int r = 0; r < nid_ctx::kSeqRing; r++) {

@@ -119,9 +119,13 @@ struct EvalParams {
   const int *Nc;        // [nloc]
   const double *Href;   // [nloc]
   int jac_cols;         // cols or cols-1
-  double u_in, v_in, u_jin;  // FAST border bounds, kBorderEps inside the reference's: cols-3-eps, rows-3-eps, jac_cols-3-eps
-  double u_out, v_out, u_jout;  // ... and kBorderEps outside: cols-3+eps, rows-3+eps, jac_cols-3+eps
-  double hist_dn, hist_dn1, hist_inv_scale;  // 2^(s - 562), 2^(s - 1074), 2^-s: see fx_bits
+  // FAST border bounds, as unsigned range checks on the HIGH DWORD of u, v (a non-negative double orders like its bit
+  // pattern; a negative one or a NaN falls outside every range): `inside` iff hi(u) - hu_lo <= hu_span, i.e. u in
+  // [eps', cols-3-eps'] with eps' >= kBorderEps at the granularity of the high dword (2^-11 px near 640: a few more
+  // samples take the exact decisions).  Round 4: the f64 bounds were twelve scalar registers inside both pixel loops, and
+  // the kernels are short of those (what does not fit is parked in vector lanes and read back inside the loops).
+  unsigned hu_lo, hu_span, hv_span, hj_span;  // u: [hu_lo, hu_lo + hu_span], v: [hu_lo, hu_lo + hv_span], linearizeOplus' u: hj_span
+  double hist_dn, hist_inv_scale;  // 2^(s - 562), 2^-s: see fx_bits (2^(s - 1074), for the plain weights, is hist_dn * kWcPre)
   // fused Huber + 6x6 reduction
   double huber_delta;
   float huber_dsqr;
@@ -136,6 +140,7 @@ struct EvalParams {
   int *dbg_jc;
   int dbg_jac;  // 0: the dump describes the cost phase (u, v, ic, jc, wc[4]); 1: the Jacobian phase (gx, gy, pc, jc, dw[4])
   unsigned long long *repair_count;  // cells and poses that ran the repair pass (kLinFlagW), or null
+  unsigned *repair_queue;            // [0] entries, [1] k_repair's exit ticket, [2 + i] = pose << 16 | cell: see k_repair
   // optional phase stamps (s_memtime) of wave 0 of every workgroup: [nloc][10] (8 phase stamps + s_memrealtime at start/end); diagnostic runs only
   long long *dbg_stamps;
 };
@@ -609,6 +614,9 @@ constexpr int kFineLevels = 5;
 #ifndef NID_REPAIR
 #define NID_REPAIR 1   // 0: experiment builds without the flags, the detection and the repair pass (tools/build_variant.py)
 #endif
+#ifndef NID_REPAIR_STAGE
+#define NID_REPAIR_STAGE 3   // experiment builds: 1 = the flags only, 2 = + the fold's detection, 3 = + the repair pass
+#endif
 constexpr double kLinFlagW = 0x1p-16;
 constexpr double kRepairMass = 0x1p-12;
 __device__ __forceinline__ int fine_level(double w) {
@@ -1019,7 +1027,14 @@ __device__ __forceinline__ void finish_and_reduce_w0(const EvalParams &P, const 
 // and the scheduler hides the load / LDS latencies that one wave per SIMD exposes.
 // guard bands of the FAST-mode decision re-check (see exact_decisions)
 // clamp guard: ic within 1e-4 of 0 or of 255 (the clamp replaces ic >= 255 by 254.999), as ONE compare |ic - mid| > half
-constexpr double kGuardMid = 127.5, kGuardHalf = 127.4999;
+// (as an unsigned range check on the sample's high dword: [kGuardLoHi, kGuardLoHi + kGuardSpanHi] lies inside [1e-4,
+// 254.9999]; 32-bit literals in the instruction instead of two f64 constants in scalar registers)
+constexpr unsigned kGuardLoHi = 0x3F1A36E3u;                  // high dword of 1e-4, plus one
+constexpr unsigned kGuardSpanHi = 0x406FDFFEu - kGuardLoHi;    // ... up to the high dword of 254.9999, minus one
+__device__ __forceinline__ bool outside_clamp_guard(double ic) {
+  return (unsigned)__double2hiint(ic) - kGuardLoHi > kGuardSpanHi;
+}
+constexpr unsigned kBorderEpsHi = 0x3EB00000u;                  // high dword of kBorderEps = 2^-20
 // A sample the FAST main passes take lies inside the clamp guard: 1e-4 <= ic <= 254.9999, so the clamp ic >= 255 and
 // the u == 0 quirk of the B-spline derivative (pc == 0) cannot apply to it; only the second passes (exact_decisions)
 // carry those selects.  (The NID_EXP_NO_GUARD experiment build has no guard and keeps them everywhere.)
@@ -1183,9 +1198,10 @@ __device__ __forceinline__ void pixel_front(const EvalParams &P, const SlotArgs 
     // The window origin is NOT clamped: ((int)u - 1, (int)v - 1) may be -1 (the image buffer has zeroed
     // margins), so the fixed-tap sample applies to every in-frame pixel.
     // (plain `&`: five compares in a row; `&&` makes the compiler branch around the later ones)
-    const bool in = (f.jr >= 0) & (u >= kBorderEps) & (u <= P.u_in) & (v >= kBorderEps) & (v <= P.v_in);
+    const unsigned hu = (unsigned)__double2hiint(u) - P.hu_lo, hv = (unsigned)__double2hiint(v) - P.hu_lo;
+    const bool in = (f.jr >= 0) & (hu <= P.hu_span) & (hv <= P.hv_span);
     f.in = in;
-    f.jin = in && (u <= P.u_jin);
+    f.jin = in && (hu <= P.hj_span);
     f.redo = (f.jr >= 0) && !f.jin;
 #ifdef NID_EXP_NO_REDO
     f.redo = false;
@@ -1198,12 +1214,17 @@ __device__ __forceinline__ void pixel_front(const EvalParams &P, const SlotArgs 
 // FAST: what `redo` means for a pixel, from FAST values that are at least kBorderEps away from every border they
 // are compared with.  Returns true when the pixel needs exact_decisions (a border within kBorderEps, or NaN).
 __device__ __forceinline__ bool classify_redo(const EvalParams &P, PixelFront &f) {
-  const double u = f.u, v = f.v;
-  if (u < -kBorderEps || v < -kBorderEps || u > P.u_out || v > P.v_out) {
+  // (conservative integer forms of u < -eps, u > cols-3+eps, ...: the upper bounds from the ranges' ends -- the high
+  // dword of cols-3+eps is at most one above that of cols-3-eps --, so that no further scalar registers are needed;
+  // a NaN is "clearly out" like in the reference, whose comparisons all fail)
+  const int hu = __double2hiint(f.u), hv = __double2hiint(f.v);
+  const unsigned neg_out = 0x80000000u + kBorderEpsHi;  // below -eps' (the sign bit set, magnitude beyond the band)
+  const int u_top = (int)(P.hu_lo + P.hu_span + 2u), v_top = (int)(P.hu_lo + P.hv_span + 2u), j_top = (int)(P.hu_lo + P.hj_span + 2u);
+  if ((unsigned)hu > neg_out || (unsigned)hv > neg_out || hu > u_top || hv > v_top) {
     f.in = false; f.jin = false;  // clearly out of frame
     return false;
   }
-  if (f.in && u > P.u_jout) {
+  if (f.in && hu > j_top) {
     f.jin = false;  // clearly in frame for the cost, clearly outside linearizeOplus' narrower bound (cols-1, :433)
     return false;
   }
@@ -1364,7 +1385,22 @@ struct ResCell {
 // The body of the evaluation kernels: one cell at one pose by one workgroup.  RES: called from the resident kernel
 // (k_resident) -- the B-spline table is in LDS already, the cell's count and reference entropy are in registers, and
 // the histograms were zeroed behind the previous request (by the waves that had nothing left to do).
-template <int NT, bool JAC, bool STRICT, int NB, bool DBG, bool EXT, int LAT, bool BIG, bool RES>
+// REPAIR_INLINE: the repair pass (kLinFlagW) is part of this instantiation.  The loop-form kernels -- the throughput
+// path -- are compiled WITHOUT it: merely carrying its code between the two phases cost them 7 % on data that never needs
+// it (same-box A/B, profiles/r04_ablations_A.txt: the flags and the fold's detection cost nothing, the repair block's
+// presence does -- the kernel sits at the limit of its scalar registers, the block's needs come on top of everything
+// that lives across the fold, and the allocator parks the LONGEST lives, the pointers and bounds of both pixel loops,
+// in vector lanes: v_readlane + hazard nops inside the hot loops.  A second copy of the body behind the first, an
+// out-of-line function, arguments re-read per phase, a scalar-register diet: all measured, all slower than no repair
+// code).  A workgroup of theirs whose fold finds a bin to repair publishes NOTHING: it puts (pose, cell) into the
+// launch's repair queue and leaves; k_repair -- a kernel of its own, enqueued behind every such launch -- does the queued
+// cells from the start with the instantiation that repairs inline and publishes them like any other (the in-launch
+// reduction is "whoever arrives last", across kernels too; the DIRECT protocol's host polls every record).  Same
+// algorithm either way: the same bits.  The latency-form, resident, diagnostic and big-cell kernels repair inline
+// (other register budgets; the latency paths measured unchanged).
+__device__ __forceinline__ constexpr bool repair_inline_default(int lat, bool res, bool dbg, bool big) { return lat > 0 || res || dbg || big; }
+
+template <int NT, bool JAC, bool STRICT, int NB, bool DBG, bool EXT, int LAT, bool BIG, bool RES, bool REPAIR_INLINE = repair_inline_default(LAT, RES, DBG, BIG)>
 __device__ __forceinline__ void eval_cell(const EvalParams &P, const SlotArgs &SA, const int cl, const int pose_idx, unsigned char *smem,
                                           const ResCell rc = ResCell{0, 0.0, true}) {
   static_assert(LAT == 0 || (!STRICT && !EXT), "the latency form exists for FAST math launches of <= kMaxBatch poses (DBG: phase stamps only)");
@@ -1415,6 +1451,7 @@ __device__ __forceinline__ void eval_cell(const EvalParams &P, const SlotArgs &S
     if (tid >= 64) return;
     if (direct_launch) {  // see the cost-only tail
       if (tid < kCellOut && SA.cellout_host) store_sys(out + tid, (tid == kCellOut - 1) ? (double)n_c : NAN);
+      else if (!RES && tid < kCellOut && want_cellout) out[tid] = (tid == kCellOut - 1) ? (double)n_c : NAN;  // the slot's device block (nid_slot_buffers; the resident kernel's `cellout` is the per-cell calls' host buffer)
       if (tid < kDirectRec && SA.host_quad == 1) {  // both records: the host does not know yet that the cell is a level-1 edge
         store_sys(SA.quad + (size_t)cl * kDirectRec + tid, 0.0);
         if (JAC) store_sys(SA.quad + ((size_t)P.g.nloc + cl) * kDirectRec + tid, 0.0);
@@ -1485,10 +1522,13 @@ __device__ __forceinline__ void eval_cell(const EvalParams &P, const SlotArgs &S
   // = wc * kWcPre, PRESCALED); the rare branches below get the plain weights back by the inverse scale (exact).
   // The reference weights take hist_dn (four multiplications per sample), and every add is the bit pattern of a
   // subnormal product (fx_bits).
-  const double tiny_scaled = kTinyW * kWcPre;
+  // (kTinyW * kWcPre as a signed compare on the high dwords: a weight that is negative by rounding takes the rare branch
+  // too; a 32-bit literal instead of an f64 constant in scalar registers)
+  constexpr int tiny_scaled_hi = (int)((1023u - 512u - (unsigned)NID_TINY_W_EXP) << 20);
   // REPAIR (see kLinFlagW): the same routing of every addend, but nothing is added except what NORMAL mode sent to the
   // COARSE copies of a bin in the repair set -- to the fine level of its own exponent
   unsigned rep_col1 = 0u, rep_colz = 0u;  // repair_set[0], [1] (wave-uniform; loaded before the repair pass)
+  bool repaired = false;                  // this cell ran the repair pass (wave-uniform)
   auto hist_add = [&](int jr, int jc, const double (&wr_in)[4], const double (&win)[4], auto prescaled, double pcv, int group, auto repair_tag) {
     constexpr bool PRESCALED = decltype(prescaled)::value;
     constexpr bool REPAIR = decltype(repair_tag)::value;
@@ -1497,21 +1537,21 @@ __device__ __forceinline__ void eval_cell(const EvalParams &P, const SlotArgs &S
       unsigned long long *hx = (group == 2 ? nsb : clampb) + ((unsigned)copy & (kClampCopies - 1));
       unsigned long long *hlo = group == 2 ? ns_lo : clamp_lo;
 #ifdef NID_EXP_CLAMP_COUNT_PER_LANE
-      atomicAdd(hx + nb * kClampCopies, fx_bits(P.hist_dn1));
+      atomicAdd(hx + nb * kClampCopies, fx_bits(P.hist_dn * kWcPre));
 #else
       {
         // the count: every lane of the wave in this group would add the same number to the same bin -- one lane adds the lot
         const unsigned long long in2 = __builtin_amdgcn_ballot_w64(group == 2);
         const unsigned long long act = group == 2 ? in2 : (__builtin_amdgcn_ballot_w64(true) & ~in2);
         if ((unsigned)__builtin_ctzll(act) == (unsigned)(tid & 63))
-          atomicAdd(hx + nb * kClampCopies, (unsigned long long)__builtin_popcountll(act) * fx_bits(P.hist_dn1));
+          atomicAdd(hx + nb * kClampCopies, (unsigned long long)__builtin_popcountll(act) * fx_bits(P.hist_dn * kWcPre));
       }
 #endif
 #pragma unroll
       for (int m = 0; m < 4; m++) {
         const double w = m == 0 ? fabs(wr_in[0]) : wr_in[m];
         if (w >= kFineW) {
-          atomicAdd(hx + (jr + m) * kClampCopies, fx_bits(w * P.hist_dn1));
+          atomicAdd(hx + (jr + m) * kClampCopies, fx_bits(w * (P.hist_dn * kWcPre)));
         } else if (w > kNegligibleW) {
           const int lv = fine_level(w);
           atomicAdd(hlo + lv * kClampBins(nb) + (unsigned)(jr + m), fx_encode(w, fine_scale(lv)));
@@ -1594,7 +1634,7 @@ __device__ __forceinline__ void eval_cell(const EvalParams &P, const SlotArgs &S
     // first stored weight (min(wr[0], wr[3]) < kTinyW and != 0 <=> wr_in[0] < 0): one compare here instead of
     // five instructions per sample; |wr_in[0]| is a free source modifier of the products below
     const bool ref_tiny = wr_in[0] < 0.0;
-    if (fmin(wcs[0], wcs[3]) < tiny_scaled || ref_tiny) {
+    if (min(__double2hiint(wcs[0]), __double2hiint(wcs[3])) < tiny_scaled_hi || ref_tiny) {
       double wc[4];
       if (!STRICT && PRESCALED) {
         // FAST: the weights once more, each with an error relative to ITSELF (bspline4_vals_both_ends; the same values
@@ -1788,7 +1828,7 @@ __device__ __forceinline__ void eval_cell(const EvalParams &P, const SlotArgs &S
       // fixed-tap sample (a convex combination of u8 taps: never negative), computed for every lane -- lanes
       // without a sample hold a harmless window
       ic = sample_fast_c(wc2, f.u, f.v);
-      rare = f.in && fabs(ic - kGuardMid) > kGuardHalf;
+      rare = f.in && outside_clamp_guard(ic);
       if (f.redo && classify_redo(P, f)) rare = true;  // (waves that meet the frame border)
       go = f.in && !rare;
       }
@@ -1836,7 +1876,7 @@ __device__ __forceinline__ void eval_cell(const EvalParams &P, const SlotArgs &S
       WinC wc2;
       load_win_centre(P, f.w.wx, f.w.wy, wc2);
       double ic = sample_fast_c(wc2, f.u, f.v);
-      bool rare = f.in && fabs(ic - kGuardMid) > kGuardHalf;
+      bool rare = f.in && outside_clamp_guard(ic);
       if (f.redo && classify_redo(P, f)) rare = true;
       bool go = f.in && !rare;
       if (rare) {
@@ -1904,7 +1944,7 @@ __device__ __forceinline__ void eval_cell(const EvalParams &P, const SlotArgs &S
           double ic, gx = 0.0, gy = 0.0;
           if (JAC) gradient_fast_j(wjn[q], f.u, f.v, gx, gy, ic);  // its centre sample IS sample_fast_c's
           else ic = sample_fast_c(wcn[q], f.u, f.v);
-          bool rare = f.in && fabs(ic - kGuardMid) > kGuardHalf;
+          bool rare = f.in && outside_clamp_guard(ic);
           if (f.redo && classify_redo(P, f)) rare = true;
           double wc[4], dw[4], pc = 0.0;
           int jc = -1;
@@ -1988,8 +2028,8 @@ __device__ __forceinline__ void eval_cell(const EvalParams &P, const SlotArgs &S
     __syncthreads();
     flagw = *reinterpret_cast<const uint4 *>(clamp_flag);
   }
-  const unsigned lin_col1 = NID_REPAIR ? (unsigned)__builtin_amdgcn_readfirstlane((int)flagw.z) : 0u;
-  const unsigned lin_colz = NID_REPAIR ? (unsigned)__builtin_amdgcn_readfirstlane((int)flagw.w) : 0u;
+  const unsigned lin_col1 = (NID_REPAIR && NID_REPAIR_STAGE >= 2) ? (unsigned)__builtin_amdgcn_readfirstlane((int)flagw.z) : 0u;
+  const unsigned lin_colz = (NID_REPAIR && NID_REPAIR_STAGE >= 2) ? (unsigned)__builtin_amdgcn_readfirstlane((int)flagw.w) : 0u;
   // One bin: its mass from the copies (COARSE = false: without them, after a repair), the fine levels and the two
   // groups; p = mass / N_c, W = -(1 + log2 p), p log2 p into the tables.  Returns the copies' integer sum.
   auto fold_bin = [&](int b, auto coarse_tag, double &mass_out) -> unsigned long long {
@@ -2074,11 +2114,22 @@ __device__ __forceinline__ void eval_cell(const EvalParams &P, const SlotArgs &S
     rep_colz = (unsigned)__builtin_amdgcn_readfirstlane((int)rs.y);
     rep_col1 = (rep_col1 >> 31) ? (rep_col1 & 0x1FFFFu) : 0u;
     rep_colz = (rep_colz >> 31) ? (rep_colz & 0x1FFFFu) : 0u;
-    if (__builtin_expect((rep_col1 | rep_colz) != 0u, 0)) {
+    if constexpr (!REPAIR_INLINE) {
+      // (workgroup-uniform: every wave leaves; nothing has been published: k_repair does this cell and pose)
+      if (NID_REPAIR_STAGE >= 3 && __builtin_expect((rep_col1 | rep_colz) != 0u, 0)) {
+        if (tid == 0) {
+          const unsigned i = __hip_atomic_fetch_add(P.repair_queue, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          P.repair_queue[2 + i] = ((unsigned)pose_idx << 16) | (unsigned)cl;
+        }
+        return;
+      }
+    } else
+    if (NID_REPAIR_STAGE >= 3 && __builtin_expect((rep_col1 | rep_colz) != 0u, 0)) {
       // REPAIR (see kLinFlagW): the pixel loops once more; what they sent to the coarse copies of a bin in the repair
       // set goes to its fine levels now, and the bin is folded again without the copies.  Same lane -> sample
       // assignment, integer adds: run-to-run reproducible like everything else.
       if (tid == 0 && P.repair_count) atomicAdd(P.repair_count, 1ull);  // (diagnostics: nid_debug_repair_count)
+      repaired = true;
       if constexpr (STRICT) {
         strict_cost_loop(std::true_type{});
       } else {
@@ -2141,6 +2192,8 @@ __device__ __forceinline__ void eval_cell(const EvalParams &P, const SlotArgs &S
       if (tid < kCellOut && SA.cellout_host) {
         const double o = tid == 0 ? Hc : (tid == 1 ? Hj : (tid == 2 ? err : (tid == kCellOut - 1 ? (double)n_c : NAN)));
         store_sys(out + tid, o);  // (cost-only: the Jacobian slots hold NaN)
+      } else if (!RES && tid < kCellOut && want_cellout) {  // the slot's device block stays valid for callers that gather it (nid_slot_buffers)
+        out[tid] = tid == 0 ? Hc : (tid == 1 ? Hj : (tid == 2 ? err : (tid == kCellOut - 1 ? (double)n_c : NAN)));
       }
       if (tid < kDirectRec && SA.host_quad == 1)
         store_sys(SA.quad + (size_t)cl * kDirectRec + tid, tid == 0 ? err : (tid == 1 ? 1.0 : 0.0));
@@ -2354,7 +2407,7 @@ __device__ __forceinline__ void eval_cell(const EvalParams &P, const SlotArgs &S
 #ifdef NID_EXP_NO_GUARD
       bool exact = false;
 #else
-      bool exact = f.in && fabs(ic - kGuardMid) > kGuardHalf;
+      bool exact = f.in && outside_clamp_guard(ic);
 #endif
       if (f.redo && classify_redo(P, f)) exact = true;
       bool go = f.jin && !exact;
@@ -2403,7 +2456,7 @@ __device__ __forceinline__ void eval_cell(const EvalParams &P, const SlotArgs &S
       // point then lives across the prefetch and is copied from round to round again)
       asm volatile("" : "+v"(f.u), "+v"(f.v));
       if (sb + NT < g.pstride) load_tile_xyz(P, base + (unsigned)(s + NT), nxt);
-      const bool go = ((gomask >> r) & 1u) != 0u && f.u <= P.u_jin;
+      const bool go = ((gomask >> r) & 1u) != 0u && (unsigned)__double2hiint(f.u) - P.hu_lo <= P.hj_span;
       WinJ wj;
       load_win_jac(P, go ? (int)f.u - 1 : 0, go ? (int)f.v - 1 : 0, wj);
       TileIn tw;
@@ -2422,9 +2475,10 @@ __device__ __forceinline__ void eval_cell(const EvalParams &P, const SlotArgs &S
     };
     unsigned long long rare2 = 0ull;
     int r = 0;
-    if constexpr (LAT > 0) {
+    if (LAT > 0 && !repaired) {
       // main pass from the registers the cost phase left (same values, same per-lane order as the loop form);
       // the rare samples are the cost phase's rare samples (same classification on the same values)
+      if constexpr (LAT > 0) {
 #pragma unroll
       for (int q = 0; q < LAT; q++)
         if (lat[q].go) {
@@ -2432,8 +2486,12 @@ __device__ __forceinline__ void eval_cell(const EvalParams &P, const SlotArgs &S
           bspline4_poly_der(lat[q].pc, lat[q].jc, rtab, dw);
           jac_accumulate(lat[q], lat[q].iz, lat[q].gx, lat[q].gy, lat[q].pc, lat[q].jc, dw, std::integral_constant<bool, kMainPassClamps>{});
         }
+      }
       rare2 = rare_rounds;
     } else {
+      // (LAT after a repair pass -- rare --: the loop form, which takes nothing from the cost phase's registers: they
+      // would have to live across the repair pass, and a cell that ran it evaluates its Jacobian from memory like the
+      // loop-form kernels do; the same operations on the same values: the same bits)
       if (wave_base < g.pstride) load_tile_xyz(P, base + (unsigned)(wave_base + lane), prej);
       if constexpr (use_gomask) {
         // the cost phase's decisions (gomask) instead of a second classification; the rounds with rare samples are
@@ -2536,6 +2594,7 @@ __device__ __forceinline__ void eval_cell(const EvalParams &P, const SlotArgs &S
 #pragma unroll
       for (int n = 0; n < 6; n++) { if (tid == 3 + n) o = J[n]; if (tid == n) r = J[n]; }
       if (tid < kCellOut && SA.cellout_host) store_sys(out + tid, o);
+      else if (!RES && tid < kCellOut && want_cellout) out[tid] = o;  // the slot's device block (nid_slot_buffers)
       if (tid < kDirectRec && SA.host_quad == 1) store_sys(SA.quad + ((size_t)P.g.nloc + cl) * kDirectRec + tid, r);
       NID_STAMP(6);
       NID_STAMP(7);
@@ -2611,6 +2670,43 @@ void k_eval2(EvalParams P) {
   }
   const SlotArgs &SA = EXT ? sa_ext : P.slot[pose_idx];
   eval_cell<NT, JAC, STRICT, NB, DBG, EXT, LAT, BIG, false>(P, SA, cl, pose_idx, smem);
+}
+
+// The cells and poses a loop-form launch left in its repair queue (eval_cell's REPAIR_INLINE; rare: kLinFlagW), done from
+// the start by the instantiation that repairs inline.  Enqueued behind EVERY loop-form launch on its stream, with the
+// same arguments; a small grid whose workgroups stride over the queue -- an empty queue costs one load per workgroup.
+// The last workgroup out clears the queue for the stream's next launch (arrival ticket; the stream keeps the next
+// launch's kernels behind this one).  Registers instead of occupancy: no scratch segment.
+template <int NT, bool JAC, bool STRICT, int NB, bool EXT>
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 2))) void k_repair(EvalParams P) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned *q = P.repair_queue;
+  const unsigned count = (unsigned)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+  for (unsigned i = blockIdx.x; i < count; i += gridDim.x) {
+    __syncthreads();  // every wave is back from the previous entry (its tail is wave 0's business)
+    const unsigned e = (unsigned)__builtin_amdgcn_readfirstlane((int)q[2 + i]);
+    const int cl = (int)(e & 0xFFFFu), pose_idx = (int)(e >> 16);
+    SlotArgs sa_ext;
+    if (EXT) {
+      typedef const unsigned __attribute__((address_space(4))) *ConstDwords;
+      ConstDwords src = (ConstDwords)(reinterpret_cast<uintptr_t>(P.slots_ext + pose_idx));
+      unsigned *dst = reinterpret_cast<unsigned *>(&sa_ext);
+#pragma unroll
+      for (unsigned k = STRICT ? 0u : kPoseQuatDwords; k < sizeof(SlotArgs) / 4; k++) dst[k] = src[k];
+    }
+    const SlotArgs &SA = EXT ? sa_ext : P.slot[pose_idx];
+    eval_cell<NT, JAC, STRICT, NB, false, EXT, 0, false, false, true>(P, SA, cl, pose_idx, smem);
+  }
+  if (count == 0u && blockIdx.x != 0u) return;  // (nothing queued: one workgroup keeps the ticket's books)
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned arrivals = count == 0u ? 1u : gridDim.x;
+    __threadfence();
+    if (__hip_atomic_fetch_add(q + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == arrivals - 1u) {
+      __hip_atomic_store(q, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(q + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------

@@ -20,6 +20,7 @@
 //     per call).  NID_LEGACY_ALWAYS_UPLOAD=1 restores that behaviour.
 #include "nid/legacy_ops.h"
 
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -73,6 +74,25 @@ int jac_threads_for(int cells, int shards) {
 }
 nid_comm *g_comm = nullptr;  // lives across nid_legacy_reset(): one communicator per process, however many pairs / levels
 long g_uploads = 0;
+
+// NID_LEGACY_TRACE=1: microseconds of every step of the per-pair setup on stderr (tools/pair_setup.py collects them
+// into profiles/r04_pair_setup.txt)
+struct StepTrace {
+  bool on;
+  const char *what;
+  std::chrono::steady_clock::time_point t;
+  explicit StepTrace(const char *w) : what(w) {
+    static const bool env = getenv("NID_LEGACY_TRACE") != nullptr;
+    on = env;
+    if (on) t = std::chrono::steady_clock::now();
+  }
+  void step(const char *name) {
+    if (!on) return;
+    const auto n = std::chrono::steady_clock::now();
+    std::fprintf(stderr, "[nid trace] %s: %s %.1f us\n", what, name, std::chrono::duration<double, std::micro>(n - t).count());
+    t = n;
+  }
+};
 
 bool always_upload() {
   static const bool v = getenv("NID_LEGACY_ALWAYS_UPLOAD") != nullptr;
@@ -239,27 +259,34 @@ int ensure_reference(LegacyState &S, const double *im0, const double *points3d, 
 
 void Calculate3Dpoint(double *depth, double *pose_c2w, double *points_3d, double *camera_intrincis, int rows,
                       int cols) {
+  StepTrace tr("Calculate3Dpoint");
   int rc = nid_backproject(depth, pose_c2w, camera_intrincis[0], camera_intrincis[1], camera_intrincis[2],
                            camera_intrincis[3], rows, cols, g_devices[0], points_3d);
   if (rc != NID_OK) report("Calculate3Dpoint", rc, nullptr);
+  tr.step("upload depth, kernel, points back");
 }
 
 void CudaComputeHref(double *im0, double *points3d, double *pose, double *camera_intrincis, int bin_num,
                      int bs_degree, int cell_num, int rows, int cols, double *bs_value, int *bs_index,
                      int *bs_counter, double *Href) {
+  StepTrace tr("CudaComputeHref");
   nid_multi *m = get_multi(rows, cols, cell_num, bin_num, bs_degree, camera_intrincis);
   if (!m) return;
+  tr.step("context (created or reused)");
   LegacyState &S = g_state;
   int rc = upload_reference(S, im0, points3d, nullptr, false);  // once per frame pair: always fresh
   if (rc != NID_OK) { report("CudaComputeHref(reference upload)", rc, m); return; }
+  tr.step("reference: im0 -> u8, content keys, upload, tile kernel");
   S.have_target = false;                        // a new pair: the next CudaComputeH re-checks its target
   const size_t N = (size_t)rows * cols;
   const int ncell = cell_num * cell_num;
   std::vector<int32_t> cnt(ncell), idx(bs_index ? N : 0);
   std::vector<double> href(ncell);
   if (bs_value) std::memset(bs_value, 0, 4 * N * sizeof(double));  // a process that owns some of the cells fills those
+  tr.step("output buffers cleared");
   rc = nid_multi_compute_href_matrix(m, pose, cnt.data(), href.data(), bs_value, bs_index ? idx.data() : nullptr);
   if (rc != NID_OK) { report("CudaComputeHref", rc, m); return; }
+  tr.step("k_href + bs_value / bs_index back to the caller");
   for (int c = 0; c < ncell; c++) {
     bs_counter[c] = cnt[c];
     // CudaComputeHref.cu:205-220: NaN when inactive, otherwise subtract onto the caller's value
@@ -274,11 +301,13 @@ void CudaComputeHref(double *im0, double *points3d, double *pose, double *camera
     }
   }
   if (bs_index) for (size_t i = 0; i < N; i++) bs_index[i] = idx[i];
+  tr.step("NaN markers, bs_index copy");
   // the device already holds these weights (CPU-edge convention: 0 instead of NaN)
   S.have_href = true;
   remember(S.k_bs_ref, bs_value, bs_value ? 4 * N : 0);
   remember(S.k_counter, bs_counter, (size_t)ncell);
   remember(S.k_href, Href, (size_t)ncell);
+  tr.step("content keys of the outputs");
 }
 
 namespace {
@@ -321,6 +350,9 @@ nid_multi *ensure_state(double *im0, double *im1, double *points3d, int *bs_coun
   LegacyState &S = g_state;
   const size_t N = (size_t)rows * cols;
   const int ncell = cell_num * cell_num;
+  const bool first_of_pair = !S.have_target;
+  StepTrace tr("CudaComputeH state check");
+  tr.on = tr.on && first_of_pair;  // (every later call of a pair takes about a microsecond: not traced)
   // the full hashes: whenever a key's cheap part changed (same_content), every kRehashEvery-th call, after an invalidate
   S.calls++;
   const bool periodic = S.calls % kRehashEvery == 0;
@@ -341,6 +373,7 @@ nid_multi *ensure_state(double *im0, double *im1, double *points3d, int *bs_coun
       g_uploads++;
     }
   }
+  tr.step("reference keys checked, target -> u8 + upload + margins");
   // Href is only READ by the reference with calculate_der (computeH.cu:428-429); the kernels also need it to know
   // which cells are active.  A NULL Href gives zeros (cost-only outputs do not depend on it) and the first call
   // that brings one replaces them: Href is part of the key.  The per-cell arrays are small: full hashes every call.
@@ -361,6 +394,7 @@ nid_multi *ensure_state(double *im0, double *im1, double *points3d, int *bs_coun
     S.have_href = true;
     g_uploads++;
   }
+  tr.step("href state keys checked");
   return m;
 }
 

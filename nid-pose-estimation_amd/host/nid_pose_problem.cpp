@@ -23,6 +23,14 @@ void nid_host_set_rank(int device, int rank, int world, const uint8_t *rccl_id12
 int nid_host_run_lm(const nid_pose_problem *pb, double *pose7_inout, nid_host_lm_record *trace,
                     int max_trace, char *log_buf, int log_cap) {
   if (!pb || !pose7_inout) return -1;
+  static const bool step_trace = getenv("NID_LEGACY_TRACE") != nullptr;
+  auto t_last = std::chrono::steady_clock::now();
+  auto stamp = [&](const char *name) {
+    if (!step_trace) return;
+    const auto n = std::chrono::steady_clock::now();
+    std::fprintf(stderr, "[nid trace] nid_host_run_lm: %s %.1f us\n", name, std::chrono::duration<double, std::micro>(n - t_last).count());
+    t_last = n;
+  };
   const int rows = pb->rows, cols = pb->cols, cell = pb->cell_num, bin_num = pb->bin_num, bs_degree = 3;
   const size_t N = (size_t)rows * cols;
   nid_legacy_reset();
@@ -37,6 +45,7 @@ int nid_host_run_lm(const nid_pose_problem *pb, double *pose7_inout, nid_host_lm
   std::vector<double> depth(N);
   for (size_t i = 0; i < N; i++) depth[i] = (double)pb->depth_u16[i] * pb->depth_factor;  // convertTo(CV_64F, 1/5000), :106
   std::vector<double> T_wc0(pb->T_wc0_colmajor, pb->T_wc0_colmajor + 16);
+  stamp("caller's buffers (u8 / u16 -> f64, allocations)");
 
   g2o::SparseOptimizer optimizer;
   g2o::BlockSolver_6_X::LinearSolverType *linearSolver = new g2o::LinearSolverDense();
@@ -58,11 +67,14 @@ int nid_host_run_lm(const nid_pose_problem *pb, double *pose7_inout, nid_host_lm
   optimizer.addVertex(vSE3);
 
   // :253, :257
+  stamp("optimizer, solver, vertex");
   Calculate3Dpoint(depth.data(), T_wc0.data(), points_3d_all.data(), intrinscis.data(), rows, cols);
+  stamp("Calculate3Dpoint");
   g2o::Matrix4d M0 = vSE3->estimate().to_homogeneous_matrix();
   CudaComputeHref(im0_data.data(), points_3d_all.data(), M0.data(), intrinscis.data(), bin_num, bs_degree, cell,
                   rows, cols, bs_value.data(), bin_index.data(), bs_counter.data(), Href.data());
 
+  stamp("CudaComputeHref");
   if (!nid_legacy_multi()) {  // the operators print and carry on like the reference's (computeH.cu:454-473); a run must not
     if (log_buf && log_cap > 0) std::snprintf(log_buf, (size_t)log_cap, "the NID operators could not set up their device state (see stderr)");
     nid_legacy_reset();
@@ -92,9 +104,11 @@ int nid_host_run_lm(const nid_pose_problem *pb, double *pose7_inout, nid_host_lm
     }
 
   optimizer.initializeOptimization(0);
+  stamp("edges, initializeOptimization");
   const auto t_opt0 = std::chrono::steady_clock::now();
   const int done = optimizer.optimize(pb->iterations);  // :349-350
   g_last_optimize_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_opt0).count();
+  stamp("optimize()");
 
   vSE3->estimate().toPose7(pose7_inout);
   const std::vector<g2o::IterationRecord> &tr = optimizer.trace();
@@ -109,6 +123,7 @@ int nid_host_run_lm(const nid_pose_problem *pb, double *pose7_inout, nid_host_lm
     std::snprintf(log_buf, (size_t)log_cap, "%s", s.c_str());
   }
   nid_legacy_reset();
+  stamp("trace copy, nid_legacy_reset");
   return done;
 }
 
