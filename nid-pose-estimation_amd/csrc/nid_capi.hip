@@ -249,7 +249,7 @@ size_t eval_lds_bytes(const Geometry &g, int nt, bool resident = false) {
   const size_t clamp_bytes = (size_t)kClampBins(g.nb) * (kClampCopies + kFineLevels + 1) * 8 + (size_t)kFlagWords * 4 + (size_t)(g.nb + 1) * 8 +
                              ((near_sat_aliased(g.nb) && !resident) ? 0 : (size_t)kNearSatBinBytes(g.nb) + 8);
   const size_t hist_bytes = std::max((size_t)nbins * (eval_hist_copies(nt) + kFineLevels) * 8 + clamp_bytes, (size_t)kXposeDoubles(nt) * 8);
-  return hist_bytes + 2 * (size_t)((nbins + 1) & ~1) * 8 + (size_t)g.S * kCoefRow * 8 + (size_t)kRedDoubles(nt) * 8;
+  return hist_bytes + 2 * (size_t)((nbins + 1) & ~1) * 8 + (size_t)g.S * kCoefRow * 8 + (size_t)kFlagDoubles * 8 + (size_t)kRedDoubles(nt) * 8;
 }
 
 constexpr int lat_rounds(int nt) { return nt == 512 ? 3 : (nt == 1024 ? 2 : 0); }

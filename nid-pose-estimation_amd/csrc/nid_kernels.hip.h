@@ -618,7 +618,10 @@ constexpr int kFineLevels = 5;
 #define NID_REPAIR_STAGE 3   // experiment builds: 1 = the flags only, 2 = + the fold's detection, 3 = + the repair pass
 #endif
 constexpr double kLinFlagW = 0x1p-16;
-constexpr double kRepairMass = 0x1p-12;
+#ifndef NID_REPAIR_MASS_EXP
+#define NID_REPAIR_MASS_EXP 12
+#endif
+constexpr double kRepairMass = 1.0 / (double)(1ull << NID_REPAIR_MASS_EXP);
 __device__ __forceinline__ int fine_level(double w) {
   const int e = __builtin_amdgcn_frexp_exp(w);  // w = m * 2^e, m in [0.5, 1): e <= -8 for w < 2^-8
   const int x = min(max(-8 - e, 0), 119);
@@ -905,6 +908,7 @@ constexpr int kRedDoubles(int nt) { return (nt <= 256 && NID_XPOSE_SUM) ? 0 : ((
 // fed only by clamped samples is c_k * this sum: it needs the sum to ~1e-9 relative even when it is one weight of 1e-8).
 constexpr int kClampBins(int nb) { return (nb + 2) & ~1; }
 constexpr int kFlagWords = 6;  // clamp_flag[2] | lin_flag[2] | repair_set[2] (eval_cell): 24 bytes, 16-byte aligned start
+constexpr int kFlagDoubles = 4;  // ... in a 32-byte slot between the tables and the histogram area
 // (more copies would thin out the same-address conflicts of a saturated patch, but the workgroup's LDS request sits at the
 // 15 360 bytes ten workgroups per CU allow: 8 or 16 copies cost the plain pair 4 %, profiles/r03_ablations_A.txt)
 #ifndef NID_CLAMP_COPIES
@@ -1400,6 +1404,19 @@ struct ResCell {
 // (other register budgets; the latency paths measured unchanged).
 __device__ __forceinline__ constexpr bool repair_inline_default(int lat, bool res, bool dbg, bool big) { return lat > 0 || res || dbg || big; }
 
+// The kernel's arguments ONCE MORE, through a pointer the optimiser cannot connect with the one it has been using: what is
+// read through it is a NEW scalar load from the kernarg segment where it is needed, not a longer life of a register
+// loaded at the head of the kernel (EvalParams is the FIRST argument of every kernel that runs eval_cell, i.e. it sits
+// at the start of the kernarg segment).  For what only a cold block needs: the kernels sit at the limit of their scalar
+// registers, and two more that live from the head of the kernel to the fold change what the allocator parks in vector
+// lanes inside the pixel loops (measured: the repair queue's pointer alone, +8 % kernel time).
+__device__ __forceinline__ const EvalParams &reread_args() {
+  typedef const EvalParams __attribute__((address_space(4))) *ConstParams;
+  uintptr_t a = reinterpret_cast<uintptr_t>(__builtin_amdgcn_kernarg_segment_ptr());
+  asm volatile("" : "+s"(a));
+  return *(const EvalParams *)(ConstParams)a;
+}
+
 template <int NT, bool JAC, bool STRICT, int NB, bool DBG, bool EXT, int LAT, bool BIG, bool RES, bool REPAIR_INLINE = repair_inline_default(LAT, RES, DBG, BIG)>
 __device__ __forceinline__ void eval_cell(const EvalParams &P, const SlotArgs &SA, const int cl, const int pose_idx, unsigned char *smem,
                                           const ResCell rc = ResCell{0, 0.0, true}) {
@@ -1415,18 +1432,21 @@ __device__ __forceinline__ void eval_cell(const EvalParams &P, const SlotArgs &S
   double *tab = reinterpret_cast<double *>(smem);
   double *term = tab + ((nbins + 1) & ~1);  // p log2 p of every bin (entropy sums in a workgroup-shape independent order)
   double *rtab = term + ((nbins + 1) & ~1);
-  double *red = rtab + S * kCoefRow;  // S rows of kCoefRow (FAST) or kRcpRow <= kCoefRow (STRICT) doubles
+  // (the cell's flag words sit in front of the histogram area: the Jacobian block sum reuses that area, and the tails
+  // still look at repair_set)
+  unsigned *clamp_flag = reinterpret_cast<unsigned *>(rtab + S * kCoefRow);  // [0]: clamped samples seen, [1]: near-saturated ones
+  double *red = rtab + S * kCoefRow + kFlagDoubles;  // (the tables: S rows of kCoefRow (FAST) or kRcpRow <= kCoefRow (STRICT) doubles)
   unsigned long long *hist = reinterpret_cast<unsigned long long *>(red + kRedDoubles(NT));
   unsigned long long *hist_lo = hist + nbins * NC;  // [kFineLevels][nbins], single copies (see kTinyW)
   unsigned long long *clampb = hist_lo + kFineLevels * nbins;                   // [kClampBins(nb)][kClampCopies]: see kClampBins
   unsigned long long *clamp_lo = clampb + kClampBins(nb) * kClampCopies;         // [kFineLevels][kClampBins(nb)], single copies
   double *rclamp = reinterpret_cast<double *>(clamp_lo + kFineLevels * kClampBins(nb));  // [kClampBins(nb)] folded sums, then the flags
-  unsigned *clamp_flag = reinterpret_cast<unsigned *>(rclamp + kClampBins(nb));          // [0]: clamped samples seen, [1]: near-saturated ones
+  unsigned *flag_pad = reinterpret_cast<unsigned *>(rclamp + kClampBins(nb));            // (24 bytes, unused: keeps the alignment of what follows)
   unsigned *lin_flag = clamp_flag + 2;  // [0]: target column 1, [1]: column nb - 2 -- bit a: joint row a, bit 16: the marginal bin (kLinFlagW)
   unsigned *repair_set = clamp_flag + 4;  // the bins of those two columns that the fold wants repaired (same bits)
   // ... and the same for the NEAR-SATURATED samples (see kNearSatIc): folded sums behind the flags; the bins themselves
   // borrow the area of the two weight tables, which nobody touches before the fold (when they fit there: nb >= 5)
-  double *rns = reinterpret_cast<double *>(clamp_flag + kFlagWords);                      // [nb + 1]
+  double *rns = reinterpret_cast<double *>(flag_pad + kFlagWords);                        // [nb + 1]
   // (not in the resident kernel, which clears the bins for the next request while wave 0 still reads the tables)
   const bool ns_alias = !RES && near_sat_aliased(nb);
   unsigned long long *ns_own = reinterpret_cast<unsigned long long *>(rns + ((nb + 1) | 1));  // (rns sits 8 bytes past a 16-byte boundary: an odd count ends on one)
@@ -2108,22 +2128,43 @@ __device__ __forceinline__ void eval_cell(const EvalParams &P, const SlotArgs &S
     }
   }
   __syncthreads();
+  // !REPAIR_INLINE (the loop-form kernels): NOTHING happens here -- not even a branch: a conditional exit at this point
+  // cost the throughput kernel 8 % (profiles/r04_ablations_A.txt).  The cell goes through its Jacobian phase with the
+  // tables as they are and its TAIL looks at repair_set (deferred_to_repair): a cell with a bin to repair publishes
+  // nothing and is queued for k_repair.
+  auto repair_wanted = [&]() -> bool {  // (the fold's verdict, from LDS: wave-uniform)
+    if constexpr (REPAIR_INLINE || !NID_REPAIR || NID_REPAIR_STAGE < 3) {
+      return false;
+    } else {
+      const uint2 rs = *reinterpret_cast<const uint2 *>(repair_set);
+      unsigned a = (unsigned)__builtin_amdgcn_readfirstlane((int)rs.x), b = (unsigned)__builtin_amdgcn_readfirstlane((int)rs.y);
+      a = (a >> 31) ? (a & 0x1FFFFu) : 0u;
+      b = (b >> 31) ? (b & 0x1FFFFu) : 0u;
+      return (a | b) != 0u;
+    }
+  };
+  auto deferred_to_repair = [&]() -> bool {  // wave 0, in a tail
+    if constexpr (REPAIR_INLINE || !NID_REPAIR || NID_REPAIR_STAGE < 3) {
+      return false;
+    } else {
+      if (__builtin_expect(!repair_wanted(), 1)) return false;
+      if (tid == 0) {
+        unsigned *q = reread_args().repair_queue;  // (loaded here, not at the head of the kernel: see reread_args)
+        const unsigned i = __hip_atomic_fetch_add(q, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // (a launch pushes at most one entry per workgroup and k_repair empties the queue behind it: the bound only
+        // holds against a queue that was never drained)
+        if (i < (unsigned)P.g.nloc * (unsigned)kMaxBatchExt) q[2 + i] = ((unsigned)pose_idx << 16) | (unsigned)cl;
+      }
+      return true;
+    }
+  };
+  if constexpr (REPAIR_INLINE)
   if (__builtin_expect((lin_col1 | lin_colz) != 0u, 0)) {
     const uint2 rs = *reinterpret_cast<const uint2 *>(repair_set);
     rep_col1 = (unsigned)__builtin_amdgcn_readfirstlane((int)rs.x);
     rep_colz = (unsigned)__builtin_amdgcn_readfirstlane((int)rs.y);
     rep_col1 = (rep_col1 >> 31) ? (rep_col1 & 0x1FFFFu) : 0u;
     rep_colz = (rep_colz >> 31) ? (rep_colz & 0x1FFFFu) : 0u;
-    if constexpr (!REPAIR_INLINE) {
-      // (workgroup-uniform: every wave leaves; nothing has been published: k_repair does this cell and pose)
-      if (NID_REPAIR_STAGE >= 3 && __builtin_expect((rep_col1 | rep_colz) != 0u, 0)) {
-        if (tid == 0) {
-          const unsigned i = __hip_atomic_fetch_add(P.repair_queue, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          P.repair_queue[2 + i] = ((unsigned)pose_idx << 16) | (unsigned)cl;
-        }
-        return;
-      }
-    } else
     if (NID_REPAIR_STAGE >= 3 && __builtin_expect((rep_col1 | rep_colz) != 0u, 0)) {
       // REPAIR (see kLinFlagW): the pixel loops once more; what they sent to the coarse copies of a bin in the repair
       // set goes to its fine levels now, and the bin is folded again without the copies.  Same lane -> sample
@@ -2181,6 +2222,7 @@ __device__ __forceinline__ void eval_cell(const EvalParams &P, const SlotArgs &S
       if (RES) zero_histograms(64);  // ... in the resident kernel after clearing the histograms for the next request
       return;
     }
+    if (deferred_to_repair()) return;
     if (direct_launch) {
       // DIRECT launch (one pose, the host is waiting for it): the cell's record (err, J[6], active) -- or, for the
       // per-cell calls, its outputs -- goes straight to pinned host memory, word by word, and the HOST forms the
@@ -2213,7 +2255,8 @@ __device__ __forceinline__ void eval_cell(const EvalParams &P, const SlotArgs &S
   // DIRECT launch: the residual goes to the host NOW -- while the Jacobian phase runs here, the host works out the
   // cells' Huber weights (a square root and a division each) and their chi2 sum; what is left to it behind the
   // Jacobians' arrival is multiplications and additions (wait_direct in nid_capi.hip)
-  if (direct_launch && SA.host_quad == 1 && tid < kDirectRec)
+  // (not for a cell that k_repair will do again: its record comes from there)
+  if (direct_launch && SA.host_quad == 1 && tid < kDirectRec && !repair_wanted())
     store_sys(SA.quad + (size_t)cl * kDirectRec + tid, tid == 0 ? (2 * Hj - href - Hc) / Hj : (tid == 1 ? 1.0 : 0.0));
 
   // ---- phase 2: Jacobian (recompute, see header comment) -------------------------------
@@ -2581,6 +2624,7 @@ __device__ __forceinline__ void eval_cell(const EvalParams &P, const SlotArgs &S
     }
   }
   NID_STAMP(5, acc[0], acc[2], acc[3], acc[5]);
+  if (deferred_to_repair()) return;
   {
     const double kappa = (double)S / 255.0;  // d_mi_i (:393), 1/N_c (:488,494), 1/Hj^2 (:521)
     const double scale = (kappa / (double)n_c) * (1.0 / (Hj * Hj));
