@@ -622,6 +622,10 @@ constexpr double kLinFlagW = 0x1p-16;
 #define NID_REPAIR_MASS_EXP 12
 #endif
 constexpr double kRepairMass = 1.0 / (double)(1ull << NID_REPAIR_MASS_EXP);
+#ifndef NID_REPAIR_REL_EXP
+#define NID_REPAIR_REL_EXP 12
+#endif
+constexpr double kRepairRel = 1.0 / (double)(1ull << NID_REPAIR_REL_EXP);
 __device__ __forceinline__ int fine_level(double w) {
   const int e = __builtin_amdgcn_frexp_exp(w);  // w = m * 2^e, m in [0.5, 1): e <= -8 for w < 2^-8
   const int x = min(max(-8 - e, 0), 119);
@@ -907,8 +911,9 @@ constexpr int kRedDoubles(int nt) { return (nt <= 256 && NID_XPOSE_SUM) ? 0 : ((
 // The coarse sums have kClampCopies copies (same scale as the histograms); reference weights below 2^-8 go to fine levels of their own exponent like everywhere else (a joint bin
 // fed only by clamped samples is c_k * this sum: it needs the sum to ~1e-9 relative even when it is one weight of 1e-8).
 constexpr int kClampBins(int nb) { return (nb + 2) & ~1; }
-constexpr int kFlagWords = 6;  // clamp_flag[2] | lin_flag[2] | repair_set[2] (eval_cell): 24 bytes, 16-byte aligned start
+constexpr int kFlagWords = 7;  // clamp_flag[2] | lin_flag[2] | repair_set[2] | grp_flag (eval_cell), 16-byte aligned start
 constexpr int kFlagDoubles = 4;  // ... in a 32-byte slot between the tables and the histogram area
+constexpr int kFlagPadWords = 6;  // (where the first six used to sit, behind the clamped samples' sums: kept as padding)
 // (more copies would thin out the same-address conflicts of a saturated patch, but the workgroup's LDS request sits at the
 // 15 360 bytes ten workgroups per CU allow: 8 or 16 copies cost the plain pair 4 %, profiles/r03_ablations_A.txt)
 #ifndef NID_CLAMP_COPIES
@@ -1444,9 +1449,11 @@ __device__ __forceinline__ void eval_cell(const EvalParams &P, const SlotArgs &S
   unsigned *flag_pad = reinterpret_cast<unsigned *>(rclamp + kClampBins(nb));            // (24 bytes, unused: keeps the alignment of what follows)
   unsigned *lin_flag = clamp_flag + 2;  // [0]: target column 1, [1]: column nb - 2 -- bit a: joint row a, bit 16: the marginal bin (kLinFlagW)
   unsigned *repair_set = clamp_flag + 4;  // the bins of those two columns that the fold wants repaired (same bits)
+  unsigned *grp_flag = clamp_flag + 6;    // column nb - 2 again: the bins the clamped / near-saturated GROUPS' linear weight lands in (their
+                                          // reference weights are known as sums per row: a bound relative to them, kRepairRel)
   // ... and the same for the NEAR-SATURATED samples (see kNearSatIc): folded sums behind the flags; the bins themselves
   // borrow the area of the two weight tables, which nobody touches before the fold (when they fit there: nb >= 5)
-  double *rns = reinterpret_cast<double *>(flag_pad + kFlagWords);                        // [nb + 1]
+  double *rns = reinterpret_cast<double *>(flag_pad + kFlagPadWords);                     // [nb + 1]
   // (not in the resident kernel, which clears the bins for the next request while wave 0 still reads the tables)
   const bool ns_alias = !RES && near_sat_aliased(nb);
   unsigned long long *ns_own = reinterpret_cast<unsigned long long *>(rns + ((nb + 1) | 1));  // (rns sits 8 bytes past a 16-byte boundary: an odd count ends on one)
@@ -2009,6 +2016,7 @@ __device__ __forceinline__ void eval_cell(const EvalParams &P, const SlotArgs &S
   double cw[4] = {0.0, 0.0, 0.0, 0.0};  // their four target weights, as the sample path computes them
   double nw[4] = {0.0, 0.0, 0.0, 0.0};  // ... and the near-saturated samples'
   int jc_cl = 0, jc_ns = 0;
+  unsigned grp_colz = 0u;  // grp_flag (wave-uniform)
   if (any_sat) {
     double ic_cl = 254.999, pc_cl;
     jc_cl = fast_bin<false, true>(ic_cl, S, pc_cl);  // (as the second pass places a sample)
@@ -2043,10 +2051,11 @@ __device__ __forceinline__ void eval_cell(const EvalParams &P, const SlotArgs &S
       // bins it lands in like a sample of the rare branches does (flag_linear in hist_add; e == nb: the marginal bin)
       const double wlin = ns ? nw[2] : cw[2];
       if (NID_REPAIR && sum != 0.0 && wlin < kLinFlagW && wlin > kNegligibleW && (ns ? jc_ns : jc_cl) == S - 1)
-        atomicOr(lin_flag + 1, e < nb ? (1u << e) : (1u << 16));
+        atomicOr(grp_flag, e < nb ? (1u << e) : (1u << 16));
     }
     __syncthreads();
     flagw = *reinterpret_cast<const uint4 *>(clamp_flag);
+    grp_colz = (NID_REPAIR && NID_REPAIR_STAGE >= 2) ? (unsigned)__builtin_amdgcn_readfirstlane((int)*grp_flag) : 0u;
   }
   const unsigned lin_col1 = (NID_REPAIR && NID_REPAIR_STAGE >= 2) ? (unsigned)__builtin_amdgcn_readfirstlane((int)flagw.z) : 0u;
   const unsigned lin_colz = (NID_REPAIR && NID_REPAIR_STAGE >= 2) ? (unsigned)__builtin_amdgcn_readfirstlane((int)flagw.w) : 0u;
@@ -2114,14 +2123,24 @@ __device__ __forceinline__ void eval_cell(const EvalParams &P, const SlotArgs &S
   for (int b = tid; b < nbins; b += NT) {
     double mass;
     const unsigned long long acc = fold_bin(b, std::true_type{}, mass);
-    if (__builtin_expect((lin_col1 | lin_colz) != 0u, 0)) {  // (workgroup-uniform, rare: some bin received a tiny linear end-span weight)
+    if (__builtin_expect((lin_col1 | lin_colz | grp_colz) != 0u, 0)) {  // (workgroup-uniform, rare: some bin received a tiny linear end-span weight)
       // A flagged bin with less than kRepairMass is repaired -- if the COLUMN has coarse addends at all: a joint product
       // may have rounded to zero in the copies (1e-8 * 1e-9 against the 2^-52 quantum), a marginal weight of a coarse
       // sample never does (>= kTinyW), so the marginal bin's copies say whether any sample went that way (bit 31)
       int bit;
       const int wsel = lin_word(b, bit);
       if (wsel >= 0) {
-        unsigned bits = ((((wsel == 0 ? lin_col1 : lin_colz) >> bit) & 1u) && mass < kRepairMass) ? (1u << bit) : 0u;
+        // flagged by a sample of the rare branches: kRepairMass.  Flagged by the groups only: their reference weights
+        // in this row are known (the folded sums), and what the bin's W is multiplied with is 3 x that sum -- a row the
+        // group barely touches tolerates a coarser mass: kRepairRel x the sum, at most kRepairMass
+        double thr = 0.0;
+        if (((wsel == 0 ? lin_col1 : lin_colz) >> bit) & 1u) thr = kRepairMass;
+        else if (wsel == 1 && ((grp_colz >> bit) & 1u)) {
+          const int e = bit == 16 ? nb : bit;
+          const double wsum = (any_ns ? rns[e] : 0.0) + ((any_clamped && cw[2] < kLinFlagW) ? rclamp[e] : 0.0);
+          thr = fmin(kRepairMass, kRepairRel * wsum);
+        }
+        unsigned bits = mass < thr ? (1u << bit) : 0u;
         if (b < nb && acc != 0ull) bits |= 1u << 31;
         if (bits) atomicOr(repair_set + wsel, bits);
       }
@@ -2159,7 +2178,7 @@ __device__ __forceinline__ void eval_cell(const EvalParams &P, const SlotArgs &S
     }
   };
   if constexpr (REPAIR_INLINE)
-  if (__builtin_expect((lin_col1 | lin_colz) != 0u, 0)) {
+  if (__builtin_expect((lin_col1 | lin_colz | grp_colz) != 0u, 0)) {
     const uint2 rs = *reinterpret_cast<const uint2 *>(repair_set);
     rep_col1 = (unsigned)__builtin_amdgcn_readfirstlane((int)rs.x);
     rep_colz = (unsigned)__builtin_amdgcn_readfirstlane((int)rs.y);
