@@ -77,6 +77,9 @@ void nid_legacy_set_devices(const int32_t *devices, int n, int reduce_rccl);
 void nid_legacy_set_rank(int device, int rank, int world, const uint8_t *rccl_id128);
 // drop every cached context (e.g. before the caller frees its buffers)
 void nid_legacy_reset(void);
+// done with the GPU for now, keep everything for the next frame pair: takes a running resident kernel off the device
+// (the context, its buffers and its communicator stay: the next pair of the same geometry costs no context creation)
+void nid_legacy_quiesce(void);
 // The caller has changed, IN PLACE, the content of the buffers named by `parts` since its last call: the next
 // CudaComputeH recomputes their full hashes (and uploads what differs) instead of trusting address + samples.
 enum { NID_LEGACY_REFERENCE = 1 /* im0, points3d */, NID_LEGACY_TARGET = 2 /* im1 */, NID_LEGACY_HREF_STATE = 4 /* bs_ref */ };

@@ -135,6 +135,9 @@ int nid_set_direct_results(nid_ctx *ctx, int on);
  * NID_ERR_STATE while a launch is pending. */
 int nid_set_resident(nid_ctx *ctx, int on);
 /* requests served by the resident kernel, requests re-issued as ordinary launches, kernel starts */
+/* Takes a running resident kernel off the device (it holds most of every CU) without disabling the mode: for a caller
+ * that is done with this context for now and lets others use the GPU.  The next request starts another. */
+int nid_resident_pause(nid_ctx *ctx);
 int nid_resident_stats(const nid_ctx *ctx, int64_t *served, int64_t *fallbacks, int64_t *starts);
 /* both at once (0 = the defaults above) */
 int nid_set_block_threads(nid_ctx *ctx, int threads);

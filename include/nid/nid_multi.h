@@ -109,6 +109,7 @@ int nid_multi_set_launch_shape(nid_multi *m, int jac_threads, int cost_threads);
  * resident kernels on one device would each be checked against the whole device); the other shards keep launching.
  * Returns the first shard's error. */
 int nid_multi_set_resident(nid_multi *m, int on);
+int nid_multi_resident_pause(nid_multi *m); /* nid_resident_pause on every shard */
 int nid_multi_set_reference_depth(nid_multi *m, const double *depth_m, const uint8_t *im0, const double *T_wc0_colmajor16);
 int nid_multi_set_reference_points(nid_multi *m, const double *points3d, const uint8_t *im0);
 int nid_multi_set_target_u8(nid_multi *m, const uint8_t *im1);

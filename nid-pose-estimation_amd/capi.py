@@ -43,7 +43,7 @@ SYMBOLS = [
     "nid_set_reference_depth", "nid_set_reference_points", "nid_backproject", "nid_get_points3d", "nid_set_target_u8",
     "nid_set_target_f64", "nid_set_reference_image_f64", "nid_compute_href",
     "nid_compute_href_matrix", "nid_set_href_state", "nid_plain_nid", "nid_evaluate", "nid_evaluate_matrix",
-    "nid_normal_equations", "nid_launch", "nid_launch_batch", "nid_launch_chain", "nid_launch_batch_to", "nid_run_sequence", "nid_run_chain", "nid_set_loop_form", "nid_set_direct_results", "nid_set_resident", "nid_resident_stats", "nid_wait", "nid_slot_buffers", "nid_launch_to",
+    "nid_normal_equations", "nid_launch", "nid_launch_batch", "nid_launch_chain", "nid_launch_batch_to", "nid_run_sequence", "nid_run_chain", "nid_set_loop_form", "nid_set_direct_results", "nid_set_resident", "nid_resident_pause", "nid_resident_stats", "nid_wait", "nid_slot_buffers", "nid_launch_to",
     "nid_unpack_reduced", "nid_debug_enable_pixel_dump", "nid_debug_get_pixel_dump",
     "nid_debug_enable_stamps", "nid_debug_get_stamps", "nid_bspline4_host", "nid_bspline4_poly_host", "nid_log2_fast_host", "nid_div_small_host", "nid_last_kernel_ms", "nid_enable_timing", "nid_time_launches",
     "nid_contract_bytes", "nid_debug_repair_count", "nid_set_short_sequence_policy",
@@ -453,7 +453,7 @@ PARTITION_CONTIGUOUS, PARTITION_INTERLEAVED = 0, 1
 EXCHANGE_FN = C.CFUNCTYPE(C.c_int, c_dp, C.c_int64, C.c_void_p)
 RCCL_ID_BYTES = 128
 MULTI_SYMBOLS = [
-    "nid_multi_cell_range", "nid_multi_cell_partition", "nid_multi_create", "nid_multi_create_rank", "nid_multi_create_partitioned", "nid_multi_destroy", "nid_multi_last_error",
+    "nid_multi_cell_range", "nid_multi_cell_partition", "nid_multi_resident_pause", "nid_multi_create", "nid_multi_create_rank", "nid_multi_create_partitioned", "nid_multi_destroy", "nid_multi_last_error",
     "nid_multi_shards", "nid_multi_shard", "nid_multi_world", "nid_multi_comm_unique_id", "nid_comm_create_rank",
     "nid_comm_create_local", "nid_comm_destroy", "nid_comm_ranks", "nid_multi_attach_comm", "nid_multi_comm_init",
     "nid_multi_comm_init_local", "nid_multi_comm_ranks", "nid_multi_time_exchange", "nid_multi_set_exchange_hook", "nid_multi_set_reduce_mode",

@@ -108,6 +108,9 @@ struct nid_ctx {
   double *dbg_u = nullptr, *dbg_v = nullptr, *dbg_ic = nullptr, *dbg_wc = nullptr;
   int *dbg_jc = nullptr;
   long long *dbg_stamps = nullptr;
+  // compute_href's per-pixel outputs in image order (k_untile_bs) and their pinned staging, created on first use
+  double *bsv_img_dev = nullptr, *bsv_stage = nullptr;
+  int *bsi_img_dev = nullptr, *bsi_stage = nullptr;
   unsigned long long *repair_count_dev = nullptr;  // EvalParams::repair_count (nid_debug_repair_count)
   unsigned *repair_queue_dev[2] = {nullptr, nullptr};  // EvalParams::repair_queue of launches on `stream` / on aux_stream (k_repair)
   bool dbg_enabled = false;
@@ -1180,19 +1183,40 @@ int href_common(nid_ctx *ctx, const Pose &pose, int32_t *bs_counter, double *Hre
     if (Href) Href[ctx->g.cell_begin + cl * ctx->g.cell_stride] = hr[cl];
   }
   if (bs_value || bs_index) {
+    // The per-pixel outputs are put into the caller's layout ON THE DEVICE (k_untile_bs), come home through pinned
+    // staging and are copied out row by row (whole, when this context owns every pixel): a pageable copy of the tile
+    // plus a scalar scatter loop on the host was 1.4 ms of every frame pair (profiles/r04_pair_setup.txt).
     const Geometry &g = ctx->g;
-    const size_t plane = (size_t)g.nloc * g.pstride;
-    std::vector<double> W(bs_value ? 4 * plane : 0);
-    std::vector<int8_t> JR(plane);
-    if (bs_value) NID_HIP(ctx, hipMemcpy(W.data(), ctx->t.W, 4 * plane * sizeof(double), hipMemcpyDeviceToHost));
-    NID_HIP(ctx, hipMemcpy(JR.data(), ctx->t.JR, plane, hipMemcpyDeviceToHost));
-    for (int cl = 0; cl < g.nloc; cl++) {
-      const int c = g.cell_begin + cl * g.cell_stride, ci = c / g.cell_num, cj = c % g.cell_num;
-      for (int s = 0; s < g.ps; s++) {
-        const size_t id = (size_t)(ci * g.rb + s / g.cb) * g.cols + cj * g.cb + s % g.cb;
-        const size_t gi = (size_t)cl * g.pstride + s;
-        if (bs_value) for (int k = 0; k < 4; k++) bs_value[4 * id + k] = k == 0 ? std::fabs(W[4 * gi]) : W[4 * gi + k];  // sign of the first weight: the kernel's knot flag (k_href)
-        if (bs_index) bs_index[id] = JR[gi];
+    const size_t N = (size_t)g.rows * g.cols;
+    if (bs_value && !ctx->bsv_img_dev) {
+      int rc = dev_alloc(ctx, &ctx->bsv_img_dev, 4 * N);
+      if (rc) return rc;
+      if (hipHostMalloc(reinterpret_cast<void **>(&ctx->bsv_stage), 4 * N * sizeof(double), hipHostMallocDefault) != hipSuccess) return NID_ERR_NOMEM;
+    }
+    if (bs_index && !ctx->bsi_img_dev) {
+      int rc = dev_alloc(ctx, &ctx->bsi_img_dev, N);
+      if (rc) return rc;
+      if (hipHostMalloc(reinterpret_cast<void **>(&ctx->bsi_stage), N * sizeof(int), hipHostMallocDefault) != hipSuccess) return NID_ERR_NOMEM;
+    }
+    const long total = (long)g.nloc * g.pstride;
+    hipLaunchKernelGGL(k_untile_bs, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, g, ctx->t,
+                       bs_value ? ctx->bsv_img_dev : nullptr, bs_index ? ctx->bsi_img_dev : nullptr);
+    NID_HIP(ctx, hipGetLastError());
+    if (bs_value) NID_HIP(ctx, hipMemcpyAsync(ctx->bsv_stage, ctx->bsv_img_dev, 4 * N * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    if (bs_index) NID_HIP(ctx, hipMemcpyAsync(ctx->bsi_stage, ctx->bsi_img_dev, N * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    NID_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const bool whole = g.cell_stride == 1 && g.nloc == g.cell_num * g.cell_num && g.rb * g.cell_num == g.rows && g.cb * g.cell_num == g.cols;
+    if (whole) {
+      if (bs_value) std::memcpy(bs_value, ctx->bsv_stage, 4 * N * sizeof(double));
+      if (bs_index) std::memcpy(bs_index, ctx->bsi_stage, N * sizeof(int));
+    } else {
+      for (int cl = 0; cl < g.nloc; cl++) {
+        const int c = g.cell_begin + cl * g.cell_stride, ci = c / g.cell_num, cj = c % g.cell_num;
+        for (int r = 0; r < g.rb; r++) {
+          const size_t id = (size_t)(ci * g.rb + r) * g.cols + (size_t)cj * g.cb;
+          if (bs_value) std::memcpy(bs_value + 4 * id, ctx->bsv_stage + 4 * id, 4 * (size_t)g.cb * sizeof(double));
+          if (bs_index) std::memcpy(bs_index + id, ctx->bsi_stage + id, (size_t)g.cb * sizeof(int));
+        }
       }
     }
   }
@@ -1399,6 +1423,9 @@ int nid_destroy(nid_ctx *ctx) {
   (void)hipFree(ctx->im1_dev); (void)hipFree(ctx->im1s_dev); (void)hipFree(ctx->im0_dev); (void)hipFree(ctx->depth_dev);
   (void)hipFree(ctx->points_dev); (void)hipFree(ctx->Twc_dev);
   (void)hipFree(ctx->Nc_dev); (void)hipFree(ctx->Href_dev); (void)hipFree(ctx->ctab_dev); (void)hipFree(ctx->repair_count_dev);
+  (void)hipFree(ctx->bsv_img_dev); (void)hipFree(ctx->bsi_img_dev);
+  if (ctx->bsv_stage) (void)hipHostFree(ctx->bsv_stage);
+  if (ctx->bsi_stage) (void)hipHostFree(ctx->bsi_stage);
   (void)hipFree(ctx->repair_queue_dev[0]); (void)hipFree(ctx->repair_queue_dev[1]);
   (void)hipFree(ctx->dbg_u); (void)hipFree(ctx->dbg_v); (void)hipFree(ctx->dbg_ic);
   (void)hipFree(ctx->dbg_wc); (void)hipFree(ctx->dbg_jc); (void)hipFree(ctx->dbg_stamps);
@@ -1515,6 +1542,25 @@ int nid_get_points3d(nid_ctx *ctx, double *points3d) {
   return NID_OK;
 }
 
+namespace {
+// nid_backproject's scratch, kept from call to call (one frame pair after the other, the same size): device buffers,
+// pinned staging and a stream -- three hipMalloc + three hipFree (each a device-wide wait) and two pageable copies per
+// call were most of its 0.8 ms (profiles/r04_pair_setup.txt).  Not thread safe, like the contexts.
+struct BackprojectScratch {
+  int device = -1;
+  size_t cap = 0;
+  double *d_depth = nullptr, *d_T = nullptr, *d_pts = nullptr, *h_stage = nullptr;  // h_stage: [3 cap] pinned
+  hipStream_t stream = nullptr;
+  void release() {
+    if (device >= 0) (void)hipSetDevice(device);
+    (void)hipFree(d_depth); (void)hipFree(d_T); (void)hipFree(d_pts);
+    if (h_stage) (void)hipHostFree(h_stage);
+    if (stream) (void)hipStreamDestroy(stream);
+    *this = BackprojectScratch();
+  }
+} g_bp;
+}  // namespace
+
 int nid_backproject(const double *depth_m, const double *T_wc0, double fx, double fy, double cx, double cy,
                     int32_t rows, int32_t cols, int32_t device, double *points3d) {
   // context-free twin of Calculate3Dpoint (CudaPoints3d.cu:35-73)
@@ -1523,23 +1569,37 @@ int nid_backproject(const double *depth_m, const double *T_wc0, double fx, doubl
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return NID_ERR_NO_DEVICE;
   if (device < 0 || device >= ndev || hipSetDevice(device) != hipSuccess) return NID_ERR_INVALID_ARG;
   const size_t N = (size_t)rows * cols;
-  double *d_depth = nullptr, *d_T = nullptr, *d_pts = nullptr;
-  int rc = NID_OK;
-  if (hipMalloc(reinterpret_cast<void **>(&d_depth), N * 8) != hipSuccess ||
-      hipMalloc(reinterpret_cast<void **>(&d_T), 16 * 8) != hipSuccess ||
-      hipMalloc(reinterpret_cast<void **>(&d_pts), 3 * N * 8) != hipSuccess) rc = NID_ERR_NOMEM;
-  if (rc == NID_OK) {
-    Geometry g{};
-    g.rows = rows; g.cols = cols; g.fx = fx; g.fy = fy; g.cx = cx; g.cy = cy;
-    if (hipMemcpy(d_depth, depth_m, N * 8, hipMemcpyHostToDevice) != hipSuccess ||
-        hipMemcpy(d_T, T_wc0, 16 * 8, hipMemcpyHostToDevice) != hipSuccess) rc = NID_ERR_HIP;
-    if (rc == NID_OK) {
-      hipLaunchKernelGGL(k_backproject_plain, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, 0, g, d_depth, d_T, d_pts);
-      if (hipGetLastError() != hipSuccess ||
-          hipMemcpy(points3d, d_pts, 3 * N * 8, hipMemcpyDeviceToHost) != hipSuccess) rc = NID_ERR_HIP;
+  BackprojectScratch &B = g_bp;
+  if (B.device != device || B.cap < N) {
+    B.release();
+    if (hipSetDevice(device) != hipSuccess) return NID_ERR_INVALID_ARG;
+    if (hipMalloc(reinterpret_cast<void **>(&B.d_depth), N * 8) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void **>(&B.d_T), 16 * 8) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void **>(&B.d_pts), 3 * N * 8) != hipSuccess ||
+        hipHostMalloc(reinterpret_cast<void **>(&B.h_stage), 3 * N * 8, hipHostMallocDefault) != hipSuccess ||
+        hipStreamCreateWithFlags(&B.stream, hipStreamNonBlocking) != hipSuccess) {
+      (void)hipGetLastError();
+      B.release();
+      return NID_ERR_NOMEM;
     }
+    B.device = device; B.cap = N;
   }
-  (void)hipFree(d_depth); (void)hipFree(d_T); (void)hipFree(d_pts);
+  Geometry g{};
+  g.rows = rows; g.cols = cols; g.fx = fx; g.fy = fy; g.cx = cx; g.cy = cy;
+  // depth and pose go down through the pinned block (its first N + 16 doubles), the points come back into all of it
+  std::memcpy(B.h_stage, depth_m, N * 8);
+  std::memcpy(B.h_stage + N, T_wc0, 16 * 8);
+  int rc = NID_OK;
+  if (hipMemcpyAsync(B.d_depth, B.h_stage, N * 8, hipMemcpyHostToDevice, B.stream) != hipSuccess ||
+      hipMemcpyAsync(B.d_T, B.h_stage + N, 16 * 8, hipMemcpyHostToDevice, B.stream) != hipSuccess) rc = NID_ERR_HIP;
+  if (rc == NID_OK) {
+    hipLaunchKernelGGL(k_backproject_plain, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, B.stream, g, B.d_depth, B.d_T, B.d_pts);
+    if (hipGetLastError() != hipSuccess ||
+        hipMemcpyAsync(B.h_stage, B.d_pts, 3 * N * 8, hipMemcpyDeviceToHost, B.stream) != hipSuccess ||
+        hipStreamSynchronize(B.stream) != hipSuccess) rc = NID_ERR_HIP;
+  }
+  if (rc == NID_OK) std::memcpy(points3d, B.h_stage, 3 * N * 8);
+  else (void)hipGetLastError();
   return rc;
 }
 
@@ -1992,6 +2052,15 @@ int nid_set_resident(nid_ctx *ctx, int on) {
   int rc = resident_probe(ctx);
   if (rc) { ctx->last_error = "resident evaluator unavailable: " + (ctx->res.why.empty() ? std::string("mailbox setup failed") : ctx->res.why); return rc; }
   ctx->res.enabled = true;
+  return NID_OK;
+}
+
+int nid_resident_pause(nid_ctx *ctx) {
+  if (!ctx) return NID_ERR_INVALID_ARG;
+  if (!ctx->res.running) return NID_OK;
+  for (int s = 0; s < NID_SLOTS; s++) if (ctx->slots[s].pending) return NID_ERR_STATE;
+  NID_HIP(ctx, hipSetDevice(ctx->cfg.device));
+  resident_retire(ctx);  // (the next request starts another)
   return NID_OK;
 }
 

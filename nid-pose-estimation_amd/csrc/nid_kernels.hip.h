@@ -728,6 +728,22 @@ __global__ void k_backproject_plain(Geometry g, const double *__restrict__ depth
   pts[3 * id] = X; pts[3 * id + 1] = Y; pts[3 * id + 2] = Z;
 }
 
+// The reference stage's per-pixel outputs in the caller's layout (CudaComputeHref's bs_value / bs_index, image order):
+// one thread per tile slot writes its pixel's four weights (the sign of the first is the evaluation kernel's knot flag:
+// stripped) and its bin index.  Pixels of no cell of this context are not written.
+__global__ void k_untile_bs(Geometry g, Tiles t, double *__restrict__ bsv /*4N or null*/, int *__restrict__ bsi /*N or null*/) {
+  const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= (long)g.nloc * g.pstride) return;
+  const int cl = (int)(gid / g.pstride), s = (int)(gid % g.pstride);
+  if (s >= g.ps) return;
+  const int c = g.cell_begin + cl * g.cell_stride;
+  const long id = (long)((c / g.cell_num) * g.rb + s / g.cb) * g.cols + (c % g.cell_num) * g.cb + s % g.cb;
+  if (bsv) {
+    const double4 w = *reinterpret_cast<const double4 *>(t.W + 4 * gid);
+    *reinterpret_cast<double4 *>(bsv + 4 * id) = make_double4(fabs(w.x), w.y, w.z, w.w);
+  }
+  if (bsi) bsi[id] = (int)t.JR[gid];
+}
 #endif  // NID_SETUP_KERNELS
 
 // ---------------------------------------------------------------------------
@@ -1040,8 +1056,18 @@ __device__ __forceinline__ void finish_and_reduce_w0(const EvalParams &P, const 
 // 254.9999]; 32-bit literals in the instruction instead of two f64 constants in scalar registers)
 constexpr unsigned kGuardLoHi = 0x3F1A36E3u;                  // high dword of 1e-4, plus one
 constexpr unsigned kGuardSpanHi = 0x406FDFFEu - kGuardLoHi;    // ... up to the high dword of 254.9999, minus one
+#ifndef NID_DIET_GUARD
+#define NID_DIET_GUARD 1
+#endif
+#ifndef NID_DIET_TINY
+#define NID_DIET_TINY 1
+#endif
 __device__ __forceinline__ bool outside_clamp_guard(double ic) {
+#if NID_DIET_GUARD
   return (unsigned)__double2hiint(ic) - kGuardLoHi > kGuardSpanHi;
+#else
+  return fabs(ic - 127.5) > 127.4999;
+#endif
 }
 constexpr unsigned kBorderEpsHi = 0x3EB00000u;                  // high dword of kBorderEps = 2^-20
 // A sample the FAST main passes take lies inside the clamp guard: 1e-4 <= ic <= 254.9999, so the clamp ic >= 255 and
@@ -1207,10 +1233,19 @@ __device__ __forceinline__ void pixel_front(const EvalParams &P, const SlotArgs 
     // The window origin is NOT clamped: ((int)u - 1, (int)v - 1) may be -1 (the image buffer has zeroed
     // margins), so the fixed-tap sample applies to every in-frame pixel.
     // (plain `&`: five compares in a row; `&&` makes the compiler branch around the later ones)
+#ifndef NID_DIET_BORDER
+#define NID_DIET_BORDER 1
+#endif
+#if NID_DIET_BORDER == 1 || NID_DIET_BORDER == 2
     const unsigned hu = (unsigned)__double2hiint(u) - P.hu_lo, hv = (unsigned)__double2hiint(v) - P.hu_lo;
     const bool in = (f.jr >= 0) & (hu <= P.hu_span) & (hv <= P.hv_span);
     f.in = in;
     f.jin = in && (hu <= P.hj_span);
+#else
+    const bool in = (f.jr >= 0) & (u >= kBorderEps) & (u <= (double)g.cols - 3.0 - kBorderEps) & (v >= kBorderEps) & (v <= (double)g.rows - 3.0 - kBorderEps);
+    f.in = in;
+    f.jin = in && (u <= (double)P.jac_cols - 3.0 - kBorderEps);
+#endif
     f.redo = (f.jr >= 0) && !f.jin;
 #ifdef NID_EXP_NO_REDO
     f.redo = false;
@@ -1226,6 +1261,14 @@ __device__ __forceinline__ bool classify_redo(const EvalParams &P, PixelFront &f
   // (conservative integer forms of u < -eps, u > cols-3+eps, ...: the upper bounds from the ranges' ends -- the high
   // dword of cols-3+eps is at most one above that of cols-3-eps --, so that no further scalar registers are needed;
   // a NaN is "clearly out" like in the reference, whose comparisons all fail)
+#if NID_DIET_BORDER == 0 || NID_DIET_BORDER == 2
+  {
+    const double u = f.u, v = f.v;
+    if (u < -kBorderEps || v < -kBorderEps || u > (double)P.g.cols - 3.0 + kBorderEps || v > (double)P.g.rows - 3.0 + kBorderEps) { f.in = false; f.jin = false; return false; }
+    if (f.in && u > (double)P.jac_cols - 3.0 + kBorderEps) { f.jin = false; return false; }
+    return true;
+  }
+#endif
   const int hu = __double2hiint(f.u), hv = __double2hiint(f.v);
   const unsigned neg_out = 0x80000000u + kBorderEpsHi;  // below -eps' (the sign bit set, magnitude beyond the band)
   const int u_top = (int)(P.hu_lo + P.hu_span + 2u), v_top = (int)(P.hu_lo + P.hv_span + 2u), j_top = (int)(P.hu_lo + P.hj_span + 2u);
@@ -1661,7 +1704,11 @@ __device__ __forceinline__ void eval_cell(const EvalParams &P, const SlotArgs &S
     // first stored weight (min(wr[0], wr[3]) < kTinyW and != 0 <=> wr_in[0] < 0): one compare here instead of
     // five instructions per sample; |wr_in[0]| is a free source modifier of the products below
     const bool ref_tiny = wr_in[0] < 0.0;
+#if NID_DIET_TINY
     if (min(__double2hiint(wcs[0]), __double2hiint(wcs[3])) < tiny_scaled_hi || ref_tiny) {
+#else
+    if (fmin(wcs[0], wcs[3]) < kTinyW * kWcPre || ref_tiny) {
+#endif
       double wc[4];
       if (!STRICT && PRESCALED) {
         // FAST: the weights once more, each with an error relative to ITSELF (bspline4_vals_both_ends; the same values
@@ -2480,7 +2527,11 @@ __device__ __forceinline__ void eval_cell(const EvalParams &P, const SlotArgs &S
         // the six sums -- skipped.  (Only if the reference's window is this window: (u, v) away from integer
         // coordinates by more than FAST arithmetic's error, or its truncation could pick the neighbouring pixel.)
 #ifndef NID_EXP_NO_FLAT
-        if (exact) {
+        // (... and only if `wj` IS the sample's window: a sample the FAST front does not place in the frame -- within
+        // the border band, which the integer range checks make 2^-11 px wide -- has the window of pixel (0, 0) in `wj`;
+        // taken for the sample's, a flat image corner silently dropped such samples' contributions: up to 12 % of a
+        // border cell's Jacobian in sweep seed 502812.  The f64 tests of rounds 2-3 had the same hole, 2^-20 px wide.)
+        if (exact && f.in) {
           const unsigned t0 = wj.r1.x;
           const bool flat = (t0 == wj.r1.y) & (t0 == wj.r2.x) & (t0 == wj.r2.y) & (t0 == wj.c0) & (t0 == wj.c3) & ((t0 >> 16) == (t0 & 0xFFFFu));
           const double fu = f.u - floor(f.u), fv = f.v - floor(f.v);

@@ -141,6 +141,34 @@ uint64_t full_hash(const T *a, size_t n) {
   return r ? r : 2;
 }
 
+// CudaComputeHref's bs_value on its way out, in ONE pass over its 9.8 MB: the legacy NaN markers (CudaComputeHref.cu:82-87,
+// 126-130: NaN weights for pixels that are invalid or out of frame at this pose -- in-frame weights sum to 1, so an
+// all-zero row is exactly that set) and the content key's full hash, identical to full_hash() of the marked buffer.
+uint64_t mark_nan_and_hash(double *bs, size_t npix) {
+  const size_t bytes = npix * 4 * sizeof(double), words = bytes / 8;
+  constexpr int L = 8;
+  uint64_t h[L] = {0x9E3779B97F4A7C15ull ^ bytes, 0xC2B2AE3D27D4EB4Full, 0x165667B19E3779F9ull, 0x27D4EB2F165667C5ull,
+                   0x85EBCA77C2B2AE63ull, 0xD6E8FEB86659FD93ull, 0xA0761D6478BD642Full, 0xE7037ED1A0B428DBull};
+  auto mark = [](double *w) {
+    if (w[0] == 0.0 && w[1] == 0.0 && w[2] == 0.0 && w[3] == 0.0) w[0] = w[1] = w[2] = w[3] = NAN;
+  };
+  size_t i = 0;
+  for (; i + L <= words; i += L) {  // two pixels per step: the eight lanes of full_hash
+    mark(bs + i); mark(bs + i + 4);
+    uint64_t w[L];
+    std::memcpy(w, bs + i, 8 * L);
+    for (int k = 0; k < L; k++) { h[k] = (h[k] ^ w[k]) * 0x9FB21C651E98DF25ull; h[k] ^= h[k] >> 29; }
+  }
+  for (; i < words; i += 4) {  // an odd pixel count: the last pixel, word by word like full_hash's tail
+    mark(bs + i);
+    for (size_t t = i; t < i + 4; t++) { uint64_t w; std::memcpy(&w, bs + t, 8); h[t % L] = (h[t % L] ^ w) * 0x9FB21C651E98DF25ull; h[t % L] ^= h[t % L] >> 29; }
+  }
+  uint64_t r = h[0];
+  for (int k = 1; k < L; k++) r = (r ^ h[k]) * 0xFF51AFD7ED558CCDull + k;
+  r ^= r >> 32;
+  return r ? r : 2;
+}
+
 // Does the caller's buffer still hold what is resident?  Updates the key; `force`: recompute the full hash even if
 // address, length and the quick fingerprint are unchanged.
 template <typename T>
@@ -282,7 +310,10 @@ void CudaComputeHref(double *im0, double *points3d, double *pose, double *camera
   const int ncell = cell_num * cell_num;
   std::vector<int32_t> cnt(ncell), idx(bs_index ? N : 0);
   std::vector<double> href(ncell);
-  if (bs_value) std::memset(bs_value, 0, 4 * N * sizeof(double));  // a process that owns some of the cells fills those
+  // (every pixel of a cell is written by the shard that owns the cell; what belongs to no cell of this process -- trailing
+  // rows / columns of a size the cell count does not divide, other ranks' cells -- must read as zero)
+  const bool every_pixel_ours = g_world == 1 && rows % cell_num == 0 && cols % cell_num == 0;
+  if (bs_value && !every_pixel_ours) std::memset(bs_value, 0, 4 * N * sizeof(double));
   tr.step("output buffers cleared");
   rc = nid_multi_compute_href_matrix(m, pose, cnt.data(), href.data(), bs_value, bs_index ? idx.data() : nullptr);
   if (rc != NID_OK) { report("CudaComputeHref", rc, m); return; }
@@ -292,22 +323,19 @@ void CudaComputeHref(double *im0, double *points3d, double *pose, double *camera
     // CudaComputeHref.cu:205-220: NaN when inactive, otherwise subtract onto the caller's value
     Href[c] = std::isnan(href[c]) ? NAN : Href[c] + href[c];
   }
-  if (bs_value) {
-    // legacy marker (CudaComputeHref.cu:82-87,126-130): NaN weights for pixels that are invalid or
-    // out of frame at this pose.  In-frame weights sum to 1, so an all-zero row is exactly that set.
-    for (size_t i = 0; i < N; i++) {
-      double *w = bs_value + 4 * i;
-      if (w[0] == 0.0 && w[1] == 0.0 && w[2] == 0.0 && w[3] == 0.0) w[0] = w[1] = w[2] = w[3] = NAN;
-    }
-  }
   if (bs_index) for (size_t i = 0; i < N; i++) bs_index[i] = idx[i];
-  tr.step("NaN markers, bs_index copy");
   // the device already holds these weights (CPU-edge convention: 0 instead of NaN)
   S.have_href = true;
-  remember(S.k_bs_ref, bs_value, bs_value ? 4 * N : 0);
+  if (bs_value) {  // the legacy NaN markers and the buffer's content key in one pass (mark_nan_and_hash)
+    S.k_bs_ref.addr = bs_value; S.k_bs_ref.n = 4 * N; S.k_bs_ref.full = mark_nan_and_hash(bs_value, N);
+    S.k_bs_ref.quick = fingerprint(bs_value, 4 * N); S.k_bs_ref.valid = true;
+  } else {
+    remember(S.k_bs_ref, bs_value, 0);
+  }
+  tr.step("NaN markers + content key of bs_value, bs_index copy");
   remember(S.k_counter, bs_counter, (size_t)ncell);
   remember(S.k_href, Href, (size_t)ncell);
-  tr.step("content keys of the outputs");
+  tr.step("content keys of the per-cell outputs");
 }
 
 namespace {
@@ -457,6 +485,10 @@ void nid_legacy_invalidate(unsigned parts) { g_state.force_full |= parts; }
 void nid_legacy_reset(void) {
   if (g_state.m) nid_multi_destroy(g_state.m);
   g_state = LegacyState();
+}
+
+void nid_legacy_quiesce(void) {
+  if (g_state.m) (void)nid_multi_resident_pause(g_state.m);
 }
 
 nid_multi *nid_legacy_prepare(double *im0, double *im1, double *points3d, int *bs_counter, double *bs_ref,

@@ -33,16 +33,20 @@ int nid_host_run_lm(const nid_pose_problem *pb, double *pose7_inout, nid_host_lm
   };
   const int rows = pb->rows, cols = pb->cols, cell = pb->cell_num, bin_num = pb->bin_num, bs_degree = 3;
   const size_t N = (size_t)rows * cols;
-  nid_legacy_reset();
+  // (the operators' device state is keyed on geometry and content: a pair of the geometry of the last one reuses its
+  // context -- creating and destroying one per pair was 18 ms of a 24 ms call, profiles/r04_pair_setup.txt)
   nid_legacy_set_jacobian_bound(pb->jac_bound_cuda ? 1 : 0);
   nid_legacy_set_math_mode(pb->strict_math ? 1 : 0);
 
-  // NID_pose_estimation.cpp:229-251 -- buffers owned by the caller of the operators
+  // NID_pose_estimation.cpp:229-251 -- buffers owned by the caller of the operators (kept from call to call: 30 MB of
+  // fresh pages per pair were 0.4 ms of page faults)
   std::vector<double> intrinscis = {pb->fx, pb->fy, pb->cx, pb->cy, pb->depth_factor};
-  std::vector<double> bs_value(4 * N), Href(cell * cell, 0.0), points_3d_all(3 * N), im0_data(N), im1_data(N);
-  std::vector<int> bin_index(N), bs_counter(cell * cell);
+  static thread_local std::vector<double> bs_value, points_3d_all, im0_data, im1_data, depth;
+  static thread_local std::vector<int> bin_index;
+  bs_value.resize(4 * N); points_3d_all.resize(3 * N); im0_data.resize(N); im1_data.resize(N); depth.resize(N); bin_index.resize(N);
+  std::vector<double> Href(cell * cell, 0.0);
+  std::vector<int> bs_counter(cell * cell);
   for (size_t i = 0; i < N; i++) { im0_data[i] = (double)pb->im0[i]; im1_data[i] = (double)pb->im1[i]; }
-  std::vector<double> depth(N);
   for (size_t i = 0; i < N; i++) depth[i] = (double)pb->depth_u16[i] * pb->depth_factor;  // convertTo(CV_64F, 1/5000), :106
   std::vector<double> T_wc0(pb->T_wc0_colmajor, pb->T_wc0_colmajor + 16);
   stamp("caller's buffers (u8 / u16 -> f64, allocations)");
@@ -122,8 +126,8 @@ int nid_host_run_lm(const nid_pose_problem *pb, double *pose7_inout, nid_host_lm
     const std::string s = log.str();
     std::snprintf(log_buf, (size_t)log_cap, "%s", s.c_str());
   }
-  nid_legacy_reset();
-  stamp("trace copy, nid_legacy_reset");
+  nid_legacy_quiesce();  // (a resident kernel leaves the device; the context stays for the next pair)
+  stamp("trace copy, nid_legacy_quiesce");
   return done;
 }
 
