@@ -108,9 +108,18 @@ int nid_set_launch_shape(nid_ctx *ctx, int jac_threads, int cost_threads);
 int nid_set_loop_form(nid_ctx *ctx, int on);
 /* DIRECT results (default on): a launch of ONE pose whose result the host waits for (nid_launch + nid_wait,
  * nid_normal_equations, nid_evaluate, nid_run_chain, the first pose of nid_launch_chain) lets every cell's workgroup
- * write its 32-double block straight to pinned host memory and the HOST adds the blocks up, in the order the in-launch
- * reduction uses: the same bits, without that reduction's device-scope round trips behind the last cell.  on == 0:
- * always the in-launch reduction.  Timed and diagnostic launches always use the in-launch reduction.
+ * write a 64-byte record -- err, J[6], an active flag -- straight to pinned host memory; the HOST applies the Huber
+ * kernel, forms each cell's quadratic form (the kernel's operations in the kernel's order, all IEEE) and adds them up
+ * in the order the in-launch reduction uses: the same bits, without that reduction's device-scope round trips behind
+ * the last cell.  (So in this mode the last step of the path -- robustify + J^T w J + the 256-way sum, ~2 us of host
+ * work -- runs on the CPU; on == 0 keeps it on the device.)  The slot's cellout_dev block is written either way, its
+ * reduced_dev block by neither (nid_slot_buffers).  on == 0: always the in-launch reduction.
+ * on == 2, GROUP-DIRECT (nid_launch / nid_normal_equations / nid_run_chain): Huber, quadratic form and the first level
+ * of the reduction stay on the device; every group's sum (256 bytes, at most 32 groups) goes straight to pinned host
+ * memory and the host adds the groups up -- the whole of a15 on the GPU except the last <= 32 additions per entry, one
+ * device-scope round trip instead of two behind the last cell.  Same bits.  The resident evaluator is not used in this
+ * mode.  (Measured: profiles/r04_latency_A.txt; the default stays 1, which is faster.)
+ * Timed and diagnostic launches always use the in-launch reduction.  NID_ERR_INVALID_ARG for any other value.
  * NID_ERR_STATE while a launch is pending. */
 int nid_set_direct_results(nid_ctx *ctx, int on);
 /* The RESIDENT evaluator (default off): DIRECT single-pose launches of a context in FAST math whose cost + Jacobian
@@ -131,13 +140,21 @@ int nid_set_direct_results(nid_ctx *ctx, int on);
  * on 256 CUs: BASELINE configs[1] at 1280x960) is answered by ordinary launches -- the first request finds that out,
  * nid_resident_stats keeps saying served == 0, and later nid_set_resident(ctx, 1) calls return NID_ERR_UNSUPPORTED with
  * the reason in nid_last_error.
- * NID_ERR_UNSUPPORTED also if the platform does not let the CPU address the device's fine-grained memory;
+ * Sharing the device: the co-residency of one workgroup per cell is an assumption about the WHOLE device, so
+ *  - one resident kernel per device and process: while one context's kernel is on a device, other contexts' requests
+ *    on that device are answered by ordinary launches (the owner's pause / retire / destroy frees the place);
+ *  - a request the kernel does not pick up within its deadline (another process's work holds CUs: some workgroups
+ *    are not on the device) is re-issued as an ordinary launch and counted in `fallbacks`; after 3 such requests in
+ *    a row, or once there are more than 8 and more than the requests served, the mode switches itself off for the
+ *    context (reason in nid_last_error; nid_set_resident(ctx, 1) arms it again).
+ * NID_ERR_UNSUPPORTED also if the device's memory is not CPU-addressable as a whole (no large PCIe BAR: the
+ * hipDeviceAttributeIsLargeBar attribute; nothing is probed by touching the mapping);
  * NID_ERR_STATE while a launch is pending. */
 int nid_set_resident(nid_ctx *ctx, int on);
-/* requests served by the resident kernel, requests re-issued as ordinary launches, kernel starts */
 /* Takes a running resident kernel off the device (it holds most of every CU) without disabling the mode: for a caller
  * that is done with this context for now and lets others use the GPU.  The next request starts another. */
 int nid_resident_pause(nid_ctx *ctx);
+/* requests served by the resident kernel, requests re-issued as ordinary launches, kernel starts */
 int nid_resident_stats(const nid_ctx *ctx, int64_t *served, int64_t *fallbacks, int64_t *starts);
 /* both at once (0 = the defaults above) */
 int nid_set_block_threads(nid_ctx *ctx, int threads);
@@ -230,10 +247,21 @@ int nid_run_sequence(nid_ctx *ctx, const double *poses7, int n, int batch, int w
 int nid_run_chain(nid_ctx *ctx, const double *poses7, int n, int want_jac, double huber_delta, double *reduced_out,
                   double *seconds);
 /* device address of slot's reduced block (NID_REDUCED_LEN doubles) and of its
- * per-cell block (cells_local x NID_CELL_OUT doubles: Hc,Hj,err,J[6], pad) so
- * that a caller can run a collective on them (RCCL all-reduce / all-gather) */
+ * per-cell block (cells_local x NID_CELL_OUT doubles: Hc,Hj,err,J[6], n_c) so
+ * that a caller can run a collective on them (RCCL all-reduce / all-gather).  Who writes them:
+ *  - cellout_dev: every LAUNCHED evaluation of the slot through nid_launch / nid_launch_to / nid_launch_batch(_to) /
+ *    nid_launch_chain (DIRECT or not), complete when nid_wait(slot) returns.  Not the pipelined loops
+ *    (nid_run_sequence / nid_run_chain hand the kernels no per-cell block), not nid_evaluate (its per-cell values go
+ *    straight to the caller), and not a request the RESIDENT evaluator answered (nid_set_resident: nothing is
+ *    launched; its records go to the host);
+ *  - reduced_dev: nobody, unless the caller names it as the target of nid_launch_to / nid_launch_batch_to (it is a
+ *    device block the context owns for that purpose: slot k's is good for one pose, a batch of n needs n blocks of
+ *    the caller's).  Every other launch reports through pinned host memory (the in-launch reduction's last workgroup
+ *    writes the block there; a DIRECT launch forms it on the host) and nid_wait hands that over. */
 #define NID_CELL_OUT 10
 int nid_slot_buffers(nid_ctx *ctx, int slot, void **reduced_dev, void **cellout_dev);
+/* test / tool helper: blocking copy of `bytes` from a device address of this context's device */
+int nid_debug_read_device(nid_ctx *ctx, const void *dev, void *host, size_t bytes);
 /* launch variant that writes the reduced block into a caller-owned DEVICE
  * buffer (e.g. a torch tensor that torch.distributed all-reduces) */
 int nid_launch_to(nid_ctx *ctx, int slot, const double *pose7, int want_jac, double huber_delta,

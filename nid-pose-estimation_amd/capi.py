@@ -43,7 +43,7 @@ SYMBOLS = [
     "nid_set_reference_depth", "nid_set_reference_points", "nid_backproject", "nid_get_points3d", "nid_set_target_u8",
     "nid_set_target_f64", "nid_set_reference_image_f64", "nid_compute_href",
     "nid_compute_href_matrix", "nid_set_href_state", "nid_plain_nid", "nid_evaluate", "nid_evaluate_matrix",
-    "nid_normal_equations", "nid_launch", "nid_launch_batch", "nid_launch_chain", "nid_launch_batch_to", "nid_run_sequence", "nid_run_chain", "nid_set_loop_form", "nid_set_direct_results", "nid_set_resident", "nid_resident_pause", "nid_resident_stats", "nid_wait", "nid_slot_buffers", "nid_launch_to",
+    "nid_normal_equations", "nid_launch", "nid_launch_batch", "nid_launch_chain", "nid_launch_batch_to", "nid_run_sequence", "nid_run_chain", "nid_set_loop_form", "nid_set_direct_results", "nid_set_resident", "nid_resident_pause", "nid_resident_stats", "nid_wait", "nid_slot_buffers", "nid_debug_read_device", "nid_launch_to",
     "nid_unpack_reduced", "nid_debug_enable_pixel_dump", "nid_debug_get_pixel_dump",
     "nid_debug_enable_stamps", "nid_debug_get_stamps", "nid_bspline4_host", "nid_bspline4_poly_host", "nid_log2_fast_host", "nid_div_small_host", "nid_last_kernel_ms", "nid_enable_timing", "nid_time_launches",
     "nid_contract_bytes", "nid_debug_repair_count", "nid_set_short_sequence_policy",
@@ -101,6 +101,7 @@ def load():
     lib.nid_run_chain.argtypes = [vp, c_dp, C.c_int, C.c_int, C.c_double, c_dp, c_dp]
     lib.nid_wait.argtypes = [vp, C.c_int, c_dp, c_dp, c_dp, c_ip]
     lib.nid_slot_buffers.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(vp)]
+    lib.nid_debug_read_device.argtypes = [vp, vp, C.POINTER(C.c_double), C.c_size_t]
     lib.nid_unpack_reduced.argtypes = [c_dp, c_dp, c_dp, c_dp, c_ip]
     lib.nid_debug_enable_pixel_dump.argtypes = [vp, C.c_int]
     lib.nid_debug_get_pixel_dump.argtypes = [vp, c_dp, c_dp, c_dp, c_ip, c_dp]
@@ -117,6 +118,7 @@ def load():
     lib.nid_set_loop_form.argtypes = [vp, C.c_int]
     lib.nid_set_direct_results.argtypes = [vp, C.c_int]
     lib.nid_set_resident.argtypes = [vp, C.c_int]
+    lib.nid_resident_pause.argtypes = [vp]
     lib.nid_resident_stats.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     lib.nid_time_launches.argtypes = [vp, C.c_int, c_dp, C.c_int, C.c_double, C.c_int, c_fp]
     if hasattr(lib, "nid_debug_repair_count"):   # (an older experiment build, NID_HIP_LIB, may lack the newest diagnostics)
@@ -320,6 +322,17 @@ class Context:
         self._check(self.lib.nid_wait(self.h, slot, _dp(H), _dp(b), C.byref(chi2), C.byref(na)), "nid_wait")
         return H.reshape(6, 6), b, chi2.value, na.value
 
+    def slot_buffers(self, slot):
+        """(reduced_dev, cellout_dev): device addresses of the slot's blocks (nid_slot_buffers)"""
+        r, c = C.c_void_p(0), C.c_void_p(0)
+        self._check(self.lib.nid_slot_buffers(self.h, int(slot), C.byref(r), C.byref(c)), "nid_slot_buffers")
+        return r.value, c.value
+
+    def read_device(self, dev, shape):
+        out = np.zeros(shape)
+        self._check(self.lib.nid_debug_read_device(self.h, C.c_void_p(dev), _dp(out), out.nbytes), "nid_debug_read_device")
+        return out
+
     def set_math_mode(self, mode):
         self._check(self.lib.nid_set_math_mode(self.h, int(mode)), "nid_set_math_mode")
 
@@ -336,10 +349,13 @@ class Context:
         self._check(self.lib.nid_set_loop_form(self.h, 1 if on else 0), "nid_set_loop_form")
 
     def set_direct_results(self, on=True):
-        self._check(self.lib.nid_set_direct_results(self.h, 1 if on else 0), "nid_set_direct_results")
+        self._check(self.lib.nid_set_direct_results(self.h, int(on)), "nid_set_direct_results")
 
     def set_resident(self, on=True):
         self._check(self.lib.nid_set_resident(self.h, 1 if on else 0), "nid_set_resident")
+
+    def resident_pause(self):
+        self._check(self.lib.nid_resident_pause(self.h), "nid_resident_pause")
 
     def resident_stats(self):
         a, b, c = C.c_int64(0), C.c_int64(0), C.c_int64(0)

@@ -8,9 +8,7 @@
 // is [evaluation kernel -> reduction kernel -> small D2H].
 #include <hip/hip_runtime.h>
 
-#include <setjmp.h>
-#include <signal.h>
-
+#include <atomic>
 #include <algorithm>
 #include <chrono>
 #include <cmath>
@@ -41,6 +39,10 @@ struct Slot {
   double *reduced_host_devptr = nullptr;
   double *quad_host = nullptr;     // pinned, mapped, created on first use: [nloc][kDirectRec] per-cell records of a DIRECT launch (wait_direct)
   double *quad_host_devptr = nullptr;
+  double *groups_host = nullptr;   // pinned, mapped, created on first use: [ngroups][32] group sums of a GROUP-DIRECT launch (wait_groups)
+  double *groups_host_devptr = nullptr;
+  bool groups = false;             // the launch in flight is a GROUP-DIRECT one (nid_set_direct_results(ctx, 2))
+  bool groups_dirty = false;
   bool direct = false;             // the launch in flight is a DIRECT one: the host forms and sums the cells' quadratic forms
   bool resident = false;           // ... it is a request to the resident kernel (its records arrive in ctx->res.rec_host)
   bool collected = false;          // its result is in reduced_host already (resident_quiesce): nid_wait only hands it over
@@ -64,6 +66,7 @@ struct nid_ctx {
   int xform = NID_XFORM_QUAT;
   int jac_threads = 0, cost_threads = 0;  // nid_set_launch_shape: 0 = default (128) / automatic (pick_threads)
   bool loop_form = false;                  // nid_set_loop_form (diagnostics)
+  int direct_mode = 1;                     // nid_set_direct_results: 0 in-launch reduction, 1 DIRECT records, 2 GROUP-DIRECT (group sums on the device)
   bool direct_results = true;              // nid_set_direct_results: single-pose launches whose result the host waits for are DIRECT
   int seq_chunk = 0, seq_streams = 0;      // nid_set_short_sequence_policy: poses per launch / streams of a SHORT sequence (0 = the measured table)
   // the RESIDENT evaluator (nid_set_resident; k_resident in nid_kernels.hip.h)
@@ -82,6 +85,7 @@ struct nid_ctx {
     Pose pose{};
     bool jac = false, want_cellout = false;
     long served = 0, fallbacks = 0, starts = 0;
+    int fallback_run = 0;          // consecutive requests that timed out (resident_fallback switches the mode off after a few)
     std::string why;               // probed < 0: which step said no
   } res;
   std::vector<double> direct_rho1;  // wait_direct: the cells' Huber weights between its two passes
@@ -293,7 +297,7 @@ int launch_eval2(nid_ctx *ctx, EvalParams &P, bool jac, hipStream_t stream, int 
   size_t lds = eval_lds_bytes(P.g, nt);
   set_hist_params(P);
   if (lds > 160 * 1024) return NID_ERR_UNSUPPORTED;
-  static const char *pad_env = getenv("NID_EXP_LDS_PAD");  // occupancy experiments: pad the LDS request
+  static const char *pad_env = getenv("NID_OCCUPANCY_LDS_PAD");  // occupancy experiments: pad the LDS request
   if (pad_env) lds = std::min<size_t>(160 * 1024, lds + (size_t)atoi(pad_env));
   const bool strict = ctx->math_mode == NID_MATH_STRICT;
   // The kernels live in one translation unit per workgroup shape and kind (nid_eval_launch.h).  Families: the latency
@@ -417,6 +421,31 @@ int ensure_quad_host(nid_ctx *ctx, Slot &S) {
 // the same buffers before the host has looked)
 bool direct_ok(const nid_ctx *ctx) {
   return ctx->direct_results && !ctx->timing && !ctx->dbg_enabled && !ctx->dbg_stamps;
+}
+
+// GROUP-DIRECT (nid_set_direct_results(ctx, 2)): the whole per-cell tail stays on the device -- Huber kernel, quadratic
+// form, and the first level of the reduction (every group's last workgroup sums its group's blocks) -- and the group
+// sums go straight to pinned host memory, one 256-byte block per group; the host adds the <= 32 group blocks in
+// sum_blocks_w0's order (the second level: even-numbered groups ascending plus the odd-numbered ones).  Against the
+// in-launch reduction it saves the second ticket round trip, the re-read of the group sums and the system-scope fence;
+// against DIRECT it keeps a15 on the GPU and costs the first ticket round trip.  Same bits as both.
+int ensure_groups_host(nid_ctx *ctx, Slot &S) {
+  const int ngroups = (ctx->g.nloc + ctx->group_size - 1) / ctx->group_size;
+  const size_t n = (size_t)ngroups * kQuad;
+  if (S.groups_host && S.groups_dirty) {
+    NID_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    NID_HIP(ctx, hipStreamSynchronize(ctx->aux_stream));
+    fill_sentinel(S.groups_host, n);
+    S.groups_dirty = false;
+  }
+  if (S.groups_host) return NID_OK;
+  if (hipHostMalloc(reinterpret_cast<void **>(&S.groups_host), n * sizeof(double), hipHostMallocMapped) != hipSuccess) {
+    S.groups_host = nullptr;
+    return NID_ERR_NOMEM;
+  }
+  fill_sentinel(S.groups_host, n);
+  NID_HIP(ctx, hipHostGetDevicePointer(reinterpret_cast<void **>(&S.groups_host_devptr), S.groups_host, 0));
+  return NID_OK;
 }
 
 // true when all `n` words at p have arrived
@@ -617,8 +646,28 @@ int wait_direct(nid_ctx *ctx, Slot &S) {
     }
     break;
   }
-  if (S.resident) { ctx->res.pending_slot = -1; ctx->res.served++; S.resident = false; }
+  if (S.resident) { ctx->res.pending_slot = -1; ctx->res.served++; ctx->res.fallback_run = 0; S.resident = false; }
   else S.quad_dirty = false;
+  return NID_OK;
+}
+
+int wait_groups(nid_ctx *ctx, Slot &S) {
+  const int ngroups = (ctx->g.nloc + ctx->group_size - 1) / ctx->group_size;
+  alignas(64) double top[2][32] = {};
+  unsigned long spins = 0;
+  bool synced = false, waited = false;
+  for (int gq = 0; gq < ngroups; gq++) {
+    double *blk = S.groups_host + (size_t)gq * kQuad;
+    int rc = spin_until(ctx, [&] { return words_arrived(blk, kQuad); }, spins, synced, waited);
+    if (rc) return rc;
+    if (gq + 2 < ngroups) __builtin_prefetch(blk + 2 * kQuad, 0, 3);
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    double *t = top[gq & 1];
+    for (int v = 0; v < kQuad; v++) t[v] += blk[v];
+    fill_sentinel(blk, kQuad);
+  }
+  for (int v = 0; v < kReducedLen; v++) S.reduced_host[v] = top[0][v] + top[1][v];
+  S.groups_dirty = false;
   return NID_OK;
 }
 
@@ -648,7 +697,7 @@ int wait_direct_cellout(nid_ctx *ctx, Slot &S) {
     if (!again) break;
   }
   __atomic_thread_fence(__ATOMIC_ACQUIRE);
-  if (S.resident) { ctx->res.pending_slot = -1; ctx->res.served++; S.resident = false; }
+  if (S.resident) { ctx->res.pending_slot = -1; ctx->res.served++; ctx->res.fallback_run = 0; S.resident = false; }
   return NID_OK;
 }
 
@@ -682,13 +731,42 @@ int timing_events(nid_ctx *ctx, Slot &S) {
 // word) by every call that changes what it has cached or frees device memory, and by the next request after
 // kResidentHostIdle without one; a kernel that is gone nevertheless (its own idle limit) is noticed by the unanswered
 // request, which is then re-issued as an ordinary DIRECT launch (resident_fallback).
-static sigjmp_buf g_res_probe;
-static void res_probe_fault(int) { siglongjmp(g_res_probe, 1); }
+// One resident kernel per DEVICE in this process: its workgroups hold most of every CU, a second context's kernel would
+// not be scheduled beside it (its requests would time out into fallbacks while the first one sits there).  The registry
+// names the context that holds a device; another context's nid_set_resident / request is refused (it keeps launching).
+constexpr int kResMaxDevices = 64;
+static std::atomic<nid_ctx *> g_res_owner[kResMaxDevices];  // (contexts of one device may live on different threads)
+static bool res_claim(nid_ctx *ctx) {
+  const int d = ctx->cfg.device;
+  if (d < 0 || d >= kResMaxDevices) return true;
+  nid_ctx *none = nullptr;
+  return g_res_owner[d].compare_exchange_strong(none, ctx) || none == ctx;
+}
+static void res_release(nid_ctx *ctx) {
+  const int d = ctx->cfg.device;
+  nid_ctx *me = ctx;
+  if (d >= 0 && d < kResMaxDevices) g_res_owner[d].compare_exchange_strong(me, nullptr);
+}
+static bool res_held_by_other(const nid_ctx *ctx) {
+  const int d = ctx->cfg.device;
+  if (d < 0 || d >= kResMaxDevices) return false;
+  const nid_ctx *o = g_res_owner[d].load();
+  return o && o != ctx;
+}
 
 int resident_probe(nid_ctx *ctx) {
   nid_ctx::Resident &R = ctx->res;
   if (R.probed) return R.probed > 0 ? NID_OK : NID_ERR_UNSUPPORTED;
   R.probed = -1;
+  // Can the CPU store to device memory?  Asked, not tried: the device's large-BAR attribute (a store to memory the CPU
+  // cannot reach faults, and a fault probe would have to swap the process's SIGSEGV / SIGBUS handlers under the feet
+  // of every other thread).
+  int large_bar = 0;
+  if (hipDeviceGetAttribute(&large_bar, hipDeviceAttributeIsLargeBar, ctx->cfg.device) != hipSuccess || !large_bar) {
+    (void)hipGetLastError();
+    R.why = "the device's memory is not CPU-addressable here (no large BAR): resident requests need a mailbox the host can write";
+    return NID_ERR_UNSUPPORTED;
+  }
   void *p = nullptr;
   hipError_t e = hipExtMallocWithFlags(&p, 4096, hipDeviceMallocFinegrained);
   if (e != hipSuccess) {
@@ -696,39 +774,24 @@ int resident_probe(nid_ctx *ctx) {
     R.why = std::string("hipExtMallocWithFlags(hipDeviceMallocFinegrained): ") + hipGetErrorString(e);
     return NID_ERR_UNSUPPORTED;
   }
-  e = hipMemset(p, 0, 4096);
-  if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
-  if (e != hipSuccess) {
+  auto fail = [&](const char *what, int rc) {  // every failure path gives back what was created
     (void)hipGetLastError();
     (void)hipFree(p);
-    R.why = std::string("clearing the mailbox: ") + hipGetErrorString(e);
-    return NID_ERR_UNSUPPORTED;
-  }
-  // can the CPU store to it?  (a platform without a large BAR faults: that is the answer "no")
-  struct sigaction sa = {}, old_segv, old_bus;
-  sa.sa_handler = res_probe_fault;
-  sigaction(SIGSEGV, &sa, &old_segv);
-  sigaction(SIGBUS, &sa, &old_bus);
-  bool ok = false;
-  if (sigsetjmp(g_res_probe, 1) == 0) {
-    volatile unsigned *w = reinterpret_cast<volatile unsigned *>(p) + 1000;
-    *w = 0x5A5Au;
-    ok = (*w == 0x5A5Au);
-    *w = 0u;
-  }
-  sigaction(SIGSEGV, &old_segv, nullptr);
-  sigaction(SIGBUS, &old_bus, nullptr);
-  if (!ok) {
-    (void)hipFree(p);
-    R.why = "the device's fine-grained memory is not CPU-addressable here (a store from the host faulted)";
-    return NID_ERR_UNSUPPORTED;
-  }
+    if (R.stream) { (void)hipStreamDestroy(R.stream); R.stream = nullptr; }
+    if (R.rec_host) { (void)hipHostFree(R.rec_host); R.rec_host = nullptr; }
+    R.ctl = nullptr; R.rec_devptr = nullptr;
+    R.why = what;
+    return rc;
+  };
+  e = hipMemset(p, 0, 4096);
+  if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
+  if (e != hipSuccess) return fail("clearing the mailbox failed", NID_ERR_UNSUPPORTED);
   R.ctl = static_cast<ResidentCtl *>(p);
-  if (hipStreamCreateWithFlags(&R.stream, hipStreamNonBlocking) != hipSuccess) { (void)hipFree(p); R.ctl = nullptr; return NID_ERR_HIP; }
+  if (hipStreamCreateWithFlags(&R.stream, hipStreamNonBlocking) != hipSuccess) return fail("no stream for the resident kernel", NID_ERR_HIP);
   const size_t n = (size_t)2 * ctx->g.nloc * kDirectRec;
-  if (hipHostMalloc(reinterpret_cast<void **>(&R.rec_host), n * sizeof(double), hipHostMallocMapped) != hipSuccess) return NID_ERR_NOMEM;
+  if (hipHostMalloc(reinterpret_cast<void **>(&R.rec_host), n * sizeof(double), hipHostMallocMapped) != hipSuccess) return fail("no pinned memory for the records", NID_ERR_NOMEM);
   fill_sentinel(R.rec_host, n);
-  NID_HIP(ctx, hipHostGetDevicePointer(reinterpret_cast<void **>(&R.rec_devptr), R.rec_host, 0));
+  if (hipHostGetDevicePointer(reinterpret_cast<void **>(&R.rec_devptr), R.rec_host, 0) != hipSuccess) return fail("hipHostGetDevicePointer failed", NID_ERR_HIP);
   R.probed = 1;
   return NID_OK;
 }
@@ -746,6 +809,7 @@ void resident_retire(nid_ctx *ctx) {
   w[7] = R.seq << 8;                     // (a word no request carries: the next kernel starts from it)
   store_fence();
   R.running = false;
+  res_release(ctx);
 }
 
 int resident_launch(nid_ctx *ctx, const EvalParams &P, size_t lds, unsigned grid) {
@@ -792,8 +856,9 @@ int resident_start(nid_ctx *ctx, int nt) {
   const unsigned grid = (unsigned)(((P.g.nloc + 7) / 8) * 8);
   const int nb = P.g.nb;
   if (nt != 512) { ctx->last_error = "resident evaluator: shape " + std::to_string(nt); return NID_ERR_UNSUPPORTED; }
+  if (!res_claim(ctx)) { ctx->last_error = "resident evaluator: another context's resident kernel holds this device"; return NID_ERR_STATE; }
   rc = resident_launch(ctx, P, lds, grid);
-  if (rc) return rc;
+  if (rc) { res_release(ctx); return rc; }
   R.running = true;
   R.nt = nt;
   R.starts++;
@@ -807,6 +872,8 @@ int resident_start(nid_ctx *ctx, int nt) {
 bool resident_usable(const nid_ctx *ctx) {
   const nid_ctx::Resident &R = ctx->res;
   if (!R.enabled || R.probed < 0 || R.pending_slot >= 0 || !direct_ok(ctx)) return false;
+  // another context's resident kernel holds this device: launch (see g_res_owner)
+  if (res_held_by_other(ctx)) return false;
   if (ctx->math_mode != NID_MATH_FAST || ctx->loop_form) return false;
   const int nt = ctx->jac_threads;
   if (nt != 512) return false;
@@ -885,6 +952,17 @@ int resident_fallback(nid_ctx *ctx, Slot &S) {
   nid_ctx::Resident &R = ctx->res;
   resident_retire(ctx);  // (if it was still there: no late writes after this)
   R.fallbacks++;
+  // A request that times out costs 2 ms of spinning plus a launch.  One such event after an idle spell is the kernel's
+  // own idle limit at work; a run of them -- the workgroups are not co-resident: a shared GPU, another process's kernels
+  // -- means the mode does not work here: it is switched off, with the reason on record (nid_last_error,
+  // nid_resident_stats), instead of making every evaluation 100x slower than a launch.
+  R.fallback_run++;
+  if (R.fallback_run >= 3 || (R.fallbacks > 8 && R.fallbacks > R.served)) {
+    R.enabled = false;
+    R.why = "resident evaluator switched off: " + std::to_string(R.fallbacks) + " requests timed out (" + std::to_string(R.served) +
+            " served) -- its workgroups are not staying on the device (a shared GPU?); requests are launched from now on";
+    ctx->last_error = R.why;
+  }
   fill_sentinel(R.rec_host, (size_t)2 * ctx->g.nloc * kDirectRec);
   if (R.want_cellout) fill_sentinel(ctx->slots[0].cellout_host, (size_t)ctx->g.nloc * kCellOut);
   int rc = ensure_quad_host(ctx, S);
@@ -921,23 +999,34 @@ int launch_slot(nid_ctx *ctx, int slot, const Pose &pose, int want_jac, double d
       S.external_target ? nullptr : reinterpret_cast<unsigned long long *>(S.reduced_host_devptr + kReducedLen);
   EvalParams P{};
   fill_eval_params(ctx, pose, S, delta, target, host_seq, &P);
-  S.direct = S.resident = false;
+  S.direct = S.resident = S.groups = false;
   if (!S.external_target && direct_ok(ctx)) {
     S.direct = true;
     S.direct_jac = want_jac != 0;
     S.direct_delta = delta;
-    if (resident_usable(ctx) && resident_post(ctx, slot, pose, want_jac != 0, false) == NID_OK) {
+    if (ctx->direct_mode != 2 && resident_usable(ctx) && resident_post(ctx, slot, pose, want_jac != 0, false) == NID_OK) {
       S.resident = true;  // no launch at all: the resident kernel has the request
       S.timed = false;
       S.done_slot = slot;
       S.pending = true;
       return NID_OK;
     }
-    rc = ensure_quad_host(ctx, S);
-    if (rc) return rc;
-    P.slot[0].quad = S.quad_host_devptr;
-    P.slot[0].host_quad = 1;
-    S.quad_dirty = true;
+    if (ctx->direct_mode == 2) {  // GROUP-DIRECT: the in-launch tail up to the group sums, those straight to the host
+      rc = ensure_groups_host(ctx, S);
+      if (rc) return rc;
+      P.slot[0].out_reduced = S.groups_host_devptr;
+      P.slot[0].host_seq = nullptr;
+      P.slot[0].host_quad = 3;
+      S.direct = false;
+      S.groups = true;
+      S.groups_dirty = true;
+    } else {
+      rc = ensure_quad_host(ctx, S);
+      if (rc) return rc;
+      P.slot[0].quad = S.quad_host_devptr;
+      P.slot[0].host_quad = 1;
+      S.quad_dirty = true;
+    }
   }
   if (ctx->dbg_enabled) {
     const size_t N = (size_t)ctx->g.rows * ctx->g.cols;
@@ -1443,6 +1532,7 @@ int nid_destroy(nid_ctx *ctx) {
     Slot &S = ctx->slots[s];
     if (S.cellout_host) (void)hipHostFree(S.cellout_host);
     if (S.quad_host) (void)hipHostFree(S.quad_host);
+    if (S.groups_host) (void)hipHostFree(S.groups_host);
     if (S.done) (void)hipEventDestroy(S.done);
     if (S.e0) (void)hipEventDestroy(S.e0);
     if (S.e1) (void)hipEventDestroy(S.e1);
@@ -1934,10 +2024,11 @@ int nid_wait(nid_ctx *ctx, int slot, double *H36, double *b6, double *chi2, int3
   if (S.collected) {
     S.collected = false;
   } else {
-    int rc = S.direct ? wait_direct(ctx, S) : wait_host_seq(ctx, S);
+    int rc = S.direct ? wait_direct(ctx, S) : (S.groups ? wait_groups(ctx, S) : wait_host_seq(ctx, S));
     if (rc) return rc;
   }
   S.direct = false;
+  S.groups = false;
   S.pending = false;
   return nid_unpack_reduced(S.reduced_host, H36, b6, chi2, n_active);
 }
@@ -1955,6 +2046,14 @@ int nid_slot_buffers(nid_ctx *ctx, int slot, void **reduced_dev, void **cellout_
   if (!ctx || slot < 0 || slot >= NID_SLOTS) return NID_ERR_INVALID_ARG;
   if (reduced_dev) *reduced_dev = ctx->slots[slot].reduced_dev;
   if (cellout_dev) *cellout_dev = ctx->slots[slot].cellout_dev;
+  return NID_OK;
+}
+
+int nid_debug_read_device(nid_ctx *ctx, const void *dev, void *host, size_t bytes) {
+  if (!ctx || !dev || !host) return NID_ERR_INVALID_ARG;
+  NID_HIP(ctx, hipSetDevice(ctx->cfg.device));
+  resident_retire(ctx);  // (a blocking copy on the null stream would wait for the resident kernel to leave)
+  NID_HIP(ctx, hipMemcpy(host, dev, bytes, hipMemcpyDeviceToHost));
   return NID_OK;
 }
 
@@ -2036,7 +2135,9 @@ double nid_div_small_host(double x, double d) { return nid::div_small(x, d); }
 int nid_set_direct_results(nid_ctx *ctx, int on) {
   if (!ctx) return NID_ERR_INVALID_ARG;
   for (int s = 0; s < NID_SLOTS; s++) if (ctx->slots[s].pending) return NID_ERR_STATE;
+  if (on < 0 || on > 2) return NID_ERR_INVALID_ARG;
   ctx->direct_results = on != 0;
+  ctx->direct_mode = on;
   return NID_OK;
 }
 
@@ -2052,6 +2153,7 @@ int nid_set_resident(nid_ctx *ctx, int on) {
   int rc = resident_probe(ctx);
   if (rc) { ctx->last_error = "resident evaluator unavailable: " + (ctx->res.why.empty() ? std::string("mailbox setup failed") : ctx->res.why); return rc; }
   ctx->res.enabled = true;
+  ctx->res.fallback_run = 0;  // (asked for again: the back-off of resident_fallback starts over)
   return NID_OK;
 }
 

@@ -103,7 +103,9 @@ struct SlotArgs {
   int host_quad;                   // DIRECT launch (one pose, the host is waiting for it): no in-launch reduction.  1: `quad` is
                                    // mapped pinned host memory, [2][nloc][kDirectRec]: every cell's workgroup writes its two
                                    // records (residual, Jacobian) straight there and the HOST forms and sums the quadratic
-                                   // forms; 2: only the per-cell outputs, to `cellout` (mapped pinned host memory too)
+                                   // forms; 2: only the per-cell outputs, to `cellout` (mapped pinned host memory too);
+                                   // 3: GROUP-DIRECT -- the in-launch tail up to the group sums, which go to `out_reduced` =
+                                   // mapped pinned host memory [ngroups][32] (the host adds the groups up)
 };
 // A cell's records of a DIRECT launch, one 64-byte line each, every line written by ONE store instruction (a line
 // written in two instalments sat in a write combiner for ~30 us):
@@ -611,21 +613,9 @@ constexpr int kFineLevels = 5;
 // What an unflagged or heavier bin loses is bounded by n * 2^-53 * 3 / kLinFlagW resp. n * 2^-53 / kRepairMass per unit of
 // the flagged samples' reference weight: 1e-11 * n.  Cells that need a repair: one in ~45 000 random cases, and cells on
 // the rim of a saturated patch (counted: EvalParams::repair_count, nid_debug_repair_count).
-#ifndef NID_REPAIR
-#define NID_REPAIR 1   // 0: experiment builds without the flags, the detection and the repair pass (tools/build_variant.py)
-#endif
-#ifndef NID_REPAIR_STAGE
-#define NID_REPAIR_STAGE 3   // experiment builds: 1 = the flags only, 2 = + the fold's detection, 3 = + the repair pass
-#endif
 constexpr double kLinFlagW = 0x1p-16;
-#ifndef NID_REPAIR_MASS_EXP
-#define NID_REPAIR_MASS_EXP 12
-#endif
-constexpr double kRepairMass = 1.0 / (double)(1ull << NID_REPAIR_MASS_EXP);
-#ifndef NID_REPAIR_REL_EXP
-#define NID_REPAIR_REL_EXP 12
-#endif
-constexpr double kRepairRel = 1.0 / (double)(1ull << NID_REPAIR_REL_EXP);
+constexpr double kRepairMass = 0x1p-12;
+constexpr double kRepairRel = 0x1p-12;
 __device__ __forceinline__ int fine_level(double w) {
   const int e = __builtin_amdgcn_frexp_exp(w);  // w = m * 2^e, m in [0.5, 1): e <= -8 for w < 2^-8
   const int x = min(max(-8 - e, 0), 119);
@@ -950,11 +940,7 @@ constexpr int kClampCopies = NID_CLAMP_COPIES;
 constexpr double kNearSatIc = 255.0 - 0x1p-45;  // the largest double below 255
 constexpr int kNearSatBinBytes(int nb) { return kClampBins(nb) * (kClampCopies + kFineLevels) * 8; }
 // the two weight tables (tab, term: (nbins + 1) & ~1 doubles each) lend the bins their area when it is large enough
-#ifdef NID_EXP_NEAR_SAT_NO_ALIAS
-__host__ __device__ constexpr bool near_sat_aliased(int) { return false; }
-#else
 __host__ __device__ constexpr bool near_sat_aliased(int nb) { return 16 * ((nb * nb + nb + 1) & ~1) >= kNearSatBinBytes(nb); }
-#endif
 constexpr int kXposeStride(int nt) { return nt + 8; }
 constexpr int kXposeDoubles(int nt) { return (nt <= 256 && NID_XPOSE_SUM) ? 6 * kXposeStride(nt) : 0; }
 constexpr int kQuad = 32;  // per-cell block: rho0 | b[6] | H upper[21] | 1.0 | 0 0 0
@@ -1006,6 +992,14 @@ __device__ __forceinline__ void finish_and_reduce_w0(const EvalParams &P, const 
   }
   if (__builtin_amdgcn_readfirstlane(last) == 0u) return;
   double r = sum_blocks_w0(SA.quad + (size_t)gq * gs * kQuad, gcount, lane);
+  if (SA.host_quad == 3) {
+    // GROUP-DIRECT: the group's sum straight to its 256-byte block in pinned host memory (out_reduced: [ngroups][32]);
+    // the host adds the groups up (wait_groups in nid_capi.hip).  No second ticket, no fence, no sequence word: every
+    // word is polled against a sentinel.
+    if (lane < 32) store_sys(SA.out_reduced + (size_t)gq * kQuad + lane, r);
+    if (lane == 0) __hip_atomic_store(SA.ticket + 1 + gq, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return;
+  }
   // level 1: publish the group sum, take the top ticket
   if (lane < 32) store_sc1(SA.gpart + (size_t)gq * kQuad + lane, r);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1056,28 +1050,14 @@ __device__ __forceinline__ void finish_and_reduce_w0(const EvalParams &P, const 
 // 254.9999]; 32-bit literals in the instruction instead of two f64 constants in scalar registers)
 constexpr unsigned kGuardLoHi = 0x3F1A36E3u;                  // high dword of 1e-4, plus one
 constexpr unsigned kGuardSpanHi = 0x406FDFFEu - kGuardLoHi;    // ... up to the high dword of 254.9999, minus one
-#ifndef NID_DIET_GUARD
-#define NID_DIET_GUARD 1
-#endif
-#ifndef NID_DIET_TINY
-#define NID_DIET_TINY 1
-#endif
 __device__ __forceinline__ bool outside_clamp_guard(double ic) {
-#if NID_DIET_GUARD
   return (unsigned)__double2hiint(ic) - kGuardLoHi > kGuardSpanHi;
-#else
-  return fabs(ic - 127.5) > 127.4999;
-#endif
 }
 constexpr unsigned kBorderEpsHi = 0x3EB00000u;                  // high dword of kBorderEps = 2^-20
 // A sample the FAST main passes take lies inside the clamp guard: 1e-4 <= ic <= 254.9999, so the clamp ic >= 255 and
 // the u == 0 quirk of the B-spline derivative (pc == 0) cannot apply to it; only the second passes (exact_decisions)
-// carry those selects.  (The NID_EXP_NO_GUARD experiment build has no guard and keeps them everywhere.)
-#ifdef NID_EXP_NO_GUARD
-constexpr bool kMainPassClamps = true;
-#else
+// carry those selects.
 constexpr bool kMainPassClamps = false;
-#endif
 constexpr double kBorderEps = 0x1p-20;  // FAST u, v are within ~1e-12 of the reference's (|u| < 2^11): a wide margin
 struct PixelFront {
   bool in, jin;
@@ -1233,23 +1213,11 @@ __device__ __forceinline__ void pixel_front(const EvalParams &P, const SlotArgs 
     // The window origin is NOT clamped: ((int)u - 1, (int)v - 1) may be -1 (the image buffer has zeroed
     // margins), so the fixed-tap sample applies to every in-frame pixel.
     // (plain `&`: five compares in a row; `&&` makes the compiler branch around the later ones)
-#ifndef NID_DIET_BORDER
-#define NID_DIET_BORDER 1
-#endif
-#if NID_DIET_BORDER == 1 || NID_DIET_BORDER == 2
     const unsigned hu = (unsigned)__double2hiint(u) - P.hu_lo, hv = (unsigned)__double2hiint(v) - P.hu_lo;
     const bool in = (f.jr >= 0) & (hu <= P.hu_span) & (hv <= P.hv_span);
     f.in = in;
     f.jin = in && (hu <= P.hj_span);
-#else
-    const bool in = (f.jr >= 0) & (u >= kBorderEps) & (u <= (double)g.cols - 3.0 - kBorderEps) & (v >= kBorderEps) & (v <= (double)g.rows - 3.0 - kBorderEps);
-    f.in = in;
-    f.jin = in && (u <= (double)P.jac_cols - 3.0 - kBorderEps);
-#endif
     f.redo = (f.jr >= 0) && !f.jin;
-#ifdef NID_EXP_NO_REDO
-    f.redo = false;
-#endif
     f.w.wx = in ? (int)u - 1 : 0;
     f.w.wy = in ? (int)v - 1 : 0;
   }
@@ -1261,14 +1229,6 @@ __device__ __forceinline__ bool classify_redo(const EvalParams &P, PixelFront &f
   // (conservative integer forms of u < -eps, u > cols-3+eps, ...: the upper bounds from the ranges' ends -- the high
   // dword of cols-3+eps is at most one above that of cols-3-eps --, so that no further scalar registers are needed;
   // a NaN is "clearly out" like in the reference, whose comparisons all fail)
-#if NID_DIET_BORDER == 0 || NID_DIET_BORDER == 2
-  {
-    const double u = f.u, v = f.v;
-    if (u < -kBorderEps || v < -kBorderEps || u > (double)P.g.cols - 3.0 + kBorderEps || v > (double)P.g.rows - 3.0 + kBorderEps) { f.in = false; f.jin = false; return false; }
-    if (f.in && u > (double)P.jac_cols - 3.0 + kBorderEps) { f.jin = false; return false; }
-    return true;
-  }
-#endif
   const int hu = __double2hiint(f.u), hv = __double2hiint(f.v);
   const unsigned neg_out = 0x80000000u + kBorderEpsHi;  // below -eps' (the sign bit set, magnitude beyond the band)
   const int u_top = (int)(P.hu_lo + P.hu_span + 2u), v_top = (int)(P.hu_lo + P.hv_span + 2u), j_top = (int)(P.hu_lo + P.hj_span + 2u);
@@ -1330,21 +1290,13 @@ __device__ __forceinline__ void exact_decisions(const EvalParams &P, const SlotA
   if (in) {
     // the whole window around the REFERENCE's (u, v) -- which may truncate to the pixel next to FAST's
     f.w.wx = (int)u - 1; f.w.wy = (int)v - 1;
-#ifdef NID_EXP_SECOND_NO_WINDOW
-    f.w.r0 = f.w.r1 = f.w.r2 = f.w.r3 = make_uint2(0x00ff00ffu, 0x00ff00ffu);
-#else
     load_window(P, f.w);
-#endif
     ic = bilinear_rows(win_rows(f.w, v), f.w.wx, u);
     if (ic < 0) ic = 0.0;                              // :574-575
     // linearizeOplus' own projection fx*(x/z)+cx (:407-422, Q6) differs from u by a rounding: it can decide a border
     // test differently only within an ulp of the border -- two more divisions, taken only by samples that close
     double uj = u, vj = v;
-#ifdef NID_EXP_NO_NEARJ
-    if (true ||
-#else
     if (
-#endif
         fabs(u) < kBorderEps || fabs(v) < kBorderEps || fabs(u + 3 - (double)P.jac_cols) < kBorderEps || fabs(v + 3 - (double)g.rows) < kBorderEps) {
       uj = g.fx * (qx / qz) + g.cx;
       vj = g.fy * (qy / qz) + g.cy;
@@ -1507,15 +1459,11 @@ __device__ __forceinline__ void eval_cell(const EvalParams &P, const SlotArgs &S
 
   // DIRECT launches are launches of ONE pose: the kernels for more than kMaxBatch poses (EXT: the throughput path) are
   // compiled without that code (five registers of the hot kernel)
-  const bool direct_launch = !EXT && SA.host_quad != 0;
+  const bool direct_launch = !EXT && (unsigned)(SA.host_quad - 1) < 2u;  // (3: GROUP-DIRECT keeps the in-launch tail, see finish_and_reduce_w0)
   const int n_c = RES ? rc.n_c : P.Nc[cl];
   const double href = RES ? rc.href : P.Href[cl];
   double *out = SA.cellout + (size_t)cl * kCellOut;
-#ifdef NID_EXP_ALWAYS_CELLOUT
-  const bool want_cellout = true;
-#else
   const bool want_cellout = SA.cellout != nullptr;  // (the pipelined loops hand over none: ten stores per cell and pose nobody reads)
-#endif
   double *quad = SA.quad + (size_t)cl * kQuad;
   if (n_c < 300 || isnan(href)) {  // level-1 edge: never evaluated (computeH.cu:271-275)
     if (tid >= 64) return;
@@ -1606,9 +1554,6 @@ __device__ __forceinline__ void eval_cell(const EvalParams &P, const SlotArgs &S
       if (REPAIR) return;  // (their sums are exact relative to themselves: coarse copies for weights >= 2^-8 only)
       unsigned long long *hx = (group == 2 ? nsb : clampb) + ((unsigned)copy & (kClampCopies - 1));
       unsigned long long *hlo = group == 2 ? ns_lo : clamp_lo;
-#ifdef NID_EXP_CLAMP_COUNT_PER_LANE
-      atomicAdd(hx + nb * kClampCopies, fx_bits(P.hist_dn * kWcPre));
-#else
       {
         // the count: every lane of the wave in this group would add the same number to the same bin -- one lane adds the lot
         const unsigned long long in2 = __builtin_amdgcn_ballot_w64(group == 2);
@@ -1616,7 +1561,6 @@ __device__ __forceinline__ void eval_cell(const EvalParams &P, const SlotArgs &S
         if ((unsigned)__builtin_ctzll(act) == (unsigned)(tid & 63))
           atomicAdd(hx + nb * kClampCopies, (unsigned long long)__builtin_popcountll(act) * fx_bits(P.hist_dn * kWcPre));
       }
-#endif
 #pragma unroll
       for (int m = 0; m < 4; m++) {
         const double w = m == 0 ? fabs(wr_in[0]) : wr_in[m];
@@ -1662,7 +1606,7 @@ __device__ __forceinline__ void eval_cell(const EvalParams &P, const SlotArgs &S
     // NORMAL mode, rare branches: a LINEAR end-span weight below kLinFlagW flags the bins it lands in (kLinFlagW)
     auto flag_linear = [&](int k, double w, const double (&wrm)[4]) {
       const bool last = k == 2 && jc == S - 1;
-      if (NID_REPAIR && w < kLinFlagW && ((k == 1 && jc == 0) || last)) {
+      if (w < kLinFlagW && ((k == 1 && jc == 0) || last)) {
         unsigned bits = 1u << 16;
 #pragma unroll
         for (int m = 0; m < 4; m++) bits |= (wrm[m] * w > kNegligibleW) ? (1u << (jr + m)) : 0u;
@@ -1689,9 +1633,6 @@ __device__ __forceinline__ void eval_cell(const EvalParams &P, const SlotArgs &S
 #endif
       atomicAdd(hist_lo + idx, val);
     };
-#ifdef NID_EXP_NO_LO
-    wr[0] = fabs(wr[0]);
-#else
     // Rare: the TARGET sample sits next to a knot (also: clamped saturated, black, integer-position samples) -- its
     // small weights, and their products with the reference weights, go to the fine level of their own exponent --
     // or the REFERENCE sample does with NON-ZERO tiny weights (a saturated reference pixel: I0 = 255 -> 254.999 has
@@ -1704,11 +1645,7 @@ __device__ __forceinline__ void eval_cell(const EvalParams &P, const SlotArgs &S
     // first stored weight (min(wr[0], wr[3]) < kTinyW and != 0 <=> wr_in[0] < 0): one compare here instead of
     // five instructions per sample; |wr_in[0]| is a free source modifier of the products below
     const bool ref_tiny = wr_in[0] < 0.0;
-#if NID_DIET_TINY
     if (min(__double2hiint(wcs[0]), __double2hiint(wcs[3])) < tiny_scaled_hi || ref_tiny) {
-#else
-    if (fmin(wcs[0], wcs[3]) < kTinyW * kWcPre || ref_tiny) {
-#endif
       double wc[4];
       if (!STRICT && PRESCALED) {
         // FAST: the weights once more, each with an error relative to ITSELF (bspline4_vals_both_ends; the same values
@@ -1776,7 +1713,6 @@ __device__ __forceinline__ void eval_cell(const EvalParams &P, const SlotArgs &S
       }
       return;
     }
-#endif
     if constexpr (REPAIR) {  // an ordinary sample: all twenty addends went to the coarse copies
 #pragma unroll
       for (int k = 0; k < 4; k++) {
@@ -1830,11 +1766,7 @@ __device__ __forceinline__ void eval_cell(const EvalParams &P, const SlotArgs &S
   // lanes, taken once after the loop (instead of a ballot and six scalar instructions per round).
   unsigned raremask = 0u;
   (void)raremask;
-#ifdef NID_EXP_NO_GUARD
-  constexpr bool use_lane_masks = false;
-#else
   constexpr bool use_lane_masks = !STRICT && LAT == 0 && !DBG && !BIG;
-#endif
   constexpr bool use_gomask = JAC && use_lane_masks;
   LatPix lat[LAT > 0 ? LAT : 1];  // LAT + JAC: the cost phase's hand-over to the Jacobian phase
   (void)lat;
@@ -2097,15 +2029,15 @@ __device__ __forceinline__ void eval_cell(const EvalParams &P, const SlotArgs &S
       // the groups' LINEAR end-span weight (last span, column nb - 2; the near-saturated samples': 3 ulps of S) flags the
       // bins it lands in like a sample of the rare branches does (flag_linear in hist_add; e == nb: the marginal bin)
       const double wlin = ns ? nw[2] : cw[2];
-      if (NID_REPAIR && sum != 0.0 && wlin < kLinFlagW && wlin > kNegligibleW && (ns ? jc_ns : jc_cl) == S - 1)
+      if (sum != 0.0 && wlin < kLinFlagW && wlin > kNegligibleW && (ns ? jc_ns : jc_cl) == S - 1)
         atomicOr(grp_flag, e < nb ? (1u << e) : (1u << 16));
     }
     __syncthreads();
     flagw = *reinterpret_cast<const uint4 *>(clamp_flag);
-    grp_colz = (NID_REPAIR && NID_REPAIR_STAGE >= 2) ? (unsigned)__builtin_amdgcn_readfirstlane((int)*grp_flag) : 0u;
+    grp_colz = (unsigned)__builtin_amdgcn_readfirstlane((int)*grp_flag);
   }
-  const unsigned lin_col1 = (NID_REPAIR && NID_REPAIR_STAGE >= 2) ? (unsigned)__builtin_amdgcn_readfirstlane((int)flagw.z) : 0u;
-  const unsigned lin_colz = (NID_REPAIR && NID_REPAIR_STAGE >= 2) ? (unsigned)__builtin_amdgcn_readfirstlane((int)flagw.w) : 0u;
+  const unsigned lin_col1 = (unsigned)__builtin_amdgcn_readfirstlane((int)flagw.z);
+  const unsigned lin_colz = (unsigned)__builtin_amdgcn_readfirstlane((int)flagw.w);
   // One bin: its mass from the copies (COARSE = false: without them, after a repair), the fine levels and the two
   // groups; p = mass / N_c, W = -(1 + log2 p), p log2 p into the tables.  Returns the copies' integer sum.
   auto fold_bin = [&](int b, auto coarse_tag, double &mass_out) -> unsigned long long {
@@ -2199,7 +2131,7 @@ __device__ __forceinline__ void eval_cell(const EvalParams &P, const SlotArgs &S
   // tables as they are and its TAIL looks at repair_set (deferred_to_repair): a cell with a bin to repair publishes
   // nothing and is queued for k_repair.
   auto repair_wanted = [&]() -> bool {  // (the fold's verdict, from LDS: wave-uniform)
-    if constexpr (REPAIR_INLINE || !NID_REPAIR || NID_REPAIR_STAGE < 3) {
+    if constexpr (REPAIR_INLINE) {
       return false;
     } else {
       const uint2 rs = *reinterpret_cast<const uint2 *>(repair_set);
@@ -2210,7 +2142,7 @@ __device__ __forceinline__ void eval_cell(const EvalParams &P, const SlotArgs &S
     }
   };
   auto deferred_to_repair = [&]() -> bool {  // wave 0, in a tail
-    if constexpr (REPAIR_INLINE || !NID_REPAIR || NID_REPAIR_STAGE < 3) {
+    if constexpr (REPAIR_INLINE) {
       return false;
     } else {
       if (__builtin_expect(!repair_wanted(), 1)) return false;
@@ -2231,7 +2163,7 @@ __device__ __forceinline__ void eval_cell(const EvalParams &P, const SlotArgs &S
     rep_colz = (unsigned)__builtin_amdgcn_readfirstlane((int)rs.y);
     rep_col1 = (rep_col1 >> 31) ? (rep_col1 & 0x1FFFFu) : 0u;
     rep_colz = (rep_colz >> 31) ? (rep_colz & 0x1FFFFu) : 0u;
-    if (NID_REPAIR_STAGE >= 3 && __builtin_expect((rep_col1 | rep_colz) != 0u, 0)) {
+    if (__builtin_expect((rep_col1 | rep_colz) != 0u, 0)) {
       // REPAIR (see kLinFlagW): the pixel loops once more; what they sent to the coarse copies of a bin in the repair
       // set goes to its fine levels now, and the bin is folded again without the copies.  Same lane -> sample
       // assignment, integer adds: run-to-run reproducible like everything else.
@@ -2513,11 +2445,7 @@ __device__ __forceinline__ void eval_cell(const EvalParams &P, const SlotArgs &S
       f.wr[0] = fabs(f.wr[0]);  // the sign of the first reference weight is k_href's knot flag (hist_add)
       double ic, gx, gy;
       gradient_fast_j(wj, f.u, f.v, gx, gy, ic);  // every lane, see the cost phase
-#ifdef NID_EXP_NO_GUARD
-      bool exact = false;
-#else
       bool exact = f.in && outside_clamp_guard(ic);
-#endif
       if (f.redo && classify_redo(P, f)) exact = true;
       bool go = f.jin && !exact;
       if (SECOND) {
@@ -2526,7 +2454,6 @@ __device__ __forceinline__ void eval_cell(const EvalParams &P, const SlotArgs &S
         // samples of a flash pair) has the gradient (0, 0): whatever the exact decisions say, it adds exact zeros to
         // the six sums -- skipped.  (Only if the reference's window is this window: (u, v) away from integer
         // coordinates by more than FAST arithmetic's error, or its truncation could pick the neighbouring pixel.)
-#ifndef NID_EXP_NO_FLAT
         // (... and only if `wj` IS the sample's window: a sample the FAST front does not place in the frame -- within
         // the border band, which the integer range checks make 2^-11 px wide -- has the window of pixel (0, 0) in `wj`;
         // taken for the sample's, a flat image corner silently dropped such samples' contributions: up to 12 % of a
@@ -2537,7 +2464,6 @@ __device__ __forceinline__ void eval_cell(const EvalParams &P, const SlotArgs &S
           const double fu = f.u - floor(f.u), fv = f.v - floor(f.v);
           if (flat && fu > kBorderEps && fu < 1.0 - kBorderEps && fv > kBorderEps && fv < 1.0 - kBorderEps) exact = false;
         }
-#endif
         if (exact) {
           exact_decisions<EXT>(P, SA, pose_idx, tin, f, ic);
           go = f.jin;
@@ -2621,9 +2547,6 @@ __device__ __forceinline__ void eval_cell(const EvalParams &P, const SlotArgs &S
           if (jac_round(sb, r, prej, prej, std::false_type{})) rare2 |= 1ull << min(r, 63);
       }
     }
-#ifdef NID_EXP_DROP_RARE_JAC
-    rare2 = 0ull;
-#endif
     if (rare2 != 0ull) {
       r = 0;
 #pragma clang loop unroll(disable)

@@ -174,7 +174,8 @@ static double bilinear_u8(const unsigned char *im, int cols, double x, double y)
  * ROUNDING NOISE the twin returns another rounding of the same quantity: a constant or saturated patch, where the
  * four-term form returns the constant +- an ulp and its central differences are 1e-14-level noise; a lone sample whose
  * constant intensity sits on a knot of the B-spline, where that ulp decides between an exactly symmetric (zero)
- * derivative and 1e-13.  |J(oracle) - J(twin)| per cell is the measured width of the reference's own Jacobian; tests
+ * derivative and 1e-13.  The centre sample is also taken one ulp up in u and v (the reference's u is itself a few
+ * roundings away from the exact projection).  |J(oracle) - J(twin)| per cell is the measured width of the reference's own Jacobian; tests
  * allow for it instead of a chosen floor (tests/test_parity_gpu.py).  The reference's DECISIONS are not re-rounded: a
  * centre sample keeps the reference's value when either form puts it at a clamp (ic >= 255 -> 254.999, ic < 0 -> 0,
  * :572-575), so the histograms' discontinuities -- which the HIP path reproduces exactly -- stay where they are and
@@ -568,7 +569,13 @@ static void cell_compute_h(nid_oracle *o, const xform_t *xf, int ci, int cj) {
         o->ic[id] = bilinear_u8(o->im1, o->cols, u, v);
 #ifdef NID_ORACLE_TWIN
         {
-          double il = bilinear_grad(o->im1, o->cols, u, v);
+          /* ... one ulp up in u and v (the reference's own u carries a few ulps of rounding from the pose transform
+           * and the division; its two functions even associate the projection differently, Q6), as long as that names
+           * the same pixel: the centre sample's sensitivity to the last bit of its position -- a sample on a steep edge
+           * just below the 255 clamp moves its end-span weight, and a cell that hangs on it, by 1e-9 of itself */
+          double u2 = nextafter(u, INFINITY), v2 = nextafter(v, INFINITY);
+          if ((int)u2 != (int)u || (int)v2 != (int)v) { u2 = u; v2 = v; }
+          double il = bilinear_grad(o->im1, o->cols, u2, v2);
           if (o->ic[id] < 255 && o->ic[id] >= 0 && il < 255 && il >= 0) o->ic[id] = il;
         }
 #endif

@@ -19,9 +19,12 @@ RTOL_J = 1e-9
 # Each cell's Jacobian is held to RTOL_J relative to ITS OWN largest component, whatever its size against
 # the rest of the frame.  What is allowed on top of that is the REFERENCE'S OWN NOISE, measured, not a chosen floor:
 # N(cell) = |J_o - J_twin|, the twin being the same oracle source built with the pixels of a cell visited in the
-# opposite order and every bilinear sample in the two-lerp association (oracle/Makefile: libnid_oracle_twin.so; a
-# sample at a clamp keeps the reference's value, so saturated cells get no allowance): the reference's arithmetic,
-# every sum and every image sample rounded differently.  The
+# opposite order, every bilinear sample in the two-lerp association and the centre sample taken one ulp up in u and v
+# (oracle/Makefile: libnid_oracle_twin.so; a sample at a clamp keeps the reference's value, so saturated cells get no
+# allowance): the reference's arithmetic, every sum, every image sample and the last bit of every position rounded
+# differently.  (The last bit of u: FAST math's u, v are within two ulps of the reference's -- x * (1/z) instead of
+# x / z --; a cell whose Jacobian hangs on ONE sample of a steep edge just below the 255 clamp moves by 1.5e-9 of itself
+# per ulp of that sample's u: sweep seed 511576, profiles/r04_parity_sweeps.txt.)  The
 # reference's four-term bilinear form returns a constant image's value +- an ulp, its central differences are then
 # 1e-14-level noise, and the Jacobian of a constant or fully saturated cell is that noise times the cell's weights
 # (1e-13 .. 1e-12).  A cell passes if |J - J_o| <= RTOL_J * max|J_o(cell)| + NOISE_K * N(cell) + J_EPS * frame scale;
@@ -794,6 +797,14 @@ SWEEP_SEEDS += [407031]
 # 4's integer range checks, which is what made it show); a flat image corner then dropped such samples.  The shortcut now
 # requires the window to be the sample's.
 SWEEP_SEEDS += [502812, 503912, 500953]
+# Round 4's sweeps, second pass (1 of 7 600): 511576, pose 2, cell 7, FAST only -- 1.53e-9 of the cell's scale.  No
+# histogram quantum and no decision: ONE sample of a steep edge at ic = 254.9947 (last span, 1.9e-4 below its end; its
+# linear end-span weight 5.6e-4 is most of two joint bins' mass) whose u FAST math has one ulp (2.8e-14) away from the
+# reference's: times the edge's gradient 3.8e-12 in ic, 7.2e-10 of that weight, 1.5e-9 of the cell's Jacobian -- which
+# is also what the REFERENCE's Jacobian of that cell does when its own u moves by one ulp (1.49e-9: the twin oracle now
+# takes the centre sample one ulp up in u, v; the other 15 cells of the frame move by 1e-14).  STRICT math has the
+# reference's u to the bit (3e-14).  Passes on the measured-noise term, listed in the summary.
+SWEEP_SEEDS += [511576]
 
 
 @pytest.mark.gpu
@@ -1064,6 +1075,25 @@ def test_direct_results_equal_in_launch_reduction(capi, synth, pair_S_edge, cfg,
             blocks, _ = ctx.run_chain(poses, DELTA, want_jac=want_jac)
             for blk, r in zip(blocks, ref):
                 assert _same_bits(blk[0], r[2]) and blk[28] == r[3]
+            # GROUP-DIRECT (mode 2): Huber, quadratic forms and the groups' sums on the device, the <= 32 group blocks
+            # added by the host -- the same bits again, repeatedly, with a batch in between
+            ctx.set_direct_results(2)
+            for rep in range(2):
+                for p, r in zip(poses, ref):
+                    got = ctx.normal_equations(p, DELTA, want_jac=want_jac)
+                    assert _same_bits(got[0], r[0]) and _same_bits(got[1], r[1])
+                    assert _same_bits(got[2], r[2]) and got[3] == r[3]
+                    ctx.launch(5, p, DELTA, want_jac=want_jac)
+                    ctx.launch_batch(16, poses, DELTA, want_jac=want_jac)
+                    g5 = ctx.wait(5)
+                    assert _same_bits(g5[0], r[0]) and _same_bits(g5[1], r[1]) and _same_bits(g5[2], r[2]) and g5[3] == r[3]
+                    for k, rk in enumerate(ref):
+                        gk = ctx.wait(16 + k)
+                        assert _same_bits(gk[0], rk[0]) and _same_bits(gk[2], rk[2])
+            blocks, _ = ctx.run_chain(poses, DELTA, want_jac=want_jac)
+            for blk, r in zip(blocks, ref):
+                assert _same_bits(blk[0], r[2]) and blk[28] == r[3]
+            ctx.set_direct_results(True)
             # timed launches are re-issued into the same buffers before the host looks: never DIRECT, and they leave
             # nothing behind for the next DIRECT launch of the slot to mistake for its own records
             ctx.time_launches(np.stack(poses[:1]), DELTA, repeats=3, want_jac=want_jac)
@@ -1097,6 +1127,75 @@ def test_resident_evaluator_needs_one_workgroup_per_cell_on_the_chip(capi, synth
     got = ctx.normal_equations(poses[0], DELTA)
     assert _same_bits(got[2], ref[0][2])
     ctx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("direct", [True, False])
+def test_slot_device_blocks_after_a_plain_launch(capi, synth, direct):
+    """nid_slot_buffers: a LAUNCHED single-pose evaluation leaves the slot's per-cell block in device memory -- DIRECT
+    results or the in-launch reduction, cost + Jacobian and cost only, level-1 edges (never evaluated) as NaN; the
+    slot's reduced block is written when the caller names it as the target (nid_c.h says who writes what)."""
+    pair = synth.make_pair("S", edge_cases=True)
+    nb = 8
+    ctx = capi.from_pair(pair, nb)
+    cnt, _ = ctx.compute_href(pair.pose_init)
+    ctx.set_direct_results(direct)
+    ncell = cnt.size
+    for k, pose in enumerate(_poses(synth, pair).values()):
+        cells = ctx.evaluate(pose, True)                  # (Hc, Hj, err, J) per cell, the blocking per-cell call
+        for want_jac in (True, False):
+            slot = 2 + (k & 1)
+            ctx.launch(slot, pose, DELTA, want_jac=want_jac)
+            H, b, chi2, na = ctx.wait(slot)
+            red_dev, cell_dev = ctx.slot_buffers(slot)
+            blk = ctx.read_device(cell_dev, (ncell, 10))
+            assert np.array_equal(blk[:, 9], cnt.astype(float))
+            for c in range(3):
+                assert _same_bits(blk[:, c], cells[c])
+            if want_jac:
+                assert _same_bits(blk[:, 3:9], cells[3])
+            # ... and the reduced block, when the caller names the slot's device block as the target (nid_launch_to)
+            ctx.launch(slot, pose, DELTA, want_jac=want_jac, reduced_dev=red_dev)
+            ctx.wait(slot)
+            red = ctx.read_device(red_dev, (32,))
+            assert red[0] == chi2 and red[28] == na and (not want_jac or _same_bits(red[1:7], b))
+    ctx.close()
+
+
+@pytest.mark.gpu
+def test_resident_evaluator_one_kernel_per_device(capi, synth):
+    """One resident kernel per device and process (its workgroups hold most of every CU: a second one would not be
+    scheduled beside it): while context a's kernel is on the device, context b's requests are ordinary launches --
+    same bits, no time-outs --, and the place changes hands on pause / destroy."""
+    pair = synth.make_pair("S")
+    nb = 8
+    pose = list(_poses(synth, pair).values())[1]
+    a, b = capi.from_pair(pair, nb), capi.from_pair(pair, nb)
+    for c in (a, b):
+        c.compute_href(pair.pose_init)
+        c.set_launch_shape(512, 0)
+    ref = a.normal_equations(pose, DELTA)
+
+    def same(got):
+        return _same_bits(got[0], ref[0]) and _same_bits(got[1], ref[1]) and _same_bits(got[2], ref[2]) and got[3] == ref[3]
+
+    a.set_resident(True)
+    b.set_resident(True)
+    assert same(a.normal_equations(pose, DELTA))      # a's kernel starts and answers
+    assert same(b.normal_equations(pose, DELTA))      # a holds the device: b launches
+    sa, sb = a.resident_stats(), b.resident_stats()
+    assert sa["served"] == 1 and sa["starts"] == 1
+    assert sb == dict(served=0, fallbacks=0, starts=0)
+    a.resident_pause()                                 # a steps aside: the next request of either context takes the place
+    assert same(b.normal_equations(pose, DELTA))
+    assert same(a.normal_equations(pose, DELTA))      # now b holds it
+    sa, sb = a.resident_stats(), b.resident_stats()
+    assert sb["served"] == 1 and sb["starts"] == 1 and sb["fallbacks"] == 0
+    assert sa["served"] == 1 and sa["starts"] == 1 and sa["fallbacks"] == 0
+    b.close()                                          # destroy retires b's kernel
+    assert same(a.normal_equations(pose, DELTA))
+    assert a.resident_stats()["served"] == 2 and a.resident_stats()["starts"] == 2
+    a.close()
 
 
 @pytest.mark.gpu

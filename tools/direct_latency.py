@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """tools/direct_latency.py [A|B] [bins]: the dependent evaluation (one pose per launch, result awaited on the host before
 the next launch: what a Gauss-Newton / LM loop does) with DIRECT results (every cell's block straight to pinned host
-memory, summed by the host) against the in-launch two-level reduction, per workgroup shape; us per evaluation."""
+memory, summed by the host), GROUP-DIRECT results (the groups' sums formed on the device, added up by the host) and the
+in-launch two-level reduction, per workgroup shape; us per evaluation."""
 import importlib, os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -18,7 +19,7 @@ ctx.compute_href(pair.pose_init)
 seq = poses[np.arange(4000) % 16]
 ctx.run_sequence(seq, delta, batch=16, collect=False)   # clocks up
 print(f"config {cfg}, {bins} bins, {pair.cell ** 2} cells: us per dependent evaluation (nid_run_chain, best of 5 runs of 2000)")
-print("threads | J in-launch | J direct | J resident | cost in-launch | cost direct | cost resident | evaluate() in-launch | direct | resident (python loop)")
+print("threads | J in-launch | J group-direct | J direct | J resident | cost in-launch | cost group-direct | cost direct | cost resident | evaluate() in-launch | direct | resident (python loop)")
 resident_why = ""
 
 
@@ -36,7 +37,7 @@ for nt in (128, 256, 512, 1024):
     row = []
     modes = ((False, False), (True, False), (True, True))   # (direct, resident)
     for jac in (True, False):
-        for direct, resident in modes:
+        for direct, resident in ((0, False), (2, False), (1, False), (1, True)):
             ctx.set_direct_results(direct)
             set_resident(resident and nt >= 512)
             ctx.run_chain(seq[:200], delta, want_jac=jac, collect=False)
@@ -50,5 +51,5 @@ for nt in (128, 256, 512, 1024):
             ctx.evaluate(poses[i % 16], True)
         ev.append((time.perf_counter() - t0) / 300 * 1e6)
     ctx.set_resident(False)
-    print(f"{nt:7d} | {row[0]:11.1f} | {row[1]:8.1f} | {row[2]:10.1f} | {row[3]:14.1f} | {row[4]:11.1f} | {row[5]:13.1f} | {ev[0]:20.1f} | {ev[1]:6.1f} | {ev[2]:8.1f}")
+    print(f"{nt:7d} | {row[0]:11.1f} | {row[1]:14.1f} | {row[2]:8.1f} | {row[3]:10.1f} | {row[4]:14.1f} | {row[5]:17.1f} | {row[6]:11.1f} | {row[7]:13.1f} | {ev[0]:20.1f} | {ev[1]:6.1f} | {ev[2]:8.1f}")
 print("resident evaluator:", ctx.resident_stats(), resident_why)
