@@ -115,6 +115,7 @@ struct nid_ctx {
   // compute_href's per-pixel outputs in image order (k_untile_bs) and their pinned staging, created on first use
   double *bsv_img_dev = nullptr, *bsv_stage = nullptr;
   int *bsi_img_dev = nullptr, *bsi_stage = nullptr;
+  hipEvent_t bs_part_done[4] = {nullptr, nullptr, nullptr, nullptr};  // (kBsParts)
   unsigned long long *repair_count_dev = nullptr;  // EvalParams::repair_count (nid_debug_repair_count)
   unsigned *repair_queue_dev[2] = {nullptr, nullptr};  // EvalParams::repair_queue of launches on `stream` / on aux_stream (k_repair)
   bool dbg_enabled = false;
@@ -1253,6 +1254,8 @@ int evaluate_common(nid_ctx *ctx, const Pose &pose, int want_jac, double *Ht, do
   return NID_OK;
 }
 
+constexpr int kBsParts = 4;
+
 int href_common(nid_ctx *ctx, const Pose &pose, int32_t *bs_counter, double *Href, double *bs_value,
                 int32_t *bs_index) {
   if (!ctx) return NID_ERR_INVALID_ARG;
@@ -1291,10 +1294,31 @@ int href_common(nid_ctx *ctx, const Pose &pose, int32_t *bs_counter, double *Hre
     hipLaunchKernelGGL(k_untile_bs, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, g, ctx->t,
                        bs_value ? ctx->bsv_img_dev : nullptr, bs_index ? ctx->bsi_img_dev : nullptr);
     NID_HIP(ctx, hipGetLastError());
+    const bool whole = g.cell_stride == 1 && g.nloc == g.cell_num * g.cell_num && g.rb * g.cell_num == g.rows && g.cb * g.cell_num == g.cols;
+    if (whole && bs_value) {
+      // bs_value (9.8 MB at 640x480) comes home in kBsParts pieces, each copied out to the caller while the next is
+      // still crossing PCIe (the copy-out is as long as the transfer: one after the other they were 0.5 ms)
+      for (int p = 0; p < kBsParts; p++) if (!ctx->bs_part_done[p]) NID_HIP(ctx, hipEventCreateWithFlags(&ctx->bs_part_done[p], hipEventDisableTiming));
+      const size_t part = ((4 * N / kBsParts) + 7) & ~(size_t)7;
+      for (int p = 0; p < kBsParts; p++) {
+        const size_t lo = std::min(4 * N, part * p), hi = p == kBsParts - 1 ? 4 * N : std::min(4 * N, part * (p + 1));
+        if (hi > lo) NID_HIP(ctx, hipMemcpyAsync(ctx->bsv_stage + lo, ctx->bsv_img_dev + lo, (hi - lo) * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        NID_HIP(ctx, hipEventRecord(ctx->bs_part_done[p], ctx->stream));
+      }
+      if (bs_index) NID_HIP(ctx, hipMemcpyAsync(ctx->bsi_stage, ctx->bsi_img_dev, N * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+      for (int p = 0; p < kBsParts; p++) {
+        const size_t lo = std::min(4 * N, part * p), hi = p == kBsParts - 1 ? 4 * N : std::min(4 * N, part * (p + 1));
+        NID_HIP(ctx, hipEventSynchronize(ctx->bs_part_done[p]));
+        if (hi > lo) std::memcpy(bs_value + lo, ctx->bsv_stage + lo, (hi - lo) * sizeof(double));
+      }
+      NID_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      if (bs_index) std::memcpy(bs_index, ctx->bsi_stage, N * sizeof(int));
+      ctx->have_href = true;
+      return NID_OK;
+    }
     if (bs_value) NID_HIP(ctx, hipMemcpyAsync(ctx->bsv_stage, ctx->bsv_img_dev, 4 * N * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     if (bs_index) NID_HIP(ctx, hipMemcpyAsync(ctx->bsi_stage, ctx->bsi_img_dev, N * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     NID_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    const bool whole = g.cell_stride == 1 && g.nloc == g.cell_num * g.cell_num && g.rb * g.cell_num == g.rows && g.cb * g.cell_num == g.cols;
     if (whole) {
       if (bs_value) std::memcpy(bs_value, ctx->bsv_stage, 4 * N * sizeof(double));
       if (bs_index) std::memcpy(bs_index, ctx->bsi_stage, N * sizeof(int));
@@ -1515,6 +1539,7 @@ int nid_destroy(nid_ctx *ctx) {
   (void)hipFree(ctx->bsv_img_dev); (void)hipFree(ctx->bsi_img_dev);
   if (ctx->bsv_stage) (void)hipHostFree(ctx->bsv_stage);
   if (ctx->bsi_stage) (void)hipHostFree(ctx->bsi_stage);
+  for (hipEvent_t e : ctx->bs_part_done) if (e) (void)hipEventDestroy(e);
   (void)hipFree(ctx->repair_queue_dev[0]); (void)hipFree(ctx->repair_queue_dev[1]);
   (void)hipFree(ctx->dbg_u); (void)hipFree(ctx->dbg_v); (void)hipFree(ctx->dbg_ic);
   (void)hipFree(ctx->dbg_wc); (void)hipFree(ctx->dbg_jc); (void)hipFree(ctx->dbg_stamps);
@@ -1636,16 +1661,24 @@ namespace {
 // nid_backproject's scratch, kept from call to call (one frame pair after the other, the same size): device buffers,
 // pinned staging and a stream -- three hipMalloc + three hipFree (each a device-wide wait) and two pageable copies per
 // call were most of its 0.8 ms (profiles/r04_pair_setup.txt).  Not thread safe, like the contexts.
+constexpr int kBpParts = 4;
 struct BackprojectScratch {
   int device = -1;
   size_t cap = 0;
   double *d_depth = nullptr, *d_T = nullptr, *d_pts = nullptr, *h_stage = nullptr;  // h_stage: [3 cap] pinned
   hipStream_t stream = nullptr;
+  hipEvent_t part_done[kBpParts] = {};
+  bool make_events() {
+    for (hipEvent_t &e : part_done)
+      if (!e && hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return false;
+    return true;
+  }
   void release() {
     if (device >= 0) (void)hipSetDevice(device);
     (void)hipFree(d_depth); (void)hipFree(d_T); (void)hipFree(d_pts);
     if (h_stage) (void)hipHostFree(h_stage);
     if (stream) (void)hipStreamDestroy(stream);
+    for (hipEvent_t e : part_done) if (e) (void)hipEventDestroy(e);
     *this = BackprojectScratch();
   }
 } g_bp;
@@ -1667,7 +1700,7 @@ int nid_backproject(const double *depth_m, const double *T_wc0, double fx, doubl
         hipMalloc(reinterpret_cast<void **>(&B.d_T), 16 * 8) != hipSuccess ||
         hipMalloc(reinterpret_cast<void **>(&B.d_pts), 3 * N * 8) != hipSuccess ||
         hipHostMalloc(reinterpret_cast<void **>(&B.h_stage), 3 * N * 8, hipHostMallocDefault) != hipSuccess ||
-        hipStreamCreateWithFlags(&B.stream, hipStreamNonBlocking) != hipSuccess) {
+        hipStreamCreateWithFlags(&B.stream, hipStreamNonBlocking) != hipSuccess || !B.make_events()) {
       (void)hipGetLastError();
       B.release();
       return NID_ERR_NOMEM;
@@ -1684,12 +1717,22 @@ int nid_backproject(const double *depth_m, const double *T_wc0, double fx, doubl
       hipMemcpyAsync(B.d_T, B.h_stage + N, 16 * 8, hipMemcpyHostToDevice, B.stream) != hipSuccess) rc = NID_ERR_HIP;
   if (rc == NID_OK) {
     hipLaunchKernelGGL(k_backproject_plain, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, B.stream, g, B.d_depth, B.d_T, B.d_pts);
-    if (hipGetLastError() != hipSuccess ||
-        hipMemcpyAsync(B.h_stage, B.d_pts, 3 * N * 8, hipMemcpyDeviceToHost, B.stream) != hipSuccess ||
-        hipStreamSynchronize(B.stream) != hipSuccess) rc = NID_ERR_HIP;
+    if (hipGetLastError() != hipSuccess) rc = NID_ERR_HIP;
+    // the points (7.4 MB at 640x480) come home in pieces, each copied out to the caller while the next crosses PCIe
+    const size_t total = 3 * N, part = ((total / kBpParts) + 7) & ~(size_t)7;
+    for (int p = 0; p < kBpParts && rc == NID_OK; p++) {
+      const size_t lo = std::min(total, part * p), hi = p == kBpParts - 1 ? total : std::min(total, part * (p + 1));
+      if ((hi > lo && hipMemcpyAsync(B.h_stage + lo, B.d_pts + lo, (hi - lo) * 8, hipMemcpyDeviceToHost, B.stream) != hipSuccess) ||
+          hipEventRecord(B.part_done[p], B.stream) != hipSuccess) rc = NID_ERR_HIP;
+    }
+    for (int p = 0; p < kBpParts && rc == NID_OK; p++) {
+      const size_t lo = std::min(total, part * p), hi = p == kBpParts - 1 ? total : std::min(total, part * (p + 1));
+      if (hipEventSynchronize(B.part_done[p]) != hipSuccess) { rc = NID_ERR_HIP; break; }
+      if (hi > lo) std::memcpy(points3d + lo, B.h_stage + lo, (hi - lo) * 8);
+    }
+    if (rc != NID_OK) (void)hipStreamSynchronize(B.stream);
   }
-  if (rc == NID_OK) std::memcpy(points3d, B.h_stage, 3 * N * 8);
-  else (void)hipGetLastError();
+  if (rc != NID_OK) (void)hipGetLastError();
   return rc;
 }
 

@@ -1225,22 +1225,19 @@ __device__ __forceinline__ void pixel_front(const EvalParams &P, const SlotArgs 
 
 // FAST: what `redo` means for a pixel, from FAST values that are at least kBorderEps away from every border they
 // are compared with.  Returns true when the pixel needs exact_decisions (a border within kBorderEps, or NaN).
-__device__ __forceinline__ bool classify_redo(const EvalParams &P, PixelFront &f) {
+__device__ __forceinline__ bool classify_redo(const EvalParams &P, const PixelFront &f) {
   // (conservative integer forms of u < -eps, u > cols-3+eps, ...: the upper bounds from the ranges' ends -- the high
   // dword of cols-3+eps is at most one above that of cols-3-eps --, so that no further scalar registers are needed;
   // a NaN is "clearly out" like in the reference, whose comparisons all fail)
   const int hu = __double2hiint(f.u), hv = __double2hiint(f.v);
   const unsigned neg_out = 0x80000000u + kBorderEpsHi;  // below -eps' (the sign bit set, magnitude beyond the band)
   const int u_top = (int)(P.hu_lo + P.hu_span + 2u), v_top = (int)(P.hu_lo + P.hv_span + 2u), j_top = (int)(P.hu_lo + P.hj_span + 2u);
-  if ((unsigned)hu > neg_out || (unsigned)hv > neg_out || hu > u_top || hv > v_top) {
-    f.in = false; f.jin = false;  // clearly out of frame
-    return false;
-  }
-  if (f.in && hu > j_top) {
-    f.jin = false;  // clearly in frame for the cost, clearly outside linearizeOplus' narrower bound (cols-1, :433)
-    return false;
-  }
-  return true;
+  // (a pure function: `redo` lanes have jin == false already, and one that is clearly out of frame cannot have passed
+  // pixel_front's range checks, so in == false too -- writing them again made every flag a phi of this branch)
+  const bool clearly_out = ((unsigned)hu > neg_out) | ((unsigned)hv > neg_out) | (hu > u_top) | (hv > v_top);
+  // clearly in frame for the cost, clearly outside linearizeOplus' narrower bound (cols-1, :433)
+  const bool in_not_jin = f.in & (hu > j_top);
+  return !(clearly_out | in_not_jin);
 }
 
 // ---- FAST math: decisions that are discontinuous in the arithmetic -----------------------------------

@@ -25,6 +25,11 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
+#include <thread>
+#include <unistd.h>
 #include <vector>
 
 #include "nid/nid_c.h"
@@ -117,56 +122,127 @@ uint64_t fingerprint(const T *a, size_t n) {
   return h ? h : 2;
 }
 
-// the whole content, 64 bits: eight interleaved multiply-xor lanes over the 8-byte words (eight independent dependency
-// chains keep the multiplier busy: memory-bound, ~0.05 ms/MB on one core)
-template <typename T>
-uint64_t full_hash(const T *a, size_t n) {
-  if (!a) return 1;
-  const size_t bytes = n * sizeof(T), words = bytes / 8;
-  const unsigned char *b = reinterpret_cast<const unsigned char *>(a);
+// ---- content hashes -------------------------------------------------------------------------------------------
+// A frame pair's big buffers (points3d 7.4 MB, bs_value 9.8 MB at 640x480) are hashed once per pair; one core does
+// ~20 GB/s, i.e. 0.4-0.5 ms each -- a third of the pair's set-up time.  Buffers of 1 MB and more are therefore hashed
+// in kHashParts contiguous parts by a small pool of worker threads (created at the first use, parked on a condition
+// variable in between), and the key is the combination of the parts' hashes in order.
+constexpr int kHashParts = 4;
+constexpr size_t kHashParallelBytes = 1u << 20;
+
+class HashPool {
+ public:
+  static HashPool &get() { static HashPool *p = new HashPool;  return *p; }  // (never destroyed: its parked workers end with the process)
+  // runs job(0..kHashParts-1): parts 1.. on the workers, part 0 on the caller; returns when all are done
+  template <typename F>
+  void run(F &&job) {
+    if (getpid() != owner_) {  // a fork()ed child has no workers (threads do not survive a fork): all parts here
+      for (int p = 0; p < kHashParts; p++) job(p);
+      return;
+    }
+    std::unique_lock<std::mutex> one(call_);  // one parallel job at a time
+    {
+      std::lock_guard<std::mutex> g(m_);
+      job_ = [&](int part) { job(part); };
+      pending_ = kHashParts - 1;
+      generation_++;
+    }
+    wake_.notify_all();
+    job(0);
+    std::unique_lock<std::mutex> g(m_);
+    done_.wait(g, [&] { return pending_ == 0; });
+    job_ = nullptr;
+  }
+
+ private:
+  HashPool() : owner_(getpid()) {
+    for (int w = 1; w < kHashParts; w++) workers_.emplace_back([this, w] { loop(w); });
+  }
+  void loop(int part) {
+    unsigned long seen = 0;
+    for (;;) {
+      std::function<void(int)> job;
+      {
+        std::unique_lock<std::mutex> g(m_);
+        wake_.wait(g, [&] { return stop_ || generation_ != seen; });
+        if (stop_) return;
+        seen = generation_;
+        job = job_;
+      }
+      job(part);
+      { std::lock_guard<std::mutex> g(m_); pending_--; }
+      done_.notify_one();
+    }
+  }
+  std::mutex call_, m_;
+  std::condition_variable wake_, done_;
+  std::function<void(int)> job_;
+  std::vector<std::thread> workers_;
+  unsigned long generation_ = 0;
+  int pending_ = 0;
+  bool stop_ = false;
+  const pid_t owner_;
+};
+
+// one contiguous run of bytes, 64 bits: eight interleaved multiply-xor lanes over the 8-byte words (eight independent
+// dependency chains keep the multiplier busy: memory-bound, ~0.05 ms/MB on one core).  MARK: the words are bs_value rows of
+// four doubles -- an all-zero row becomes four NaNs first (see mark_nan_and_hash) and is hashed as such.
+template <bool MARK>
+uint64_t hash_run(unsigned char *b, size_t bytes, uint64_t salt) {
+  const size_t words = bytes / 8;
   constexpr int L = 8;
-  uint64_t h[L] = {0x9E3779B97F4A7C15ull ^ bytes, 0xC2B2AE3D27D4EB4Full, 0x165667B19E3779F9ull, 0x27D4EB2F165667C5ull,
+  uint64_t h[L] = {0x9E3779B97F4A7C15ull ^ salt, 0xC2B2AE3D27D4EB4Full, 0x165667B19E3779F9ull, 0x27D4EB2F165667C5ull,
                    0x85EBCA77C2B2AE63ull, 0xD6E8FEB86659FD93ull, 0xA0761D6478BD642Full, 0xE7037ED1A0B428DBull};
+  auto mark = [](double *w) {
+    if (w[0] == 0.0 && w[1] == 0.0 && w[2] == 0.0 && w[3] == 0.0) w[0] = w[1] = w[2] = w[3] = NAN;
+  };
   size_t i = 0;
   for (; i + L <= words; i += L) {
+    if (MARK) { mark(reinterpret_cast<double *>(b) + i); mark(reinterpret_cast<double *>(b) + i + 4); }
     uint64_t w[L];
     std::memcpy(w, b + 8 * i, 8 * L);
     for (int k = 0; k < L; k++) { h[k] = (h[k] ^ w[k]) * 0x9FB21C651E98DF25ull; h[k] ^= h[k] >> 29; }
   }
+  if (MARK && i < words) mark(reinterpret_cast<double *>(b) + i);  // (a run of whole rows: at most one row is left)
   for (; i < words; i++) { uint64_t w; std::memcpy(&w, b + 8 * i, 8); h[i % L] = (h[i % L] ^ w) * 0x9FB21C651E98DF25ull; h[i % L] ^= h[i % L] >> 29; }
   for (size_t t = 8 * words; t < bytes; t++) h[0] = (h[0] ^ b[t]) * 0x100000001B3ull;
   uint64_t r = h[0];
   for (int k = 1; k < L; k++) r = (r ^ h[k]) * 0xFF51AFD7ED558CCDull + k;
   r ^= r >> 32;
+  return r;
+}
+
+// the whole content: one run, or kHashParts runs (split at multiples of 64 bytes -- whole bs_value rows) combined in order
+template <bool MARK>
+uint64_t hash_bytes(unsigned char *b, size_t bytes) {
+  uint64_t r;
+  if (bytes < kHashParallelBytes) {
+    r = hash_run<MARK>(b, bytes, bytes);
+  } else {
+    const size_t part = (bytes / kHashParts) & ~(size_t)63;
+    uint64_t h[kHashParts];
+    HashPool::get().run([&](int p) {
+      const size_t lo = part * p, hi = p == kHashParts - 1 ? bytes : part * (p + 1);
+      h[p] = hash_run<MARK>(b + lo, hi - lo, bytes + p);
+    });
+    r = h[0];
+    for (int p = 1; p < kHashParts; p++) r = (r ^ h[p]) * 0xFF51AFD7ED558CCDull + p;
+    r ^= r >> 32;
+  }
   return r ? r : 2;
+}
+
+template <typename T>
+uint64_t full_hash(const T *a, size_t n) {
+  if (!a) return 1;
+  return hash_bytes<false>(reinterpret_cast<unsigned char *>(const_cast<T *>(a)), n * sizeof(T));
 }
 
 // CudaComputeHref's bs_value on its way out, in ONE pass over its 9.8 MB: the legacy NaN markers (CudaComputeHref.cu:82-87,
 // 126-130: NaN weights for pixels that are invalid or out of frame at this pose -- in-frame weights sum to 1, so an
 // all-zero row is exactly that set) and the content key's full hash, identical to full_hash() of the marked buffer.
 uint64_t mark_nan_and_hash(double *bs, size_t npix) {
-  const size_t bytes = npix * 4 * sizeof(double), words = bytes / 8;
-  constexpr int L = 8;
-  uint64_t h[L] = {0x9E3779B97F4A7C15ull ^ bytes, 0xC2B2AE3D27D4EB4Full, 0x165667B19E3779F9ull, 0x27D4EB2F165667C5ull,
-                   0x85EBCA77C2B2AE63ull, 0xD6E8FEB86659FD93ull, 0xA0761D6478BD642Full, 0xE7037ED1A0B428DBull};
-  auto mark = [](double *w) {
-    if (w[0] == 0.0 && w[1] == 0.0 && w[2] == 0.0 && w[3] == 0.0) w[0] = w[1] = w[2] = w[3] = NAN;
-  };
-  size_t i = 0;
-  for (; i + L <= words; i += L) {  // two pixels per step: the eight lanes of full_hash
-    mark(bs + i); mark(bs + i + 4);
-    uint64_t w[L];
-    std::memcpy(w, bs + i, 8 * L);
-    for (int k = 0; k < L; k++) { h[k] = (h[k] ^ w[k]) * 0x9FB21C651E98DF25ull; h[k] ^= h[k] >> 29; }
-  }
-  for (; i < words; i += 4) {  // an odd pixel count: the last pixel, word by word like full_hash's tail
-    mark(bs + i);
-    for (size_t t = i; t < i + 4; t++) { uint64_t w; std::memcpy(&w, bs + t, 8); h[t % L] = (h[t % L] ^ w) * 0x9FB21C651E98DF25ull; h[t % L] ^= h[t % L] >> 29; }
-  }
-  uint64_t r = h[0];
-  for (int k = 1; k < L; k++) r = (r ^ h[k]) * 0xFF51AFD7ED558CCDull + k;
-  r ^= r >> 32;
-  return r ? r : 2;
+  return hash_bytes<true>(reinterpret_cast<unsigned char *>(bs), npix * 4 * sizeof(double));
 }
 
 // Does the caller's buffer still hold what is resident?  Updates the key; `force`: recompute the full hash even if
@@ -308,14 +384,16 @@ void CudaComputeHref(double *im0, double *points3d, double *pose, double *camera
   S.have_target = false;                        // a new pair: the next CudaComputeH re-checks its target
   const size_t N = (size_t)rows * cols;
   const int ncell = cell_num * cell_num;
-  std::vector<int32_t> cnt(ncell), idx(bs_index ? N : 0);
+  static_assert(sizeof(int) == sizeof(int32_t), "bs_index is handed through as int32_t");
+  std::vector<int32_t> cnt(ncell);
   std::vector<double> href(ncell);
   // (every pixel of a cell is written by the shard that owns the cell; what belongs to no cell of this process -- trailing
   // rows / columns of a size the cell count does not divide, other ranks' cells -- must read as zero)
   const bool every_pixel_ours = g_world == 1 && rows % cell_num == 0 && cols % cell_num == 0;
   if (bs_value && !every_pixel_ours) std::memset(bs_value, 0, 4 * N * sizeof(double));
+  if (bs_index && !every_pixel_ours) std::memset(bs_index, 0, N * sizeof(int));
   tr.step("output buffers cleared");
-  rc = nid_multi_compute_href_matrix(m, pose, cnt.data(), href.data(), bs_value, bs_index ? idx.data() : nullptr);
+  rc = nid_multi_compute_href_matrix(m, pose, cnt.data(), href.data(), bs_value, reinterpret_cast<int32_t *>(bs_index));
   if (rc != NID_OK) { report("CudaComputeHref", rc, m); return; }
   tr.step("k_href + bs_value / bs_index back to the caller");
   for (int c = 0; c < ncell; c++) {
@@ -323,7 +401,6 @@ void CudaComputeHref(double *im0, double *points3d, double *pose, double *camera
     // CudaComputeHref.cu:205-220: NaN when inactive, otherwise subtract onto the caller's value
     Href[c] = std::isnan(href[c]) ? NAN : Href[c] + href[c];
   }
-  if (bs_index) for (size_t i = 0; i < N; i++) bs_index[i] = idx[i];
   // the device already holds these weights (CPU-edge convention: 0 instead of NaN)
   S.have_href = true;
   if (bs_value) {  // the legacy NaN markers and the buffer's content key in one pass (mark_nan_and_hash)
@@ -332,7 +409,7 @@ void CudaComputeHref(double *im0, double *points3d, double *pose, double *camera
   } else {
     remember(S.k_bs_ref, bs_value, 0);
   }
-  tr.step("NaN markers + content key of bs_value, bs_index copy");
+  tr.step("NaN markers + content key of bs_value");
   remember(S.k_counter, bs_counter, (size_t)ncell);
   remember(S.k_href, Href, (size_t)ncell);
   tr.step("content keys of the per-cell outputs");
