@@ -153,6 +153,36 @@ def test_rccl_one_rank_communicator(capi, synth, pair_A):
         two.set_reduce_mode(capi.REDUCE_RCCL)
 
 
+def test_two_physical_devices_over_rccl(capi, synth, pair_A):
+    """Two shards on two DISTINCT devices of one process: nid_multi_comm_init_local (ncclCommInitAll: RCCL over xGMI, no
+    launcher) and the pipelined sequence with one all-reduce per group -- every pose's summed block equals the
+    single-device evaluation's up to the summation tree (chi2, b, H to 1e-12 relative), the active count exactly.
+    Needs two GPUs: skipped on a one-GPU box (RCCL refuses two ranks on one device, see the test above)."""
+    if capi.load().nid_device_count() < 2:
+        pytest.skip("needs two GPUs")
+    pair, nb = pair_A, 8
+    host = capi.from_pair(pair, nb)
+    host.compute_href(pair.pose_init)
+    m = capi.multi_from_pair(pair, nb, devices=[0, 1])
+    m.compute_href(pair.pose_init)
+    m.comm_init_local()
+    assert m.comm_ranks() == 2
+    m.set_reduce_mode(capi.REDUCE_RCCL)
+    rng = np.random.default_rng(11)
+    poses = np.stack([synth.perturb_pose7(pair.pose_init, rng.normal(0, 1e-3, 3), rng.normal(0, 2e-3, 3)) for _ in range(24)])
+    seq = poses[np.arange(2 * 16 * 4 + 19) % len(poses)]
+    out = m.run_sequence(seq, DELTA, batch=16, group=4)
+    ref = host.run_sequence(seq, DELTA, batch=16)
+    assert out.shape == ref.shape
+    assert np.array_equal(out[:, 28], ref[:, 28])
+    np.testing.assert_allclose(out[:, :28], ref[:, :28], rtol=1e-12, atol=1e-12 * np.abs(ref[:, :28]).max())
+    for i in (0, 17, len(seq) - 1):
+        H, b, chi2, na = m.normal_equations(seq[i], DELTA)
+        Hs, bs, chi2s, nas = capi.unpack_reduced(out[i])
+        assert np.array_equal(_bits(H), _bits(Hs)) and np.array_equal(_bits(b), _bits(bs)) and chi2 == chi2s and na == nas
+    m.close(); host.close()
+
+
 @pytest.mark.parametrize("batch,group", [(64, 1), (16, 4), (8, 3)])
 def test_pipelined_sequence_on_shards(capi, synth, pair_A, batch, group):
     """nid_multi_run_sequence (the bench's timed region at N > 1): groups of launches on two streams per shard, one
