@@ -123,7 +123,8 @@ int nid_set_loop_form(nid_ctx *ctx, int on);
  * NID_ERR_STATE while a launch is pending. */
 int nid_set_direct_results(nid_ctx *ctx, int on);
 /* The RESIDENT evaluator (default off): DIRECT single-pose launches of a context in FAST math whose cost + Jacobian
- * shape is 512 threads (nid_set_launch_shape) and whose cells fit that shape's latency form (at most 1536 slots) are
+ * shape is 512 threads (nid_set_launch_shape) and whose cells fit that shape's latency form (at most 1536 slots) -- or
+ * 256 threads, see below -- are
  * not launched at all -- a kernel started once per frame pair keeps one workgroup per cell on the device; the host writes the pose
  * into a mailbox in device memory (through the PCIe BAR), every workgroup evaluates its cell and writes its record to
  * pinned host memory, and waits for the next request.  Same bits as the launched form; ~4 us less per dependent
@@ -136,10 +137,15 @@ int nid_set_direct_results(nid_ctx *ctx, int on);
  * flight, if any, is collected before), so mixing the two costs a restart each time -- it pays for chains of
  * single-pose evaluations, which is what a Gauss-Newton / LM loop is.  A process-wide device synchronisation (hipDeviceSynchronize,
  * hipFree outside this library) waits until the kernel leaves -- at most its 200 ms.
- * One workgroup per cell has to be ON the device at once: a context of more cells than the device has CUs (1024 cells
- * on 256 CUs: BASELINE configs[1] at 1280x960) is answered by ordinary launches -- the first request finds that out,
- * nid_resident_stats keeps saying served == 0, and later nid_set_resident(ctx, 1) calls return NID_ERR_UNSUPPORTED with
- * the reason in nid_last_error.
+ * One workgroup per cell has to be ON the device at once.  In the 512-thread shape a workgroup fills a CU: a context of
+ * more cells than the device has CUs (1024 cells on 256 CUs: BASELINE configs[1] at 1280x960) is answered by ordinary
+ * launches -- the first request finds that out, nid_resident_stats keeps saying served == 0, and later
+ * nid_set_resident(ctx, 1) calls in that shape return NID_ERR_UNSUPPORTED with the reason in nid_last_error.
+ * In the 256-thread shape (nid_set_launch_shape(ctx, 256, 0): the loop form of the kernels, at most 128 registers) four
+ * resident workgroups share a CU: contexts of up to 4 x CUs cells are served.  Measured (profiles/r04_latency_B.txt): it
+ * pays for cost-only requests (configs[1]: 23.3 us instead of 25.1; 640x480: 13.9 instead of 17.2) and is a wash for
+ * cost + Jacobian ones (36.6 vs 35.4 us; 21.3 vs 22.2) -- four workgroups per CU move through the phases of an evaluation
+ * in lockstep, which is what a single pose of 1024 cells costs, launched or not.
  * Sharing the device: the co-residency of one workgroup per cell is an assumption about the WHOLE device, so
  *  - one resident kernel per device and process: while one context's kernel is on a device, other contexts' requests
  *    on that device are answered by ordinary launches (the owner's pause / retire / destroy frees the place);

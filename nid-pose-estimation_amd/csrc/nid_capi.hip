@@ -86,7 +86,8 @@ struct nid_ctx {
     bool jac = false, want_cellout = false;
     long served = 0, fallbacks = 0, starts = 0;
     int fallback_run = 0;          // consecutive requests that timed out (resident_fallback switches the mode off after a few)
-    std::string why;               // probed < 0: which step said no
+    std::string why;               // probed < 0 / unfit_nt: which step said no
+    int unfit_nt = 0;              // the launch shape a start was refused for (its workgroups do not all fit the device)
   } res;
   std::vector<double> direct_rho1;  // wait_direct: the cells' Huber weights between its two passes
   // own_stream: setup + blocking calls; aux_stream: odd slots of the pipelined path, so that
@@ -813,17 +814,22 @@ void resident_retire(nid_ctx *ctx) {
   res_release(ctx);
 }
 
-int resident_launch(nid_ctx *ctx, const EvalParams &P, size_t lds, unsigned grid) {
+int resident_launch(nid_ctx *ctx, const EvalParams &P, int nt, size_t lds, unsigned grid) {
   nid_ctx::Resident &R = ctx->res;
   // every workgroup must be ON the device for a request to be answered.  A 512-thread workgroup of this kernel is two
   // waves per SIMD with up to 256 registers each and > 100 KB of LDS: exactly one fits a CU, so the grid must not
   // exceed the CU count.  (Not hipOccupancyMaxActiveBlocksPerMultiprocessor: the ROCm 7.0 runtime a torch process
   // carries answers 0 for any kernel with more than 64 KB of dynamic LDS, which the device runs all the same.)
+  // The 256-thread form (k_resident<256, NB, 0>: the loop form, one wave per SIMD and workgroup, at most 128 registers,
+  // ~15-25 KB of LDS) fits FOUR workgroups per CU: contexts of up to 4 x CUs cells (BASELINE configs[1]: 1024 cells on 256
+  // CUs) -- as long as the device is otherwise empty; a workgroup that is not on the device shows as a request that
+  // times out (resident_fallback backs off).
   int cus = 0;
   NID_HIP(ctx, hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->cfg.device));
-  if ((long)cus < (long)grid) {
-    ctx->last_error = "resident evaluator: " + std::to_string(grid) + " workgroups of " + std::to_string(lds) + " B of LDS on " +
-                      std::to_string(cus) + " CUs";
+  const long per_cu = nt == 512 ? 1 : std::min<long>(4, (long)((160 * 1024) / std::max<size_t>(lds, 1)));
+  if ((long)cus * per_cu < (long)grid) {
+    ctx->last_error = "resident evaluator: " + std::to_string(grid) + " workgroups of " + std::to_string(nt) + " threads and " +
+                      std::to_string(lds) + " B of LDS on " + std::to_string(cus) + " CUs";
     return NID_ERR_UNSUPPORTED;
   }
   long long idle_ticks = kResidentIdleTicks;
@@ -832,7 +838,7 @@ int resident_launch(nid_ctx *ctx, const EvalParams &P, size_t lds, unsigned grid
   volatile unsigned long long *w = R.ctl->w;
   w[7] = R.seq << 8;
   store_fence();
-  launch_resident_512(P, lds, grid, R.stream, (const ResidentCtl *)R.ctl, R.seq << 8, idle_ticks, ctx->xform);
+  launch_resident(P, nt, lds, grid, R.stream, (const ResidentCtl *)R.ctl, R.seq << 8, idle_ticks, ctx->xform);
   NID_HIP(ctx, hipGetLastError());
   return NID_OK;
 }
@@ -852,13 +858,13 @@ int resident_start(nid_ctx *ctx, int nt) {
   A.gpart = nullptr; A.ticket = nullptr; A.out_reduced = nullptr; A.host_seq = nullptr;
   A.launch_seq = 0; A.cellout_host = 0; A.host_quad = 1;
   // eval_cell's LDS + the cell's tile entries (k_eval2's LAT branch, RES): rounds x threads x (7 doubles + 1 int)
-  const size_t lds = eval_lds_bytes(P.g, nt, true) + 16 + (size_t)lat_rounds(nt) * nt * (7 * 8 + 4);
+  if (nt != 512 && nt != 256) { ctx->last_error = "resident evaluator: shape " + std::to_string(nt); return NID_ERR_UNSUPPORTED; }
+  const size_t lds = eval_lds_bytes(P.g, nt, true) + 16 + (size_t)lat_rounds(nt) * nt * (7 * 8 + 4);  // (256 threads: the loop form, no tile entries in LDS)
   if (lds > 160 * 1024) { ctx->last_error = "resident evaluator: LDS request " + std::to_string(lds); return NID_ERR_UNSUPPORTED; }
   const unsigned grid = (unsigned)(((P.g.nloc + 7) / 8) * 8);
   const int nb = P.g.nb;
-  if (nt != 512) { ctx->last_error = "resident evaluator: shape " + std::to_string(nt); return NID_ERR_UNSUPPORTED; }
   if (!res_claim(ctx)) { ctx->last_error = "resident evaluator: another context's resident kernel holds this device"; return NID_ERR_STATE; }
-  rc = resident_launch(ctx, P, lds, grid);
+  rc = resident_launch(ctx, P, nt, lds, grid);
   if (rc) { res_release(ctx); return rc; }
   R.running = true;
   R.nt = nt;
@@ -877,9 +883,9 @@ bool resident_usable(const nid_ctx *ctx) {
   if (res_held_by_other(ctx)) return false;
   if (ctx->math_mode != NID_MATH_FAST || ctx->loop_form) return false;
   const int nt = ctx->jac_threads;
-  if (nt != 512) return false;
+  if ((nt != 512 && nt != 256) || nt == R.unfit_nt) return false;
   if (ctx->cost_threads != 0 && ctx->cost_threads != nt) return false;  // (cost-only results are the same bits in every shape)
-  return ctx->g.pstride <= lat_rounds(nt) * nt;
+  return nt == 256 ? ctx->g.pstride <= 32 * nt : ctx->g.pstride <= lat_rounds(nt) * nt;  // (256: the loop form's lane masks cover 32 rounds)
 }
 
 // hand one request to the resident kernel (starting it if need be); NID_ERR_UNSUPPORTED: use an ordinary launch
@@ -902,7 +908,7 @@ int resident_post(nid_ctx *ctx, int slot, const Pose &pose, bool jac, bool want_
     int rc = resident_start(ctx, ctx->jac_threads);
     if (rc) {
       if (getenv("NID_RESIDENT_DEBUG")) fprintf(stderr, "[nid resident] start failed: %d %s\n", rc, ctx->last_error.c_str());
-      if (rc == NID_ERR_UNSUPPORTED) { R.probed = -1; R.why = ctx->last_error; }  // (this geometry never fits: later nid_set_resident(1) calls say so)
+      if (rc == NID_ERR_UNSUPPORTED) { R.unfit_nt = ctx->jac_threads; R.why = ctx->last_error; }  // (this geometry never fits this shape: later nid_set_resident(1) calls say so)
       return rc;
     }
   }
@@ -2194,6 +2200,7 @@ int nid_set_resident(nid_ctx *ctx, int on) {
     return NID_OK;
   }
   int rc = resident_probe(ctx);
+  if (rc == NID_OK && ctx->res.unfit_nt != 0 && ctx->res.unfit_nt == ctx->jac_threads) rc = NID_ERR_UNSUPPORTED;
   if (rc) { ctx->last_error = "resident evaluator unavailable: " + (ctx->res.why.empty() ? std::string("mailbox setup failed") : ctx->res.why); return rc; }
   ctx->res.enabled = true;
   ctx->res.fallback_run = 0;  // (asked for again: the back-off of resident_fallback starts over)

@@ -29,7 +29,7 @@ NID_DECLARE_EVAL_TU(1024, jac) NID_DECLARE_EVAL_TU(1024, cost)
 #undef NID_DECLARE_EVAL_TU
 
 // k_resident<512, NB, 3> (nid_resident_tu.hip): sets the kernel's dynamic LDS limit and launches it
-void launch_resident_512(const EvalParams &P, size_t lds, unsigned grid, hipStream_t s, const ResidentCtl *ctl,
+void launch_resident(const EvalParams &P, int nt, size_t lds, unsigned grid, hipStream_t s, const ResidentCtl *ctl,
                          unsigned long long word0, long long idle_ticks, int xform_mode);
 
 }  // namespace nid

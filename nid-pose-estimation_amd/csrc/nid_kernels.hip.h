@@ -1515,7 +1515,10 @@ __device__ __forceinline__ void eval_cell(const EvalParams &P, const SlotArgs &S
       }
     }
   };
-  if (!RES || rc.fresh) zero_histograms(0);
+  // (RES: the previous request's tail has cleared the histograms -- except in the throughput shapes, whose Jacobian block
+  // sum goes through the histogram area AFTER the fold (NID_XPOSE_SUM) while the other waves are already gone)
+  constexpr bool kResRezero = RES && NT <= 256 && NID_XPOSE_SUM;
+  if (!RES || rc.fresh || kResRezero) zero_histograms(0);
   if (RES) {
     // (the resident kernel has loaded the table once)
   } else if (STRICT) {
@@ -1527,7 +1530,7 @@ __device__ __forceinline__ void eval_cell(const EvalParams &P, const SlotArgs &S
     // (the host's table carries kWcPre on its value coefficients, see hist_add / fx_bits)
     for (int i = tid; i < S * kCoefRow; i += NT) rtab[i] = P.ctab[i];
   }
-  if (!RES || rc.fresh) __syncthreads();  // (a later resident request: the waves have met at the kernel's own barriers since)
+  if (!RES || rc.fresh || kResRezero) __syncthreads();  // (a later resident request: the waves have met at the kernel's own barriers since)
   NID_STAMP(1);
 
   // ---- phase 1: cost ---------------------------------------------------------------

@@ -1126,6 +1126,21 @@ def test_resident_evaluator_needs_one_workgroup_per_cell_on_the_chip(capi, synth
     ctx.set_resident(False)   # (always accepted)
     got = ctx.normal_equations(poses[0], DELTA)
     assert _same_bits(got[2], ref[0][2])
+    # ... in the 256-thread shape four resident workgroups share a CU: this context (400 cells) does fit
+    ctx.set_launch_shape(256, 0)
+    ref = [(ctx.normal_equations(p, DELTA), ctx.normal_equations(p, DELTA, want_jac=False), ctx.evaluate(p, True)) for p in poses]
+    ctx.set_resident(True)
+    for rep in range(3):
+        for p, (rj, rc, rcell) in zip(poses, ref):
+            got = ctx.normal_equations(p, DELTA)
+            assert _same_bits(got[0], rj[0]) and _same_bits(got[1], rj[1]) and _same_bits(got[2], rj[2]) and got[3] == rj[3]
+            got = ctx.normal_equations(p, DELTA, want_jac=False)
+            assert _same_bits(got[2], rc[2]) and got[3] == rc[3]
+            cells = ctx.evaluate(p, True)
+            for k in range(4):
+                assert _same_bits(cells[k], rcell[k])
+    st = ctx.resident_stats()
+    assert st["served"] == 9 * len(poses) and st["starts"] == 1 and st["fallbacks"] == 0
     ctx.close()
 
 
@@ -1199,8 +1214,8 @@ def test_resident_evaluator_one_kernel_per_device(capi, synth):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("cfg", ["S", "A"])
-def test_resident_evaluator_equals_launches(capi, synth, cfg, monkeypatch, shape=512):
+@pytest.mark.parametrize("cfg,shape", [("S", 512), ("A", 512), ("A", 256), ("B", 256)])
+def test_resident_evaluator_equals_launches(capi, synth, cfg, shape, monkeypatch):
     """The resident evaluator (nid_set_resident): single-pose requests are answered by a kernel that stays on the
     device -- the SAME BITS as the launched kernels (6x6 system, chi2, count, per-cell outputs; cost + Jacobian and
     cost-only), through every single-pose entry point; it is retired and restarted by a new target image, by an idle
@@ -1208,7 +1223,7 @@ def test_resident_evaluator_equals_launches(capi, synth, cfg, monkeypatch, shape
     shortened here) is noticed and the request is re-issued as an ordinary launch."""
     import time
     pair = synth.make_pair(cfg)
-    other = synth.make_pair(cfg, flash=True) if cfg == "A" else synth.make_pair("S", edge_cases=True)
+    other = synth.make_pair(cfg, flash=True) if cfg in ("A", "B") else synth.make_pair("S", edge_cases=True)
     nb = 8
     ctx = capi.from_pair(pair, nb)
     ctx.compute_href(pair.pose_init)

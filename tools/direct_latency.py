@@ -39,13 +39,13 @@ for nt in (128, 256, 512, 1024):
     for jac in (True, False):
         for direct, resident in ((0, False), (2, False), (1, False), (1, True)):
             ctx.set_direct_results(direct)
-            set_resident(resident and nt >= 512)
+            set_resident(resident and nt in (256, 512))
             ctx.run_chain(seq[:200], delta, want_jac=jac, collect=False)
             row.append(min(ctx.run_chain(seq[:2000], delta, want_jac=jac, collect=False)[1] for _ in range(5)) / 2000 * 1e6)
     ev = []
     for direct, resident in modes:
         ctx.set_direct_results(direct)
-        set_resident(resident and nt >= 512)
+        set_resident(resident and nt in (256, 512))
         t0 = time.perf_counter()
         for i in range(300):
             ctx.evaluate(poses[i % 16], True)
