@@ -19,3 +19,8 @@ python tools/lm_trace.py 4 resident > /dev/null 2> gpurun_out/$tag/lm_trace_fuse
 python tools/flash_rate.py > gpurun_out/$tag/flash_rate.txt 2> gpurun_out/$tag/flash_rate.err; echo "flash rc=$?"
 ./tools/ubench/mailbox_latency > gpurun_out/$tag/mailbox_latency.txt 2>&1; echo "mailbox rc=$?"
 NID_DIRECT_TRACE=1 python tools/direct_trace.py > gpurun_out/$tag/direct_trace.txt 2>&1; echo "direct trace rc=$?"
+python tools/short_seq_sweep.py A 8 > gpurun_out/$tag/short_seq_A.txt 2> gpurun_out/$tag/short_seq_A.err; echo "short seq rc=$?"
+python tools/timed_region_probe.py > gpurun_out/$tag/timed_region_probe.txt 2> gpurun_out/$tag/timed_region_probe.err; echo "probe rc=$?"
+python tools/pair_setup.py A 8 > gpurun_out/$tag/pair_setup.txt 2> gpurun_out/$tag/pair_setup.err; echo "pair setup rc=$?"
+ROUNDS=2 python tools/flash_ab.py exp/libnid_r03.so exp/libnid_norepair.so default > gpurun_out/$tag/flash_ab.txt 2> gpurun_out/$tag/flash_ab.err; echo "ab rc=$?"
+
