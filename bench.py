@@ -72,6 +72,9 @@ def parse():
     ap.add_argument("--strict", action="store_true",
                     help="NID_MATH_STRICT (every rounding of the reference path) instead of the default FAST math; not the metric")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-flash", action="store_true",
+                    help="skip the flash-pair leg (profiling passes: its launches run the SAME kernel and would be averaged into "
+                         "the per-kernel figures of a rocprofv3 --stats table)")
     ap.add_argument("--quick", action="store_true", help="skip the sustained / cold / sequential / STRICT side measurements")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     ap.add_argument("--sustained-seconds", type=float, default=1.5)
@@ -708,6 +711,8 @@ def main():
             # black / saturated patches, depth holes -- what the exact-decision second passes and the clamped-sample
             # accumulation cost on such data
             try:
+                if args.no_flash:
+                    raise RuntimeError("skipped (--no-flash)")
                 fpair = synth.make_pair(args.config, flash=True, edge_cases=True)
                 fctx = capi.from_pair(fpair, args.bins, device=local_rank)
                 fctx.set_math_mode(math_mode)

@@ -101,7 +101,8 @@ def load():
     lib.nid_run_chain.argtypes = [vp, c_dp, C.c_int, C.c_int, C.c_double, c_dp, c_dp]
     lib.nid_wait.argtypes = [vp, C.c_int, c_dp, c_dp, c_dp, c_ip]
     lib.nid_slot_buffers.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(vp)]
-    lib.nid_debug_read_device.argtypes = [vp, vp, C.POINTER(C.c_double), C.c_size_t]
+    if hasattr(lib, "nid_debug_read_device"):  # (tools/build_variant.py builds of earlier trees lack the newest entry points)
+        lib.nid_debug_read_device.argtypes = [vp, vp, C.POINTER(C.c_double), C.c_size_t]
     lib.nid_unpack_reduced.argtypes = [c_dp, c_dp, c_dp, c_dp, c_ip]
     lib.nid_debug_enable_pixel_dump.argtypes = [vp, C.c_int]
     lib.nid_debug_get_pixel_dump.argtypes = [vp, c_dp, c_dp, c_dp, c_ip, c_dp]
@@ -118,7 +119,8 @@ def load():
     lib.nid_set_loop_form.argtypes = [vp, C.c_int]
     lib.nid_set_direct_results.argtypes = [vp, C.c_int]
     lib.nid_set_resident.argtypes = [vp, C.c_int]
-    lib.nid_resident_pause.argtypes = [vp]
+    if hasattr(lib, "nid_resident_pause"):
+        lib.nid_resident_pause.argtypes = [vp]
     lib.nid_resident_stats.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     lib.nid_time_launches.argtypes = [vp, C.c_int, c_dp, C.c_int, C.c_double, C.c_int, c_fp]
     if hasattr(lib, "nid_debug_repair_count"):   # (an older experiment build, NID_HIP_LIB, may lack the newest diagnostics)
