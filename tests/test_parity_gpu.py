@@ -686,6 +686,48 @@ def test_latency_form_equals_loop_form(capi, synth, nb, nt):
             assert np.array_equal(_bits(a[0]), _bits(b[0])) and np.array_equal(_bits(a[1]), _bits(b[1])) and a[2:] == b[2:]
 
 
+def test_short_sequences_and_the_repair_queue(capi, synth):
+    """Short sequences (<= 64 poses) are split into launches of <= 16 poses on one or two streams by a measured table
+    (nid_set_short_sequence_policy overrides it): every split gives the bits of single launches.  On the flash pair some
+    cells of every pose are deferred to k_repair (the repair queue behind a loop-form launch; nid_debug_repair_count says
+    how many): the deferred cells' results are the bits of the kernels that repair inline (single-pose launches in the
+    512-thread latency form after set_loop_form(False) are such kernels; the default shape's single launches defer too)."""
+    for flash in (False, True):
+        pair = synth.make_pair("A", flash=flash, edge_cases=flash)
+        ctx = capi.from_pair(pair, 8)
+        ctx.compute_href(pair.pose_init)
+        rng = np.random.default_rng(3)
+        poses = np.stack([synth.perturb_pose7(pair.pose_init, rng.normal(0, 1e-3, 3), rng.normal(0, 2e-3, 3)) for _ in range(20)])
+        ctx.repair_count(reset=True)
+        single = [ctx.normal_equations(p, DELTA) for p in poses]
+        n_rep = ctx.repair_count(reset=True)
+        assert (n_rep > 0) == flash, f"repairs {n_rep} on the {'flash' if flash else 'plain'} pair"
+        for want_jac in (True, False):
+            ref = single if want_jac else [ctx.normal_equations(p, DELTA, want_jac=False) for p in poses]
+            for policy in ((0, 0), (20, 1), (10, 2), (7, 2), (3, 2), (16, 1), (1, 2)):
+                ctx.set_short_sequence_policy(*policy)
+                out = ctx.run_sequence(poses, DELTA, batch=256, want_jac=want_jac)
+                for k, r in enumerate(ref):
+                    H, b, chi2, na = capi.unpack_reduced(out[k])
+                    assert _same_bits(H, r[0]) and _same_bits(b, r[1]) and chi2 == r[2] and na == r[3], (policy, k)
+                ctx.launch_batch(0, poses[:13], DELTA, want_jac=want_jac)
+                for k in range(13):
+                    g = ctx.wait(k)
+                    assert _same_bits(g[0], ref[k][0]) and g[2] == ref[k][2] and g[3] == ref[k][3], (policy, k)
+            ctx.set_short_sequence_policy(0, 0)
+        if flash:
+            # a 256-pose launch defers the same cells (EXT kernels) and k_repair delivers the same bits
+            seq = poses[np.arange(256) % 20]
+            ctx.repair_count(reset=True)
+            out = ctx.run_sequence(seq, DELTA, batch=256)
+            assert ctx.repair_count() > 0
+            for k in (0, 19, 20, 255):
+                H, b, chi2, na = capi.unpack_reduced(out[k])
+                r = single[k % 20]
+                assert _same_bits(H, r[0]) and _same_bits(b, r[1]) and chi2 == r[2] and na == r[3]
+        ctx.close()
+
+
 @pytest.mark.parametrize("math", MODES)
 def test_launch_chain(capi, synth, pair_A, math):
     """nid_launch_chain: the rejection chain of one LM iteration -- the first n_jac trial poses with the Jacobian
