@@ -1073,7 +1073,7 @@ def _same_bits(a, b):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("math", MODES)
-@pytest.mark.parametrize("cfg", ["S", "A", "edge", "many"])
+@pytest.mark.parametrize("cfg", ["S", "A", "edge", "many", "flash"])
 def test_direct_results_equal_in_launch_reduction(capi, synth, pair_S_edge, cfg, math):
     """DIRECT launches (nid_set_direct_results, the default for a single pose the host waits for): every cell's
     record (err, J[6], active) goes straight to pinned host memory, the host forms the Huber-weighted quadratic forms
@@ -1085,6 +1085,8 @@ def test_direct_results_equal_in_launch_reduction(capi, synth, pair_S_edge, cfg,
         pair = pair_S_edge
     elif cfg == "many":
         pair = synth.make_pair("S", rows=480, cols=640, cell=20)     # 400 cells, 20 groups of 20
+    elif cfg == "flash":
+        pair = synth.make_pair("A", flash=True, edge_cases=True)     # some cells of every pose go through k_repair
     else:
         pair = synth.make_pair(cfg)
     nb = 8
