@@ -328,7 +328,7 @@ __device__ __forceinline__ void gradient_fast_interior(const Win &w, double u, d
 // B-spline values/derivatives from the per-span polynomial table (kCoefRow doubles per span):
 // row layout [k][a0 a1 a2 a3 d0 d1 d2], k = 0..3.  t = u - jc in [0,1).  The reference's u == 0
 // quirk (derivative identically 0 at exactly 0, Q5) is kept by a select.
-// Experiment switches of the LDS read scheduling (tools/build_variant.sh; profiles/r02_ablations_A.txt): left to itself
+// Experiment switches of the LDS read scheduling (tools/build_variant.py; profiles/r02_ablations_A.txt): left to itself
 // the scheduler sends the table reads of a sample through one register quad, one dependent LDS round trip after the
 // other.  NID_BS_BATCH (cost phase, 16 value coefficients; 2 or 4 rows per wait), NID_BSD_BATCH (Jacobian phase, 12
 // derivative coefficients at once), NID_LDS_BATCH (Jacobian contraction, rows of the weight table per wait).
@@ -1345,7 +1345,7 @@ __device__ __forceinline__ int pixel_sample(const PixelFront &f, int nb, int S, 
   return jc;
 }
 
-// Tuning switches (tools/build_variant.sh; results in profiles/r02_ablations_A.txt).  NID_FAST_WAVES: occupancy target
+// Tuning switches (tools/build_variant.py; results in profiles/r02_ablations_A.txt).  NID_FAST_WAVES: occupancy target
 // of the FAST kernels (5 waves/SIMD = 96 VGPRs; 6 spills inside the loops: 216.8 k).  The EXT kernels (the throughput
 // launches) are compiled with a budget of 128 registers: the cost + Jacobian kernel still ends at 95 (five waves per
 // SIMD), but the scheduler, no longer at its limit, orders the window loads and their first uses better -- the same
@@ -2269,7 +2269,7 @@ __device__ __forceinline__ void eval_cell(const EvalParams &P, const SlotArgs &S
     const double *tj = tab + ((unsigned)nb + (unsigned)(__mul24(f.jr, nb) + jc));
     double tt = 0.0, ss = 0.0;
 #if NID_LDS_BATCH
-    // EXPERIMENT (tools/build_variant.sh -DNID_LDS_BATCH=1|2): the 20 table values in batches of NID_LDS_BATCH rows, a
+    // EXPERIMENT (tools/build_variant.py -DNID_LDS_BATCH=1|2): the 20 table values in batches of NID_LDS_BATCH rows, a
     // batch's reads issued together and waited for once (left to itself the scheduler sends every ds_read2 through one
     // register quad: ten dependent LDS round trips per sample).  The empty asm statements pin the order.
     {

@@ -1,6 +1,6 @@
 #!/bin/bash
 # tools/bench_variants.sh OUTDIR NAME...: bench.py (N=1, no CPU legs) once per experiment build exp/libnid_NAME.so
-# (tools/build_variant.sh), one line per variant: sustained it/s, kernel ms for 64 poses alone.
+# (tools/build_variant.py), one line per variant: sustained it/s, kernel ms for 64 poses alone.
 out=$1; shift
 mkdir -p $out
 for v in "$@"; do

@@ -1,6 +1,6 @@
 #!/bin/bash
 # tools/lat_throughput_sweep.sh [THREADS...]: cost + Jacobian throughput at 16 poses per launch (the launches whose
-# per-pose records ride in the kernel arguments) per workgroup shape; honours NID_HIP_LIB (tools/build_variant.sh).
+# per-pose records ride in the kernel arguments) per workgroup shape; honours NID_HIP_LIB (tools/build_variant.py).
 mkdir -p gpurun_out/lat_sweep
 for nt in ${@:-128 256 512 1024}; do
   for b in 16; do
