@@ -133,45 +133,61 @@ constexpr size_t kHashParallelBytes = 1u << 20;
 class HashPool {
  public:
   static HashPool &get() { static HashPool *p = new HashPool;  return *p; }  // (never destroyed: its parked workers end with the process)
-  // runs job(0..kHashParts-1): parts 1.. on the workers, part 0 on the caller; returns when all are done
-  template <typename F>
-  void run(F &&job) {
-    if (getpid() != owner_) {  // a fork()ed child has no workers (threads do not survive a fork): all parts here
-      for (int p = 0; p < kHashParts; p++) job(p);
-      return;
-    }
-    std::unique_lock<std::mutex> one(call_);  // one parallel job at a time
+  // start(job): job(0..kHashParts-1) is handed to the workers -- each takes the next part that nobody has taken -- and the
+  // call returns; finish(): the caller takes what is left and waits for the rest.  One job at a time (start() holds a
+  // lock until finish()); run() = start + finish.  The job must stay valid until finish().
+  void start(std::function<void(int)> job) {
+    call_.lock();
+    forked_ = getpid() != owner_;  // a fork()ed child has no workers (threads do not survive a fork): finish() does all parts
     {
       std::lock_guard<std::mutex> g(m_);
-      job_ = [&](int part) { job(part); };
-      pending_ = kHashParts - 1;
+      job_ = std::move(job);
+      next_ = 0;
+      remaining_ = kHashParts;
       generation_++;
     }
-    wake_.notify_all();
-    job(0);
-    std::unique_lock<std::mutex> g(m_);
-    done_.wait(g, [&] { return pending_ == 0; });
-    job_ = nullptr;
+    if (!forked_) wake_.notify_all();
   }
+  void finish() {
+    help();
+    {
+      std::unique_lock<std::mutex> g(m_);
+      done_.wait(g, [&] { return remaining_ == 0; });
+      job_ = nullptr;
+    }
+    call_.unlock();
+  }
+  void run(std::function<void(int)> job) { start(std::move(job)); finish(); }
 
  private:
   HashPool() : owner_(getpid()) {
-    for (int w = 1; w < kHashParts; w++) workers_.emplace_back([this, w] { loop(w); });
+    for (int w = 1; w < kHashParts; w++) workers_.emplace_back([this] { loop(); });
   }
-  void loop(int part) {
+  void help() {  // take parts until none is left
+    for (;;) {
+      std::function<void(int)> *job;
+      int part;
+      {
+        std::lock_guard<std::mutex> g(m_);
+        if (next_ >= kHashParts || !job_) return;
+        part = next_++;
+        job = &job_;
+      }
+      (*job)(part);
+      bool last;
+      { std::lock_guard<std::mutex> g(m_); last = --remaining_ == 0; }
+      if (last) done_.notify_all();
+    }
+  }
+  void loop() {
     unsigned long seen = 0;
     for (;;) {
-      std::function<void(int)> job;
       {
         std::unique_lock<std::mutex> g(m_);
-        wake_.wait(g, [&] { return stop_ || generation_ != seen; });
-        if (stop_) return;
+        wake_.wait(g, [&] { return generation_ != seen; });
         seen = generation_;
-        job = job_;
       }
-      job(part);
-      { std::lock_guard<std::mutex> g(m_); pending_--; }
-      done_.notify_one();
+      help();
     }
   }
   std::mutex call_, m_;
@@ -179,8 +195,8 @@ class HashPool {
   std::function<void(int)> job_;
   std::vector<std::thread> workers_;
   unsigned long generation_ = 0;
-  int pending_ = 0;
-  bool stop_ = false;
+  int next_ = 0, remaining_ = 0;
+  bool forked_ = false;
   const pid_t owner_;
 };
 
@@ -212,24 +228,40 @@ uint64_t hash_run(unsigned char *b, size_t bytes, uint64_t salt) {
   return r;
 }
 
-// the whole content: one run, or kHashParts runs (split at multiples of 64 bytes -- whole bs_value rows) combined in order
+// the whole content: one run, or kHashParts runs (split at multiples of 64 bytes -- whole bs_value rows) combined in order.
+// PendingHash: the parts are on the pool's workers; get() takes what is left, waits and combines (the caller may have
+// done something else in between: upload_reference hashes the points while they cross PCIe)
+struct PendingHash {
+  uint64_t h[kHashParts] = {};
+  uint64_t direct = 0;
+  bool pooled = false;
+  uint64_t get() {
+    uint64_t r = direct;
+    if (pooled) {
+      HashPool::get().finish();
+      pooled = false;
+      r = h[0];
+      for (int p = 1; p < kHashParts; p++) r = (r ^ h[p]) * 0xFF51AFD7ED558CCDull + p;
+      r ^= r >> 32;
+    }
+    return r ? r : 2;
+  }
+};
+template <bool MARK>
+void hash_bytes_begin(unsigned char *b, size_t bytes, PendingHash *ph) {
+  if (bytes < kHashParallelBytes) { ph->direct = hash_run<MARK>(b, bytes, bytes); ph->pooled = false; return; }
+  const size_t part = (bytes / kHashParts) & ~(size_t)63;
+  ph->pooled = true;
+  HashPool::get().start([b, bytes, part, ph](int p) {
+    const size_t lo = part * p, hi = p == kHashParts - 1 ? bytes : part * (p + 1);
+    ph->h[p] = hash_run<MARK>(b + lo, hi - lo, bytes + p);
+  });
+}
 template <bool MARK>
 uint64_t hash_bytes(unsigned char *b, size_t bytes) {
-  uint64_t r;
-  if (bytes < kHashParallelBytes) {
-    r = hash_run<MARK>(b, bytes, bytes);
-  } else {
-    const size_t part = (bytes / kHashParts) & ~(size_t)63;
-    uint64_t h[kHashParts];
-    HashPool::get().run([&](int p) {
-      const size_t lo = part * p, hi = p == kHashParts - 1 ? bytes : part * (p + 1);
-      h[p] = hash_run<MARK>(b + lo, hi - lo, bytes + p);
-    });
-    r = h[0];
-    for (int p = 1; p < kHashParts; p++) r = (r ^ h[p]) * 0xFF51AFD7ED558CCDull + p;
-    r ^= r >> 32;
-  }
-  return r ? r : 2;
+  PendingHash ph;
+  hash_bytes_begin<MARK>(b, bytes, &ph);
+  return ph.get();
 }
 
 template <typename T>
@@ -336,9 +368,15 @@ int upload_reference(LegacyState &S, const double *im0, const double *points3d, 
     if (rc != NID_OK) return rc;
     im = &local;
   }
+  // the points' content key is taken WHILE they cross PCIe (7.4 MB at 640x480: 0.2 ms on the pool's threads, hidden)
+  PendingHash ph;
+  if (!points_keyed) hash_bytes_begin<false>(reinterpret_cast<unsigned char *>(const_cast<double *>(points3d)), 3 * N * sizeof(double), &ph);
   int rc = nid_multi_set_reference_points(S.m, points3d, im->data());
+  if (!points_keyed) {
+    const uint64_t f = ph.get();  // (on every path: the pool is held until then)
+    if (rc == NID_OK) { S.k_points.addr = points3d; S.k_points.n = 3 * N; S.k_points.quick = fingerprint(points3d, 3 * N); S.k_points.full = f; S.k_points.valid = true; }
+  }
   if (rc != NID_OK) return rc;
-  if (!points_keyed) remember(S.k_points, points3d, 3 * N);
   S.have_ref = true; S.have_href = false;
   g_uploads++;
   return NID_OK;
