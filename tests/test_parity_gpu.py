@@ -33,9 +33,11 @@ RTOL_J = 1e-9
 NOISE_K = 4.0
 J_EPS = 64 * 2.0 ** -53
 # The allowance is BOUNDED (round 4): a cell may call on it only while the measured noise is small -- at most NOISE_CAP_REL
-# of the cell's own Jacobian scale, or below NOISE_CAP_ABS outright (the Jacobian of a constant / saturated cell IS
-# noise: 1e-13-level numbers, 100 % of "their own scale").  A larger difference between the oracle and its twin is a
-# sample that changed its bin between the two roundings -- a discontinuity, not noise -- and buys nothing.
+# of the cell's own Jacobian scale, or, for a cell whose Jacobian IS noise (a constant / saturated patch: 100 % of "its own
+# scale"), below NOISE_CAP_ABS outright or below RTOL_J of the FRAME's largest Jacobian component (a cell that the
+# tolerance itself makes invisible in the 6x6 system: sweep seed 564566, a cell that keeps a handful of samples on a flat
+# patch at one pose -- reference 1.6e-11, its twin 0, the frame 0.93).  A larger difference between the oracle and its
+# twin is a sample that changed its bin between the two roundings -- a discontinuity, not noise -- and buys nothing.
 NOISE_CAP_REL = 1e-6
 NOISE_CAP_ABS = 1e-11
 DELTA = float(np.sqrt(0.95))
@@ -87,7 +89,7 @@ def _jac_excess(J, J_o, m, noise=None):
     allowed = RTOL_J * percell + J_EPS * max(percell.max(), 1.0)
     if noise is not None:
         n = noise[m]
-        allowed = allowed + NOISE_K * np.where((n <= NOISE_CAP_REL * percell) | (n <= NOISE_CAP_ABS), n, 0.0)
+        allowed = allowed + NOISE_K * np.where((n <= NOISE_CAP_REL * percell) | (n <= max(NOISE_CAP_ABS, RTOL_J * percell.max())), n, 0.0)
     return np.abs(J[m] - J_o[m]).max(axis=1) / allowed, percell
 
 
@@ -847,6 +849,11 @@ SWEEP_SEEDS += [502812, 503912, 500953]
 # takes the centre sample one ulp up in u, v; the other 15 cells of the frame move by 1e-14).  STRICT math has the
 # reference's u to the bit (3e-14).  Passes on the measured-noise term, listed in the summary.
 SWEEP_SEEDS += [511576]
+# ... third pass (1 of 24 000): 564566, pose 2, cell 0 -- an 8-grey-level target; at that pose the cell keeps a few samples on a
+# flat patch: the reference's Jacobian of the cell is 1.6e-11 (the frame: 0.93), its twin's 0, the HIP path's 0 in both
+# modes.  Pure rounding noise like a constant image's, but 1.6e-11 is above the absolute cap of 1e-11 the allowance had:
+# the cap now also admits noise below RTOL_J of the frame's scale (NOISE_CAP_*).
+SWEEP_SEEDS += [564566]
 
 
 @pytest.mark.gpu
