@@ -29,7 +29,11 @@
 // between two CudaComputeH calls, without a CudaComputeHref in between, says so
 // with nid_legacy_invalidate(parts) -- otherwise the change may go unnoticed for
 // up to 128 calls.  NID_LEGACY_ALWAYS_UPLOAD=1 restores the reference's
-// upload-everything-every-call behaviour.  Out-of-frame reference weights are NaN in the
+// upload-everything-every-call behaviour.  (The bs_value array CudaComputeHref hands back is keyed by
+// address, length and the sampled fingerprint only -- hashing its 9.8 MB is a tenth of a pair's
+// set-up time --: the first FULL check that reaches it, the 128th CudaComputeH call of the pair or an
+// nid_legacy_invalidate, counts as "changed": the caller's array is uploaded once and hashed then.)
+// Out-of-frame reference weights are NaN in the
 // arrays handed back (as CudaComputeHref.cu:126-130 writes them) but are treated
 // as 0 inside, the CPU edge's convention; the Jacobian in-frame
 // test defaults to the CPU edge's `cols-1` (the parity target),

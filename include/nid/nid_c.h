@@ -87,6 +87,11 @@ int nid_create_strided(const nid_config *cfg, int32_t cell_stride, nid_ctx **out
 int nid_destroy(nid_ctx *ctx);
 int nid_set_options(nid_ctx *ctx, int jac_bound_mode, int xform_mode);
 int nid_set_math_mode(nid_ctx *ctx, int mode);
+/* bs_value of nid_compute_href[_matrix]: by default a pixel without a sample (invalid depth, out of frame at the pose) has
+ * four zero weights (the CPU edge's convention, types_six_dof_expmap.cpp:655-725); on != 0: four NaNs, the CUDA operator's
+ * convention (CudaComputeHref.cu:82-87, 126-130) -- written on the device, so that the legacy wrapper need not pass over
+ * the 9.8 MB again.  The device-resident weights are not affected. */
+int nid_set_href_nan_markers(nid_ctx *ctx, int on);
 /* run every kernel of this context on a caller-owned hipStream_t (e.g. the
  * current torch stream) instead of the context's own stream; NULL restores it */
 int nid_set_stream(nid_ctx *ctx, void *hip_stream);

@@ -103,6 +103,7 @@ int nid_multi_set_reduce_mode(nid_multi *m, int mode);
 /* ---- the nid_c.h calls, on every shard ------------------------------------------------------------------- */
 int nid_multi_set_options(nid_multi *m, int jac_bound_mode, int xform_mode);
 int nid_multi_set_math_mode(nid_multi *m, int mode);
+int nid_multi_set_href_nan_markers(nid_multi *m, int on);
 int nid_multi_set_block_threads(nid_multi *m, int threads);
 int nid_multi_set_launch_shape(nid_multi *m, int jac_threads, int cost_threads);
 /* nid_set_resident (nid_c.h) on every shard that has its device to itself among the shards of this process (two

@@ -39,7 +39,7 @@ class NidConfig(C.Structure):
 # every symbol include/nid/nid_c.h declares (tests/test_abi.py checks the export table)
 SYMBOLS = [
     "nid_abi_version", "nid_status_string", "nid_last_error", "nid_device_count", "nid_create", "nid_create_strided",
-    "nid_destroy", "nid_set_options", "nid_set_math_mode", "nid_set_stream", "nid_set_block_threads", "nid_set_launch_shape",
+    "nid_destroy", "nid_set_options", "nid_set_math_mode", "nid_set_href_nan_markers", "nid_set_stream", "nid_set_block_threads", "nid_set_launch_shape",
     "nid_set_reference_depth", "nid_set_reference_points", "nid_backproject", "nid_get_points3d", "nid_set_target_u8",
     "nid_set_target_f64", "nid_set_reference_image_f64", "nid_compute_href",
     "nid_compute_href_matrix", "nid_set_href_state", "nid_plain_nid", "nid_evaluate", "nid_evaluate_matrix",
@@ -476,7 +476,7 @@ MULTI_SYMBOLS = [
     "nid_comm_create_local", "nid_comm_destroy", "nid_comm_ranks", "nid_multi_attach_comm", "nid_multi_comm_init",
     "nid_multi_comm_init_local", "nid_multi_comm_ranks", "nid_multi_time_exchange", "nid_multi_set_exchange_hook", "nid_multi_set_reduce_mode",
     "nid_multi_set_options",
-    "nid_multi_set_math_mode", "nid_multi_set_block_threads", "nid_multi_set_launch_shape", "nid_multi_set_resident", "nid_multi_set_reference_depth",
+    "nid_multi_set_math_mode", "nid_multi_set_href_nan_markers", "nid_multi_set_block_threads", "nid_multi_set_launch_shape", "nid_multi_set_resident", "nid_multi_set_reference_depth",
     "nid_multi_set_reference_points", "nid_multi_set_target_u8", "nid_multi_compute_href",
     "nid_multi_compute_href_matrix", "nid_multi_set_href_state", "nid_multi_evaluate", "nid_multi_evaluate_matrix",
     "nid_multi_normal_equations", "nid_multi_launch_batch", "nid_multi_launch_chain", "nid_multi_wait", "nid_multi_run_sequence",

@@ -66,6 +66,7 @@ struct nid_ctx {
   int xform = NID_XFORM_QUAT;
   int jac_threads = 0, cost_threads = 0;  // nid_set_launch_shape: 0 = default (128) / automatic (pick_threads)
   bool loop_form = false;                  // nid_set_loop_form (diagnostics)
+  bool href_nan_rows = false;              // nid_set_href_nan_markers: bs_value rows of pixels without a sample read NaN (the legacy operators' convention)
   int direct_mode = 1;                     // nid_set_direct_results: 0 in-launch reduction, 1 DIRECT records, 2 GROUP-DIRECT (group sums on the device)
   bool direct_results = true;              // nid_set_direct_results: single-pose launches whose result the host waits for are DIRECT
   int seq_chunk = 0, seq_streams = 0;      // nid_set_short_sequence_policy: poses per launch / streams of a SHORT sequence (0 = the measured table)
@@ -1298,7 +1299,7 @@ int href_common(nid_ctx *ctx, const Pose &pose, int32_t *bs_counter, double *Hre
     }
     const long total = (long)g.nloc * g.pstride;
     hipLaunchKernelGGL(k_untile_bs, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, g, ctx->t,
-                       bs_value ? ctx->bsv_img_dev : nullptr, bs_index ? ctx->bsi_img_dev : nullptr);
+                       bs_value ? ctx->bsv_img_dev : nullptr, bs_index ? ctx->bsi_img_dev : nullptr, ctx->href_nan_rows ? 1 : 0);
     NID_HIP(ctx, hipGetLastError());
     const bool whole = g.cell_stride == 1 && g.nloc == g.cell_num * g.cell_num && g.rb * g.cell_num == g.rows && g.cb * g.cell_num == g.cols;
     if (whole && bs_value) {
@@ -2180,6 +2181,12 @@ void nid_bspline4_host(double u, int bin_num, double *B4, double *D4) {
 }
 
 double nid_div_small_host(double x, double d) { return nid::div_small(x, d); }
+
+int nid_set_href_nan_markers(nid_ctx *ctx, int on) {
+  if (!ctx) return NID_ERR_INVALID_ARG;
+  ctx->href_nan_rows = on != 0;
+  return NID_OK;
+}
 
 int nid_set_direct_results(nid_ctx *ctx, int on) {
   if (!ctx) return NID_ERR_INVALID_ARG;

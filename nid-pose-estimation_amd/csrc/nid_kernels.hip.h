@@ -721,7 +721,7 @@ __global__ void k_backproject_plain(Geometry g, const double *__restrict__ depth
 // The reference stage's per-pixel outputs in the caller's layout (CudaComputeHref's bs_value / bs_index, image order):
 // one thread per tile slot writes its pixel's four weights (the sign of the first is the evaluation kernel's knot flag:
 // stripped) and its bin index.  Pixels of no cell of this context are not written.
-__global__ void k_untile_bs(Geometry g, Tiles t, double *__restrict__ bsv /*4N or null*/, int *__restrict__ bsi /*N or null*/) {
+__global__ void k_untile_bs(Geometry g, Tiles t, double *__restrict__ bsv /*4N or null*/, int *__restrict__ bsi /*N or null*/, int nan_rows) {
   const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (gid >= (long)g.nloc * g.pstride) return;
   const int cl = (int)(gid / g.pstride), s = (int)(gid % g.pstride);
@@ -730,7 +730,11 @@ __global__ void k_untile_bs(Geometry g, Tiles t, double *__restrict__ bsv /*4N o
   const long id = (long)((c / g.cell_num) * g.rb + s / g.cb) * g.cols + (c % g.cell_num) * g.cb + s % g.cb;
   if (bsv) {
     const double4 w = *reinterpret_cast<const double4 *>(t.W + 4 * gid);
-    *reinterpret_cast<double4 *>(bsv + 4 * id) = make_double4(fabs(w.x), w.y, w.z, w.w);
+    // nan_rows (nid_set_href_nan_markers): the legacy operators' convention -- a pixel that is invalid or out of frame at
+    // this pose reads NaN, NaN, NaN, NaN (CudaComputeHref.cu:82-87, 126-130); in-frame weights sum to 1, so an all-zero
+    // row is exactly that set
+    const bool none = nan_rows && w.x == 0.0 && w.y == 0.0 && w.z == 0.0 && w.w == 0.0;
+    *reinterpret_cast<double4 *>(bsv + 4 * id) = none ? make_double4(NAN, NAN, NAN, NAN) : make_double4(fabs(w.x), w.y, w.z, w.w);
   }
   if (bsi) bsi[id] = (int)t.JR[gid];
 }

@@ -47,6 +47,7 @@ struct LegacyState {
     size_t n = 0;
     uint64_t quick = 0, full = 0;
     bool valid = false;
+    bool full_known = true;  // false: `full` was never taken (CudaComputeHref's bs_value: see there) -- a full check then counts as "changed"
   };
   Key k_im0, k_points, k_im1, k_bs_ref, k_counter, k_href;
   bool have_ref = false, have_target = false, have_href = false;
@@ -201,8 +202,8 @@ class HashPool {
 };
 
 // one contiguous run of bytes, 64 bits: eight interleaved multiply-xor lanes over the 8-byte words (eight independent
-// dependency chains keep the multiplier busy: memory-bound, ~0.05 ms/MB on one core).  MARK: the words are bs_value rows of
-// four doubles -- an all-zero row becomes four NaNs first (see mark_nan_and_hash) and is hashed as such.
+// dependency chains keep the multiplier busy: memory-bound, ~0.05 ms/MB on one core).  MARK (unused since the NaN rows of
+// bs_value are written on the device): rows of four doubles, an all-zero row becomes four NaNs first and is hashed as such.
 template <bool MARK>
 uint64_t hash_run(unsigned char *b, size_t bytes, uint64_t salt) {
   const size_t words = bytes / 8;
@@ -270,13 +271,6 @@ uint64_t full_hash(const T *a, size_t n) {
   return hash_bytes<false>(reinterpret_cast<unsigned char *>(const_cast<T *>(a)), n * sizeof(T));
 }
 
-// CudaComputeHref's bs_value on its way out, in ONE pass over its 9.8 MB: the legacy NaN markers (CudaComputeHref.cu:82-87,
-// 126-130: NaN weights for pixels that are invalid or out of frame at this pose -- in-frame weights sum to 1, so an
-// all-zero row is exactly that set) and the content key's full hash, identical to full_hash() of the marked buffer.
-uint64_t mark_nan_and_hash(double *bs, size_t npix) {
-  return hash_bytes<true>(reinterpret_cast<unsigned char *>(bs), npix * 4 * sizeof(double));
-}
-
 // Does the caller's buffer still hold what is resident?  Updates the key; `force`: recompute the full hash even if
 // address, length and the quick fingerprint are unchanged.
 template <typename T>
@@ -284,13 +278,13 @@ bool same_content(LegacyState::Key &k, const T *a, size_t n, bool force) {
   const uint64_t q = fingerprint(a, n);
   if (k.valid && !force && k.addr == (const void *)a && k.n == n && k.quick == q) return true;
   const uint64_t f = full_hash(a, n);
-  const bool same = k.valid && k.n == n && k.full == f;
-  k.addr = a; k.n = n; k.quick = q; k.full = f; k.valid = true;
+  const bool same = k.valid && k.n == n && k.full_known && k.full == f;
+  k.addr = a; k.n = n; k.quick = q; k.full = f; k.valid = true; k.full_known = true;
   return same;
 }
 template <typename T>
 void remember(LegacyState::Key &k, const T *a, size_t n) {
-  k.addr = a; k.n = n; k.quick = fingerprint(a, n); k.full = full_hash(a, n); k.valid = true;
+  k.addr = a; k.n = n; k.quick = fingerprint(a, n); k.full = full_hash(a, n); k.valid = true; k.full_known = true;
 }
 
 bool to_u8(const double *im, size_t n, std::vector<uint8_t> *out);
@@ -344,6 +338,7 @@ nid_multi *get_multi(int rows, int cols, int cell, int bins, int deg, const doub
   // the operator signatures carry a 4x4 matrix: computeH.cu:152-154 semantics for the transform
   nid_multi_set_options(m, g_jac_bound, NID_XFORM_MATRIX);
   nid_multi_set_math_mode(m, g_math_mode);
+  nid_multi_set_href_nan_markers(m, 1);  // CudaComputeHref's bs_value with the CUDA operator's NaN rows, written on the device
   // the operators are blocking, one pose (or one LM rejection chain) at a time: latency matters, not the
   // pipelined throughput the 128-thread default is tuned for (nid_set_launch_shape, tools/latency_sweep.py)
   nid_multi_set_launch_shape(m, jac_threads_for(cell * cell, g_world > 1 ? g_world : (int)g_devices.size()), g_cost_threads);
@@ -374,7 +369,7 @@ int upload_reference(LegacyState &S, const double *im0, const double *points3d, 
   int rc = nid_multi_set_reference_points(S.m, points3d, im->data());
   if (!points_keyed) {
     const uint64_t f = ph.get();  // (on every path: the pool is held until then)
-    if (rc == NID_OK) { S.k_points.addr = points3d; S.k_points.n = 3 * N; S.k_points.quick = fingerprint(points3d, 3 * N); S.k_points.full = f; S.k_points.valid = true; }
+    if (rc == NID_OK) { S.k_points.addr = points3d; S.k_points.n = 3 * N; S.k_points.quick = fingerprint(points3d, 3 * N); S.k_points.full = f; S.k_points.valid = true; S.k_points.full_known = true; }
   }
   if (rc != NID_OK) return rc;
   S.have_ref = true; S.have_href = false;
@@ -428,7 +423,7 @@ void CudaComputeHref(double *im0, double *points3d, double *pose, double *camera
   // (every pixel of a cell is written by the shard that owns the cell; what belongs to no cell of this process -- trailing
   // rows / columns of a size the cell count does not divide, other ranks' cells -- must read as zero)
   const bool every_pixel_ours = g_world == 1 && rows % cell_num == 0 && cols % cell_num == 0;
-  if (bs_value && !every_pixel_ours) std::memset(bs_value, 0, 4 * N * sizeof(double));
+  if (bs_value && !every_pixel_ours) std::fill(bs_value, bs_value + 4 * N, (double)NAN);  // (no sample there: the NaN rows of the convention below)
   if (bs_index && !every_pixel_ours) std::memset(bs_index, 0, N * sizeof(int));
   tr.step("output buffers cleared");
   rc = nid_multi_compute_href_matrix(m, pose, cnt.data(), href.data(), bs_value, reinterpret_cast<int32_t *>(bs_index));
@@ -441,13 +436,18 @@ void CudaComputeHref(double *im0, double *points3d, double *pose, double *camera
   }
   // the device already holds these weights (CPU-edge convention: 0 instead of NaN)
   S.have_href = true;
-  if (bs_value) {  // the legacy NaN markers and the buffer's content key in one pass (mark_nan_and_hash)
-    S.k_bs_ref.addr = bs_value; S.k_bs_ref.n = 4 * N; S.k_bs_ref.full = mark_nan_and_hash(bs_value, N);
+  if (bs_value) {
+    // The legacy NaN rows (CudaComputeHref.cu:82-87, 126-130) were written on the device (nid_set_href_nan_markers).
+    // The buffer's content key gets address, length and the sampled fingerprint now and NO full hash (9.8 MB: 0.25 ms
+    // even on the pool): a key without one answers a full check -- every kRehashEvery-th call, nid_legacy_invalidate --
+    // with "changed", i.e. the caller's array is uploaded once and hashed then.  Conservative, and never reached by an
+    // optimisation of fewer than kRehashEvery CudaComputeH calls.
+    S.k_bs_ref.addr = bs_value; S.k_bs_ref.n = 4 * N; S.k_bs_ref.full = 0; S.k_bs_ref.full_known = false;
     S.k_bs_ref.quick = fingerprint(bs_value, 4 * N); S.k_bs_ref.valid = true;
   } else {
     remember(S.k_bs_ref, bs_value, 0);
   }
-  tr.step("NaN markers + content key of bs_value");
+  tr.step("content key of bs_value (fingerprint; NaN rows came from the device)");
   remember(S.k_counter, bs_counter, (size_t)ncell);
   remember(S.k_href, Href, (size_t)ncell);
   tr.step("content keys of the per-cell outputs");
