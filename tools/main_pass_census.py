@@ -4,7 +4,7 @@ k_eval2 instantiation (tools/kernel_regs.py --keep DIR writes the assembly): the
 body holds the twenty ds_add_u64 of a sample and no IEEE division, the Jacobian phase's main pass = the small loop with
 the sixteen weight-table reads; blocks that only rare lanes enter are left out (a block is on the common path if it is
 reached by fall-through / s_cbranch_execz skipping from the loop header to the back edge)."""
-import collections, re, sys
+import collections, os, re, sys
 txt = open(sys.argv[1]).read()
 want = sys.argv[2]
 m = [x for x in re.finditer(r'^(_ZN3nid7k_eval2\S*):.*\n', txt, re.M) if want in x.group(1)]
@@ -111,7 +111,8 @@ for h in heads:
     cnt = lambda n, pre: sum(1 for x in blocks[n] if x.startswith(pre))
     badd = max(lb, key=lambda n: cnt(n, 'ds_add_u64')); bread = max(lb, key=lambda n: cnt(n, 'ds_read'))
     div = sum(cnt(n, 'v_div_') for n in lb)
-    if cnt(badd, 'ds_add_u64') >= 20 and cost is None and div < 8: cost = (h, badd)
-    if cnt(badd, 'ds_add_u64') == 0 and cnt(bread, 'ds_read') >= 16 and len(lb) <= 6 and jac is None: jac = (h, bread)
+    strict = 'ELb1ELb1E' in want or os.environ.get('CENSUS_STRICT')  # (STRICT kernels: one pass per phase, IEEE divisions in it)
+    if cnt(badd, 'ds_add_u64') >= 20 and cost is None and (div < 8 or strict): cost = (h, badd)
+    if cnt(badd, 'ds_add_u64') == 0 and cnt(bread, 'ds_read') >= 12 and len(lb) <= (12 if strict else 6) and jac is None: jac = (h, bread)
 if cost: show(cost[0], cost[1], "cost phase, main pass")
 if jac: show(jac[0], jac[1], "Jacobian phase, main pass")
