@@ -38,3 +38,32 @@ for label, warm in (("warmup 5 poses before the shot", seq5), ("warmup 20 poses 
         shots.append((t1 - t0) * 1e6)
     shots = np.array(shots)
     print(f"single shots, {label}: median {np.median(shots):.1f} us, min {shots.min():.1f}, max {shots.max():.1f}")
+# does a device that is not idle take the first launch faster?  A second, small context keeps its resident evaluator on 16 CUs
+# (one request every now and then keeps it from retiring) while the same single shots are taken
+if os.environ.get("PROBE_KEEPALIVE"):
+    small = synth.make_pair("S")
+    c2 = capi.from_pair(small, 8); c2.compute_href(small.pose_init); c2.set_launch_shape(512, 0)
+    try:
+        c2.set_resident(True)
+        c2.normal_equations(small.pose_init, delta)
+        shots = []
+        for _ in range(40):
+            for _ in range(50): ctx.run_sequence(seq20, delta, batch=256, collect=False)
+            c2.normal_equations(small.pose_init, delta)   # (keeps the resident kernel alive)
+            torch.cuda.synchronize(dev) if False else None  # a device-wide synchronize would wait for the resident kernel: the streams instead
+            t0 = time.perf_counter(); r = ctx.run_sequence(seq20, delta, batch=256); t1 = time.perf_counter()
+            shots.append((t1 - t0) * 1e6)
+            time.sleep(0.002)
+        shots = np.array(shots)
+        print(f"single shots 2 ms after the last work, another context's resident kernel on the device: median {np.median(shots):.1f} us, min {shots.min():.1f}, max {shots.max():.1f}  {c2.resident_stats()}")
+        c2.set_resident(False)
+        shots = []
+        for _ in range(40):
+            for _ in range(50): ctx.run_sequence(seq20, delta, batch=256, collect=False)
+            t0 = time.perf_counter(); r = ctx.run_sequence(seq20, delta, batch=256); t1 = time.perf_counter()
+            shots.append((t1 - t0) * 1e6)
+            time.sleep(0.002)
+        shots = np.array(shots)
+        print(f"single shots 2 ms after the last work, idle device:                                      median {np.median(shots):.1f} us, min {shots.min():.1f}, max {shots.max():.1f}")
+    except capi.NidError as e:
+        print("keep-alive probe skipped:", e)
