@@ -20,19 +20,20 @@
 //
 // Differences, all deliberate: no per-call allocation / memset / re-upload.  The
 // frame-pair state is cached per (rows, cols, cell_num, bin_num) and re-uploaded
-// when the CONTENT of a caller buffer has changed -- judged by a full 64-bit hash
-// of the buffer, which is recomputed whenever its address, its length or a quick
-// fingerprint of 64 samples changes, on every 128th call, and after
-// nid_legacy_invalidate(); the two per-cell arrays are fully hashed on every call.
-// THE CONTRACT: a new frame pair (new buffers, or CudaComputeHref) is always
-// noticed; a caller that rewrites part of im0 / points3d / im1 / bs_ref IN PLACE
-// between two CudaComputeH calls, without a CudaComputeHref in between, says so
-// with nid_legacy_invalidate(parts) -- otherwise the change may go unnoticed for
-// up to 128 calls.  NID_LEGACY_ALWAYS_UPLOAD=1 restores the reference's
-// upload-everything-every-call behaviour.  (The bs_value array CudaComputeHref hands back is keyed by
-// address, length and the sampled fingerprint only -- hashing its 9.8 MB is a tenth of a pair's
-// set-up time --: the first FULL check that reaches it, the 128th CudaComputeH call of the pair or an
-// nid_legacy_invalidate, counts as "changed": the caller's array is uploaded once and hashed then.)
+// when the CONTENT of a caller buffer has changed.
+// THE CONTRACT: none beyond the reference's.  Every CudaComputeH call reads all of
+// im0 / points3d / im1 / bs_ref (a 64-bit hash of each, taken on a small pool of
+// worker threads: NID_LEGACY_HASH_THREADS, default 3 beside the caller, 0 = none)
+// and all of bs_counter / Href, and uploads what differs from what the device
+// holds: a buffer rewritten in place between two calls is followed on the next
+// call, like with the reference, which uploads everything on every call
+// (computeH.cu:420-429).  Cost per call: profiles/r05_pair_setup.txt.
+// OPT-IN, nid_legacy_set_trust_buffers(1) (or NID_LEGACY_TRUST_BUFFERS=1): a call
+// checks address, length and 64 samples of each big buffer (a microsecond in all)
+// and takes the full hashes only when one of those changed, on every 128th call of
+// a pair and after nid_legacy_invalidate(parts) -- for callers that do not rewrite
+// their buffers in place between two calls of a pair, or say so when they do.
+// NID_LEGACY_ALWAYS_UPLOAD=1 uploads everything on every call.
 // Out-of-frame reference weights are NaN in the
 // arrays handed back (as CudaComputeHref.cu:126-130 writes them) but are treated
 // as 0 inside, the CPU edge's convention; the Jacobian in-frame
@@ -84,8 +85,10 @@ void nid_legacy_reset(void);
 // done with the GPU for now, keep everything for the next frame pair: takes a running resident kernel off the device
 // (the context, its buffers and its communicator stay: the next pair of the same geometry costs no context creation)
 void nid_legacy_quiesce(void);
-// The caller has changed, IN PLACE, the content of the buffers named by `parts` since its last call: the next
-// CudaComputeH recomputes their full hashes (and uploads what differs) instead of trusting address + samples.
+// 1: trust the caller's big buffers between full checks (see THE CONTRACT above); 0 (default): verify them on every call
+void nid_legacy_set_trust_buffers(int on);
+// Trusted buffers only: the caller has changed, IN PLACE, the content of the buffers named by `parts` since its last call:
+// the next CudaComputeH recomputes their full hashes (and uploads what differs) instead of trusting address + samples.
 enum { NID_LEGACY_REFERENCE = 1 /* im0, points3d */, NID_LEGACY_TARGET = 2 /* im1 */, NID_LEGACY_HREF_STATE = 4 /* bs_ref */ };
 void nid_legacy_invalidate(unsigned parts);
 // the context the legacy calls are currently using (NULL before the first call); lets a host

@@ -93,7 +93,10 @@ int nid_set_math_mode(nid_ctx *ctx, int mode);
  * the 9.8 MB again.  The device-resident weights are not affected. */
 int nid_set_href_nan_markers(nid_ctx *ctx, int on);
 /* run every kernel of this context on a caller-owned hipStream_t (e.g. the
- * current torch stream) instead of the context's own stream; NULL restores it */
+ * current torch stream) instead of the context's own stream; NULL restores it.  NID_ERR_STATE while a launch
+ * is uncollected (nid_wait it first); the streams used so far are drained before the switch, so that work of this
+ * context never runs on two unordered streams at once.  With an external stream every launch goes to THAT stream
+ * (the pipelined calls stop alternating with the context's second stream). */
 int nid_set_stream(nid_ctx *ctx, void *hip_stream);
 /* Threads per workgroup of the evaluation kernel (one workgroup per cell and pose): 128, 256, 512 or 1024.
  * jac_threads: cost + Jacobian launches; 0 = 128, the throughput shape.  The six Jacobian sums depend on the
@@ -181,6 +184,9 @@ int nid_set_reference_points(nid_ctx *ctx, const double *points3d, const uint8_t
 /* context-free Calculate3Dpoint (CudaPoints3d.cuh:6): depth f64 metres -> AoS world points, NaN = invalid */
 int nid_backproject(const double *depth_m, const double *T_wc0_colmajor16, double fx, double fy, double cx,
                     double cy, int32_t rows, int32_t cols, int32_t device, double *points3d);
+/* nid_backproject keeps device and pinned scratch (sized by its largest image) from call to call, one per process, its
+ * callers serialised by a mutex; this frees it (nid_legacy_reset does) */
+int nid_backproject_release(void);
 /* copy the back-projected points back in Calculate3Dpoint's output layout */
 int nid_get_points3d(nid_ctx *ctx, double *points3d);
 int nid_set_target_u8(nid_ctx *ctx, const uint8_t *im1);

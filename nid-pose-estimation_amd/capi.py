@@ -40,7 +40,7 @@ class NidConfig(C.Structure):
 SYMBOLS = [
     "nid_abi_version", "nid_status_string", "nid_last_error", "nid_device_count", "nid_create", "nid_create_strided",
     "nid_destroy", "nid_set_options", "nid_set_math_mode", "nid_set_href_nan_markers", "nid_set_stream", "nid_set_block_threads", "nid_set_launch_shape",
-    "nid_set_reference_depth", "nid_set_reference_points", "nid_backproject", "nid_get_points3d", "nid_set_target_u8",
+    "nid_set_reference_depth", "nid_set_reference_points", "nid_backproject", "nid_backproject_release", "nid_get_points3d", "nid_set_target_u8",
     "nid_set_target_f64", "nid_set_reference_image_f64", "nid_compute_href",
     "nid_compute_href_matrix", "nid_set_href_state", "nid_plain_nid", "nid_evaluate", "nid_evaluate_matrix",
     "nid_normal_equations", "nid_launch", "nid_launch_batch", "nid_launch_chain", "nid_launch_batch_to", "nid_run_sequence", "nid_run_chain", "nid_set_loop_form", "nid_set_direct_results", "nid_set_resident", "nid_resident_pause", "nid_resident_stats", "nid_wait", "nid_slot_buffers", "nid_debug_read_device", "nid_launch_to",

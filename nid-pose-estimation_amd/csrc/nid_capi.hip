@@ -15,6 +15,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -1615,7 +1616,20 @@ void nid_bspline4_poly_host(double u, int bin_num, double *B4, double *D4) {
 
 int nid_set_stream(nid_ctx *ctx, void *hip_stream) {
   if (!ctx) return NID_ERR_INVALID_ARG;
-  ctx->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : ctx->own_stream;
+  hipStream_t next = hip_stream ? static_cast<hipStream_t>(hip_stream) : ctx->own_stream;
+  if (next == ctx->stream) return NID_OK;
+  // Evaluation launches of a context run on `stream` and (own streams only) on aux_stream, and each of the two has ONE
+  // repair queue (launch_eval2): a launch still in flight on the old stream and one on the new stream would share
+  // queue 0 without being ordered -- k_repair of the one could read or reset the count while k_eval2 of the other
+  // pushes, and a lost cell never publishes (its nid_wait would run into the time-out).  So: no switch while a launch
+  // is uncollected, and the old streams are drained (k_repair behind a collected launch may still be running).
+  for (int s = 0; s < NID_SLOTS; s++)
+    if (ctx->slots[s].pending) { ctx->last_error = "nid_set_stream: a launch is still pending: nid_wait() it first"; return NID_ERR_STATE; }
+  NID_HIP(ctx, hipSetDevice(ctx->cfg.device));
+  resident_retire(ctx);
+  if (ctx->stream) NID_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (ctx->aux_stream) NID_HIP(ctx, hipStreamSynchronize(ctx->aux_stream));
+  ctx->stream = next;
   ctx->external_stream = hip_stream != nullptr;
   return NID_OK;
 }
@@ -1667,12 +1681,14 @@ int nid_get_points3d(nid_ctx *ctx, double *points3d) {
 namespace {
 // nid_backproject's scratch, kept from call to call (one frame pair after the other, the same size): device buffers,
 // pinned staging and a stream -- three hipMalloc + three hipFree (each a device-wide wait) and two pageable copies per
-// call were most of its 0.8 ms (profiles/r04_pair_setup.txt).  Not thread safe, like the contexts.
+// call were most of its 0.8 ms (profiles/r04_pair_setup.txt).  The function has no context, so the scratch is the
+// process's: callers are serialised by g_bp_mutex (the function was re-entrant before it kept a scratch), and
+// nid_backproject_release() -- called by nid_legacy_reset -- gives the ~25 MB per 640x480 back.
 constexpr int kBpParts = 4;
 struct BackprojectScratch {
   int device = -1;
   size_t cap = 0;
-  double *d_depth = nullptr, *d_T = nullptr, *d_pts = nullptr, *h_stage = nullptr;  // h_stage: [3 cap] pinned
+  double *d_depth = nullptr, *d_T = nullptr, *d_pts = nullptr, *h_stage = nullptr;  // h_stage: [max(3 cap, cap + 16)] pinned
   hipStream_t stream = nullptr;
   hipEvent_t part_done[kBpParts] = {};
   bool make_events() {
@@ -1689,7 +1705,14 @@ struct BackprojectScratch {
     *this = BackprojectScratch();
   }
 } g_bp;
+std::mutex g_bp_mutex;
 }  // namespace
+
+int nid_backproject_release(void) {
+  std::lock_guard<std::mutex> lock(g_bp_mutex);
+  g_bp.release();
+  return NID_OK;
+}
 
 int nid_backproject(const double *depth_m, const double *T_wc0, double fx, double fy, double cx, double cy,
                     int32_t rows, int32_t cols, int32_t device, double *points3d) {
@@ -1699,6 +1722,7 @@ int nid_backproject(const double *depth_m, const double *T_wc0, double fx, doubl
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return NID_ERR_NO_DEVICE;
   if (device < 0 || device >= ndev || hipSetDevice(device) != hipSuccess) return NID_ERR_INVALID_ARG;
   const size_t N = (size_t)rows * cols;
+  std::lock_guard<std::mutex> lock(g_bp_mutex);
   BackprojectScratch &B = g_bp;
   if (B.device != device || B.cap < N) {
     B.release();
@@ -1706,7 +1730,8 @@ int nid_backproject(const double *depth_m, const double *T_wc0, double fx, doubl
     if (hipMalloc(reinterpret_cast<void **>(&B.d_depth), N * 8) != hipSuccess ||
         hipMalloc(reinterpret_cast<void **>(&B.d_T), 16 * 8) != hipSuccess ||
         hipMalloc(reinterpret_cast<void **>(&B.d_pts), 3 * N * 8) != hipSuccess ||
-        hipHostMalloc(reinterpret_cast<void **>(&B.h_stage), 3 * N * 8, hipHostMallocDefault) != hipSuccess ||
+        // (depth + the 4x4 pose go down through it: N + 16 doubles, more than 3 N for images of fewer than 8 pixels)
+        hipHostMalloc(reinterpret_cast<void **>(&B.h_stage), std::max(3 * N, N + 16) * 8, hipHostMallocDefault) != hipSuccess ||
         hipStreamCreateWithFlags(&B.stream, hipStreamNonBlocking) != hipSuccess || !B.make_events()) {
       (void)hipGetLastError();
       B.release();

@@ -273,6 +273,22 @@ __device__ __forceinline__ double bilinear_rows(const RowPair &r, int wx, double
   return dxdy * i11 + (dy - dxdy) * i10 + (dx - dxdy) * i01 + (1 - dx - dy + dxdy) * i00;
 }
 
+// x - (double)(int)x for x >= 0 (an in-frame coordinate, a bin position): v_fract_f64 is that difference -- exactly, the
+// subtraction of the integer part of a non-negative double is exact either way -- in ONE instruction instead of a
+// conversion back and a subtraction (round 5; tools/ubench/valu_wallclock.hip has the rates).  Lanes whose x is negative
+// or NaN get another value than the subtraction's; they hold no sample.
+#ifndef NID_USE_FRACT
+#define NID_USE_FRACT 1
+#endif
+__device__ __forceinline__ double frac_nonneg(double x, int ix) {
+#if NID_USE_FRACT
+  (void)ix;
+  return __builtin_amdgcn_fract(x);
+#else
+  return x - (double)ix;
+#endif
+}
+
 // ---- FAST math helpers (not rounding-identical to the reference; see k_eval) ----------
 // bilinear sample as two lerps on register taps
 __device__ __forceinline__ double bilinear_rows_fast(const RowPair &r, int wx, double x) {
@@ -330,20 +346,18 @@ __device__ __forceinline__ void gradient_fast_interior(const Win &w, double u, d
 // quirk (derivative identically 0 at exactly 0, Q5) is kept by a select.
 // Experiment switches of the LDS read scheduling (tools/build_variant.py; profiles/r02_ablations_A.txt): left to itself
 // the scheduler sends the table reads of a sample through one register quad, one dependent LDS round trip after the
-// other.  NID_BS_BATCH (cost phase, 16 value coefficients; 2 or 4 rows per wait), NID_BSD_BATCH (Jacobian phase, 12
-// derivative coefficients at once), NID_LDS_BATCH (Jacobian contraction, rows of the weight table per wait).
+// other.  NID_BS_BATCH (cost phase, 16 value coefficients; 2 or 4 rows per wait), NID_BSD_BATCH (derivative
+// coefficients at once; the FAST Jacobian phase reads the contracted tables instead since round 5).
 #ifndef NID_BS_BATCH
 #define NID_BS_BATCH 0
 #endif
 #ifndef NID_BSD_BATCH
 #define NID_BSD_BATCH 0
 #endif
-#ifndef NID_LDS_BATCH
-#define NID_LDS_BATCH 0
-#endif
-template <bool WANT_DER, bool BATCH = false>
+// FRAC: the caller's jc is (int)u unclamped (the main passes): t by frac_nonneg
+template <bool WANT_DER, bool BATCH = false, bool FRAC = false>
 __device__ __forceinline__ void bspline4_poly(double u, int jc, const double *ctab, double B[4], double D[4]) {
-  const double t = u - (double)jc;
+  const double t = FRAC ? frac_nonneg(u, jc) : u - (double)jc;
   const double *c = ctab + __mul24(jc, kCoefRow);
 #if NID_BS_BATCH
   if (!WANT_DER && BATCH) {
@@ -1049,16 +1063,25 @@ __device__ __forceinline__ void finish_and_reduce_w0(const EvalParams &P, const 
 // pixel loops are NOT unrolled: ~100 VGPRs instead of ~220, so 4-5 workgroups share a CU
 // and the scheduler hides the load / LDS latencies that one wave per SIMD exposes.
 // guard bands of the FAST-mode decision re-check (see exact_decisions)
-// clamp guard: ic within 1e-4 of 0 or of 255 (the clamp replaces ic >= 255 by 254.999), as ONE compare |ic - mid| > half
-// (as an unsigned range check on the sample's high dword: [kGuardLoHi, kGuardLoHi + kGuardSpanHi] lies inside [1e-4,
-// 254.9999]; 32-bit literals in the instruction instead of two f64 constants in scalar registers)
-constexpr unsigned kGuardLoHi = 0x3F1A36E3u;                  // high dword of 1e-4, plus one
-constexpr unsigned kGuardSpanHi = 0x406FDFFEu - kGuardLoHi;    // ... up to the high dword of 254.9999, minus one
+// clamp guard: ic within 1/8 of 0 or of 255 (the clamp replaces ic >= 255 by 254.999), as ONE compare: an unsigned range
+// check on the sample's high dword -- [kGuardLoHi, kGuardLoHi + kGuardSpanHi] lies inside [0.125, 254.875]; 32-bit
+// literals in the instruction instead of two f64 constants in scalar registers.
+// Why 1/8 and not the 1e-4 the clamp itself needs (rounds 2-4): the two END spans of the clamped knot vector carry a
+// weight that is LINEAR in the distance to the end knot, w = 3 d with d = ic * S / 255 resp. (255 - ic) * S / 255, and a
+// joint bin made of such a weight enters the Jacobian through log2 of its mass -- FAST math's u is an ulp or two from the
+// reference's (x * (1/z) against x / z), on a steep edge (200 grey levels per pixel) that is 4e-12 in ic, i.e.
+// 4e-12 / (255 - ic) RELATIVE in that weight: 7e-10 for a sample at 254.9947 (sweep seed 511576: 1.5e-9 of its cell's
+// Jacobian, over the 1e-9 bound in FAST math only).  Samples that close to an end knot are decided by the second
+// passes, with the reference's own (u, v, ic) (exact_decisions); at 1/8 from the knot the same ulp is 3e-11 of the weight.
+// On a natural image those are the samples of black or saturated patches and their rims, which the 1e-4 band sent there
+// already.
+constexpr unsigned kGuardLoHi = 0x3FC00001u;                  // high dword of 0.125, plus one
+constexpr unsigned kGuardSpanHi = 0x406FDBFFu - kGuardLoHi;    // ... up to the high dword of 254.875, minus one
 __device__ __forceinline__ bool outside_clamp_guard(double ic) {
   return (unsigned)__double2hiint(ic) - kGuardLoHi > kGuardSpanHi;
 }
 constexpr unsigned kBorderEpsHi = 0x3EB00000u;                  // high dword of kBorderEps = 2^-20
-// A sample the FAST main passes take lies inside the clamp guard: 1e-4 <= ic <= 254.9999, so the clamp ic >= 255 and
+// A sample the FAST main passes take lies inside the clamp guard: 0.125 < ic < 254.875, so the clamp ic >= 255 and
 // the u == 0 quirk of the B-spline derivative (pc == 0) cannot apply to it; only the second passes (exact_decisions)
 // carry those selects.
 constexpr bool kMainPassClamps = false;
@@ -1139,7 +1162,7 @@ __device__ __forceinline__ int hi16(unsigned w) { return __builtin_amdgcn_sbfe((
 // FAST centre sample from the 2x2 cell (two lerps on exact integer tap differences)
 __device__ __forceinline__ double sample_fast_c(const WinC &w, double u, double v) {
   const int ix = (int)u, iy = (int)v;
-  const double dx = u - ix, dy = v - iy;
+  const double dx = frac_nonneg(u, ix), dy = frac_nonneg(v, iy);
   const int a11 = lo16(w.c1), a12 = hi16(w.c1), a21 = lo16(w.c2), a22 = hi16(w.c2);
   const double m1 = fma(dx, (double)(a12 - a11), (double)a11);
   const double m2 = fma(dx, (double)(a22 - a21), (double)a21);
@@ -1148,7 +1171,7 @@ __device__ __forceinline__ double sample_fast_c(const WinC &w, double u, double 
 // FAST gradient (TWICE the central difference, see gradient_fast_interior) and centre sample from WinJ
 __device__ __forceinline__ void gradient_fast_j(const WinJ &w, double u, double v, double &gx, double &gy, double &ic) {
   const int ix = (int)u, iy = (int)v;
-  const double dx = u - ix, dy = v - iy;
+  const double dx = frac_nonneg(u, ix), dy = frac_nonneg(v, iy);
   const int a10 = lo16(w.r1.x), a11 = hi16(w.r1.x), a12 = lo16(w.r1.y), a13 = hi16(w.r1.y);
   const int a20 = lo16(w.r2.x), a21 = hi16(w.r2.x), a22 = lo16(w.r2.y), a23 = hi16(w.r2.y);
   const double g1 = fma(dx, (double)((a13 - a12) - (a11 - a10)), (double)(a12 - a10));
@@ -1179,7 +1202,10 @@ __device__ __forceinline__ void warp_fast(const EvalParams &P, const SlotArgs &S
   f.v = fma(g.fy * qy, iz, g.cy);
 }
 
-template <bool STRICT>
+// OPAQUE (FAST main passes): (u, v) pass through an empty asm statement right behind the warp, so that the scheduler
+// cannot hoist the next round's tile loads above it (see cost_round) -- here, in front of everything that is derived from
+// them: behind the border tests it made the sample's (int)u, (int)v a second pair of conversions of "other" values.
+template <bool STRICT, bool OPAQUE = false>
 __device__ __forceinline__ void pixel_front(const EvalParams &P, const SlotArgs &SA, const TileIn &t, PixelFront &f) {
   const Geometry &g = P.g;
   f.jr = t.jr;
@@ -1201,6 +1227,7 @@ __device__ __forceinline__ void pixel_front(const EvalParams &P, const SlotArgs 
     u = fma(g.fx * qx, iz, g.cx);
     v = fma(g.fy * qy, iz, g.cy);
     f.zq = iz;
+    if (OPAQUE) asm volatile("" : "+v"(u), "+v"(v));
   }
   f.redo = false;
   f.x = qx; f.y = qy; f.u = u; f.v = v;
@@ -1255,7 +1282,7 @@ __device__ __forceinline__ bool classify_redo(const EvalParams &P, const PixelFr
 //     four-term bilinear sum lands on either side of 255.0 by its last rounding, a 1e-3 intensity jump;
 //   * ic < 0 -> 0 (:574-575) and the u == 0 quirk of the B-spline derivative (Q5).
 // FAST arithmetic therefore decides only the pixels that are safe from all of that (the interior band of
-// pixel_front and |ic - 127.5| <= kGuardHalf); the others (PixelFront::redo, ic within 1e-4 of 0 or 255) are
+// pixel_front and the clamp guard, outside_clamp_guard); the others (PixelFront::redo, ic within 1/8 of 0 or 255) are
 // decided here with the reference's own operation order -- xform_point in the configured mode, IEEE
 // divisions, fx*x/z + cx, the (int)-truncating four-term bilinear form on the register window,
 // fx*(x/z) + cx for the Jacobian's border test (Q6) -- so FAST takes bit for bit the decisions STRICT takes
@@ -1308,14 +1335,14 @@ __device__ __forceinline__ void exact_decisions(const EvalParams &P, const SlotA
 }
 
 // FAST: clamped centre sample -> bin position -> span; returns jc, pc.  CLAMP = false: the caller knows
-// ic < 255 (the main passes only take samples inside the clamp guard |ic - 127.5| <= kGuardHalf; the clamp's
+// ic < 255 (the main passes only take samples inside the clamp guard, outside_clamp_guard; the clamp's
 // compare and two selects then cost nothing)
 // EXACT (the second passes, whose `ic` is the reference's own sample): the bin position with the reference's own
 // rounding, (ic * S) / 255 (types_six_dof_expmap.cpp:574) -- a sample an ulp below 255 sits 1 - t = one or two ulps of
 // S below the last knot, the end span's linear weight 3 (1 - t) is that distance, and a bin made of such weights alone
 // enters the Jacobian through log2 of its mass: ic * (S / 255) is the neighbouring double for some S (S = 2: twice the
 // weight, W off by 1 of 59 -- 2.3e-3 of a one-sample cell's Jacobian, sweep seed 344412).  The main passes only take
-// samples at least 1e-4 away from 0 and 255 (the clamp guard): there an ulp of S is 1e-10 of 1 - t and below.
+// samples at least 1/8 away from 0 and 255 (the clamp guard): there an ulp of S is 1e-13 of 1 - t and below.
 template <bool CLAMP = true, bool EXACT = false>
 __device__ __forceinline__ int fast_bin(double &ic, int S, double &pc) {
   if (CLAMP) { if (ic >= 255) ic = 254.999; }
@@ -1826,11 +1853,10 @@ __device__ __forceinline__ void eval_cell(const EvalParams &P, const SlotArgs &S
         rare = ((raremask >> r) & 1u) != 0u;
         go = false;
       } else {
-      pixel_front<false>(P, SA, tin, f);
       // the next round's point is requested BEHIND this round's warp: x, y, z are dead by then, so the loads land in
-      // the registers they come from and nothing is copied from round to round (the empty asm keeps the scheduler
-      // from hoisting the loads above the warp again)
-      if (!SECOND) asm volatile("" : "+v"(f.u), "+v"(f.v));
+      // the registers they come from and nothing is copied from round to round (pixel_front's empty asm keeps the
+      // scheduler from hoisting the loads above the warp again)
+      pixel_front<false, !SECOND>(P, SA, tin, f);
       if (!SECOND && sb + NT < g.pstride) load_tile_xyz(P, base + (unsigned)(s + NT), nxt);
       WinC wc2;
       load_win_centre(P, f.w.wx, f.w.wy, wc2);
@@ -1859,7 +1885,7 @@ __device__ __forceinline__ void eval_cell(const EvalParams &P, const SlotArgs &S
       if (go) {
         double pc;
         jc = fast_bin<SECOND || kMainPassClamps, SECOND>(ic, S, pc);
-        bspline4_poly<false, JAC && !SECOND>(pc, jc, rtab, wc, dw);
+        bspline4_poly<false, JAC && !SECOND, !SECOND>(pc, jc, rtab, wc, dw);
         // (second pass: `ic` is the reference's own sample, evaluated exactly and clamped like there)
         hist_add(f.jr, jc, SECOND ? f.wr : tin.wr, wc, std::true_type{}, pc,
                  (SECOND && NID_CLAMP_BINS) ? (ic == 254.999 ? 1 : ((NID_NEAR_SAT_BINS && ic == kNearSatIc) ? 2 : 0)) : 0, std::false_type{});
@@ -1960,7 +1986,7 @@ __device__ __forceinline__ void eval_cell(const EvalParams &P, const SlotArgs &S
           int jc = -1;
           if (f.in && !rare) {
             jc = fast_bin<kMainPassClamps>(ic, S, pc);
-            bspline4_poly<false>(pc, jc, rtab, wc, dw);
+            bspline4_poly<false, false, true>(pc, jc, rtab, wc, dw);
             hist_add(f.jr, jc, f.wr, wc, std::true_type{}, pc, 0, std::false_type{});
           }
           if (__builtin_amdgcn_ballot_w64(rare) != 0ull) rare_rounds |= 1ull << q;
@@ -2262,6 +2288,30 @@ __device__ __forceinline__ void eval_cell(const EvalParams &P, const SlotArgs &S
     store_sys(SA.quad + (size_t)cl * kDirectRec + tid, tid == 0 ? (2 * Hj - href - Hc) / Hj : (tid == 1 ? 1.0 : 0.0));
 
   // ---- phase 2: Jacobian (recompute, see header comment) -------------------------------
+  // FAST math: the CONTRACTED weight tables.  A sample needs s = sum_k wr[k] * G[jr + k](pc) and t = G[nb](pc) with
+  // G[a](pc) = sum_m W[a][jc + m] * B'_m(pc), and on span jc every B'_m is the quadratic d0 + d1 x + d2 x^2 of the table
+  // (x = pc - jc): G[a] is itself a quadratic in x whose three coefficients A_p[a][jc] = sum_m W[a][jc + m] * d_pm[jc]
+  // depend on the cell only.  They are formed here, ONCE per cell ((nb + 1) * S entries, a == nb: the marginal table), and
+  // a sample evaluates four + one quadratics -- 14 fused multiply-adds and 15 table values instead of 8 (the derivatives)
+  // + 24 (the contraction) and 32 (round 5; same algebra as types_six_dof_expmap.cpp:473-519, another association).
+  // The table sits at the head of the histogram area, which is dead since the fold; the Jacobian block sum of the
+  // throughput shapes reuses the same area behind the loops' barrier.
+  double *jtab = reinterpret_cast<double *>(hist);  // [(nb + 1) * S][4]: A0, A1, A2, (pad)
+  if constexpr (!STRICT) {
+    for (int e = tid; e < (nb + 1) * S; e += NT) {
+      const int a = e / S, sp = e - a * S;
+      const double *wrow = a < nb ? tab + (nb + a * nb + sp) : tab + sp;
+      const double *c = rtab + sp * kCoefRow + 4;
+      double A0 = 0.0, A1 = 0.0, A2 = 0.0;
+#pragma unroll
+      for (int m = 0; m < 4; m++) {
+        const double wm = wrow[m];
+        A0 = fma(wm, c[7 * m], A0); A1 = fma(wm, c[7 * m + 1], A1); A2 = fma(wm, c[7 * m + 2], A2);
+      }
+      *reinterpret_cast<double4 *>(jtab + 4 * e) = make_double4(A0, A1, A2, 0.0);
+    }
+    __syncthreads();
+  }
   const double cA = wave_uniform(Hc + href), cB = wave_uniform(Hj);
   double acc[6];
 #pragma unroll
@@ -2269,44 +2319,41 @@ __device__ __forceinline__ void eval_cell(const EvalParams &P, const SlotArgs &S
   // FAST-mode constants: the gradient helper returns twice the gradient, so 1/2 rides on fx, fy
   const double cAx = wave_uniform(cA * (0.5 * g.fx)), cBx = wave_uniform(cB * (0.5 * g.fx));
   const double cAy = wave_uniform(cA * (0.5 * g.fy)), cBy = wave_uniform(cB * (0.5 * g.fy));
+  // FAST: one sample's contribution to the six sums from the contracted tables (jtab).  d(u,v)/d(xi) with a = x/z, b = y/z
+  // (types_six_dof_expmap.cpp:438-450 regrouped): Ju = fx [-ab, 1+a^2, -b, 1/z, 0, -a/z], Jv = fy [-(1+b^2), ab, a, 0, 1/z, -b/z];
+  // with P = c_u gx, Q = c_v gy and R = P a + Q b the six terms are -(R b + Q), R a + P, Q a - P b, P/z, Q/z, -R/z.
+  // acc[0] and acc[5] accumulate the NEGATED sums (fixed after the loop).
+  auto jac_accumulate_fast = [&](const auto &f, double invz, double gx, double gy, double pc, int jc, auto q5_possible) {
+    // (the second passes place a sample with the reference's own rounding and may clamp jc: fast_bin<.., EXACT>)
+    const double x = decltype(q5_possible)::value ? pc - (double)jc : frac_nonneg(pc, jc);
+    const double *A = jtab + 4 * (__mul24(f.jr, S) + jc);
+    double ss = 0.0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const double *Ak = A + 4 * S * k;
+      ss = fma(f.wr[k], fma(fma(Ak[2], x, Ak[1]), x, Ak[0]), ss);
+    }
+    const double *T = jtab + 4 * (nb * S + jc);
+    const double tt = fma(fma(T[2], x, T[1]), x, T[0]);
+    double cP = fma(ss, cAx, -(tt * cBx)), cQ = fma(ss, cAy, -(tt * cBy));
+    if (decltype(q5_possible)::value) {
+      if (pc == 0.0) { cP = 0.0; cQ = 0.0; }  // Q5: B-spline derivative identically 0 at u == 0 (second passes only, see kMainPassClamps)
+    }
+    const double Pg = cP * gx, Qg = cQ * gy;
+    const double a = f.x * invz, b = f.y * invz;
+    const double R = fma(Pg, a, Qg * b);
+    acc[0] = fma(R, b, acc[0] + Qg);
+    acc[1] = fma(R, a, acc[1] + Pg);
+    acc[2] = fma(Qg, a, fma(-Pg, b, acc[2]));
+    acc[3] = fma(Pg, invz, acc[3]);
+    acc[4] = fma(Qg, invz, acc[4]);
+    acc[5] = fma(R, invz, acc[5]);
+  };
+  // STRICT: the reference's derivative values dw[4] against the weight tables
   auto jac_accumulate = [&](const auto &f, double invz, double gx, double gy, double pc, int jc, const double (&dw)[4], auto q5_possible) {
+    (void)pc; (void)q5_possible;
     const double *tj = tab + ((unsigned)nb + (unsigned)(__mul24(f.jr, nb) + jc));
     double tt = 0.0, ss = 0.0;
-#if NID_LDS_BATCH
-    // EXPERIMENT (tools/build_variant.py -DNID_LDS_BATCH=1|2): the 20 table values in batches of NID_LDS_BATCH rows, a
-    // batch's reads issued together and waited for once (left to itself the scheduler sends every ds_read2 through one
-    // register quad: ten dependent LDS round trips per sample).  The empty asm statements pin the order.
-    {
-      unsigned tjo = (unsigned)nb + (unsigned)(__mul24(f.jr, nb) + jc);  // an offset, not a pointer: the reads stay ds_read
-#pragma unroll
-      for (int k0 = 0; k0 < 4; k0 += NID_LDS_BATCH) {
-        asm volatile("" : "+v"(tjo), "+v"(ss));
-        double tv[NID_LDS_BATCH][4], tc[4];
-        if (k0 == 0) {
-#pragma unroll
-          for (int m = 0; m < 4; m++) tc[m] = tab[jc + m];
-        }
-#pragma unroll
-        for (int k = 0; k < NID_LDS_BATCH; k++)
-#pragma unroll
-          for (int m = 0; m < 4; m++) tv[k][m] = tab[tjo + (unsigned)((k0 + k) * nb + m)];
-        if (k0 == 0) asm volatile("" : "+v"(tc[0]), "+v"(tc[1]), "+v"(tc[2]), "+v"(tc[3]));
-#pragma unroll
-        for (int k = 0; k < NID_LDS_BATCH; k++) asm volatile("" : "+v"(tv[k][0]), "+v"(tv[k][1]), "+v"(tv[k][2]), "+v"(tv[k][3]));
-        if (k0 == 0) {
-#pragma unroll
-          for (int m = 0; m < 4; m++) tt = fma(tc[m], dw[m], tt);
-        }
-#pragma unroll
-        for (int k = 0; k < NID_LDS_BATCH; k++) {
-          double inner = 0.0;
-#pragma unroll
-          for (int m = 0; m < 4; m++) inner = fma(tv[k][m], dw[m], inner);
-          ss = fma(f.wr[k0 + k], inner, ss);
-        }
-      }
-    }
-#else
 #pragma unroll
     for (int m = 0; m < 4; m++) tt = fma(tab[jc + m], dw[m], tt);
 #pragma unroll
@@ -2315,26 +2362,6 @@ __device__ __forceinline__ void eval_cell(const EvalParams &P, const SlotArgs &S
 #pragma unroll
       for (int m = 0; m < 4; m++) inner = fma(tj[k * nb + m], dw[m], inner);
       ss = fma(f.wr[k], inner, ss);
-    }
-#endif
-    if (!STRICT) {
-      // d(u,v)/d(xi) with a = x/z, b = y/z (types_six_dof_expmap.cpp:438-450 regrouped):
-      //   Ju = fx [-ab, 1+a^2, -b, 1/z, 0, -a/z],  Jv = fy [-(1+b^2), ab, a, 0, 1/z, -b/z]
-      // acc[0] and acc[5] accumulate the NEGATED sums (fixed after the loop).
-      double cP = fma(ss, cAx, -(tt * cBx)), cQ = fma(ss, cAy, -(tt * cBy));
-      if (decltype(q5_possible)::value) {
-        if (pc == 0.0) { cP = 0.0; cQ = 0.0; }  // Q5: B-spline derivative identically 0 at u == 0 (second passes only, see kMainPassClamps)
-      }
-      const double Pg = cP * gx, Qg = cQ * gy;
-      const double a = f.x * invz, b = f.y * invz;
-      const double Pa = Pg * a, Qb = Qg * b;
-      acc[0] = fma(Pa, b, fma(Qb, b, Qg + acc[0]));
-      acc[1] = fma(Pa, a, fma(Qb, a, Pg + acc[1]));
-      acc[2] = fma(Qg, a, fma(-Pg, b, acc[2]));
-      acc[3] = fma(Pg, invz, acc[3]);
-      acc[4] = fma(Qg, invz, acc[4]);
-      acc[5] = fma(Pa + Qb, invz, acc[5]);
-      return;
     }
     const double c = fma(ss, cA, -(tt * cB));
     const double cgx = c * gx, cgy = c * gy;
@@ -2425,19 +2452,15 @@ __device__ __forceinline__ void eval_cell(const EvalParams &P, const SlotArgs &S
           exact_decisions<EXT>(P, SA, pose_idx, tin, f, ic);
           if (f.jin) {
             gradient_fast_interior(f.w, f.u, f.v, gx, gy, dummy);
-            double pc, dw[4];
+            double pc;
             const int jc = fast_bin<true, true>(ic, S, pc);
-            bspline4_poly_der(pc, jc, rtab, dw);
-            jac_accumulate(f, f.zq, gx, gy, pc, jc, dw, std::true_type{});
+            jac_accumulate_fast(f, f.zq, gx, gy, pc, jc, std::true_type{});
           }
         }
         return false;
       }
-      pixel_front<false>(P, SA, tin, f);
-      // the next round's point is requested BEHIND this round's warp: x, y, z are dead by then, so the loads land in
-      // the registers they come from and nothing is copied from round to round (the empty asm keeps the scheduler
-      // from hoisting the loads above the warp again)
-      if (!SECOND) asm volatile("" : "+v"(f.u), "+v"(f.v));
+      // (the next round's point behind this round's warp: see cost_round)
+      pixel_front<false, !SECOND>(P, SA, tin, f);
       if (!SECOND && sb + NT < g.pstride) load_tile_xyz(P, base + (unsigned)(s + NT), nxt);
       WinJ wj;
       load_win_jac(P, f.w.wx, f.w.wy, wj);
@@ -2478,14 +2501,14 @@ __device__ __forceinline__ void eval_cell(const EvalParams &P, const SlotArgs &S
         }
       }
       if (go) {
-        double pc, dw[4];
+        double pc;
         const int jc = fast_bin<SECOND || kMainPassClamps, SECOND>(ic, S, pc);
-        bspline4_poly_der(pc, jc, rtab, dw);
-        jac_accumulate(f, f.zq, gx, gy, pc, jc, dw, std::integral_constant<bool, SECOND || kMainPassClamps>{});
+        jac_accumulate_fast(f, f.zq, gx, gy, pc, jc, std::integral_constant<bool, SECOND || kMainPassClamps>{});
         if (DBG && P.dbg_u && P.dbg_jac && pose_idx == 0) {
-          double dq[4];
+          double dw[4], dq[4];
+          bspline4_poly_der(pc, jc, rtab, dw);  // (the dump's derivative values: the sums take them through the contracted tables)
 #pragma unroll
-          for (int k = 0; k < 4; k++) dq[k] = (pc == 0.0) ? 0.0 : dw[k];  // Q5, applied inside jac_accumulate
+          for (int k = 0; k < 4; k++) dq[k] = (pc == 0.0) ? 0.0 : dw[k];  // Q5, applied inside jac_accumulate_fast
           dump_jac(s, 0.5 * gx, 0.5 * gy, pc, jc, dq);
         }
       }
@@ -2510,10 +2533,9 @@ __device__ __forceinline__ void eval_cell(const EvalParams &P, const SlotArgs &S
       double ic, gx, gy;
       gradient_fast_j(wj, f.u, f.v, gx, gy, ic);
       if (go) {
-        double pc, dw[4];
+        double pc;
         const int jc = fast_bin<false>(ic, S, pc);
-        bspline4_poly_der(pc, jc, rtab, dw);
-        jac_accumulate(f, f.zq, gx, gy, pc, jc, dw, std::false_type{});
+        jac_accumulate_fast(f, f.zq, gx, gy, pc, jc, std::false_type{});
       }
     };
     unsigned long long rare2 = 0ull;
@@ -2525,9 +2547,7 @@ __device__ __forceinline__ void eval_cell(const EvalParams &P, const SlotArgs &S
 #pragma unroll
       for (int q = 0; q < LAT; q++)
         if (lat[q].go) {
-          double dw[4];
-          bspline4_poly_der(lat[q].pc, lat[q].jc, rtab, dw);
-          jac_accumulate(lat[q], lat[q].iz, lat[q].gx, lat[q].gy, lat[q].pc, lat[q].jc, dw, std::integral_constant<bool, kMainPassClamps>{});
+          jac_accumulate_fast(lat[q], lat[q].iz, lat[q].gx, lat[q].gy, lat[q].pc, lat[q].jc, std::integral_constant<bool, kMainPassClamps>{});
         }
       }
       rare2 = rare_rounds;

@@ -7,20 +7,25 @@
 // What is resident is identified by CONTENT, not by pointer: a caller that frees and re-mallocs its buffers per
 // pair (NID_pose_estimation.cpp:229-251, 385-392) usually gets the same addresses back.
 //   * CudaComputeHref is called once per pair: it always uploads the reference (im0, points3d) afresh;
-//   * CudaComputeH keeps, per caller buffer (im0, points3d, im1, bs_ref, bs_counter, Href), a key (address, length,
-//     quick fingerprint of 64 samples, FULL 64-bit hash of the content).  Every call checks address, length and the
-//     quick fingerprint (about a microsecond for all six); the full hash is recomputed -- and decides whether the
-//     buffer is uploaded -- whenever one of those changed, on every kRehashEvery-th call, and after
-//     nid_legacy_invalidate().  The two per-cell arrays (1-2 KB) are fully hashed on every call; the two images'
-//     full hashes are taken over their u8 conversion (check_image: the same content at an eighth of the bytes).
-//     So: a new frame pair is always noticed (new address or new samples -> full hash -> upload); a caller that rewrites
-//     part of a buffer IN PLACE between two calls without touching a sampled element is noticed within kRehashEvery
-//     calls, or at once if it says so with nid_legacy_invalidate() -- the one thing this library asks of a caller
-//     beyond the reference's contract (the reference re-uploads everything on every call, computeH.cu:420-429: 11 MB
-//     per call).  NID_LEGACY_ALWAYS_UPLOAD=1 restores that behaviour.
+//   * CudaComputeH keeps, per caller buffer (im0, points3d, im1, bs_ref, bs_counter, Href), a key: address, length, a
+//     quick fingerprint of 64 samples and a FULL 64-bit hash of the content.
+//     DEFAULT (round 5): every call recomputes the full hash of every buffer -- the caller's bytes
+//     are read on every call, like the reference, which re-uploads them on every call (computeH.cu:420-429) -- and
+//     uploads what differs: a caller that rewrites a buffer in place between two calls is followed on the NEXT call,
+//     with nothing asked of it.  22 MB of reads per call at 640x480, on a small pool of worker threads.
+//     TRUSTED buffers (opt-in: nid_legacy_set_trust_buffers(1) or NID_LEGACY_TRUST_BUFFERS=1; round 4's default): a call
+//     checks address, length and the quick fingerprint (about a microsecond for all six buffers); the full hash is
+//     recomputed -- and decides whether the buffer is uploaded -- when one of those changed, on every kRehashEvery-th
+//     call of a pair, and after nid_legacy_invalidate().  A caller in that mode that rewrites part of a buffer IN
+//     PLACE without touching a sampled element says so with nid_legacy_invalidate(), or is followed within
+//     kRehashEvery calls.
+//     The two per-cell arrays (1-2 KB) are fully hashed on every call in both modes; the images' keys carry the hash
+//     of their u8 conversion (what is uploaded) and, in the default mode, of the caller's f64 bytes (what is verified).
+//     NID_LEGACY_ALWAYS_UPLOAD=1 uploads everything on every call.
 #include "nid/legacy_ops.h"
 
 #include <chrono>
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -28,6 +33,7 @@
 #include <condition_variable>
 #include <functional>
 #include <mutex>
+#include <pthread.h>
 #include <thread>
 #include <unistd.h>
 #include <vector>
@@ -47,11 +53,13 @@ struct LegacyState {
     size_t n = 0;
     uint64_t quick = 0, full = 0;
     bool valid = false;
-    bool full_known = true;  // false: `full` was never taken (CudaComputeHref's bs_value: see there) -- a full check then counts as "changed"
+    bool full_known = true;  // false: `full` was never taken -- a full check then counts as "changed"
+    uint64_t raw = 0;        // images: the hash of the caller's f64 bytes (`full` is that of the u8 conversion)
+    bool raw_known = false;
   };
   Key k_im0, k_points, k_im1, k_bs_ref, k_counter, k_href;
   bool have_ref = false, have_target = false, have_href = false;
-  unsigned long calls = 0;      // CudaComputeH calls on this state
+  unsigned long calls = 0;      // CudaComputeH calls on this frame pair (CudaComputeHref starts a new count)
   unsigned force_full = 0;      // nid_legacy_invalidate: parts whose full hash the next call recomputes
 };
 constexpr unsigned long kRehashEvery = 128;
@@ -100,6 +108,13 @@ struct StepTrace {
   }
 };
 
+int g_trust = -1;  // nid_legacy_set_trust_buffers; -1 = the NID_LEGACY_TRUST_BUFFERS environment variable
+bool trust_buffers() {
+  if (g_trust >= 0) return g_trust != 0;
+  static const bool env = [] { const char *e = getenv("NID_LEGACY_TRUST_BUFFERS"); return e && e[0] == '1'; }();
+  return env;
+}
+
 bool always_upload() {
   static const bool v = getenv("NID_LEGACY_ALWAYS_UPLOAD") != nullptr;
   return v;
@@ -124,30 +139,31 @@ uint64_t fingerprint(const T *a, size_t n) {
 }
 
 // ---- content hashes -------------------------------------------------------------------------------------------
-// A frame pair's big buffers (points3d 7.4 MB, bs_value 9.8 MB at 640x480) are hashed once per pair; one core does
-// ~20 GB/s, i.e. 0.4-0.5 ms each -- a third of the pair's set-up time.  Buffers of 1 MB and more are therefore hashed
-// in kHashParts contiguous parts by a small pool of worker threads (created at the first use, parked on a condition
-// variable in between), and the key is the combination of the parts' hashes in order.
+// A frame pair's big buffers (points3d 7.4 MB, bs_value 9.8 MB at 640x480) are hashed once per pair -- and, in the
+// default mode, on every CudaComputeH call; one core does ~20 GB/s, i.e. 0.4-0.5 ms each.  Buffers of 1 MB and more are
+// therefore hashed in kHashParts contiguous parts by a small pool of worker threads (created at the first use, parked
+// on a condition variable in between), and the key is the combination of the parts' hashes in order.  The pool's size:
+// NID_LEGACY_HASH_THREADS workers beside the caller (default 3; 0: the caller hashes alone, no thread is created).
 constexpr int kHashParts = 4;
 constexpr size_t kHashParallelBytes = 1u << 20;
 
 class HashPool {
  public:
   static HashPool &get() { static HashPool *p = new HashPool;  return *p; }  // (never destroyed: its parked workers end with the process)
-  // start(job): job(0..kHashParts-1) is handed to the workers -- each takes the next part that nobody has taken -- and the
+  // start(n, job): job(0..n-1) is handed to the workers -- each takes the next part that nobody has taken -- and the
   // call returns; finish(): the caller takes what is left and waits for the rest.  One job at a time (start() holds a
-  // lock until finish()); run() = start + finish.  The job must stay valid until finish().
-  void start(std::function<void(int)> job) {
+  // lock until finish()); the job must stay valid until finish().
+  void start(int nparts, std::function<void(int)> job) {
     call_.lock();
-    forked_ = getpid() != owner_;  // a fork()ed child has no workers (threads do not survive a fork): finish() does all parts
     {
       std::lock_guard<std::mutex> g(m_);
       job_ = std::move(job);
       next_ = 0;
-      remaining_ = kHashParts;
+      nparts_ = nparts;
+      remaining_ = nparts;
       generation_++;
     }
-    if (!forked_) wake_.notify_all();
+    if (!workers_.empty() && getpid() == owner_) wake_.notify_all();  // (a fork()ed child has no workers: finish() does all parts)
   }
   void finish() {
     help();
@@ -158,11 +174,19 @@ class HashPool {
     }
     call_.unlock();
   }
-  void run(std::function<void(int)> job) { start(std::move(job)); finish(); }
+  void run(int nparts, std::function<void(int)> job) { start(nparts, std::move(job)); finish(); }
 
  private:
   HashPool() : owner_(getpid()) {
-    for (int w = 1; w < kHashParts; w++) workers_.emplace_back([this] { loop(); });
+    int n = 3;
+    if (const char *e = getenv("NID_LEGACY_HASH_THREADS")) n = std::max(0, std::min(15, atoi(e)));
+    for (int w = 0; w < n; w++) workers_.emplace_back([this] { loop(); });
+    // fork(): threads do not survive it, locks do -- a child forked while a worker held m_ would wait for it for ever.
+    // The handlers take both locks around the fork, so the child inherits them free (and finds itself without workers
+    // by its pid).
+    pthread_atfork([] { HashPool &p = get(); p.call_.lock(); p.m_.lock(); },
+                   [] { HashPool &p = get(); p.m_.unlock(); p.call_.unlock(); },
+                   [] { HashPool &p = get(); p.m_.unlock(); p.call_.unlock(); });
   }
   void help() {  // take parts until none is left
     for (;;) {
@@ -170,7 +194,7 @@ class HashPool {
       int part;
       {
         std::lock_guard<std::mutex> g(m_);
-        if (next_ >= kHashParts || !job_) return;
+        if (next_ >= nparts_ || !job_) return;
         part = next_++;
         job = &job_;
       }
@@ -196,8 +220,7 @@ class HashPool {
   std::function<void(int)> job_;
   std::vector<std::thread> workers_;
   unsigned long generation_ = 0;
-  int next_ = 0, remaining_ = 0;
-  bool forked_ = false;
+  int next_ = 0, nparts_ = 0, remaining_ = 0;
   const pid_t owner_;
 };
 
@@ -253,7 +276,7 @@ void hash_bytes_begin(unsigned char *b, size_t bytes, PendingHash *ph) {
   if (bytes < kHashParallelBytes) { ph->direct = hash_run<MARK>(b, bytes, bytes); ph->pooled = false; return; }
   const size_t part = (bytes / kHashParts) & ~(size_t)63;
   ph->pooled = true;
-  HashPool::get().start([b, bytes, part, ph](int p) {
+  HashPool::get().start(kHashParts, [b, bytes, part, ph](int p) {
     const size_t lo = part * p, hi = p == kHashParts - 1 ? bytes : part * (p + 1);
     ph->h[p] = hash_run<MARK>(b + lo, hi - lo, bytes + p);
   });
@@ -271,14 +294,55 @@ uint64_t full_hash(const T *a, size_t n) {
   return hash_bytes<false>(reinterpret_cast<unsigned char *>(const_cast<T *>(a)), n * sizeof(T));
 }
 
+// Several buffers in ONE pooled job (the per-call verification of the default mode: four buffers, sixteen parts): each
+// buffer's value is exactly what full_hash gives for it alone (same partition, same combination).
+struct HashReq {
+  const void *data = nullptr;
+  size_t bytes = 0;
+  uint64_t result = 0;
+};
+void hash_many(HashReq *reqs, int n) {
+  struct Part { int req, idx; unsigned char *b; size_t bytes; uint64_t salt; };
+  std::vector<Part> parts;
+  std::vector<uint64_t> h((size_t)n * kHashParts, 0);
+  for (int r = 0; r < n; r++) {
+    unsigned char *b = static_cast<unsigned char *>(const_cast<void *>(reqs[r].data));
+    const size_t bytes = reqs[r].bytes;
+    if (!b) continue;
+    if (bytes < kHashParallelBytes) { parts.push_back({r, -1, b, bytes, bytes}); continue; }
+    const size_t part = (bytes / kHashParts) & ~(size_t)63;
+    for (int p = 0; p < kHashParts; p++) {
+      const size_t lo = part * p, hi = p == kHashParts - 1 ? bytes : part * (p + 1);
+      parts.push_back({r, p, b + lo, hi - lo, bytes + p});
+    }
+  }
+  HashPool::get().run((int)parts.size(), [&](int k) {
+    const Part &pt = parts[(size_t)k];
+    h[(size_t)pt.req * kHashParts + (pt.idx < 0 ? 0 : pt.idx)] = hash_run<false>(pt.b, pt.bytes, pt.salt);
+  });
+  for (int r = 0; r < n; r++) {
+    if (!reqs[r].data) { reqs[r].result = 1; continue; }
+    uint64_t v = h[(size_t)r * kHashParts];
+    if (reqs[r].bytes >= kHashParallelBytes) {
+      for (int p = 1; p < kHashParts; p++) v = (v ^ h[(size_t)r * kHashParts + p]) * 0xFF51AFD7ED558CCDull + p;
+      v ^= v >> 32;
+    }
+    reqs[r].result = v ? v : 2;
+  }
+}
+
 // Does the caller's buffer still hold what is resident?  Updates the key; `force`: recompute the full hash even if
-// address, length and the quick fingerprint are unchanged.
+// address, length and the quick fingerprint are unchanged (`pre`: that hash, if the caller has taken it already).
 template <typename T>
-bool same_content(LegacyState::Key &k, const T *a, size_t n, bool force) {
+bool same_content(LegacyState::Key &k, const T *a, size_t n, bool force, const uint64_t *pre = nullptr) {
   const uint64_t q = fingerprint(a, n);
-  if (k.valid && !force && k.addr == (const void *)a && k.n == n && k.quick == q) return true;
-  const uint64_t f = full_hash(a, n);
-  const bool same = k.valid && k.n == n && k.full_known && k.full == f;
+  const bool cheap_same = k.valid && k.addr == (const void *)a && k.n == n && k.quick == q;
+  if (cheap_same && !force) return true;
+  const uint64_t f = pre ? *pre : full_hash(a, n);
+  // a key whose full hash was never taken (trusted mode: CudaComputeHref's bs_value) is completed by its first full
+  // check; in the default mode a key without one counts as "changed"
+  bool same = k.valid && k.n == n && k.full_known && k.full == f;
+  if (cheap_same && !k.full_known && trust_buffers()) same = true;
   k.addr = a; k.n = n; k.quick = q; k.full = f; k.valid = true; k.full_known = true;
   return same;
 }
@@ -288,19 +352,29 @@ void remember(LegacyState::Key &k, const T *a, size_t n) {
 }
 
 bool to_u8(const double *im, size_t n, std::vector<uint8_t> *out);
-// An f64 image carrying u8 values (NID_pose_estimation.cpp:245-251): its key's full hash is that of the CONVERTED image
+// An f64 image carrying u8 values (NID_pose_estimation.cpp:245-251).  Its key's `full` hash is that of the CONVERTED image
 // -- the conversion checks every value (an integer in [0, 255] or the call fails), so the u8 image determines the
-// buffer's content, at an eighth of the bytes; and the conversion is needed for the upload anyway.  `have`: something is
-// resident to compare with.  On return *same says whether the resident image can stay; u8 holds the converted image
-// whenever the full check ran (empty: address, length and quick fingerprint were unchanged and no full check was due).
-int check_image(LegacyState::Key &k, const double *im, size_t n, bool force, bool have, std::vector<uint8_t> *u8, bool *same) {
+// buffer's content, and the conversion is needed for the upload anyway; in the default mode the key also carries the
+// hash of the caller's f64 bytes (`raw`), which is what a per-call verification compares (no conversion while nothing
+// changes; `pre_raw`: that hash, if the caller has taken it already).  `have`: something is resident to compare with.
+// On return *same says whether the resident image can stay; u8 holds the converted image whenever the conversion ran.
+int check_image(LegacyState::Key &k, const double *im, size_t n, bool force, bool have, std::vector<uint8_t> *u8, bool *same,
+                const uint64_t *pre_raw = nullptr) {
   const uint64_t q = fingerprint(im, n);
   u8->clear();
-  if (have && k.valid && !force && k.addr == (const void *)im && k.n == n && k.quick == q) { *same = true; return NID_OK; }
+  const bool cheap_same = have && k.valid && k.addr == (const void *)im && k.n == n && k.quick == q;
+  if (cheap_same && !force) { *same = true; return NID_OK; }
+  const bool keep_raw = !trust_buffers();
+  uint64_t raw = 0;
+  if (keep_raw) {
+    raw = pre_raw ? *pre_raw : full_hash(im, n);
+    if (cheap_same && k.raw_known && k.raw == raw) { *same = true; return NID_OK; }
+  }
   if (!to_u8(im, n, u8)) return NID_ERR_UNSUPPORTED;
   const uint64_t f = full_hash(u8->data(), n);
   *same = have && k.valid && k.n == n && k.full == f;
-  k.addr = im; k.n = n; k.quick = q; k.full = f; k.valid = true;
+  k.addr = im; k.n = n; k.quick = q; k.full = f; k.valid = true; k.full_known = true;
+  k.raw = raw; k.raw_known = keep_raw;
   return NID_OK;
 }
 
@@ -377,15 +451,16 @@ int upload_reference(LegacyState &S, const double *im0, const double *points3d, 
   return NID_OK;
 }
 
-int ensure_reference(LegacyState &S, const double *im0, const double *points3d, bool force) {
+int ensure_reference(LegacyState &S, const double *im0, const double *points3d, bool force, const uint64_t *pre_im0 = nullptr,
+                     const uint64_t *pre_points = nullptr) {
   const size_t N = (size_t)S.rows * S.cols;
   std::vector<uint8_t> im;
   bool points_keyed = false;
   if (S.have_ref && !always_upload()) {
     bool a = false;
-    int rc = check_image(S.k_im0, im0, N, force, true, &im, &a);
+    int rc = check_image(S.k_im0, im0, N, force, true, &im, &a, pre_im0);
     if (rc != NID_OK) return rc;
-    const bool b = same_content(S.k_points, points3d, 3 * N, force);
+    const bool b = same_content(S.k_points, points3d, 3 * N, force, pre_points);
     points_keyed = true;
     if (a && b) return NID_OK;
   }
@@ -436,18 +511,20 @@ void CudaComputeHref(double *im0, double *points3d, double *pose, double *camera
   }
   // the device already holds these weights (CPU-edge convention: 0 instead of NaN)
   S.have_href = true;
-  if (bs_value) {
-    // The legacy NaN rows (CudaComputeHref.cu:82-87, 126-130) were written on the device (nid_set_href_nan_markers).
-    // The buffer's content key gets address, length and the sampled fingerprint now and NO full hash (9.8 MB: 0.25 ms
-    // even on the pool): a key without one answers a full check -- every kRehashEvery-th call, nid_legacy_invalidate --
-    // with "changed", i.e. the caller's array is uploaded once and hashed then.  Conservative, and never reached by an
-    // optimisation of fewer than kRehashEvery CudaComputeH calls.
+  S.calls = 0;  // (the trusted mode's periodic full check counts the calls of THIS pair)
+  if (bs_value && !trust_buffers()) {
+    // default mode: every CudaComputeH call compares the caller's bs_ref with this hash (9.8 MB at 640x480, on the pool).
+    // (The legacy NaN rows, CudaComputeHref.cu:82-87, 126-130, were written on the device: nid_set_href_nan_markers.)
+    remember(S.k_bs_ref, bs_value, 4 * N);
+  } else if (bs_value) {
+    // trusted buffers: address, length and the sampled fingerprint now and NO full hash (0.25 ms even on the pool); the
+    // first full check that reaches the key -- the kRehashEvery-th call of the pair, nid_legacy_invalidate -- takes it.
     S.k_bs_ref.addr = bs_value; S.k_bs_ref.n = 4 * N; S.k_bs_ref.full = 0; S.k_bs_ref.full_known = false;
     S.k_bs_ref.quick = fingerprint(bs_value, 4 * N); S.k_bs_ref.valid = true;
   } else {
     remember(S.k_bs_ref, bs_value, 0);
   }
-  tr.step("content key of bs_value (fingerprint; NaN rows came from the device)");
+  tr.step("content key of bs_value (default: full hash; trusted: fingerprint)");
   remember(S.k_counter, bs_counter, (size_t)ncell);
   remember(S.k_href, Href, (size_t)ncell);
   tr.step("content keys of the per-cell outputs");
@@ -496,18 +573,34 @@ nid_multi *ensure_state(double *im0, double *im1, double *points3d, int *bs_coun
   const bool first_of_pair = !S.have_target;
   StepTrace tr("CudaComputeH state check");
   tr.on = tr.on && first_of_pair;  // (every later call of a pair takes about a microsecond: not traced)
-  // the full hashes: whenever a key's cheap part changed (same_content), every kRehashEvery-th call, after an invalidate
+  // The full hashes.  Default: on every call, all four big buffers in one pooled job (the caller's bytes are read on every
+  // call, like the reference's uploads).  Trusted buffers: whenever a key's cheap part changed (same_content), on every
+  // kRehashEvery-th call of the pair, after an invalidate.
   S.calls++;
-  const bool periodic = S.calls % kRehashEvery == 0;
+  const bool verify = !trust_buffers() && !always_upload();
+  const bool periodic = verify || S.calls % kRehashEvery == 0;
   const unsigned force = S.force_full;
   S.force_full = 0;
-  int rc = ensure_reference(S, im0, points3d, periodic || (force & NID_LEGACY_REFERENCE));
+  uint64_t pre[4] = {0, 0, 0, 0};
+  const bool have_pre = verify && S.have_ref && S.have_target && S.have_href;
+  if (have_pre) {
+    HashReq req[4];
+    req[0].data = im0; req[0].bytes = N * sizeof(double);
+    req[1].data = points3d; req[1].bytes = 3 * N * sizeof(double);
+    req[2].data = im1; req[2].bytes = N * sizeof(double);
+    req[3].data = bs_ref; req[3].bytes = 4 * N * sizeof(double);
+    hash_many(req, 4);
+    for (int k = 0; k < 4; k++) pre[k] = req[k].result;
+    tr.on = tr.on || (StepTrace("").on && S.calls == 2);  // (traced once per pair: the second call is the first that only verifies)
+    tr.step("per-call verification: full hashes of im0, points3d, im1, bs_ref");
+  }
+  int rc = ensure_reference(S, im0, points3d, periodic || (force & NID_LEGACY_REFERENCE), have_pre ? &pre[0] : nullptr, have_pre ? &pre[1] : nullptr);
   if (rc != NID_OK) { report("CudaComputeH(reference upload)", rc, m); return nullptr; }
   {
     std::vector<uint8_t> im;
     bool same = false;
     const bool have = S.have_target && !always_upload();
-    rc = check_image(S.k_im1, im1, N, periodic || (force & NID_LEGACY_TARGET), have, &im, &same);
+    rc = check_image(S.k_im1, im1, N, periodic || (force & NID_LEGACY_TARGET), have, &im, &same, have_pre ? &pre[2] : nullptr);
     if (rc != NID_OK) { report("CudaComputeH(im1 is not u8-valued)", rc, m); return nullptr; }
     if (!same) {
       rc = nid_multi_set_target_u8(m, im.data());
@@ -523,7 +616,7 @@ nid_multi *ensure_state(double *im0, double *im1, double *points3d, int *bs_coun
   const bool fh = periodic || (force & NID_LEGACY_HREF_STATE);
   bool same = S.have_href && !always_upload();
   if (same) {
-    const bool a = same_content(S.k_bs_ref, bs_ref, 4 * N, fh), b = same_content(S.k_counter, bs_counter, (size_t)ncell, true);
+    const bool a = same_content(S.k_bs_ref, bs_ref, 4 * N, fh, have_pre ? &pre[3] : nullptr), b = same_content(S.k_counter, bs_counter, (size_t)ncell, true);
     const bool c = !Href || same_content(S.k_href, Href, (size_t)ncell, true);
     same = a && b && c;
   }
@@ -597,9 +690,12 @@ void nid_legacy_set_rank(int device, int rank, int world, const uint8_t *rccl_id
 
 void nid_legacy_invalidate(unsigned parts) { g_state.force_full |= parts; }
 
+void nid_legacy_set_trust_buffers(int on) { g_trust = on ? 1 : 0; }
+
 void nid_legacy_reset(void) {
   if (g_state.m) nid_multi_destroy(g_state.m);
   g_state = LegacyState();
+  (void)nid_backproject_release();  // Calculate3Dpoint's scratch
 }
 
 void nid_legacy_quiesce(void) {

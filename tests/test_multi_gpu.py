@@ -292,10 +292,11 @@ def test_legacy_operators_follow_buffer_contents(hostlib, oracle, synth, pair_S,
         np.testing.assert_allclose(Ht2[act], Hc_o2[act], rtol=0, atol=1e-11)
         assert not np.allclose(Ht2[act], Ht[act])
     # A change IN PLACE that touches none of the 64 sampled elements of the quick fingerprint (one pixel in the middle of
-    # a cell): declared with nid_legacy_invalidate it is followed at once; undeclared, within 128 calls -- the full hash
-    # is recomputed on every 128th call (include/nid/legacy_ops.h, "THE CONTRACT").
+    # a cell).  DEFAULT: every call reads the caller's buffers in full (include/nid/legacy_ops.h), so an UNDECLARED
+    # change is followed on the NEXT call -- of any of the four big buffers -- and nothing is uploaded while nothing changes.
     pair = pair_S
     lib.nid_legacy_invalidate.argtypes = [hostlib.C.c_uint]
+    lib.nid_legacy_set_trust_buffers.argtypes = [hostlib.C.c_int]
     samples = {int(k * (N - 1) // 63) for k in range(64)}
     cellpx = (pair.rows // pair.cell // 2) * pair.cols + pair.cols // pair.cell // 2      # inside cell 0
     assert cellpx not in samples
@@ -308,22 +309,57 @@ def test_legacy_operators_follow_buffer_contents(hostlib, oracle, synth, pair_S,
 
     base = evaluate()
     u0 = lib.nid_legacy_upload_count()
-    im1[cellpx] = 255.0 - im1[cellpx]
-    lib.nid_legacy_invalidate(2)                      # NID_LEGACY_TARGET
+    for k in range(5):
+        assert np.array_equal(evaluate(), base)
+    assert lib.nid_legacy_upload_count() == u0                     # verified on every call, uploaded on none
+    im1[cellpx] = 255.0 - im1[cellpx]                              # undeclared
     changed = evaluate()
     assert lib.nid_legacy_upload_count() == u0 + 1 and changed[0] != base[0] and np.array_equal(changed[1:], base[1:])
-    im1[cellpx] = 255.0 - im1[cellpx]                 # back, undeclared this time
-    seen_after = None
-    for k in range(130):
-        if np.array_equal(evaluate(), base):
-            seen_after = k
-            break
-    # (+1: that periodic check is also the first FULL check of bs_value since CudaComputeHref, which gives its key no full
-    # hash -- 9.8 MB at 640x480 --: the key answers "changed", the caller's array is uploaded once and hashed then)
-    assert seen_after is not None and seen_after <= 128 and lib.nid_legacy_upload_count() == u0 + 3
-    for k in range(130):                               # ... once: the next periodic check finds every key complete
+    im1[cellpx] = 255.0 - im1[cellpx]                              # back, undeclared again
+    assert np.array_equal(evaluate(), base) and lib.nid_legacy_upload_count() == u0 + 2
+    # the reference side: one reference weight of one pixel (bs_ref), one reference pixel (im0 + its point)
+    wpx = 4 * cellpx
+    assert all(wpx + q not in {int(k * (4 * N - 1) // 63) for k in range(64)} for q in range(4))
+    keep = bsv[wpx:wpx + 4].copy()
+    bsv[wpx:wpx + 4] = keep[::-1]
+    c2 = evaluate()
+    assert lib.nid_legacy_upload_count() == u0 + 3 and (np.array_equal(keep, keep[::-1]) or c2[0] != base[0]) and np.array_equal(c2[1:], base[1:])
+    bsv[wpx:wpx + 4] = keep
+    assert np.array_equal(evaluate(), base) and lib.nid_legacy_upload_count() == u0 + 4
+    pk = pts[3 * cellpx:3 * cellpx + 3].copy()
+    assert all(3 * cellpx + q not in {int(k * (3 * N - 1) // 63) for k in range(64)} for q in range(3))
+    pts[3 * cellpx:3 * cellpx + 3] = np.nan                        # the pixel loses its depth
+    c3 = evaluate()
+    # (a new reference invalidates the device's reference weights: the caller's bs_ref / counters / Href go up again too)
+    assert lib.nid_legacy_upload_count() == u0 + 6 and np.array_equal(c3[1:], base[1:])
+    pts[3 * cellpx:3 * cellpx + 3] = pk
+    assert np.array_equal(evaluate(), base)
+    u1 = lib.nid_legacy_upload_count()
+    assert np.array_equal(evaluate(), base) and lib.nid_legacy_upload_count() == u1
+
+    # TRUSTED buffers (opt-in, round 4's default): address + length + 64 samples per call; a change in place is declared
+    # with nid_legacy_invalidate and followed at once, or undeclared and followed within 128 calls of the pair.
+    lib.nid_legacy_set_trust_buffers(1)
+    try:
         assert np.array_equal(evaluate(), base)
-    assert lib.nid_legacy_upload_count() == u0 + 3
+        u0 = lib.nid_legacy_upload_count()
+        im1[cellpx] = 255.0 - im1[cellpx]
+        lib.nid_legacy_invalidate(2)                      # NID_LEGACY_TARGET
+        changed = evaluate()
+        assert lib.nid_legacy_upload_count() == u0 + 1 and changed[0] != base[0] and np.array_equal(changed[1:], base[1:])
+        im1[cellpx] = 255.0 - im1[cellpx]                 # back, undeclared this time
+        assert not np.array_equal(evaluate(), base)       # ... and not noticed by the next call: that is the trade
+        seen_after = None
+        for k in range(130):
+            if np.array_equal(evaluate(), base):
+                seen_after = k
+                break
+        assert seen_after is not None and seen_after <= 128 and lib.nid_legacy_upload_count() == u0 + 2
+        for k in range(130):                               # the next periodic check finds every key complete
+            assert np.array_equal(evaluate(), base)
+        assert lib.nid_legacy_upload_count() == u0 + 2
+    finally:
+        lib.nid_legacy_set_trust_buffers(0)
     # the small per-cell arrays are fully hashed on every call: a changed count is followed at once
     cnt_keep = cnt.copy()
     cnt[0] = 0
