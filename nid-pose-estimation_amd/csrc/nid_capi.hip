@@ -46,6 +46,7 @@ struct Slot {
   bool groups_dirty = false;
   bool direct = false;             // the launch in flight is a DIRECT one: the host forms and sums the cells' quadratic forms
   bool resident = false;           // ... it is a request to the resident kernel (its records arrive in ctx->res.rec_host)
+  bool resbatch = false;           // ... it is one pose of a request to the resident BATCH kernel (in-launch reduction into reduced_host)
   bool collected = false;          // its result is in reduced_host already (resident_quiesce): nid_wait only hands it over
   bool quad_dirty = false;         // a DIRECT launch wrote (or may still write) into quad_host and wait_direct has not consumed it
   bool direct_jac = false;         // ... it carries Jacobians
@@ -90,6 +91,21 @@ struct nid_ctx {
     int fallback_run = 0;          // consecutive requests that timed out (resident_fallback switches the mode off after a few)
     std::string why;               // probed < 0 / unfit_nt: which step said no
     int unfit_nt = 0;              // the launch shape a start was refused for (its workgroups do not all fit the device)
+    // the BATCH form (k_resident_batch): requests of up to kResBatchMax poses through the throughput form of the kernel
+    ResBatchCtl *bctl = nullptr;           // fine-grained device memory: the mailbox word
+    SlotArgs *brec_host = nullptr, *brec_devptr = nullptr;  // pinned + mapped: the request's SlotArgs records (the device fetches them)
+    unsigned long long *bfwd = nullptr;    // device memory: the kernel's fan-out state (ResBatchFan: gword, per-cell records, the request's records)
+    SlotArgs *bstage = nullptr;            // device memory, one staging record per workgroup
+    size_t bstage_n = 0;
+    bool benabled = false;                 // nid_set_resident(ctx, 2): requests of several poses go to the batch form too
+    bool brunning = false, bunfit = false;
+    double bdelta = 0.0;                   // the Huber delta the running kernel was started with
+    int breplicas = 0;
+    unsigned long long bseq = 0;
+    int bfirst = -1, bn = 0, bleft = 0;    // the request in flight: its slots, how many of them are uncollected
+    bool bjac = false;
+    Pose bposes[kResBatchMax];             // ... its poses, for the fallback
+    long bserved = 0, bfallbacks = 0, bstarts = 0;
   } res;
   std::vector<double> direct_rho1;  // wait_direct: the cells' Huber weights between its two passes
   // own_stream: setup + blocking calls; aux_stream: odd slots of the pipelined path, so that
@@ -145,6 +161,9 @@ struct nid_ctx {
 namespace {
 
 void resident_retire(nid_ctx *ctx);  // every call that changes what a resident kernel has cached, or frees memory, retires it first
+int resident_batch_fallback(nid_ctx *ctx);
+int launch_batch(nid_ctx *ctx, int first_slot, int n, const Pose *poses, int want_jac, double delta, double *reduced_dev_base = nullptr,
+                 bool on_aux_stream = false, bool relaunch_ok = false, bool allow_direct = true);
 int resident_quiesce(nid_ctx *ctx);  // ... and every ordinary evaluation launch (the resident workgroups hold most of every CU)
 
 #define NID_HIP(ctx, expr)                                                            \
@@ -804,6 +823,17 @@ inline void store_fence() { __builtin_ia32_sfence(); }
 
 void resident_retire(nid_ctx *ctx) {
   nid_ctx::Resident &R = ctx->res;
+  if (R.brunning) {  // the batch form: the exit word in its control line, every replica 0 forwards it
+    (void)hipSetDevice(ctx->cfg.device);
+    volatile unsigned long long *w = R.bctl->w;
+    w[7] = kResExitWord;
+    store_fence();
+    (void)hipStreamSynchronize(R.stream);
+    w[7] = resbatch_word(R.bseq, 0, 0);
+    store_fence();
+    R.brunning = false;
+    res_release(ctx);
+  }
   if (!R.running) return;
   (void)hipSetDevice(ctx->cfg.device);
   volatile unsigned long long *w = R.ctl->w;
@@ -881,6 +911,7 @@ int resident_start(nid_ctx *ctx, int nt) {
 bool resident_usable(const nid_ctx *ctx) {
   const nid_ctx::Resident &R = ctx->res;
   if (!R.enabled || R.probed < 0 || R.pending_slot >= 0 || !direct_ok(ctx)) return false;
+  if (R.brunning) return false;  // (the batch form is on the device: single poses go to it too, resident_batch_usable)
   // another context's resident kernel holds this device: launch (see g_res_owner)
   if (res_held_by_other(ctx)) return false;
   if (ctx->math_mode != NID_MATH_FAST || ctx->loop_form) return false;
@@ -941,8 +972,25 @@ int resident_post(nid_ctx *ctx, int slot, const Pose &pose, bool jac, bool want_
 // registers each on every CU they sit on: a launch whose workgroups do not fit beside them would wait until the
 // resident kernel leaves by itself.  So it leaves now -- after the request it may be working on has been collected
 // (its slot keeps the result for nid_wait).
+int wait_host_seq(nid_ctx *ctx, Slot &S);
+int wait_resbatch(nid_ctx *ctx, Slot &S);
+
 int resident_quiesce(nid_ctx *ctx) {
   nid_ctx::Resident &R = ctx->res;
+  if (R.brunning) {
+    // the batch kernel holds the device: the request it may be working on is collected first (its slots keep their
+    // results for nid_wait), then it leaves
+    if (R.bleft > 0)
+      for (int k = 0; k < R.bn; k++) {
+        Slot &S = ctx->slots[R.bfirst + k];
+        if (!S.resbatch || S.collected) continue;
+        int rc = wait_resbatch(ctx, S);
+        if (rc) return rc;
+        if (S.resbatch) { S.resbatch = false; S.collected = true; }  // (a fallback has made them ordinary launches: nid_wait waits for those)
+      }
+    R.bleft = 0;
+    resident_retire(ctx);
+  }
   if (!R.running) return NID_OK;
   if (R.pending_slot >= 0) {
     Slot &S = ctx->slots[R.pending_slot];
@@ -988,6 +1036,178 @@ int resident_fallback(nid_ctx *ctx, Slot &S) {
   S.resident = false;  // from here on the wait is an ordinary DIRECT wait
   R.pending_slot = -1;
   return launch_eval(ctx, P, R.jac, ctx->stream);
+}
+
+// ---- the resident BATCH evaluator (k_resident_batch): host side -------------------------------------------------------
+// A request is K <= kResBatchMax poses whose results the host collects slot by slot (nid_wait): the records a launch of
+// more than kMaxBatch poses would copy into a device array are written, through the BAR, behind the mailbox's control
+// line; every pose goes through the in-launch reduction into its slot's pinned block and sequence word, so nid_wait
+// waits for it like for a launched pose.  One request in flight at a time; the kernel is started by the first request
+// (and again when the Huber delta changes: it is a kernel argument), retired like k_resident.  Which requests take this
+// way: resident_batch_usable.  A request the kernel does not answer within kResidentPatience (it had left: its own idle
+// limit) is re-issued as ordinary launches (resident_batch_fallback).
+bool resident_batch_usable(const nid_ctx *ctx, int n, bool jac) {
+  const nid_ctx::Resident &R = ctx->res;
+  if (!R.enabled || !R.benabled || R.probed < 0 || R.bunfit || R.running || R.pending_slot >= 0 || R.bleft > 0) return false;
+  if (n < 1 || n > kResBatchMax || (n < 2 && !R.brunning)) return false;  // (a lone pose does not start it: DIRECT launches are faster)
+  if (ctx->timing || ctx->dbg_enabled || ctx->dbg_stamps || ctx->external_stream) return false;
+  if (res_held_by_other(ctx)) return false;
+  if (ctx->math_mode != NID_MATH_FAST) return false;
+  // cost + Jacobian results carry the workgroup shape in their last bits: the batch kernel is the 128-thread loop form
+  if (jac && ctx->jac_threads != 0 && ctx->jac_threads != 128) return false;
+  return ctx->g.pstride <= 32 * 128;  // (the loop form's lane masks cover 32 rounds)
+}
+
+int resident_batch_start(nid_ctx *ctx, double delta) {
+  nid_ctx::Resident &R = ctx->res;
+  int rc = resident_probe(ctx);
+  if (rc) { ctx->last_error = "resident batch evaluator: mailbox probe failed"; return rc; }
+  EvalParams P{};
+  fill_common_params(ctx, delta, &P);
+  set_hist_params(P);
+  const size_t lds = eval_lds_bytes(P.g, 128, true);
+  int cus = 0;
+  NID_HIP(ctx, hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->cfg.device));
+  // every workgroup must be ON the device: two waves of at most 128 registers each, i.e. eight workgroups per CU, and
+  // their LDS
+  const long per_cu = std::min<long>(8, (long)((160 * 1024) / std::max<size_t>(lds, 1)));
+  const long nloc8 = ((long)P.g.nloc + 7) / 8 * 8;
+  const int replicas = (int)std::min<long>(kResBatchMax, (long)cus * per_cu / nloc8);
+  if (replicas < 1) { R.bunfit = true; ctx->last_error = "resident batch evaluator: more cells than co-resident workgroups"; return NID_ERR_UNSUPPORTED; }
+  const unsigned grid = (unsigned)(nloc8 * replicas);
+  if (!R.bctl) {
+    void *p = nullptr;
+    if (hipExtMallocWithFlags(&p, sizeof(ResBatchCtl), hipDeviceMallocFinegrained) != hipSuccess) { (void)hipGetLastError(); R.bunfit = true; return NID_ERR_UNSUPPORTED; }
+    R.bctl = static_cast<ResBatchCtl *>(p);
+    NID_HIP(ctx, hipMemset(p, 0, sizeof(ResBatchCtl)));
+    NID_HIP(ctx, hipStreamSynchronize(nullptr));
+    int rc2 = dev_alloc(ctx, &R.bfwd, resbatch_fan_words(nloc8));
+    if (rc2) return rc2;
+    if (hipHostMalloc(reinterpret_cast<void **>(&R.brec_host), (size_t)kResBatchMax * sizeof(SlotArgs), hipHostMallocMapped) != hipSuccess) { (void)hipGetLastError(); return NID_ERR_NOMEM; }
+    NID_HIP(ctx, hipHostGetDevicePointer(reinterpret_cast<void **>(&R.brec_devptr), R.brec_host, 0));
+  }
+  if (R.bstage_n < grid) {
+    if (R.bstage) (void)hipFree(R.bstage);
+    R.bstage = nullptr; R.bstage_n = 0;
+    if (hipMalloc(reinterpret_cast<void **>(&R.bstage), (size_t)grid * sizeof(SlotArgs)) != hipSuccess) { (void)hipGetLastError(); return NID_ERR_NOMEM; }
+    R.bstage_n = grid;
+  }
+  P.slots_ext = R.bstage;
+  P.batch = replicas;
+  if (!res_claim(ctx)) { ctx->last_error = "resident evaluator: another context's resident kernel holds this device"; return NID_ERR_STATE; }
+  long long idle_ticks = kResidentIdleTicks;
+  if (const char *e = getenv("NID_RESIDENT_IDLE_US")) idle_ticks = std::max(1L, atol(e)) * 100;
+  // the word the kernel starts from, in the control line and in every cell's forwarding record
+  const unsigned long long word0 = resbatch_word(R.bseq, 0, 0);
+  {
+    std::vector<unsigned long long> f(resbatch_fan_words(nloc8), 0ull);
+    f[0] = word0;                                                        // gword
+    for (long c = 0; c < nloc8; c++) f[resbatch_cells_off() + 2 * c] = word0;  // every cell's {word, pose counter}
+    if (hipMemcpyAsync(R.bfwd, f.data(), f.size() * sizeof(f[0]), hipMemcpyHostToDevice, R.stream) != hipSuccess ||
+        hipStreamSynchronize(R.stream) != hipSuccess) { res_release(ctx); ctx->last_error = hipGetErrorString(hipGetLastError()); return NID_ERR_HIP; }
+  }
+  volatile unsigned long long *w = R.bctl->w;
+  w[7] = word0;
+  store_fence();
+  launch_resident_batch(P, lds, grid, R.stream, R.bctl, reinterpret_cast<const unsigned *>(R.brec_devptr), R.bfwd, word0, idle_ticks, replicas);
+  if (hipGetLastError() != hipSuccess) { res_release(ctx); ctx->last_error = "resident batch evaluator: launch failed"; return NID_ERR_HIP; }
+  R.brunning = true;
+  R.bdelta = delta;
+  R.breplicas = replicas;
+  R.bstarts++;
+  R.last_post = std::chrono::steady_clock::now();
+  return NID_OK;
+}
+
+// NID_ERR_UNSUPPORTED / NID_ERR_STATE: use ordinary launches
+int resident_batch_post(nid_ctx *ctx, int first_slot, int n, const Pose *poses, bool jac, double delta) {
+  nid_ctx::Resident &R = ctx->res;
+  const auto now = std::chrono::steady_clock::now();
+  if (R.brunning && (R.bdelta != delta || now - R.last_post > kResidentHostIdle)) resident_retire(ctx);
+  if (!R.brunning) {
+    int rc = resident_batch_start(ctx, delta);
+    if (rc) {
+      if (getenv("NID_RESIDENT_DEBUG")) fprintf(stderr, "[nid resident] batch start failed: %d %s\n", rc, ctx->last_error.c_str());
+      return rc;
+    }
+  }
+  for (int k = 0; k < n; k++) {
+    Slot &S = ctx->slots[first_slot + k];
+    S.seq++;
+    S.direct = S.resident = S.groups = false;
+    S.external_target = false;
+    SlotArgs &rec = R.brec_host[k];  // (pinned host memory: the kernel's root workgroup fetches the records over PCIe)
+    fill_slot_args(poses[k], S, S.reduced_host_devptr, reinterpret_cast<unsigned long long *>(S.reduced_host_devptr + kReducedLen), &rec);
+    rec.cellout = nullptr;  // (nobody reads the per-cell outputs of such a request)
+    R.bposes[k] = poses[k];
+  }
+  store_fence();
+  __atomic_thread_fence(__ATOMIC_SEQ_CST);  // the records are globally visible before the word leaves
+  volatile unsigned long long *w = R.bctl->w;
+  w[7] = resbatch_word(++R.bseq, n, jac ? kResJac : 0u);  // ONE store through the BAR
+  store_fence();  // out of the write-combining buffers now
+  R.last_post = std::chrono::steady_clock::now();
+  R.bfirst = first_slot; R.bn = n; R.bleft = n; R.bjac = jac;
+  for (int k = 0; k < n; k++) {
+    Slot &S = ctx->slots[first_slot + k];
+    S.resbatch = true;
+    S.collected = false;
+    S.timed = false;
+    S.done_slot = first_slot;
+    S.pending = true;
+  }
+  return NID_OK;
+}
+
+// the batch kernel did not answer: take it down and put what has not arrived through ordinary launches
+int resident_batch_fallback(nid_ctx *ctx) {
+  nid_ctx::Resident &R = ctx->res;
+  resident_retire(ctx);  // (if it was still there: no late writes after this)
+  R.bfallbacks++;
+  R.fallback_run++;
+  if (R.fallback_run >= 3 || (R.bfallbacks > 8 && R.bfallbacks > R.bserved)) {
+    R.enabled = false;
+    R.why = "resident evaluator switched off: " + std::to_string(R.bfallbacks) + " batch requests timed out (" + std::to_string(R.bserved) +
+            " served) -- its workgroups are not staying on the device (a shared GPU?); requests are launched from now on";
+    ctx->last_error = R.why;
+  }
+  NID_HIP(ctx, hipSetDevice(ctx->cfg.device));
+  const int first = R.bfirst, n = R.bn;
+  const bool jac = R.bjac;
+  const double delta = R.bdelta;
+  R.bleft = 0;
+  const size_t n_ticket = 1 + (size_t)((ctx->g.nloc + ctx->group_size - 1) / ctx->group_size);
+  for (int k = 0; k < n; k++) {
+    Slot &S = ctx->slots[first + k];
+    if (!S.resbatch || S.collected) continue;
+    S.resbatch = false;
+    volatile unsigned long long *seqw = reinterpret_cast<volatile unsigned long long *>(S.reduced_host + kReducedLen);
+    if (__atomic_load_n(seqw, __ATOMIC_ACQUIRE) == S.seq) continue;  // this one had arrived
+    // (a pose the kernel left half done: its tickets start from zero again)
+    NID_HIP(ctx, hipMemsetAsync(S.ticket_dev, 0, n_ticket * sizeof(unsigned), ctx->stream));
+    int rc = launch_batch(ctx, first + k, 1, &R.bposes[k], jac ? 1 : 0, delta, nullptr, false, /*relaunch_ok=*/true, /*allow_direct=*/false);
+    if (rc) return rc;
+  }
+  return NID_OK;
+}
+
+// nid_wait for a pose of a batch request: the slot's sequence word, like a launched pose's -- with the resident
+// kernel's patience
+int wait_resbatch(nid_ctx *ctx, Slot &S) {
+  nid_ctx::Resident &R = ctx->res;
+  volatile unsigned long long *seqw = reinterpret_cast<volatile unsigned long long *>(S.reduced_host + kReducedLen);
+  const auto t0 = std::chrono::steady_clock::now();
+  unsigned long spins = 0;
+  while (__atomic_load_n(seqw, __ATOMIC_ACQUIRE) != S.seq) {
+    if ((++spins & 1023ul) == 0 && std::chrono::steady_clock::now() - t0 > kResidentPatience) {
+      int rc = resident_batch_fallback(ctx);
+      if (rc) return rc;
+      return wait_host_seq(ctx, S);  // (an ordinary launch now; S.seq is the relaunch's)
+    }
+  }
+  S.resbatch = false;
+  if (R.bleft > 0 && --R.bleft == 0) { R.bserved++; R.fallback_run = 0; }
+  return NID_OK;
 }
 
 int launch_slot(nid_ctx *ctx, int slot, const Pose &pose, int want_jac, double delta,
@@ -1064,7 +1284,7 @@ int launch_slot(nid_ctx *ctx, int slot, const Pose &pose, int want_jac, double d
 // pinned result block), so the reduction tails and the launch cost overlap with other poses' work
 // and two workgroups share a CU.  Results are collected per slot with nid_wait().
 int launch_batch(nid_ctx *ctx, int first_slot, int n, const Pose *poses, int want_jac, double delta,
-                 double *reduced_dev_base = nullptr, bool on_aux_stream = false, bool relaunch_ok = false, bool allow_direct = true) {
+                 double *reduced_dev_base, bool on_aux_stream, bool relaunch_ok, bool allow_direct) {
   int rc = check_ready(ctx);
   if (rc) return rc;
   if (n < 1 || n > kMaxBatchExt || first_slot < 0 || first_slot + n > NID_SLOTS) return NID_ERR_INVALID_ARG;
@@ -1178,6 +1398,14 @@ SplitPlan plan_split(const nid_ctx *ctx, int n, bool jac) {
 int launch_split(nid_ctx *ctx, int first_slot, int n, const Pose *poses, int want_jac, double delta) {
   if (!ctx) return NID_ERR_INVALID_ARG;
   if (n < 1 || n > kMaxBatchExt || first_slot < 0 || first_slot + n > NID_SLOTS) return NID_ERR_INVALID_ARG;
+  if (resident_batch_usable(ctx, n, want_jac != 0)) {  // (nid_set_resident: no launch at all)
+    int rc = check_ready(ctx);
+    if (rc) return rc;
+    for (int k = 0; k < n; k++)
+      if (ctx->slots[first_slot + k].pending) { ctx->last_error = "slot still pending: nid_wait() it first"; return NID_ERR_STATE; }
+    NID_HIP(ctx, hipSetDevice(ctx->cfg.device));
+    if (resident_batch_post(ctx, first_slot, n, poses, want_jac != 0, delta) == NID_OK) return NID_OK;
+  }
   const SplitPlan plan = plan_split(ctx, n, want_jac != 0);
   if (plan.chunk >= n || ctx->dbg_enabled || ctx->timing) return launch_batch(ctx, first_slot, n, poses, want_jac, delta);
   for (int k = 0; k < n; k++)  // all or nothing: no half-launched sequence
@@ -1537,6 +1765,10 @@ int nid_destroy(nid_ctx *ctx) {
   resident_retire(ctx);
   if (ctx->res.stream) (void)hipStreamDestroy(ctx->res.stream);
   if (ctx->res.ctl) (void)hipFree(ctx->res.ctl);
+  if (ctx->res.bctl) (void)hipFree(ctx->res.bctl);
+  if (ctx->res.bfwd) (void)hipFree(ctx->res.bfwd);
+  if (ctx->res.bstage) (void)hipFree(ctx->res.bstage);
+  if (ctx->res.brec_host) (void)hipHostFree(ctx->res.brec_host);
   if (ctx->res.rec_host) (void)hipHostFree(ctx->res.rec_host);
   if (ctx->own_stream) (void)hipStreamSynchronize(ctx->own_stream);
   (void)hipFree(ctx->t.X); (void)hipFree(ctx->t.Y); (void)hipFree(ctx->t.Z); (void)hipFree(ctx->t.W);
@@ -2099,9 +2331,10 @@ int nid_wait(nid_ctx *ctx, int slot, double *H36, double *b6, double *chi2, int3
   if (S.collected) {
     S.collected = false;
   } else {
-    int rc = S.direct ? wait_direct(ctx, S) : (S.groups ? wait_groups(ctx, S) : wait_host_seq(ctx, S));
+    int rc = S.resbatch ? wait_resbatch(ctx, S) : (S.direct ? wait_direct(ctx, S) : (S.groups ? wait_groups(ctx, S) : wait_host_seq(ctx, S)));
     if (rc) return rc;
   }
+  S.resbatch = false;
   S.direct = false;
   S.groups = false;
   S.pending = false;
@@ -2228,9 +2461,11 @@ int nid_set_resident(nid_ctx *ctx, int on) {
   NID_HIP(ctx, hipSetDevice(ctx->cfg.device));
   if (!on) {
     resident_retire(ctx);
-    ctx->res.enabled = false;
+    ctx->res.enabled = ctx->res.benabled = false;
     return NID_OK;
   }
+  if (on != 2 && ctx->res.brunning) resident_retire(ctx);
+  ctx->res.benabled = on == 2;
   int rc = resident_probe(ctx);
   if (rc == NID_OK && ctx->res.unfit_nt != 0 && ctx->res.unfit_nt == ctx->jac_threads) rc = NID_ERR_UNSUPPORTED;
   if (rc) { ctx->last_error = "resident evaluator unavailable: " + (ctx->res.why.empty() ? std::string("mailbox setup failed") : ctx->res.why); return rc; }
@@ -2241,7 +2476,7 @@ int nid_set_resident(nid_ctx *ctx, int on) {
 
 int nid_resident_pause(nid_ctx *ctx) {
   if (!ctx) return NID_ERR_INVALID_ARG;
-  if (!ctx->res.running) return NID_OK;
+  if (!ctx->res.running && !ctx->res.brunning) return NID_OK;
   for (int s = 0; s < NID_SLOTS; s++) if (ctx->slots[s].pending) return NID_ERR_STATE;
   NID_HIP(ctx, hipSetDevice(ctx->cfg.device));
   resident_retire(ctx);  // (the next request starts another)
@@ -2253,6 +2488,14 @@ int nid_resident_stats(const nid_ctx *ctx, int64_t *served, int64_t *fallbacks, 
   if (served) *served = ctx->res.served;
   if (fallbacks) *fallbacks = ctx->res.fallbacks;
   if (starts) *starts = ctx->res.starts;
+  return NID_OK;
+}
+
+int nid_resident_batch_stats(const nid_ctx *ctx, int64_t *served, int64_t *fallbacks, int64_t *starts) {
+  if (!ctx) return NID_ERR_INVALID_ARG;
+  if (served) *served = ctx->res.bserved;
+  if (fallbacks) *fallbacks = ctx->res.bfallbacks;
+  if (starts) *starts = ctx->res.bstarts;
   return NID_OK;
 }
 

@@ -32,4 +32,10 @@ NID_DECLARE_EVAL_TU(1024, jac) NID_DECLARE_EVAL_TU(1024, cost)
 void launch_resident(const EvalParams &P, int nt, size_t lds, unsigned grid, hipStream_t s, const ResidentCtl *ctl,
                          unsigned long long word0, long long idle_ticks, int xform_mode);
 
+// k_resident_batch<NB>: `replicas` 128-thread workgroups per cell, all of them co-resident (the caller checks);
+// P.slots_ext = a staging array of one SlotArgs per workgroup; hrec = the request's records in pinned host memory (device
+// pointer); fan = resbatch_fan_words() u64 of device memory
+void launch_resident_batch(const EvalParams &P, size_t lds, unsigned grid, hipStream_t s, const ResBatchCtl *ctl, const unsigned *hrec,
+                           unsigned long long *fan, unsigned long long word0, long long idle_ticks, int replicas);
+
 }  // namespace nid

@@ -847,8 +847,12 @@ SWEEP_SEEDS += [502812, 503912, 500953]
 # reference's: times the edge's gradient 3.8e-12 in ic, 7.2e-10 of that weight, 1.5e-9 of the cell's Jacobian -- which
 # is also what the REFERENCE's Jacobian of that cell does when its own u moves by one ulp (1.49e-9: the twin oracle now
 # takes the centre sample one ulp up in u, v; the other 15 cells of the frame move by 1e-14).  STRICT math has the
-# reference's u to the bit (3e-14).  Passes on the measured-noise term, listed in the summary.
+# reference's u to the bit (3e-14).  Round 4 passed it on the measured-noise term.  Round 5: samples within 1/8 of an END
+# knot (0 or 255) are no longer FAST math's to place -- the clamp guard sends them to the second passes, which take the
+# reference's own (u, v, ic) (kGuardLoHi in csrc/nid_kernels.hip.h) -- and the seed holds the plain bound, no noise term,
+# in both modes (HARD_BOUND_SEEDS).
 SWEEP_SEEDS += [511576]
+HARD_BOUND_SEEDS = {511576}
 # ... third pass (1 of 24 000): 564566, pose 2, cell 0 -- an 8-grey-level target; at that pose the cell keeps a few samples on a
 # flat patch: the reference's Jacobian of the cell is 1.6e-11 (the frame: 0.93), its twin's 0, the HIP path's 0 in both
 # modes.  Pure rounding noise like a constant image's, but 1.6e-11 is above the absolute cap of 1e-11 the allowance had:
@@ -875,7 +879,7 @@ def test_randomised_pairs(capi, oracle, synth, seed):
         for pose in poses:
             ref = o.evaluate(pose, True)
             got = ctx.evaluate(pose, True)
-            _compare_cells(got, ref, cnt_o, noise=(o, pose))
+            _compare_cells(got, ref, cnt_o, noise=None if seed in HARD_BOUND_SEEDS else (o, pose))
             H, b, chi2, na = ctx.normal_equations(pose, DELTA)
             assert na == int(act.sum())
 
@@ -1225,6 +1229,104 @@ def test_slot_device_blocks_after_a_plain_launch(capi, synth, direct):
             ctx.wait(slot)
             red = ctx.read_device(red_dev, (32,))
             assert red[0] == chi2 and red[28] == na and (not want_jac or _same_bits(red[1:7], b))
+    ctx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg", ["S", "A", "flash"])
+def test_resident_batch_evaluator_equals_launches(capi, synth, cfg, monkeypatch):
+    """The resident BATCH evaluator (round 5; nid_set_resident(ctx, 2) on a context of the 128-thread shape): requests of 2..64
+    poses -- nid_launch_batch, nid_run_sequence with n <= batch -- are answered by a resident kernel in the throughput form
+    instead of launches: the SAME BITS (6x6 system, chi2, count; cost + Jacobian and cost-only), whatever the request's
+    size; a lone pose goes to it while it runs; 65 poses, a pipelined sequence and every state change retire it; on the
+    flash pair the cells that want the repair pass (kLinFlagW) are redone in place; a kernel that has left by itself is
+    noticed and the request re-issued as launches."""
+    import time
+    pair = synth.make_pair("A", flash=True) if cfg == "flash" else synth.make_pair(cfg)
+    nb = 8
+    ctx = capi.from_pair(pair, nb)
+    ctx.compute_href(pair.pose_init)
+    rng = np.random.default_rng(77)
+    base = list(_poses(synth, pair).values())
+    poses = [synth.perturb_pose7(base[k % 3], 2e-3 * rng.standard_normal(3), 2e-3 * rng.standard_normal(3)) for k in range(70)]
+
+    def batch(k, jac, first=5):
+        ctx.launch_batch(first, poses[:k], DELTA, want_jac=jac)
+        return [ctx.wait(first + i) for i in range(k)]
+
+    def same(a, b, jac):
+        for x, y in zip(a, b):
+            assert _same_bits(x[2], y[2]) and x[3] == y[3]
+            if jac:
+                assert _same_bits(x[0], y[0]) and _same_bits(x[1], y[1])
+
+    sizes = [2, 3, 10, 20, 64]
+    ctx.set_resident(False)
+    ref = {(k, jac): batch(k, jac) for k in sizes + [1, 65] for jac in (True, False)}
+    ref_seq = ctx.run_sequence(poses[:20], DELTA, batch=256)
+    ctx.set_resident(2)
+    if cfg == "flash":
+        ctx.repair_count(reset=True)
+    s0 = ctx.resident_batch_stats()
+    n_req = 0
+    for rep in range(2):
+        for k in sizes:
+            for jac in (True, False):
+                same(batch(k, jac, first=5 + rep), ref[(k, jac)], jac)
+                n_req += 1
+    s1 = ctx.resident_batch_stats()
+    assert s1["served"] - s0["served"] == n_req and s1["fallbacks"] == s0["fallbacks"] and s1["starts"] == s0["starts"] + 1
+    if cfg == "flash":
+        assert ctx.repair_count() > 0      # cells redone with the inline repair (counted by the instantiation that repairs)
+        s1 = ctx.resident_batch_stats()    # (reading the counter retires the kernel)
+    # a lone pose while the kernel is on the device goes to it too; nid_run_sequence's short form likewise
+    same(batch(2, True), ref[(2, True)], True)
+    same(batch(1, True), ref[(1, True)], True)
+    same(batch(1, False), ref[(1, False)], False)
+    seq = ctx.run_sequence(poses[:20], DELTA, batch=256)
+    assert _same_bits(seq, ref_seq)
+    s2 = ctx.resident_batch_stats()
+    assert s2["served"] - s1["served"] == 4 and s2["fallbacks"] == s1["fallbacks"]
+    # more poses than a request holds, and a pipelined sequence: launches (the kernel is retired first), then back
+    same(batch(65, True), ref[(65, True)], True)
+    seq = ctx.run_sequence(poses[:40], DELTA, batch=8)
+    assert _same_bits(seq[:20], ref_seq)
+    same(batch(10, False), ref[(10, False)], False)
+    s3 = ctx.resident_batch_stats()
+    assert s3["served"] == s2["served"] + 1 and s3["starts"] == s2["starts"] + 1 and s3["fallbacks"] == s2["fallbacks"]
+    # an idle host retires the kernel; a new target image retires it and the results follow
+    time.sleep(0.08)
+    same(batch(20, True), ref[(20, True)], True)
+    assert ctx.resident_batch_stats()["starts"] == s3["starts"] + 1
+    other = synth.make_pair("S", edge_cases=True) if cfg == "S" else (synth.make_pair("A") if cfg == "flash" else synth.make_pair("A", flash=True))
+    ctx.set_target(other.im1)
+    ctx.set_resident(False)
+    ref2 = batch(10, True)
+    ctx.set_resident(2)
+    assert not _same_bits(ref2[0][2], ref[(10, True)][0][2])
+    same(batch(10, True), ref2, True)
+    # the 512-thread shape: cost + Jacobian requests keep their launches (the Jacobian's last bits carry the shape), cost-only ones are served
+    ctx.set_launch_shape(512, 0)
+    ctx.set_resident(False)
+    r512 = batch(10, True), batch(10, False)
+    ctx.set_resident(2)
+    before = ctx.resident_batch_stats()["served"]
+    same(batch(10, True), r512[0], True)
+    assert ctx.resident_batch_stats()["served"] == before
+    same(batch(10, False), r512[1], False)
+    assert ctx.resident_batch_stats()["served"] == before + 1
+    ctx.close()
+    # a kernel that leaves by itself after 1 ms: the unanswered request is re-issued as ordinary launches
+    monkeypatch.setenv("NID_RESIDENT_IDLE_US", "1000")
+    ctx = capi.from_pair(pair, nb)
+    ctx.compute_href(pair.pose_init)
+    ctx.set_resident(2)
+    same(batch(20, True), ref[(20, True)], True)
+    for _ in range(2):
+        time.sleep(0.01)
+        same(batch(20, True), ref[(20, True)], True)
+    st = ctx.resident_batch_stats()
+    assert st["fallbacks"] >= 1
     ctx.close()
 
 
