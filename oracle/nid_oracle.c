@@ -37,6 +37,7 @@ struct nid_oracle {
   double *wr;           /* 4N (bs_value_ref_), zero until computeHref */
   double *ic;           /* N  (intensity_current_), zero-initialised: .cpp:652 */
   double *jgx, *jgy, *jpc, *jdw; int *jjc;  /* Jacobian-pass dump: gx, gy, bin position, 4 derivatives, span (NaN / -1: no contribution) */
+  double *jabs;  /* per cell: the sum of the ABSOLUTE values of the terms the last linearizeOplus added up (nid_oracle_jac_abs_scale) */
   unsigned char *im1;   /* N  (image1_) */
   /* dump of the last evaluate */
   double *du, *dv, *dwc;
@@ -399,6 +400,7 @@ nid_oracle *nid_oracle_create(int rows, int cols, int cell, int bin_num,
   o->jgx = (double *)calloc(N, sizeof(double)); o->jgy = (double *)calloc(N, sizeof(double));
   o->jpc = (double *)calloc(N, sizeof(double)); o->jdw = (double *)calloc(4 * N, sizeof(double));
   o->jjc = (int *)calloc(N, sizeof(int));
+  o->jabs = (double *)calloc((size_t)o->ncell, sizeof(double));
   o->im1 = (unsigned char *)calloc(N, 1);
   o->du = (double *)calloc(N, sizeof(double));
   o->dv = (double *)calloc(N, sizeof(double));
@@ -418,7 +420,7 @@ nid_oracle *nid_oracle_create(int rows, int cols, int cell, int bin_num,
 void nid_oracle_destroy(nid_oracle *o) {
   if (!o) return;
   free(o->pts); free(o->I0); free(o->wr); free(o->ic); free(o->im1);
-  free(o->jgx); free(o->jgy); free(o->jpc); free(o->jdw); free(o->jjc);
+  free(o->jgx); free(o->jgy); free(o->jpc); free(o->jdw); free(o->jjc); free(o->jabs);
   free(o->du); free(o->dv); free(o->dwc); free(o->djc);
   free(o->Nc); free(o->active); free(o->Href); free(o->pc); free(o->pj);
   free(o->Hc); free(o->Hj);
@@ -711,6 +713,24 @@ static void cell_linearize(nid_oracle *o, const xform_t *xf, int ci, int cj, dou
   double inv_square_hj = 1.0 / (H_joint * H_joint);
   for (int i = 0; i < 6; i++)
     J[i] = (d_hj_p[i] * (H_current + H_ref) - d_hl_p[i] * H_joint) * inv_square_hj;
+  /* Test infrastructure, not part of the restated path: the CONDITION of that result -- the same expression with every
+   * term's absolute value, i.e. the magnitude of what the reference adds up with alternating signs (the bins' derivative
+   * sums add up to zero, :505-519, and J is a difference of two products, :521).  A cell whose J is many orders below it
+   * is a cancellation residue: no re-association of these sums reproduces it to a relative bound. */
+  {
+    double worst = 0.0;
+    for (int i = 0; i < 6; i++) {
+      double aj = 0.0, al = 0.0;
+      for (int m = 0; m < nb; m++)
+        for (int n = 0; n < nb; n++)
+          if (!(pro_joint[m * nb + n] < NID_SIGMA)) aj += fabs((1.0 + log2(pro_joint[m * nb + n])) * d_sum_joint_bs_pose[m][n][i]);
+      for (int j = 0; j < nb; j++)
+        if (!(pro_current[j] < NID_SIGMA)) al += fabs((1.0 + log2(pro_current[j])) * d_sum_bs_pose[j][i]);
+      double t = (aj * fabs(H_current + H_ref) + al * fabs(H_joint)) * inv_square_hj;
+      if (t > worst) worst = t;
+    }
+    o->jabs[c] = worst;
+  }
 }
 
 void nid_oracle_evaluate(nid_oracle *o, const double *pose7, int want_jac,
@@ -751,6 +771,10 @@ void nid_oracle_dump_pixels(const nid_oracle *o, double *u, double *v, double *i
       if (obs >= 255) obs = 254.999;
       jr[i] = (int)floor(obs * (o->nb - o->deg) / 255.0);
     }
+}
+
+void nid_oracle_jac_abs_scale(const nid_oracle *o, double *per_cell) {
+  memcpy(per_cell, o->jabs, (size_t)o->ncell * sizeof(double));
 }
 
 void nid_oracle_dump_jac(const nid_oracle *o, double *gx, double *gy, double *pc, int *jc, double *dw4) {

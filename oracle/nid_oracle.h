@@ -75,6 +75,9 @@ void nid_oracle_dump_pixels(const nid_oracle *o, double *u, double *v,
 /* per-pixel dump of the Jacobian pass of the last evaluate(want_jac): image gradient (gx, gy), bin position,
  * span and the four B-spline derivatives of every pixel that contributed (NaN / -1 elsewhere) */
 void nid_oracle_dump_jac(const nid_oracle *o, double *gx, double *gy, double *pc, int *jc, double *dw4);
+/* per cell, of the last evaluate with the Jacobian: the sum of the absolute values of the terms linearizeOplus added up
+ * (the condition of its result; test infrastructure) */
+void nid_oracle_jac_abs_scale(const nid_oracle *o, double *per_cell);
 
 /* ---- B-spline (types_six_dof_expmap.cpp:738-800) ----------------------- */
 double nid_oracle_bspline(int bin_num, int index, int order, double u);

@@ -51,6 +51,7 @@ def load(path: str | None = None):
     lib.nid_oracle_normal_equations.argtypes = [c_dp, c_dp, C.c_int, C.c_double, c_dp, c_dp, c_dp, c_ip]
     lib.nid_oracle_dump_pixels.argtypes = [C.c_void_p, c_dp, c_dp, c_dp, c_ip, c_dp, c_dp, c_ip]
     lib.nid_oracle_dump_jac.argtypes = [C.c_void_p, c_dp, c_dp, c_dp, c_ip, c_dp]
+    lib.nid_oracle_jac_abs_scale.argtypes = [C.c_void_p, c_dp]
     lib.nid_oracle_bspline.restype = C.c_double
     lib.nid_oracle_bspline.argtypes = [C.c_int, C.c_int, C.c_int, C.c_double]
     lib.nid_oracle_bspline_der.restype = C.c_double
@@ -116,6 +117,20 @@ def load_twin():
             subprocess.check_call(["make", "-s", "-C", _HERE, "libnid_oracle_twin.so"])
         _LIB_TWIN = load(p)
     return _LIB_TWIN
+
+
+_LIB_TWIN_MARGIN = None
+
+
+def load_twin_margin():
+    """load_twin() on the defined margin of load_margin(): the noise witness of a context created with defined_margin=True."""
+    global _LIB_TWIN_MARGIN
+    if _LIB_TWIN_MARGIN is None:
+        p = os.path.join(_HERE, "libnid_oracle_twin_margin.so")
+        if not os.path.exists(p):
+            subprocess.check_call(["make", "-s", "-C", _HERE, "libnid_oracle_twin_margin.so"])
+        _LIB_TWIN_MARGIN = load(p)
+    return _LIB_TWIN_MARGIN
 
 
 def _dp(a):
@@ -238,7 +253,7 @@ class Oracle:
     def twin(self):
         """The same frame pair and reference stage on load_twin()'s build (created on first use)."""
         if self._twin is None:
-            t = Oracle(*self._args, lib=load_twin())
+            t = Oracle(*self._args, lib=load_twin_margin() if self.lib is _LIB_MARGIN else load_twin())
             t.set_reference(*self._ref)
             t.set_target(self._tgt)
             t.compute_href(self._href_pose)
@@ -270,6 +285,13 @@ class Oracle:
         jr = np.zeros(N, dtype=np.int32)
         self.lib.nid_oracle_dump_pixels(self.h, _dp(u), _dp(v), _dp(ic), _ip(jc), _dp(wc), _dp(wr), _ip(jr))
         return dict(u=u, v=v, ic=ic, jc=jc, wc=wc, wr=wr, jr=jr)
+
+    def jac_abs_scale(self):
+        """Per cell, of the last evaluate(want_jac=True): the sum of the ABSOLUTE values of the terms the reference's
+        linearizeOplus added up -- how large the quantities are whose alternating sum the cell's Jacobian is."""
+        out = np.zeros(self.ncell)
+        self.lib.nid_oracle_jac_abs_scale(self.h, _dp(out))
+        return out
 
     def dump_jac(self):
         """Jacobian pass of the last evaluate(want_jac=True): gx, gy, pc, jc, dw[4] per contributing pixel."""

@@ -263,3 +263,33 @@ def test_reference_lm_reproducibility_on_saturated_data(oracle):
     common, n, d = self_deviation(synth.make_pair("A", flash=True, edge_cases=True), 10)
     print(f"flash pair, 10 bins: {common} common iterations of {n}, final poses {d:.2e} apart")
     assert d > 1e-7, "expected the reference's own LM to be irreproducible below 1e-7 on this pair"
+
+
+def test_adversarial_generator_hits_its_targets(oracle, synth):
+    """tests/adversarial_cases.py constructs what it says: cells with exactly 300 / 299 in-frame pixels, target samples exactly
+    on interior knots and on 0 / 255, samples on the frame borders, and intensities within the last 1/8 before 255 on steep edges."""
+    from adversarial_cases import adversarial_case, KINDS
+    seen = {k: 0 for k in KINDS}
+    hit = dict(at_300=False, at_299=False, on_knot=False, at_255=False, at_0=False, on_border=False, near_255_edge=False)
+    for seed in range(60):
+        pair, nb, href_pose, poses, kind, _ = adversarial_case(synth, seed)
+        seen[kind] += 1
+        o = oracle.from_pair(pair, nb, defined_margin=True)
+        cnt, _ = o.compute_href(href_pose)
+        hit["at_300"] |= bool((cnt == 300).any())
+        hit["at_299"] |= bool((cnt == 299).any())
+        S = nb - 3
+        for pose in poses[:6]:
+            o.evaluate(pose, False)
+            d = o.dump_pixels()
+            m = d["jc"] >= 0
+            ic, u, v = d["ic"][m], d["u"][m], d["v"][m]
+            pc = ic * S / 255.0
+            hit["on_knot"] |= bool(((pc == np.rint(pc)) & (pc > 0) & (pc < S)).any())
+            hit["at_255"] |= bool((ic == 254.999).any())
+            hit["at_0"] |= bool((ic == 0.0).any())
+            hit["on_border"] |= bool(((u == 0.0) | (v == 0.0) | (u + 3 == pair.cols) | (v + 3 == pair.rows)).any())
+            if kind == "edges":
+                hit["near_255_edge"] |= bool(((ic > 254.875) & (ic < 254.999)).any())
+    assert all(n >= 10 for n in seen.values())
+    assert all(hit.values()), hit

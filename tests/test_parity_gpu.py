@@ -40,6 +40,15 @@ J_EPS = 64 * 2.0 ** -53
 # twin is a sample that changed its bin between the two roundings -- a discontinuity, not noise -- and buys nothing.
 NOISE_CAP_REL = 1e-6
 NOISE_CAP_ABS = 1e-11
+# The CONDITION of the reference's Jacobian (round 5; why: profiles/r05_adversarial.txt).  A cell's J is an alternating sum:
+# the bins' derivative sums add up to zero against weights -(1 + log2 p) (types_six_dof_expmap.cpp:505-519), and the result is
+# a difference of two products (:521).  T = the same expression with every term's absolute value (oracle.jac_abs_scale()) is
+# 20-100 times |J| on ordinary data and 1e13 times |J| in a cell whose target samples all sit on one span (a saturated patch
+# with specks: the constructed "ends" cases) -- there J is a cancellation residue of 1e-12 that no re-association of the
+# sums reproduces to a relative bound: STRICT and FAST math miss it by the SAME 3e-12 (integer histograms, two-phase
+# contraction), 2e-14..2e-13 of T in 1 500 constructed cases.  So, where a test hands over T: a cell passes within
+# max(RTOL_J * own scale, COND_RTOL * T) -- the plain bound wherever T <= 1000 |J|, the condition bound beyond.
+COND_RTOL = 1e-12
 DELTA = float(np.sqrt(0.95))
 # Every cell that passed ONLY on the noise term, for the terminal summary (tests/conftest.py) and
 # gpurun_out/noise_term_cells.txt: (test id, cell, |dJ| / own scale, noise / own scale).
@@ -77,25 +86,44 @@ def _saturated_cells(o, pair):
     return out
 
 
+def _history_dependent_cells(o, pair):
+    """Cells whose REFERENCE Jacobian, as just evaluated by oracle `o`, used a stale intensity: linearizeOplus decides
+    its in-frame test on its own projection fx * (x / z) + cx (types_six_dof_expmap.cpp:407-433, Q6) and then reads
+    intensity_current_, which computeError wrote only for pixels inside ITS test on fx * x / z + cx (:562-566).  A pixel an
+    ulp outside the one and on the border of the other (u = -7e-15 against 0.0: whole columns at an identity-like pose)
+    contributes with whatever an EARLIER evaluation -- or computeHref, :673 -- left in that slot: the reference's result
+    depends on its call history there.  The HIP path evaluates poses independently (such a pixel contributes nothing, which
+    is the reference's value when the slot still holds computeHref's zero, :652); those cells' Jacobians are not compared."""
+    d, j = o.dump_pixels(), o.dump_jac()
+    stale = (j["jc"] >= 0) & (d["jc"] < 0) & (d["ic"] != 0.0)
+    cell, inc = _cell_ids(pair)
+    out = np.zeros(pair.cell * pair.cell, dtype=bool)
+    out[np.unique(cell[stale & inc])] = True
+    return out
+
+
 def _reference_noise(o, pose, J_ref):
     """Per cell: |J_o - J_twin| (oracle.jacobian_noise)."""
     return o.jacobian_noise(pose, J_ref)
 
 
-def _jac_excess(J, J_o, m, noise=None):
+def _jac_excess(J, J_o, m, noise=None, cond=None):
     """Per selected cell: |J - J_o| / allowed, allowed = RTOL_J * own scale + NOISE_K * noise + J_EPS * frame scale
-    (the noise term only within its cap: NOISE_CAP_REL / NOISE_CAP_ABS)."""
+    (the noise term only within its cap: NOISE_CAP_REL / NOISE_CAP_ABS); with `cond` (the oracle's jac_abs_scale() of the
+    same evaluation) max(RTOL_J * own scale, COND_RTOL * cond) in place of the first term."""
     percell = np.abs(J_o[m]).max(axis=1)
-    allowed = RTOL_J * percell + J_EPS * max(percell.max(), 1.0)
+    first = RTOL_J * percell if cond is None else np.maximum(RTOL_J * percell, COND_RTOL * cond[m])
+    allowed = first + J_EPS * max(percell.max(), 1.0)
     if noise is not None:
         n = noise[m]
         allowed = allowed + NOISE_K * np.where((n <= NOISE_CAP_REL * percell) | (n <= max(NOISE_CAP_ABS, RTOL_J * percell.max())), n, 0.0)
     return np.abs(J[m] - J_o[m]).max(axis=1) / allowed, percell
 
 
-def _compare_cells(got, ref, cnt, noise=None):
+def _compare_cells(got, ref, cnt, noise=None, cond=None):
     """`noise`: None, (oracle context, pose) or a zero-argument callable returning the reference's per-cell noise
-    (_reference_noise); evaluated only if some cell misses the plain bound."""
+    (_reference_noise); evaluated only if some cell misses the plain bound.  `cond`: None or the oracle's per-cell
+    jac_abs_scale() of the evaluation `ref` came from (COND_RTOL)."""
     Hc, Hj, err, J = got
     Hc_o, Hj_o, err_o, J_o = ref
     act = cnt >= 300
@@ -110,12 +138,12 @@ def _compare_cells(got, ref, cnt, noise=None):
         assert np.array_equal(np.isfinite(J).all(axis=1)[act], fin[act])
         m = act & fin
         if m.any():
-            rel, percell = _jac_excess(J, J_o, m)
+            rel, percell = _jac_excess(J, J_o, m, cond=cond)
             used_noise = False
             if not np.all(rel <= 1.0) and noise is not None:
                 plain = rel
                 nz = noise() if callable(noise) else _reference_noise(noise[0], noise[1], J_o)
-                rel, percell = _jac_excess(J, J_o, m, nz)
+                rel, percell = _jac_excess(J, J_o, m, nz, cond=cond)
                 used_noise = True
                 import os
                 tid = os.environ.get("PYTEST_CURRENT_TEST", "?").split(" ")[0]
@@ -882,6 +910,45 @@ def test_randomised_pairs(capi, oracle, synth, seed):
             _compare_cells(got, ref, cnt_o, noise=None if seed in HARD_BOUND_SEEDS else (o, pose))
             H, b, chi2, na = ctx.normal_equations(pose, DELTA)
             assert na == int(act.sum())
+
+
+# Constructed cases (round 5; tests/adversarial_cases.py): samples PLACED within ulps of the reference's decision points --
+# B-spline knots, the clamp at 255 and the end knot at 0, the frame borders of the cost and of the Jacobian, cells at the
+# 300-pixel activity threshold and cells left with a handful of samples, steep edges under all of that.  25 of them here
+# (five of each kind), both math modes, the throughput shape and the 512-thread latency form; tools/adversarial_pairs.py runs
+# thousands through all four shapes (profiles/r05_adversarial.txt).  The reference is the oracle with the defined margin:
+# identity-like poses make linearizeOplus read im[-1] (test_identity_like_pose_border_ties).
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", list(range(25)))
+def test_adversarial_cases(capi, oracle, synth, seed):
+    from adversarial_cases import adversarial_case
+    pair, nb, href_pose, poses, kind, _ = adversarial_case(synth, seed)
+    o = oracle.from_pair(pair, nb, defined_margin=True)
+    cnt_o, href_o = o.compute_href(href_pose)
+    act = cnt_o >= 300
+    refs, skip, conds = [], [], []
+    for p in poses:
+        o.compute_href(href_pose)                    # every pose from the reference's state right after computeHref ...
+        refs.append(o.evaluate(p, True))
+        conds.append(o.jac_abs_scale())
+        skip.append(_history_dependent_cells(o, pair))   # ... and even so some cells depend on it (see there)
+    for math in MODES:
+        for shape in (0, 512):
+            ctx = capi.from_pair(pair, nb, math=_mode(capi, math))
+            if shape:
+                ctx.set_launch_shape(shape, shape)
+            cnt, href = ctx.compute_href(href_pose)
+            assert np.array_equal(cnt, cnt_o), kind
+            assert np.array_equal(np.isnan(href), ~act)
+            np.testing.assert_allclose(href[act], href_o[act], rtol=0, atol=ATOL_H)
+            for pose, ref, sk, cd in zip(poses, refs, skip, conds):
+                got = ctx.evaluate(pose, True)
+                Jg, Jo = got[3].copy(), ref[3].copy()
+                Jg[sk & act] = 0.0
+                Jo[sk & act] = 0.0
+                _compare_cells((got[0], got[1], got[2], Jg), (ref[0], ref[1], ref[2], Jo), cnt_o, noise=(o, pose), cond=cd)
+                assert ctx.normal_equations(pose, DELTA)[3] == int(act.sum())
+            ctx.close()
 
 
 @pytest.mark.gpu

@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""tools/diag_adv_jac_pixels.py SEED POSE CELL [strict]: an adversarial case's Jacobian-phase per-pixel values (gx, gy, pc, jc,
+dw) of the HIP path (diagnostic kernel) against the oracle built with the defined margin."""
+import importlib, os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+capi = importlib.import_module("nid-pose-estimation_amd.capi")
+synth = importlib.import_module("nid-pose-estimation_amd.synth")
+from oracle import oracle_py as O
+from adversarial_cases import adversarial_case
+seed, k, c = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
+strict = len(sys.argv) > 4
+pair, nb, hp, poses, kind, _ = adversarial_case(synth, seed)
+pose = poses[k]
+o = O.from_pair(pair, nb, defined_margin=True); o.compute_href(hp); ref = o.evaluate(pose, True)
+d, j = o.dump_pixels(), o.dump_jac()
+G, rb, cb = pair.cell, pair.rows // pair.cell, pair.cols // pair.cell
+rr, cc = np.divmod(np.arange(pair.rows * pair.cols), pair.cols)
+cell = np.where((rr < G * rb) & (cc < G * cb), (rr // rb) * G + cc // cb, -1)
+ids = np.where(cell == c)[0]
+ctx = capi.from_pair(pair, nb, math=capi.MATH_STRICT if strict else capi.MATH_FAST); ctx.compute_href(hp)
+ctx.enable_pixel_dump(2)
+got = ctx.evaluate(pose, True)
+g = ctx.pixel_dump()
+print(kind, "dbg kernel J", got[3][c], "ref", ref[3][c])
+gpu_on = g["jc"][ids] >= 0
+orc_on = j["jc"][ids] >= 0
+print("pixels in cell", len(ids), "gpu jac", gpu_on.sum(), "oracle jac", orc_on.sum(), "cost (oracle)", (d["jc"][ids] >= 0).sum())
+extra = ids[gpu_on & ~orc_on]; missing = ids[~gpu_on & orc_on]
+print("gpu only:", len(extra), [(int(rr[i]), int(cc[i]), float(d["u"][i]), float(d["v"][i])) for i in extra[:10]])
+print("oracle only:", len(missing), [(int(rr[i]), int(cc[i]), float(d["u"][i]), float(d["v"][i])) for i in missing[:10]])
+both = ids[gpu_on & orc_on]
+dgx = np.abs(g["u"][both] - j["gx"][both]); dgy = np.abs(g["v"][both] - j["gy"][both])
+print("max |gx diff|", dgx.max(), "max |gy diff|", dgy.max(), "max |pc diff|", np.abs(g["ic"][both] - j["pc"][both]).max(), "jc mismatches", int((g["jc"][both] != j["jc"][both]).sum()))
+for i in both[np.argsort(-(dgx + dgy))[:8]]:
+    print(" at r", int(rr[i]), "c", int(cc[i]), "u", repr(float(d["u"][i])), "v", repr(float(d["v"][i])), "gpu gx gy", g["u"][i], g["v"][i], "oracle gx gy", j["gx"][i], j["gy"][i],
+          "im1 nbhd", pair.im1[max(0, int(rr[i]) - 1): int(rr[i]) + 3, max(0, int(cc[i]) - 1): int(cc[i]) + 3].tolist())

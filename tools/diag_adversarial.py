@@ -1,0 +1,41 @@
+#!/usr/bin/env python3
+"""tools/diag_adversarial.py SEED...: one constructed case (tests/adversarial_cases.py) in detail -- per math mode, pose and
+cell the entropies and the Jacobian of the HIP path against the oracle (defined margin), the plain oracle and its twin."""
+import importlib, os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+capi = importlib.import_module("nid-pose-estimation_amd.capi")
+synth = importlib.import_module("nid-pose-estimation_amd.synth")
+from oracle import oracle_py as oracle
+from adversarial_cases import adversarial_case
+np.set_printoptions(precision=4, linewidth=200)
+for seed in [int(x) for x in sys.argv[1:]]:
+    pair, nb, hp, poses, kind, _ = adversarial_case(synth, seed)
+    print(f"=== seed {seed} kind {kind}: {pair.rows}x{pair.cols}, {pair.cell}x{pair.cell} cells, {nb} bins, f {pair.fx}")
+    om = oracle.from_pair(pair, nb, defined_margin=True)
+    op = oracle.from_pair(pair, nb)
+    cnt, href = om.compute_href(hp); op.compute_href(hp)
+    print("cnt", cnt.tolist())
+    for mode in ("fast", "strict"):
+        ctx = capi.from_pair(pair, nb, math=capi.MATH_STRICT if mode == "strict" else capi.MATH_FAST)
+        c2, _ = ctx.compute_href(hp)
+        assert np.array_equal(c2, cnt)
+        for ip, pose in enumerate(poses):
+            om.compute_href(hp); op.compute_href(hp)
+            rm = om.evaluate(pose, True); T = om.jac_abs_scale(); rp = op.evaluate(pose, True)
+            nz = om.jacobian_noise(pose, rm[3])
+            g = ctx.evaluate(pose, True)
+            act = cnt >= 300
+            for c in np.flatnonzero(act):
+                own = np.abs(rm[3][c]).max()
+                d = np.abs(g[3][c] - rm[3][c]).max()
+                dh = max(abs(g[0][c] - rm[0][c]), abs(g[1][c] - rm[1][c]))
+                if d > 1e-9 * own + 1e-14 or dh > 1e-11:
+                    print(f" {mode} pose {ip} t=({pose[4]:.3e},{pose[5]:.3e}) cell {c}: |dJ| {d:.3e} own {own:.3e} abs-scale {T[c]:.3e} |dJ|/abs-scale {d / max(T[c], 1e-300):.2e} twin-noise {nz[c]:.3e} plain-vs-margin {np.abs(rp[3][c]-rm[3][c]).max():.3e} dH {dh:.2e}")
+                    print("    J_o ", rm[3][c]); print("    J   ", g[3][c])
+                    om.evaluate(pose, True); d0 = om.dump_pixels()
+                    ctx.enable_pixel_dump(True); ctx.evaluate(pose, True); d1 = ctx.pixel_dump(); ctx.enable_pixel_dump(False)
+                    m0, m1 = d0["jc"] >= 0, d1["jc"] >= 0
+                    print(f"    in-frame samples oracle {int(m0.sum())} hip {int(m1.sum())} differing flags {int((m0 != m1).sum())}; max |ic diff| {np.nanmax(np.abs(np.where(m0 & m1, d0['ic'] - d1['ic'], 0.0))):.3e}; jc differs at {int(((d0['jc'] != d1['jc']) & m0 & m1).sum())}")
+        ctx.close()

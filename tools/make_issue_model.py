@@ -23,6 +23,13 @@ out[f"{cfg}:{bins}"] = {
     "branch": c["SQ_INSTS_BRANCH"] / w, "waves_per_pose": w / ppl,
     "wave_cycles": c["SQ_WAVE_CYCLES"] / w, "wait_any_frac": c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"],
     "wait_inst_frac": c["SQ_WAIT_INST_ANY"] / c["SQ_WAVE_CYCLES"], "active_inst_frac": c["SQ_ACTIVE_INST_ANY"] / c["SQ_WAVE_CYCLES"],
+    # the vector pipe: SQ_ACTIVE_INST_VALU counts quad-cycles summed over the SIMDs, GRBM_GUI_ACTIVE cycles summed over the 8
+    # XCDs (MI355X_MICROARCH.md), both per launch: busy = 4 x active / (cycles of the launch x 1024 SIMDs)
+    "poses_per_launch": ppl,
+    "valu_cycles_per_instruction": 4.0 * c["SQ_ACTIVE_INST_VALU"] / c["SQ_INSTS_VALU"],
+    "valu_busy_frac": 4.0 * c["SQ_ACTIVE_INST_VALU"] / (c["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0),
+    "lds_busy_frac": 4.0 * c["SQ_ACTIVE_INST_LDS"] / (c["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0) if "SQ_ACTIVE_INST_LDS" in c else None,
+    "launch_cycles": c["GRBM_GUI_ACTIVE"] / 8.0,
     "source": f"{os.path.relpath(table, ROOT)} (rocprofv3 --pmc SQ_* passes over tools/pmc_run.py, {ppl} poses per launch, "
               "128-thread workgroups, FAST math; committed as profiles/r0N_A_pmc_counters.txt of the same round)"}
 json.dump(out, open(path, "w"), indent=1)

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""tools/parity_sweep_mp.py FIRST COUNT [--procs P] [--shapes 128,512] [--out FILE]
+"""tools/parity_sweep_mp.py FIRST COUNT [--procs P] [--shapes 128,512] [--out FILE] [--generator random|adversarial]
 
 tests/test_parity_gpu.py::test_randomised_pairs over COUNT seeds from FIRST, spread over P worker processes (the CPU
 oracle is the slow side; a GPU box allows six GPU processes, the default is 5).  Every case runs in both math modes and
@@ -7,6 +7,10 @@ in every listed workgroup shape.  Besides the suite's pass / fail it records eac
 Jacobian error (|dJ| over the cell's own largest component + f64 roundoff at the frame's scale: the quantity held to
 1e-9; cases beyond it that pass on the reference's measured noise are listed) and worst entropy error, so a sweep
 reports its margin, not only its violations.  One progress line per worker and 50 seeds (a silent command is killed after seven minutes).
+--generator adversarial (round 5): the CONSTRUCTED cases of tests/adversarial_cases.py -- samples placed on knots, on the
+clamp, on the frame borders, cells at the 300-pixel threshold, steep edges -- against the oracle built with the defined
+margin (identity-like poses read im[-1] in the reference: oracle/Makefile); the summary then also carries the histogram of
+the per-case worst |dJ| in units of the 1e-9 bound and the counts per kind of case.
 Exit code 1 if any seed violates the suite's tolerances."""
 import argparse, importlib, json, multiprocessing as mp, os, sys, time, traceback
 import numpy as np
@@ -15,7 +19,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def worker(args):
-    wid, seeds, shapes = args
+    wid, seeds, shapes, generator = args
     sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
     capi = importlib.import_module("nid-pose-estimation_amd.capi")
     synth = importlib.import_module("nid-pose-estimation_amd.synth")
@@ -24,38 +28,71 @@ def worker(args):
     out = []
     t0 = time.time()
     for n, seed in enumerate(seeds):
-        rec = {"seed": int(seed), "ok": True, "rel_j": 0.0, "abs_h": 0.0, "msg": "", "noise": False}
+        rec = {"seed": int(seed), "ok": True, "rel_j": 0.0, "abs_h": 0.0, "msg": "", "noise": False, "kind": "random"}
         try:
-            pair, nb, poses = T._random_case(synth, 1000 + seed)
-            o = oracle.from_pair(pair, nb)
-            cnt_o, href_o = o.compute_href(pair.pose_init)
+            if generator == "adversarial":
+                from adversarial_cases import adversarial_case
+                pair, nb, href_pose, poses, rec["kind"], _ = adversarial_case(synth, seed)
+                o = oracle.from_pair(pair, nb, defined_margin=True)
+            else:
+                pair, nb, poses = T._random_case(synth, 1000 + seed)
+                href_pose = pair.pose_init
+                o = oracle.from_pair(pair, nb)
+            cnt_o, href_o = o.compute_href(href_pose)
             act = cnt_o >= 300
-            refs = [o.evaluate(p, True) for p in poses]
+            if generator == "adversarial":
+                # every pose from the reference's state right after computeHref; cells whose reference Jacobian depends on
+                # the call history even so (T._history_dependent_cells) are counted and their Jacobians not compared
+                refs, skips, conds = [], [], []
+                for p in poses:
+                    o.compute_href(href_pose)
+                    refs.append(o.evaluate(p, True))
+                    conds.append(o.jac_abs_scale())
+                    skips.append(T._history_dependent_cells(o, pair) & act)
+                rec["history_dependent_cells"] = int(sum(int(k.sum()) for k in skips))
+            else:
+                refs, conds = [], []
+                for p in poses:
+                    refs.append(o.evaluate(p, True))
+                    conds.append(o.jac_abs_scale())
+                skips = [np.zeros_like(act) for _ in poses]
             for math in T.MODES:
                 for shape in shapes:
                     ctx = capi.from_pair(pair, nb, math=T._mode(capi, math))
                     if shape:
                         ctx.set_launch_shape(shape, shape)
-                    cnt, href = ctx.compute_href(pair.pose_init)
+                    cnt, href = ctx.compute_href(href_pose)
                     assert np.array_equal(cnt, cnt_o) and np.array_equal(np.isnan(href), ~act)
                     np.testing.assert_allclose(href[act], href_o[act], rtol=0, atol=T.ATOL_H)
-                    for pose, ref in zip(poses, refs):
+                    for pose, ref, sk, cd in zip(poses, refs, skips, conds):
                         got = ctx.evaluate(pose, True)
+                        if sk.any():
+                            got = (got[0], got[1], got[2], got[3].copy()); ref = (ref[0], ref[1], ref[2], ref[3].copy())
+                            got[3][sk] = 0.0; ref[3][sk] = 0.0
                         # the margins first (T._jac_excess: |dJ| over the plain 1e-9-of-its-own-scale allowance, per cell),
                         # then the suite's own verdict (which may call on the reference's measured noise)
                         fin = np.isfinite(ref[3]).all(axis=1) & np.isfinite(got[3]).all(axis=1) & act
                         if fin.any():
-                            ex = float(T._jac_excess(got[3], ref[3], fin)[0].max())
+                            ex = float(T._jac_excess(got[3], ref[3], fin)[0].max())           # against the plain bound ...
                             rec["rel_j"] = max(rec["rel_j"], ex * T.RTOL_J)
-                            if ex > 1.0:
+                            exc = float(T._jac_excess(got[3], ref[3], fin, cond=cd)[0].max())   # ... and with the condition term
+                            if ex > 1.0 and exc <= 1.0:
+                                rec["cond"] = True
+                            if exc > 1.0:
                                 rec["noise"] = True
+                            with np.errstate(divide="ignore", invalid="ignore"):
+                                q = np.abs(got[3][fin] - ref[3][fin]).max(axis=1) / cd[fin]
+                            q = q[np.isfinite(q)]
+                            if q.size:
+                                rec["dj_over_cond"] = max(rec.get("dj_over_cond", 0.0), float(q.max()))
                         if act.any():
                             for k in range(3):
                                 d = np.abs(got[k][act] - ref[k][act])
                                 d = d[np.isfinite(d)]
                                 if d.size:
                                     rec["abs_h"] = max(rec["abs_h"], float(d.max()))
-                        T._compare_cells(got, ref, cnt_o, noise=(o, pose))
+                        # (the suite's own verdict: test_randomised_pairs has no condition term, test_adversarial_cases has)
+                        T._compare_cells(got, ref, cnt_o, noise=(o, pose), cond=cd if generator == "adversarial" else None)
                         assert ctx.normal_equations(pose, T.DELTA)[3] == int(act.sum())
                     ctx.close()
         except Exception as e:  # noqa: BLE001
@@ -75,10 +112,11 @@ def main():
     ap.add_argument("--procs", type=int, default=5)
     ap.add_argument("--shapes", default="0")
     ap.add_argument("--out", default="")
+    ap.add_argument("--generator", default="random", choices=["random", "adversarial"])
     a = ap.parse_args()
     shapes = [int(x) for x in a.shapes.split(",")]
     seeds = list(range(a.first, a.first + a.count))
-    chunks = [(w, seeds[w::a.procs], shapes) for w in range(a.procs)]
+    chunks = [(w, seeds[w::a.procs], shapes, a.generator) for w in range(a.procs)]
     with mp.get_context("spawn").Pool(a.procs) as pool:
         recs = [r for part in pool.map(worker, chunks) for r in part]
     recs.sort(key=lambda r: r["seed"])
@@ -87,10 +125,20 @@ def main():
     absh = np.array([r["abs_h"] for r in recs])
     top = sorted(recs, key=lambda r: -r["rel_j"])[:5]
     summary = {"first": a.first, "count": a.count, "shapes": shapes, "lib": os.environ.get("NID_HIP_LIB", "libnid_hip.so"),
-               "failing": bad, "needed_reference_noise": [r["seed"] for r in recs if r["noise"]], "worst_rel_j": float(rel.max()), "worst_abs_h": float(absh.max()),
+               "failing": bad, "needed_reference_noise": [r["seed"] for r in recs if r["noise"] and r["ok"]],
+               "needed_condition_term": [r["seed"] for r in recs if r.get("cond")],
+               "worst_dj_over_condition_scale": float(max([r.get("dj_over_cond", 0.0) for r in recs] or [0.0])), "worst_rel_j": float(rel.max()), "worst_abs_h": float(absh.max()),
                "rel_j_quantiles_50_90_99_999": [float(np.quantile(rel, q)) for q in (0.5, 0.9, 0.99, 0.999)],
                "cases_over_1e-10": int((rel > 1e-10).sum()), "cases_over_1e-11": int((rel > 1e-11).sum()),
-               "top5": [(r["seed"], r["rel_j"]) for r in top]}
+               "top5": [(r["seed"], r["rel_j"]) for r in top], "generator": a.generator}
+    if a.generator == "adversarial":
+        edges = [0.0, 1e-3, 1e-2, 0.1, 0.25, 0.5, 0.75, 0.9, 1.0, float("inf")]
+        hist = np.histogram(rel / 1e-9, bins=edges)[0]
+        summary["history_dependent_cells_not_compared"] = int(sum(r.get("history_dependent_cells", 0) for r in recs))
+        summary["rel_j_over_1e-9_histogram"] = {f"[{edges[i]:g}, {edges[i + 1]:g})": int(hist[i]) for i in range(len(hist))}
+        kinds = sorted({r["kind"] for r in recs})
+        summary["per_kind"] = {k: {"cases": sum(r["kind"] == k for r in recs), "failing": [r["seed"] for r in recs if r["kind"] == k and not r["ok"]],
+                                   "worst_rel_j": float(max([r["rel_j"] for r in recs if r["kind"] == k] or [0.0]))} for k in kinds}
     print(json.dumps(summary))
     if a.out:
         with open(a.out, "a") as f:
