@@ -21,19 +21,25 @@
 // Differences, all deliberate: no per-call allocation / memset / re-upload.  The
 // frame-pair state is cached per (rows, cols, cell_num, bin_num) and re-uploaded
 // when the CONTENT of a caller buffer has changed.
-// THE CONTRACT: none beyond the reference's.  Every CudaComputeH call reads all of
-// im0 / points3d / im1 / bs_ref (a 64-bit hash of each, taken on a small pool of
-// worker threads: NID_LEGACY_HASH_THREADS, default 3 beside the caller, 0 = none)
-// and all of bs_counter / Href, and uploads what differs from what the device
-// holds: a buffer rewritten in place between two calls is followed on the next
-// call, like with the reference, which uploads everything on every call
-// (computeH.cu:420-429).  Cost per call: profiles/r05_pair_setup.txt.
-// OPT-IN, nid_legacy_set_trust_buffers(1) (or NID_LEGACY_TRUST_BUFFERS=1): a call
-// checks address, length and 64 samples of each big buffer (a microsecond in all)
-// and takes the full hashes only when one of those changed, on every 128th call of
-// a pair and after nid_legacy_invalidate(parts) -- for callers that do not rewrite
-// their buffers in place between two calls of a pair, or say so when they do.
-// NID_LEGACY_ALWAYS_UPLOAD=1 uploads everything on every call.
+// THE CONTRACT: none beyond the reference's, in three strengths (nid_legacy_set_verify_mode):
+//  * NID_LEGACY_VERIFY_BACKGROUND (default): a call checks address, length and 64 samples of each big
+//    buffer (a microsecond in all) and evaluates; a small pool of worker threads (NID_LEGACY_HASH_THREADS,
+//    default 3; 0: none, then this mode is TRUSTED) hashes im0 / points3d / im1 / bs_ref in full beside the
+//    caller, one verification after the other (~0.4 ms each at 640x480).  A buffer rewritten IN PLACE
+//    between two calls is found by the next verification: the following call says so on stderr, counts it
+//    (nid_legacy_stale_detections) and uploads the new content -- at most a few calls have evaluated the
+//    old one, and the caller is told.  The workers read the caller's buffers between calls: a caller that
+//    frees them calls nid_legacy_reset() or nid_legacy_quiesce() first (both end the verification).
+//  * NID_LEGACY_VERIFY_EVERY_CALL: every call hashes all four buffers BEFORE it evaluates and uploads what
+//    differs -- followed on the next call, like with the reference, which uploads everything on every
+//    call (computeH.cu:420-429).  0.36 ms per call at 640x480 (profiles/r05_pair_setup.txt), ten times
+//    the evaluation itself: not the default.
+//  * NID_LEGACY_VERIFY_TRUSTED (nid_legacy_set_trust_buffers(1), NID_LEGACY_TRUST_BUFFERS=1): the cheap
+//    check only; full hashes when it fails, on every 128th call of a pair, and after
+//    nid_legacy_invalidate(parts).  For callers that do not rewrite buffers in place, or say so.
+// bs_counter / Href (1-2 KB) are hashed in full on every call in every mode; a new frame pair (new
+// buffers, or CudaComputeHref) is always noticed at once.  NID_LEGACY_ALWAYS_UPLOAD=1 uploads everything
+// on every call.
 // Out-of-frame reference weights are NaN in the
 // arrays handed back (as CudaComputeHref.cu:126-130 writes them) but are treated
 // as 0 inside, the CPU edge's convention; the Jacobian in-frame
@@ -85,9 +91,14 @@ void nid_legacy_reset(void);
 // done with the GPU for now, keep everything for the next frame pair: takes a running resident kernel off the device
 // (the context, its buffers and its communicator stay: the next pair of the same geometry costs no context creation)
 void nid_legacy_quiesce(void);
-// 1: trust the caller's big buffers between full checks (see THE CONTRACT above); 0 (default): verify them on every call
-void nid_legacy_set_trust_buffers(int on);
-// Trusted buffers only: the caller has changed, IN PLACE, the content of the buffers named by `parts` since its last call:
+// how the operators make sure the device holds what the caller's buffers hold (THE CONTRACT above)
+enum { NID_LEGACY_VERIFY_BACKGROUND = 0, NID_LEGACY_VERIFY_EVERY_CALL = 1, NID_LEGACY_VERIFY_TRUSTED = 2 };
+void nid_legacy_set_verify_mode(int mode);
+void nid_legacy_set_trust_buffers(int on);   // 1: NID_LEGACY_VERIFY_TRUSTED, 0: the default
+// in-place changes the background verification has found and reported so far
+long nid_legacy_stale_detections(void);
+// The caller has changed, IN PLACE, the content of the buffers named by `parts` since its last call (needed with trusted
+// buffers; spares the background mode its detection delay):
 // the next CudaComputeH recomputes their full hashes (and uploads what differs) instead of trusting address + samples.
 enum { NID_LEGACY_REFERENCE = 1 /* im0, points3d */, NID_LEGACY_TARGET = 2 /* im1 */, NID_LEGACY_HREF_STATE = 4 /* bs_ref */ };
 void nid_legacy_invalidate(unsigned parts);

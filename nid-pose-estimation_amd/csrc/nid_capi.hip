@@ -1312,6 +1312,9 @@ int launch_batch(nid_ctx *ctx, int first_slot, int n, const Pose *poses, int wan
     recs = ctx->ext_host[ring];
     P.slots_ext = ctx->ext_dev[ring];
   }
+  // (one awaited pose in GROUP-DIRECT mode, nid_set_direct_results(ctx, 2): the same form nid_launch takes)
+  if (n == 1 && !reduced_dev_base && !relaunch_ok && allow_direct && !on_aux_stream && ctx->direct_mode == 2 && direct_ok(ctx))
+    return launch_slot(ctx, first_slot, poses[0], want_jac, delta, nullptr);
   const bool direct = n == 1 && !reduced_dev_base && !relaunch_ok && allow_direct && direct_ok(ctx);
   if (direct && !on_aux_stream && resident_usable(ctx) && resident_post(ctx, first_slot, poses[0], want_jac != 0, false) == NID_OK) {
     Slot &S = ctx->slots[first_slot];
@@ -1414,7 +1417,17 @@ int launch_split(nid_ctx *ctx, int first_slot, int n, const Pose *poses, int wan
   for (int i = 0; i < n; i += plan.chunk, l++) {
     const int cnt = std::min(plan.chunk, n - i);
     int rc = launch_batch(ctx, first_slot + i, cnt, poses + i, want_jac, delta, nullptr, plan.two_streams && (l & 1), false, /*allow_direct=*/false);
-    if (rc) return rc;
+    if (rc) {
+      // all or nothing: the chunks that did go out are waited for and their slots released -- the caller gets the error
+      // and no slot of this sequence is left pending (it cannot know which ones were)
+      const std::string why = ctx->last_error;
+      for (int k = 0; k < i; k++) {
+        Slot &S = ctx->slots[first_slot + k];
+        if (S.pending && wait_host_seq(ctx, S) == NID_OK) S.pending = false;
+      }
+      ctx->last_error = why;
+      return rc;
+    }
   }
   return NID_OK;
 }
@@ -1516,15 +1529,17 @@ int href_common(nid_ctx *ctx, const Pose &pose, int32_t *bs_counter, double *Hre
     // plus a scalar scatter loop on the host was 1.4 ms of every frame pair (profiles/r04_pair_setup.txt).
     const Geometry &g = ctx->g;
     const size_t N = (size_t)g.rows * g.cols;
-    if (bs_value && !ctx->bsv_img_dev) {
-      int rc = dev_alloc(ctx, &ctx->bsv_img_dev, 4 * N);
-      if (rc) return rc;
-      if (hipHostMalloc(reinterpret_cast<void **>(&ctx->bsv_stage), 4 * N * sizeof(double), hipHostMallocDefault) != hipSuccess) return NID_ERR_NOMEM;
+    if (bs_value && (!ctx->bsv_img_dev || !ctx->bsv_stage)) {  // (both or neither: a half-made pair from a failed call is completed)
+      if (!ctx->bsv_img_dev) { int rc = dev_alloc(ctx, &ctx->bsv_img_dev, 4 * N); if (rc) return rc; }
+      if (!ctx->bsv_stage && hipHostMalloc(reinterpret_cast<void **>(&ctx->bsv_stage), 4 * N * sizeof(double), hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError(); ctx->bsv_stage = nullptr; return NID_ERR_NOMEM;
+      }
     }
-    if (bs_index && !ctx->bsi_img_dev) {
-      int rc = dev_alloc(ctx, &ctx->bsi_img_dev, N);
-      if (rc) return rc;
-      if (hipHostMalloc(reinterpret_cast<void **>(&ctx->bsi_stage), N * sizeof(int), hipHostMallocDefault) != hipSuccess) return NID_ERR_NOMEM;
+    if (bs_index && (!ctx->bsi_img_dev || !ctx->bsi_stage)) {
+      if (!ctx->bsi_img_dev) { int rc = dev_alloc(ctx, &ctx->bsi_img_dev, N); if (rc) return rc; }
+      if (!ctx->bsi_stage && hipHostMalloc(reinterpret_cast<void **>(&ctx->bsi_stage), N * sizeof(int), hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError(); ctx->bsi_stage = nullptr; return NID_ERR_NOMEM;
+      }
     }
     const long total = (long)g.nloc * g.pstride;
     hipLaunchKernelGGL(k_untile_bs, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, g, ctx->t,

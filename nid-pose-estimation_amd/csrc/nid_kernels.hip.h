@@ -1131,7 +1131,7 @@ __device__ __forceinline__ void load_tile(const EvalParams &P, unsigned gi, unsi
 // the 4x4 window at origin (w.wx, w.wy) >= (-1, -1); the image buffer starts at pixel (-1, -1)
 __device__ __forceinline__ void load_window(const EvalParams &P, Win &w) {
   const unsigned st = (unsigned)P.im1_stride;
-  const unsigned po = (unsigned)(w.wy + 1) * st + (unsigned)(w.wx + 1);
+  const unsigned po = __umul24((unsigned)(w.wy + 1), st) + (unsigned)(w.wx + 1);  // (rows, stride < 2^24: one v_mad_u32_u24)
   w.r0 = load_row_at(P.im1s, po);
   w.r1 = load_row_at(P.im1s, po + st);
   w.r2 = load_row_at(P.im1s, po + 2u * st);
@@ -1144,13 +1144,13 @@ struct WinC { unsigned c1, c2; };
 struct WinJ { WRow r1, r2; unsigned c0, c3; };
 __device__ __forceinline__ void load_win_centre(const EvalParams &P, int wx, int wy, WinC &w) {
   const unsigned st = (unsigned)P.im1_stride;
-  const unsigned po = (unsigned)(wy + 2) * st + (unsigned)(wx + 2);  // row 1, tap 1
+  const unsigned po = __umul24((unsigned)(wy + 2), st) + (unsigned)(wx + 2);  // row 1, tap 1
   w.c1 = load_u32_at(P.im1s, po);
   w.c2 = load_u32_at(P.im1s, po + st);
 }
 __device__ __forceinline__ void load_win_jac(const EvalParams &P, int wx, int wy, WinJ &w) {
   const unsigned st = (unsigned)P.im1_stride;
-  const unsigned po = (unsigned)(wy + 1) * st + (unsigned)(wx + 1);
+  const unsigned po = __umul24((unsigned)(wy + 1), st) + (unsigned)(wx + 1);
   w.c0 = load_u32_at(P.im1s, po + 1u);
   w.r1 = load_row_at(P.im1s, po + st);
   w.r2 = load_row_at(P.im1s, po + 2u * st);
@@ -1188,13 +1188,15 @@ __device__ __forceinline__ void gradient_fast_j(const WinJ &w, double u, double 
 
 // FAST warp of one tile entry: f.jr, f.x, f.y, f.zq = 1/z, f.u, f.v -- pixel_front<false> without its border tests
 // (the same operations on the same values: the two give the same bits)
-__device__ __forceinline__ void warp_fast(const EvalParams &P, const SlotArgs &SA, const TileIn &t, PixelFront &f) {
+// (t0, t1, t2: the matrix's translation column -- M[3], M[7], M[11] -- from VECTOR registers: an FMA takes one scalar
+// operand, so fma(M[2], z, M[3]) costs a v_mov of M[3] per sample unless the caller parks the column in registers once)
+__device__ __forceinline__ void warp_fast(const EvalParams &P, const SlotArgs &SA, const TileIn &t, PixelFront &f, double t0, double t1, double t2) {
   const Geometry &g = P.g;
   const double *M = SA.pose.M;
   const double lx = t.x, ly = t.y, lz = t.z;
-  const double qx = fma(M[0], lx, fma(M[1], ly, fma(M[2], lz, M[3])));
-  const double qy = fma(M[4], lx, fma(M[5], ly, fma(M[6], lz, M[7])));
-  const double qz = fma(M[8], lx, fma(M[9], ly, fma(M[10], lz, M[11])));
+  const double qx = fma(M[0], lx, fma(M[1], ly, fma(M[2], lz, t0)));
+  const double qy = fma(M[4], lx, fma(M[5], ly, fma(M[6], lz, t1)));
+  const double qz = fma(M[8], lx, fma(M[9], ly, fma(M[10], lz, t2)));
   const double iz = rcp_fast(qz);
   f.jr = t.jr;
   f.x = qx; f.y = qy; f.zq = iz;
@@ -1755,16 +1757,24 @@ __device__ __forceinline__ bool eval_cell(const EvalParams &P, const SlotArgs &S
       }
       return;
     }
+    // The marginal addend of column k, wcs[k] * hist_dn = wc * 2^(s - 1074), is a subnormal double whose bit pattern IS
+    // the integer I_k = RN(wc * 2^s) (fx_bits).  The joint addends of that column are taken from it: I_k * wr[m], again a
+    // subnormal product, i.e. RN(I_k * wr[m]) as an integer -- within ONE quantum (2^-s) of wr * wc * 2^s instead of half
+    // a quantum (I_k is off by at most 1/2, wr <= 1), and the four multiplications wr[m] * hist_dn per sample are gone
+    // (round 5: 24 -> 20 multiplications for the 20 adds).  The coarse copies promise an ABSOLUTE quantum either way;
+    // what needs more goes through the fine levels / the repair (above).  f64 subnormal OPERANDS cost nothing and are
+    // not flushed (tools/ubench/denorm_encode.hip).
+    double marg[4];
 #pragma unroll
-    for (int k = 0; k < 4; k++) atomicAdd(hc + k * NC, fx_bits(wcs[k] * P.hist_dn));
-    double wrs[4];
-#pragma unroll
-    for (int m = 0; m < 4; m++) wrs[m] = wr[m] * P.hist_dn;  // wr[0] >= 0 here (ref_tiny is false)
+    for (int k = 0; k < 4; k++) {
+      marg[k] = wcs[k] * P.hist_dn;
+      atomicAdd(hc + k * NC, fx_bits(marg[k]));
+    }
 #pragma unroll
     for (int m = 0; m < 4; m++)
 #pragma unroll
       for (int k = 0; k < 4; k++)
-        atomicAdd(hj + (m * nb + k) * NC, fx_bits(wrs[m] * wcs[k]));
+        atomicAdd(hj + (m * nb + k) * NC, fx_bits(marg[k] * wr[m]));  // wr[0] >= 0 here (ref_tiny is false)
   };
   auto dump_pixel = [&](int s, const PixelFront &f, double ic, int jc, const double (&wc)[4]) {
     const int c = g.cell_begin + cl * g.cell_stride;
@@ -2450,7 +2460,7 @@ __device__ __forceinline__ bool eval_cell(const EvalParams &P, const SlotArgs &S
       if constexpr (SECOND && use_lane_masks && NID_JAC_SECOND_MASK) {
         // the cost phase's rare samples are this phase's (raremask): FAST warp for d(u,v)/d(xi), then straight to the
         // exact decisions -- no window, no gradient, no classification for the lanes that are not rare
-        warp_fast(P, SA, tin, f);
+        warp_fast(P, SA, tin, f, SA.pose.M[3], SA.pose.M[7], SA.pose.M[11]);
 #pragma unroll
         for (int k = 0; k < 4; k++) f.wr[k] = k == 0 ? fabs(tin.wr[0]) : tin.wr[k];
         f.in = false; f.jin = false; f.redo = false;
@@ -2521,10 +2531,12 @@ __device__ __forceinline__ bool eval_cell(const EvalParams &P, const SlotArgs &S
       }
       return !SECOND && __builtin_amdgcn_ballot_w64(exact) != 0ull;
     };
+    double tcol0 = SA.pose.M[3], tcol1 = SA.pose.M[7], tcol2 = SA.pose.M[11];
+    asm volatile("" : "+v"(tcol0), "+v"(tcol1), "+v"(tcol2));  // (vector registers, once: see warp_fast)
     auto jac_round_masked = [&](int sb, int r, const TileIn &cur, TileIn &nxt) {
       const int s = sb + lane;
       PixelFront f;
-      warp_fast(P, SA, cur, f);
+      warp_fast(P, SA, cur, f, tcol0, tcol1, tcol2);
       // (the whole warp before the branch on `go`: left alone the compiler sinks v's arithmetic into the branch, the
       // point then lives across the prefetch and is copied from round to round again)
       asm volatile("" : "+v"(f.u), "+v"(f.v));

@@ -9,16 +9,24 @@
 //   * CudaComputeHref is called once per pair: it always uploads the reference (im0, points3d) afresh;
 //   * CudaComputeH keeps, per caller buffer (im0, points3d, im1, bs_ref, bs_counter, Href), a key: address, length, a
 //     quick fingerprint of 64 samples and a FULL 64-bit hash of the content.
-//     DEFAULT (round 5): every call recomputes the full hash of every buffer -- the caller's bytes
-//     are read on every call, like the reference, which re-uploads them on every call (computeH.cu:420-429) -- and
-//     uploads what differs: a caller that rewrites a buffer in place between two calls is followed on the NEXT call,
-//     with nothing asked of it.  22 MB of reads per call at 640x480, on a small pool of worker threads.
-//     TRUSTED buffers (opt-in: nid_legacy_set_trust_buffers(1) or NID_LEGACY_TRUST_BUFFERS=1; round 4's default): a call
-//     checks address, length and the quick fingerprint (about a microsecond for all six buffers); the full hash is
-//     recomputed -- and decides whether the buffer is uploaded -- when one of those changed, on every kRehashEvery-th
-//     call of a pair, and after nid_legacy_invalidate().  A caller in that mode that rewrites part of a buffer IN
-//     PLACE without touching a sampled element says so with nid_legacy_invalidate(), or is followed within
-//     kRehashEvery calls.
+//     Three modes (nid_legacy_set_verify_mode; round 5):
+//     BACKGROUND (default): a call checks address, length and the quick fingerprint (about a microsecond for all six
+//     buffers) and evaluates; beside it a small pool of worker threads takes the full hashes of the four big buffers --
+//     one verification at a time, started by a call whenever none is running (22 MB at 640x480: ~0.4 ms on three
+//     workers) -- and the first call after a verification that found a buffer changed IN PLACE says so loudly on stderr,
+//     counts it (nid_legacy_stale_detections), and uploads the buffer's current content: a caller that rewrites a buffer
+//     in place without saying so is followed within a verification's time, at most a few calls evaluated on the old
+//     content, and is told.  (Verifying INSIDE every call costs 0.36 ms per call -- ten times the evaluation,
+//     profiles/r05_pair_setup.txt -- which is why it is not the default.)
+//     EVERY_CALL: every call recomputes the full hash of every buffer before it evaluates -- the caller's bytes are read on
+//     every call, like the reference, which re-uploads them on every call (computeH.cu:420-429) -- and uploads what
+//     differs: a change in place is followed on the NEXT call, with nothing asked of the caller.
+//     TRUSTED (nid_legacy_set_trust_buffers(1) or NID_LEGACY_TRUST_BUFFERS=1; round 4's default): the cheap check only;
+//     the full hash is recomputed -- and decides whether the buffer is uploaded -- when the cheap part changed, on every
+//     kRehashEvery-th call of a pair, and after nid_legacy_invalidate().  No thread is started by this mode's calls
+//     once the pair is set up.
+//     In every mode a new frame pair (new buffers, or CudaComputeHref) is noticed at once, and nid_legacy_invalidate(parts)
+//     makes the next call recompute the named parts' full hashes.
 //     The two per-cell arrays (1-2 KB) are fully hashed on every call in both modes; the images' keys carry the hash
 //     of their u8 conversion (what is uploaded) and, in the default mode, of the caller's f64 bytes (what is verified).
 //     NID_LEGACY_ALWAYS_UPLOAD=1 uploads everything on every call.
@@ -60,6 +68,7 @@ struct LegacyState {
   Key k_im0, k_points, k_im1, k_bs_ref, k_counter, k_href;
   bool have_ref = false, have_target = false, have_href = false;
   unsigned long calls = 0;      // CudaComputeH calls on this frame pair (CudaComputeHref starts a new count)
+  unsigned long epoch = 0;      // bumped by every upload: a background verification that straddles one is discarded
   unsigned force_full = 0;      // nid_legacy_invalidate: parts whose full hash the next call recomputes
 };
 constexpr unsigned long kRehashEvery = 128;
@@ -108,12 +117,19 @@ struct StepTrace {
   }
 };
 
-int g_trust = -1;  // nid_legacy_set_trust_buffers; -1 = the NID_LEGACY_TRUST_BUFFERS environment variable
-bool trust_buffers() {
-  if (g_trust >= 0) return g_trust != 0;
-  static const bool env = [] { const char *e = getenv("NID_LEGACY_TRUST_BUFFERS"); return e && e[0] == '1'; }();
+int g_verify_mode = -1;  // nid_legacy_set_verify_mode; -1 = the environment (NID_LEGACY_TRUST_BUFFERS=1, NID_LEGACY_VERIFY_EVERY_CALL=1) or the default
+int verify_mode() {
+  if (g_verify_mode >= 0) return g_verify_mode;
+  static const int env = [] {
+    const char *t = getenv("NID_LEGACY_TRUST_BUFFERS"), *e = getenv("NID_LEGACY_VERIFY_EVERY_CALL");
+    if (t && t[0] == '1') return (int)NID_LEGACY_VERIFY_TRUSTED;
+    if (e && e[0] == '1') return (int)NID_LEGACY_VERIFY_EVERY_CALL;
+    return (int)NID_LEGACY_VERIFY_BACKGROUND;
+  }();
   return env;
 }
+bool trust_buffers() { return verify_mode() == NID_LEGACY_VERIFY_TRUSTED; }
+long g_stale_detections = 0;
 
 bool always_upload() {
   static const bool v = getenv("NID_LEGACY_ALWAYS_UPLOAD") != nullptr;
@@ -175,6 +191,12 @@ class HashPool {
     call_.unlock();
   }
   void run(int nparts, std::function<void(int)> job) { start(nparts, std::move(job)); finish(); }
+  // a started job whose parts the WORKERS have all done (nobody called finish() yet)?  false without workers: finish() does the work then
+  bool done_by_workers() {
+    std::lock_guard<std::mutex> g(m_);
+    return remaining_ == 0;
+  }
+  bool has_workers() const { return !workers_.empty() && getpid() == owner_; }
 
  private:
   HashPool() : owner_(getpid()) {
@@ -271,8 +293,10 @@ struct PendingHash {
     return r ? r : 2;
   }
 };
+void background_drain();
 template <bool MARK>
 void hash_bytes_begin(unsigned char *b, size_t bytes, PendingHash *ph) {
+  background_drain();
   if (bytes < kHashParallelBytes) { ph->direct = hash_run<MARK>(b, bytes, bytes); ph->pooled = false; return; }
   const size_t part = (bytes / kHashParts) & ~(size_t)63;
   ph->pooled = true;
@@ -301,34 +325,90 @@ struct HashReq {
   size_t bytes = 0;
   uint64_t result = 0;
 };
-void hash_many(HashReq *reqs, int n) {
+class ManyHash {
+ public:
+  // begin(): the parts go to the pool's workers and the call returns; ready(): the workers have done them all;
+  // end(): take what is left, wait, combine -- results in req[].result
+  void begin(const HashReq *reqs, int n) {
+    parts_.clear();
+    n_ = n;
+    for (int r = 0; r < n; r++) req[r] = reqs[r];
+    h_.assign((size_t)n * kHashParts, 0);
+    for (int r = 0; r < n; r++) {
+      unsigned char *b = static_cast<unsigned char *>(const_cast<void *>(req[r].data));
+      const size_t bytes = req[r].bytes;
+      if (!b) continue;
+      if (bytes < kHashParallelBytes) { parts_.push_back({r, -1, b, bytes, bytes}); continue; }
+      const size_t part = (bytes / kHashParts) & ~(size_t)63;
+      for (int p = 0; p < kHashParts; p++) {
+        const size_t lo = part * p, hi = p == kHashParts - 1 ? bytes : part * (p + 1);
+        parts_.push_back({r, p, b + lo, hi - lo, bytes + p});
+      }
+    }
+    HashPool::get().start((int)parts_.size(), [this](int k) {
+      const Part &pt = parts_[(size_t)k];
+      h_[(size_t)pt.req * kHashParts + (pt.idx < 0 ? 0 : pt.idx)] = hash_run<false>(pt.b, pt.bytes, pt.salt);
+    });
+    running_ = true;
+  }
+  bool running() const { return running_; }
+  bool ready() { return running_ && HashPool::get().done_by_workers(); }
+  void end() {
+    if (!running_) return;
+    HashPool::get().finish();
+    running_ = false;
+    for (int r = 0; r < n_; r++) {
+      if (!req[r].data) { req[r].result = 1; continue; }
+      uint64_t v = h_[(size_t)r * kHashParts];
+      if (req[r].bytes >= kHashParallelBytes) {
+        for (int p = 1; p < kHashParts; p++) v = (v ^ h_[(size_t)r * kHashParts + p]) * 0xFF51AFD7ED558CCDull + p;
+        v ^= v >> 32;
+      }
+      req[r].result = v ? v : 2;
+    }
+  }
+  HashReq req[4];
+
+ private:
   struct Part { int req, idx; unsigned char *b; size_t bytes; uint64_t salt; };
-  std::vector<Part> parts;
-  std::vector<uint64_t> h((size_t)n * kHashParts, 0);
-  for (int r = 0; r < n; r++) {
-    unsigned char *b = static_cast<unsigned char *>(const_cast<void *>(reqs[r].data));
-    const size_t bytes = reqs[r].bytes;
-    if (!b) continue;
-    if (bytes < kHashParallelBytes) { parts.push_back({r, -1, b, bytes, bytes}); continue; }
-    const size_t part = (bytes / kHashParts) & ~(size_t)63;
-    for (int p = 0; p < kHashParts; p++) {
-      const size_t lo = part * p, hi = p == kHashParts - 1 ? bytes : part * (p + 1);
-      parts.push_back({r, p, b + lo, hi - lo, bytes + p});
-    }
+  std::vector<Part> parts_;
+  std::vector<uint64_t> h_;
+  int n_ = 0;
+  bool running_ = false;
+};
+
+// The BACKGROUND verification (the default mode): the full hashes of the four big buffers, taken by the pool's workers
+// while the caller carries on; looked at by the next CudaComputeH call that finds them ready.  What they are compared
+// with is what the keys held when the verification STARTED; an upload in between (`epoch`) makes the result moot.
+struct Background {
+  ManyHash mh;
+  const void *addr[4] = {nullptr, nullptr, nullptr, nullptr};
+  size_t n[4] = {0, 0, 0, 0};
+  uint64_t expect[4] = {0, 0, 0, 0};
+  bool have[4] = {false, false, false, false};
+  unsigned long epoch = 0;
+  bool finished = false;  // its results wait to be looked at
+  std::chrono::steady_clock::time_point last_end{};
+} g_bg;
+// between two verifications: what the workers take of the caller's cores and memory bandwidth (back to back they slowed a
+// loop of CudaComputeH calls by 60 %: profiles/r05_pair_setup.txt); a change in place is reported within this + ~0.4 ms
+constexpr std::chrono::microseconds kBackgroundPause(2000);
+
+// every SYNCHRONOUS use of the pool first lets a background verification end (it holds the pool until then)
+void background_drain() {
+  if (g_bg.mh.running()) {
+    g_bg.mh.end();
+    g_bg.finished = true;
+    g_bg.last_end = std::chrono::steady_clock::now();
   }
-  HashPool::get().run((int)parts.size(), [&](int k) {
-    const Part &pt = parts[(size_t)k];
-    h[(size_t)pt.req * kHashParts + (pt.idx < 0 ? 0 : pt.idx)] = hash_run<false>(pt.b, pt.bytes, pt.salt);
-  });
-  for (int r = 0; r < n; r++) {
-    if (!reqs[r].data) { reqs[r].result = 1; continue; }
-    uint64_t v = h[(size_t)r * kHashParts];
-    if (reqs[r].bytes >= kHashParallelBytes) {
-      for (int p = 1; p < kHashParts; p++) v = (v ^ h[(size_t)r * kHashParts + p]) * 0xFF51AFD7ED558CCDull + p;
-      v ^= v >> 32;
-    }
-    reqs[r].result = v ? v : 2;
-  }
+}
+
+void hash_many(HashReq *reqs, int n) {
+  background_drain();
+  ManyHash m;
+  m.begin(reqs, n);
+  m.end();
+  for (int r = 0; r < n; r++) reqs[r].result = m.req[r].result;
 }
 
 // Does the caller's buffer still hold what is resident?  Updates the key; `force`: recompute the full hash even if
@@ -447,6 +527,7 @@ int upload_reference(LegacyState &S, const double *im0, const double *points3d, 
   }
   if (rc != NID_OK) return rc;
   S.have_ref = true; S.have_href = false;
+  S.epoch++;
   g_uploads++;
   return NID_OK;
 }
@@ -472,6 +553,8 @@ int ensure_reference(LegacyState &S, const double *im0, const double *points3d, 
 void Calculate3Dpoint(double *depth, double *pose_c2w, double *points_3d, double *camera_intrincis, int rows,
                       int cols) {
   StepTrace tr("Calculate3Dpoint");
+  background_drain();       // (points_3d may be the buffer a verification is reading)
+  g_bg.finished = false;
   int rc = nid_backproject(depth, pose_c2w, camera_intrincis[0], camera_intrincis[1], camera_intrincis[2],
                            camera_intrincis[3], rows, cols, g_devices[0], points_3d);
   if (rc != NID_OK) report("Calculate3Dpoint", rc, nullptr);
@@ -482,6 +565,8 @@ void CudaComputeHref(double *im0, double *points3d, double *pose, double *camera
                      int bs_degree, int cell_num, int rows, int cols, double *bs_value, int *bs_index,
                      int *bs_counter, double *Href) {
   StepTrace tr("CudaComputeHref");
+  background_drain();       // (a verification of the previous pair's buffers: over before this pair's are written)
+  g_bg.finished = false;
   nid_multi *m = get_multi(rows, cols, cell_num, bin_num, bs_degree, camera_intrincis);
   if (!m) return;
   tr.step("context (created or reused)");
@@ -577,10 +662,37 @@ nid_multi *ensure_state(double *im0, double *im1, double *points3d, int *bs_coun
   // call, like the reference's uploads).  Trusted buffers: whenever a key's cheap part changed (same_content), on every
   // kRehashEvery-th call of the pair, after an invalidate.
   S.calls++;
-  const bool verify = !trust_buffers() && !always_upload();
-  const bool periodic = verify || S.calls % kRehashEvery == 0;
-  const unsigned force = S.force_full;
+  const int mode = always_upload() ? (int)NID_LEGACY_VERIFY_TRUSTED : verify_mode();
+  const bool verify = mode == NID_LEGACY_VERIFY_EVERY_CALL;
+  const bool periodic = verify || (mode == NID_LEGACY_VERIFY_TRUSTED && S.calls % kRehashEvery == 0);
+  unsigned force = S.force_full;
   S.force_full = 0;
+  // BACKGROUND: a verification the workers have finished is looked at now.  A buffer whose content no longer hashes to
+  // what its key held when the verification started -- same address, same length, no upload in between -- was rewritten
+  // in place: said loudly, counted, and followed (its part takes the full check below, i.e. it is uploaded).
+  if (mode == NID_LEGACY_VERIFY_BACKGROUND) {
+    if (g_bg.mh.running() && (g_bg.mh.ready() || !HashPool::get().has_workers())) background_drain();
+    if (g_bg.finished) {
+      g_bg.finished = false;
+      if (g_bg.epoch == S.epoch) {
+        const void *now_addr[4] = {im0, points3d, im1, bs_ref};
+        const size_t now_n[4] = {N, 3 * N, N, 4 * N};
+        static const char *what[4] = {"im0", "points3d", "im1", "bs_ref"};
+        static const unsigned part[4] = {NID_LEGACY_REFERENCE, NID_LEGACY_REFERENCE, NID_LEGACY_TARGET, NID_LEGACY_HREF_STATE};
+        for (int k = 0; k < 4; k++)
+          if (g_bg.have[k] && g_bg.addr[k] == now_addr[k] && g_bg.n[k] == now_n[k] && g_bg.mh.req[k].result != g_bg.expect[k] && !(force & part[k])) {
+            std::fprintf(stderr, "[nid legacy] the caller's %s buffer was rewritten IN PLACE between two CudaComputeH calls (found by the background "
+                                 "verification): calls since then may have evaluated its old content; uploading the new content now.  "
+                                 "nid_legacy_invalidate() announces such a change, nid_legacy_set_verify_mode(NID_LEGACY_VERIFY_EVERY_CALL) checks every call.\n", what[k]);
+            force |= part[k];
+            g_stale_detections++;
+          }
+      }
+    }
+  } else {
+    background_drain();
+    g_bg.finished = false;
+  }
   uint64_t pre[4] = {0, 0, 0, 0};
   const bool have_pre = verify && S.have_ref && S.have_target && S.have_href;
   if (have_pre) {
@@ -606,6 +718,7 @@ nid_multi *ensure_state(double *im0, double *im1, double *points3d, int *bs_coun
       rc = nid_multi_set_target_u8(m, im.data());
       if (rc != NID_OK) { report("CudaComputeH(target upload)", rc, m); return nullptr; }
       S.have_target = true;
+      S.epoch++;
       g_uploads++;
     }
   }
@@ -628,9 +741,30 @@ nid_multi *ensure_state(double *im0, double *im1, double *points3d, int *bs_coun
     remember(S.k_bs_ref, bs_ref, 4 * N); remember(S.k_counter, bs_counter, (size_t)ncell);
     if (Href) remember(S.k_href, Href, (size_t)ncell); else S.k_href = LegacyState::Key();
     S.have_href = true;
+    S.epoch++;
     g_uploads++;
   }
   tr.step("href state keys checked");
+  // BACKGROUND: start the next verification (one at a time, with a pause between two) against what the keys hold NOW
+  // (not by a pair's first call: everything was hashed or uploaded by this very call, and a caller that continues on the
+  // nid_multi_* interface -- nid_legacy_prepare: g2o_min's fused flows -- never comes back to look at the result)
+  if (mode == NID_LEGACY_VERIFY_BACKGROUND && !first_of_pair && !g_bg.mh.running() && !g_bg.finished && HashPool::get().has_workers() &&
+      std::chrono::steady_clock::now() - g_bg.last_end > kBackgroundPause) {
+    HashReq req[4];
+    const void *addr[4] = {im0, points3d, im1, bs_ref};
+    const size_t cnt[4] = {N, 3 * N, N, 4 * N};
+    const LegacyState::Key *key[4] = {&S.k_im0, &S.k_points, &S.k_im1, &S.k_bs_ref};
+    for (int k = 0; k < 4; k++) {
+      const bool image = k == 0 || k == 2;
+      g_bg.have[k] = key[k]->valid && key[k]->addr == addr[k] && key[k]->n == cnt[k] && (image ? key[k]->raw_known : key[k]->full_known);
+      g_bg.addr[k] = addr[k]; g_bg.n[k] = cnt[k];
+      g_bg.expect[k] = image ? key[k]->raw : key[k]->full;
+      req[k].data = g_bg.have[k] ? addr[k] : nullptr;
+      req[k].bytes = cnt[k] * sizeof(double);
+    }
+    g_bg.epoch = S.epoch;
+    g_bg.mh.begin(req, 4);
+  }
   return m;
 }
 
@@ -690,15 +824,24 @@ void nid_legacy_set_rank(int device, int rank, int world, const uint8_t *rccl_id
 
 void nid_legacy_invalidate(unsigned parts) { g_state.force_full |= parts; }
 
-void nid_legacy_set_trust_buffers(int on) { g_trust = on ? 1 : 0; }
+void nid_legacy_set_verify_mode(int mode) {
+  background_drain();
+  g_bg.finished = false;
+  g_verify_mode = (mode == NID_LEGACY_VERIFY_EVERY_CALL || mode == NID_LEGACY_VERIFY_TRUSTED) ? mode : (int)NID_LEGACY_VERIFY_BACKGROUND;
+}
+void nid_legacy_set_trust_buffers(int on) { nid_legacy_set_verify_mode(on ? NID_LEGACY_VERIFY_TRUSTED : NID_LEGACY_VERIFY_BACKGROUND); }
+long nid_legacy_stale_detections(void) { return g_stale_detections; }
 
 void nid_legacy_reset(void) {
+  background_drain();  // (it reads the caller's buffers: "before the caller frees its buffers")
+  g_bg.finished = false;
   if (g_state.m) nid_multi_destroy(g_state.m);
   g_state = LegacyState();
   (void)nid_backproject_release();  // Calculate3Dpoint's scratch
 }
 
 void nid_legacy_quiesce(void) {
+  background_drain();  // (no worker reads the caller's buffers once this returns)
   if (g_state.m) (void)nid_multi_resident_pause(g_state.m);
 }
 

@@ -73,7 +73,7 @@ def test_host_library_exports(hostlib):
     nm = subprocess.run(["nm", "-D", "--defined-only", hostlib.LIB_PATH], capture_output=True, text=True).stdout
     for sym in ("nid_host_run_lm", "nid_host_run_pyramid_lm", "nid_pyr_down_u8", "nid_pyr_down_depth_u16",
                 "nid_host_standard_property", "nid_png_info", "nid_png_read_gray_u8", "nid_png_read_u16", "nid_legacy_reset", "nid_legacy_context", "nid_legacy_upload_count",
-                "nid_legacy_set_jacobian_bound", "nid_legacy_set_trust_buffers", "nid_legacy_invalidate", "nid_legacy_set_devices", "nid_legacy_set_rank", "nid_legacy_multi",
+                "nid_legacy_set_jacobian_bound", "nid_legacy_set_trust_buffers", "nid_legacy_set_verify_mode", "nid_legacy_stale_detections", "nid_legacy_invalidate", "nid_legacy_set_devices", "nid_legacy_set_rank", "nid_legacy_multi",
                 "nid_host_set_devices", "nid_host_set_rank"):
         assert re.search(rf" T {sym}\b", nm), sym
     # the three legacy operators keep their C++ linkage (mangled), as in the reference

@@ -423,6 +423,15 @@ def test_bench_multi_rank_code_path_on_one_gpu(tmp_path):
     assert len(own.stdout.strip().splitlines()) == 1, own.stdout
     ro = json.loads(own.stdout.strip())
     assert ro["n_gpus"] == 2 and ro["rccl_ranks_seen"] == 0 and "gloo" in ro["exchange"] and ro["value"] > 0
+    assert "(interleaved)" in ro["config"]["parallelism"] and ro["multi_gpu"]["launches_per_exchange"] == 2   # the defaults
+    # ... and the ranks it starts get EVERY flag as given (spawn_ranks forwards sys.argv[1:]): partition and group size
+    fwd = subprocess.run([sys.executable, bench, "--gpus", "2", "--no-cpu-baseline", "--quick", "--steps", "300", "--warmup", "70",
+                          "--backend", "gloo", "--partition", "contiguous", "--group", "3", "--batch", "16"],
+                         capture_output=True, text=True, env=env_plain, timeout=900)
+    assert fwd.returncode == 0, fwd.stderr[-3000:]
+    rw = json.loads(fwd.stdout.strip())
+    assert rw["n_gpus"] == 2 and "(contiguous)" in rw["config"]["parallelism"]
+    assert rw["multi_gpu"]["launches_per_exchange"] == 3 and rw["multi_gpu"]["poses_per_launch"] == 16
     # a launcher that started another number of ranks than --gpus says is refused
     bad = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                           "--master-addr", "127.0.0.1", "--master-port", "29515", bench, "--gpus", "4", "--no-cpu-baseline",

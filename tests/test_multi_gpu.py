@@ -292,11 +292,15 @@ def test_legacy_operators_follow_buffer_contents(hostlib, oracle, synth, pair_S,
         np.testing.assert_allclose(Ht2[act], Hc_o2[act], rtol=0, atol=1e-11)
         assert not np.allclose(Ht2[act], Ht[act])
     # A change IN PLACE that touches none of the 64 sampled elements of the quick fingerprint (one pixel in the middle of
-    # a cell).  DEFAULT: every call reads the caller's buffers in full (include/nid/legacy_ops.h), so an UNDECLARED
-    # change is followed on the NEXT call -- of any of the four big buffers -- and nothing is uploaded while nothing changes.
+    # a cell).  NID_LEGACY_VERIFY_EVERY_CALL: every call reads the caller's buffers in full (include/nid/legacy_ops.h), so an
+    # UNDECLARED change is followed on the NEXT call -- of any of the four big buffers -- and nothing is uploaded while nothing changes.
     pair = pair_S
     lib.nid_legacy_invalidate.argtypes = [hostlib.C.c_uint]
     lib.nid_legacy_set_trust_buffers.argtypes = [hostlib.C.c_int]
+    lib.nid_legacy_set_verify_mode.argtypes = [hostlib.C.c_int]
+    lib.nid_legacy_stale_detections.restype = hostlib.C.c_long
+    VERIFY_BACKGROUND, VERIFY_EVERY_CALL = 0, 1
+    lib.nid_legacy_set_verify_mode(VERIFY_EVERY_CALL)   # (the strongest of the three modes first; the default is further down)
     samples = {int(k * (N - 1) // 63) for k in range(64)}
     cellpx = (pair.rows // pair.cell // 2) * pair.cols + pair.cols // pair.cell // 2      # inside cell 0
     assert cellpx not in samples
@@ -337,6 +341,32 @@ def test_legacy_operators_follow_buffer_contents(hostlib, oracle, synth, pair_S,
     u1 = lib.nid_legacy_upload_count()
     assert np.array_equal(evaluate(), base) and lib.nid_legacy_upload_count() == u1
 
+    # The DEFAULT, NID_LEGACY_VERIFY_BACKGROUND: the calls check the cheap keys only, the pool's workers hash the buffers in
+    # full beside them; an undeclared change in place is found by the verification that follows it, and the next call after
+    # that says so (stderr, nid_legacy_stale_detections), uploads the new content and evaluates it.
+    import time
+    lib.nid_legacy_set_verify_mode(VERIFY_BACKGROUND)
+    assert np.array_equal(evaluate(), base)
+    time.sleep(0.02)
+    assert np.array_equal(evaluate(), base)
+    d0, u0 = lib.nid_legacy_stale_detections(), lib.nid_legacy_upload_count()
+    im1[cellpx] = 255.0 - im1[cellpx]                              # undeclared
+    got = None
+    for k in range(20):                                            # (a few calls may still see the old content)
+        got = evaluate()
+        if not np.array_equal(got, base):
+            break
+        time.sleep(0.005)
+    assert got[0, 0] != base[0, 0] and np.array_equal(got[1:], base[1:]), "the change was never followed"
+    assert lib.nid_legacy_stale_detections() == d0 + 1 and lib.nid_legacy_upload_count() == u0 + 1
+    im1[cellpx] = 255.0 - im1[cellpx]
+    lib.nid_legacy_invalidate(2)                                   # declared: at once, and not counted as a detection
+    assert np.array_equal(evaluate(), base) and lib.nid_legacy_stale_detections() == d0 + 1
+    for k in range(10):                                            # nothing changes: nothing is reported or uploaded
+        assert np.array_equal(evaluate(), base)
+        time.sleep(0.002)
+    assert lib.nid_legacy_stale_detections() == d0 + 1 and lib.nid_legacy_upload_count() == u0 + 2
+
     # TRUSTED buffers (opt-in, round 4's default): address + length + 64 samples per call; a change in place is declared
     # with nid_legacy_invalidate and followed at once, or undeclared and followed within 128 calls of the pair.
     lib.nid_legacy_set_trust_buffers(1)
@@ -360,12 +390,14 @@ def test_legacy_operators_follow_buffer_contents(hostlib, oracle, synth, pair_S,
         assert lib.nid_legacy_upload_count() == u0 + 2
     finally:
         lib.nid_legacy_set_trust_buffers(0)
+    lib.nid_legacy_set_verify_mode(VERIFY_EVERY_CALL)
     # the small per-cell arrays are fully hashed on every call: a changed count is followed at once
     cnt_keep = cnt.copy()
     cnt[0] = 0
     assert np.isnan(evaluate()[0, 0])
     cnt[:] = cnt_keep
     assert np.array_equal(evaluate(), base)
+    lib.nid_legacy_set_verify_mode(VERIFY_BACKGROUND)
     lib.nid_legacy_reset()
 
 

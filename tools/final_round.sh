@@ -22,5 +22,6 @@ NID_DIRECT_TRACE=1 python tools/direct_trace.py > gpurun_out/$tag/direct_trace.t
 python tools/short_seq_sweep.py A 8 > gpurun_out/$tag/short_seq_A.txt 2> gpurun_out/$tag/short_seq_A.err; echo "short seq rc=$?"
 python tools/timed_region_probe.py > gpurun_out/$tag/timed_region_probe.txt 2> gpurun_out/$tag/timed_region_probe.err; echo "probe rc=$?"
 python tools/pair_setup.py A 8 > gpurun_out/$tag/pair_setup.txt 2> gpurun_out/$tag/pair_setup.err; echo "pair setup rc=$?"
-ROUNDS=2 python tools/flash_ab.py exp/libnid_r03.so exp/libnid_norepair.so default > gpurun_out/$tag/flash_ab.txt 2> gpurun_out/$tag/flash_ab.err; echo "ab rc=$?"
+python tools/resident_batch_probe.py A > gpurun_out/$tag/short_sequences_A.txt 2> gpurun_out/$tag/short_sequences_A.err; echo "resident batch probe rc=$?"
+./tools/ubench/valu_wallclock > gpurun_out/$tag/valu_wallclock.txt 2>&1; echo "valu wallclock rc=$?"
 
