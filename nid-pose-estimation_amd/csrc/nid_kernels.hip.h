@@ -1087,6 +1087,7 @@ constexpr unsigned kBorderEpsHi = 0x3EB00000u;                  // high dword of
 constexpr bool kMainPassClamps = false;
 constexpr double kBorderEps = 0x1p-20;  // FAST u, v are within ~1e-12 of the reference's (|u| < 2^11): a wide margin
 struct PixelFront {
+  unsigned e0;  // FAST: element offset of the sample's pixel in the target image, iy * stride + ix (0 for a lane without a sample): see load_win_centre_e
   bool in, jin;
   bool redo;  // FAST: valid pixel outside the interior band -- decided by exact_decisions, not by FAST arithmetic
   int jr;
@@ -1142,19 +1143,25 @@ __device__ __forceinline__ void load_window(const EvalParams &P, Win &w) {
 // of window rows 1 and 2 (two unaligned dwords).  Jacobian phase: rows 1 and 2 whole, of rows 0 and 3 taps 1, 2.
 struct WinC { unsigned c1, c2; };
 struct WinJ { WRow r1, r2; unsigned c0, c3; };
-__device__ __forceinline__ void load_win_centre(const EvalParams &P, int wx, int wy, WinC &w) {
+// ... addressed by the element offset e0 = iy * stride + ix of the sample's own pixel (the window's origin is one up and one
+// to the left, and the buffer starts at pixel (-1, -1): the two cancel): one multiply-add, ONE select for the lanes
+// without a sample, the constant stride + 1.
+__device__ __forceinline__ unsigned win_e0(const EvalParams &P, bool in, double u, double v) {
+  const unsigned e = __umul24((unsigned)(int)v, (unsigned)P.im1_stride) + (unsigned)(int)u;
+  return in ? e : 0u;
+}
+__device__ __forceinline__ void load_win_centre_e(const EvalParams &P, unsigned e0, WinC &w) {
   const unsigned st = (unsigned)P.im1_stride;
-  const unsigned po = __umul24((unsigned)(wy + 2), st) + (unsigned)(wx + 2);  // row 1, tap 1
+  const unsigned po = e0 + (st + 1u);  // row 1, tap 1 = the sample's own pixel
   w.c1 = load_u32_at(P.im1s, po);
   w.c2 = load_u32_at(P.im1s, po + st);
 }
-__device__ __forceinline__ void load_win_jac(const EvalParams &P, int wx, int wy, WinJ &w) {
+__device__ __forceinline__ void load_win_jac_e(const EvalParams &P, unsigned e0, WinJ &w) {
   const unsigned st = (unsigned)P.im1_stride;
-  const unsigned po = __umul24((unsigned)(wy + 1), st) + (unsigned)(wx + 1);
-  w.c0 = load_u32_at(P.im1s, po + 1u);
-  w.r1 = load_row_at(P.im1s, po + st);
-  w.r2 = load_row_at(P.im1s, po + 2u * st);
-  w.c3 = load_u32_at(P.im1s, po + 3u * st + 1u);
+  w.c0 = load_u32_at(P.im1s, e0 + 1u);
+  w.r1 = load_row_at(P.im1s, e0 + st);
+  w.r2 = load_row_at(P.im1s, e0 + 2u * st);
+  w.c3 = load_u32_at(P.im1s, e0 + 3u * st + 1u);
 }
 __device__ __forceinline__ int lo16(unsigned w) { return __builtin_amdgcn_sbfe((int)w, 0u, 16u); }
 __device__ __forceinline__ int hi16(unsigned w) { return __builtin_amdgcn_sbfe((int)w, 16u, 16u); }
@@ -1253,6 +1260,7 @@ __device__ __forceinline__ void pixel_front(const EvalParams &P, const SlotArgs 
     f.redo = (f.jr >= 0) && !f.jin;
     f.w.wx = in ? (int)u - 1 : 0;
     f.w.wy = in ? (int)v - 1 : 0;
+    f.e0 = win_e0(P, in, u, v);
   }
 }
 
@@ -1869,7 +1877,7 @@ __device__ __forceinline__ bool eval_cell(const EvalParams &P, const SlotArgs &S
       pixel_front<false, !SECOND>(P, SA, tin, f);
       if (!SECOND && sb + NT < g.pstride) load_tile_xyz(P, base + (unsigned)(s + NT), nxt);
       WinC wc2;
-      load_win_centre(P, f.w.wx, f.w.wy, wc2);
+      load_win_centre_e(P, f.e0, wc2);
       if (!SECOND) load_tile_w(P, base + (unsigned)s, plane, tin);
       // fixed-tap sample (a convex combination of u8 taps: never negative), computed for every lane -- lanes
       // without a sample hold a harmless window
@@ -1920,7 +1928,7 @@ __device__ __forceinline__ bool eval_cell(const EvalParams &P, const SlotArgs &S
       load_tile(P, base + (unsigned)(sb + lane), plane, tin);
       pixel_front<false>(P, SA, tin, f);
       WinC wc2;
-      load_win_centre(P, f.w.wx, f.w.wy, wc2);
+      load_win_centre_e(P, f.e0, wc2);
       double ic = sample_fast_c(wc2, f.u, f.v);
       bool rare = f.in && outside_clamp_guard(ic);
       if (f.redo && classify_redo(P, f)) rare = true;
@@ -1979,8 +1987,8 @@ __device__ __forceinline__ bool eval_cell(const EvalParams &P, const SlotArgs &S
       for (int q = 0; q < LAT; q++)
         if (wave_base + q * NT < g.pstride) {
           pixel_front<false>(P, SA, tin[q], fr[q]);
-          if (JAC) load_win_jac(P, fr[q].w.wx, fr[q].w.wy, wjn[q]);
-          else load_win_centre(P, fr[q].w.wx, fr[q].w.wy, wcn[q]);
+          if (JAC) load_win_jac_e(P, fr[q].e0, wjn[q]);
+          else load_win_centre_e(P, fr[q].e0, wcn[q]);
         }
 #pragma unroll
       for (int q = 0; q < LAT; q++) {
@@ -2343,7 +2351,11 @@ __device__ __forceinline__ bool eval_cell(const EvalParams &P, const SlotArgs &S
   auto jac_accumulate_fast = [&](const auto &f, double invz, double gx, double gy, double pc, int jc, auto q5_possible) {
     // (the second passes place a sample with the reference's own rounding and may clamp jc: fast_bin<.., EXACT>)
     const double x = decltype(q5_possible)::value ? pc - (double)jc : frac_nonneg(pc, jc);
-    const double *A = jtab + 4 * (__mul24(f.jr, S) + jc);
+    // jr * S + jc in ONE full-rate instruction (left to itself the compiler folds the constant S into a v_mad_u64_u32: quarter rate)
+    int ent;
+    if constexpr (NB > 0) asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(ent) : "v"(f.jr), "n"(NB - 3), "v"(jc));
+    else asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(ent) : "v"(f.jr), "s"(S), "v"(jc));
+    const double *A = jtab + 4 * ent;
     double ss = 0.0;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
@@ -2480,7 +2492,7 @@ __device__ __forceinline__ bool eval_cell(const EvalParams &P, const SlotArgs &S
       pixel_front<false, !SECOND>(P, SA, tin, f);
       if (!SECOND && sb + NT < g.pstride) load_tile_xyz(P, base + (unsigned)(s + NT), nxt);
       WinJ wj;
-      load_win_jac(P, f.w.wx, f.w.wy, wj);
+      load_win_jac_e(P, f.e0, wj);
       if (!SECOND) {
         load_tile_w(P, base + (unsigned)s, plane, tin);
 #pragma unroll
@@ -2543,7 +2555,7 @@ __device__ __forceinline__ bool eval_cell(const EvalParams &P, const SlotArgs &S
       if (sb + NT < g.pstride) load_tile_xyz(P, base + (unsigned)(s + NT), nxt);
       const bool go = ((gomask >> r) & 1u) != 0u && (unsigned)__double2hiint(f.u) - P.hu_lo <= P.hj_span;
       WinJ wj;
-      load_win_jac(P, go ? (int)f.u - 1 : 0, go ? (int)f.v - 1 : 0, wj);
+      load_win_jac_e(P, win_e0(P, go, f.u, f.v), wj);
       TileIn tw;
       load_tile_w(P, base + (unsigned)s, plane, tw);
 #pragma unroll

@@ -113,6 +113,6 @@ for h in heads:
     div = sum(cnt(n, 'v_div_') for n in lb)
     strict = 'ELb1ELb1E' in want or os.environ.get('CENSUS_STRICT')  # (STRICT kernels: one pass per phase, IEEE divisions in it)
     if cnt(badd, 'ds_add_u64') >= 20 and cost is None and (div < 8 or strict): cost = (h, badd)
-    if cnt(badd, 'ds_add_u64') == 0 and cnt(bread, 'ds_read') >= 12 and len(lb) <= (12 if strict else 6) and jac is None: jac = (h, bread)
+    if cnt(badd, 'ds_add_u64') == 0 and cnt(bread, 'ds_read') >= 6 and len(lb) <= (12 if strict else 6) and jac is None: jac = (h, bread)
 if cost: show(cost[0], cost[1], "cost phase, main pass")
 if jac: show(jac[0], jac[1], "Jacobian phase, main pass")
