@@ -1624,36 +1624,6 @@ __device__ __forceinline__ bool eval_cell(const EvalParams &P, const SlotArgs &S
     unsigned long long *hc = hist + ((unsigned)jc * NC + (unsigned)copy);
     unsigned long long *hj = hist + (((unsigned)nb + hrow) * NC + (unsigned)copy);
     double wr[4] = {wr_in[0], wr_in[1], wr_in[2], wr_in[3]};
-    // a COARSE add to the marginal bin jc + k / to the joint bin (jr + m, jc + k); REPAIR: to the fine levels, if the bin
-    // is in the repair set (`w`, `pr`: the plain weight / the reference's own product, rounded once like there)
-    auto rep_set = [&](int col) -> unsigned { return col == 1 ? rep_col1 : (col == nb - 2 ? rep_colz : 0u); };
-    auto add_c = [&](int k, double wcs_k, double w) {
-      if (!REPAIR) { atomicAdd(hc + k * NC, fx_bits(wcs_k * P.hist_dn)); return; }
-      if (((rep_set(jc + k) >> 16) & 1u) && w > kNegligibleW) {
-        const int lv = fine_level(w);
-        atomicAdd(hist_lo + lv * nbins + (unsigned)(jc + k), fx_encode(w, fine_scale(lv)));
-      }
-    };
-    auto add_j = [&](int m, int k, double wr_m, double wcs_k, double w) {
-      if (!REPAIR) { atomicAdd(hj + (m * nb + k) * NC, fx_bits((wr_m * P.hist_dn) * wcs_k)); return; }
-      if ((rep_set(jc + k) >> (jr + m)) & 1u) {
-        const double pr = wr_m * w;
-        if (pr > kNegligibleW) {
-          const int lm = fine_level(pr);
-          atomicAdd(hist_lo + lm * nbins + ((unsigned)nb + hrow + (unsigned)(m * nb + k)), fx_encode(pr, fine_scale(lm)));
-        }
-      }
-    };
-    // NORMAL mode, rare branches: a LINEAR end-span weight below kLinFlagW flags the bins it lands in (kLinFlagW)
-    auto flag_linear = [&](int k, double w, const double (&wrm)[4]) {
-      const bool last = k == 2 && jc == S - 1;
-      if (w < kLinFlagW && ((k == 1 && jc == 0) || last)) {
-        unsigned bits = 1u << 16;
-#pragma unroll
-        for (int m = 0; m < 4; m++) bits |= (wrm[m] * w > kNegligibleW) ? (1u << (jr + m)) : 0u;
-        atomicOr(lin_flag + (last ? 1 : 0), bits);
-      }
-    };
     // A fine-level add of the TARGET histogram.  The fine levels are single copies; the lanes of a saturated (clamped:
     // one constant intensity) or black region all add the SAME value to the SAME bin -- a 64-way serialised LDS atomic
     // per weight and round (the flash pair ran 1.8x slower than the plain pair mostly for this).  If every active
@@ -1673,6 +1643,57 @@ __device__ __forceinline__ bool eval_cell(const EvalParams &P, const SlotArgs &S
       }
 #endif
       atomicAdd(hist_lo + idx, val);
+    };
+    // What the fine-level add of `w` at level lv LEFT OUT, one level down (round 5; the constructed cases of kind "edges",
+    // profiles/r05_adversarial.txt class F).  A level keeps 27..51 bits of an addend, depending on where in the level's
+    // 24 binary orders the addend sits; hundreds of EQUAL addends at the bottom of a level (a step edge sampled 3e-12 px
+    // past an integer position: every sample's linear end-span weight is 4e-10) leave the bin's mass with 1e-10 of
+    // relative error, W = -(1 + log2 p) with 1.4e-10 -- times an O(1) derivative, in a cell whose Jacobian is the residue
+    // of a cancellation.  For the addends that carry such derivatives -- the LINEAR end-span columns below kLinFlagW and
+    // everything the repair pass moves -- the rounding residual r = w * 2^(59 + 24 lv) - RN(...) (exact: one fma) goes,
+    // times 2^24 and rounded again, to level lv + 1 as a SIGNED integer (the fold reads the levels as signed): 51+ bits
+    // of every such addend.  Rare inside rare; the last level has no level below it (addends below 2^-104).
+    auto fine_residual = [&](int lv, unsigned bin, double w, auto marginal_tag) {
+      if (lv >= kFineLevels - 1) return;
+      const double sc = fine_scale(lv);
+      const double hi = fma(w, sc, 0x1p52) - 0x1p52;  // RN(w * sc): the integer fx_encode added
+      const double r = fma(w, sc, -hi);
+      const unsigned long long ri = (unsigned long long)__double2ll_rn(r * 0x1p24);
+      if (decltype(marginal_tag)::value) lo_add_marginal((unsigned)(lv + 1) * nbins + bin, ri);
+      else atomicAdd(hist_lo + (unsigned)(lv + 1) * nbins + bin, ri);
+    };
+    auto linear_end_small = [&](int k, double w) { return w < kLinFlagW && ((k == 1 && jc == 0) || (k == 2 && jc == S - 1)); };
+    // a COARSE add to the marginal bin jc + k / to the joint bin (jr + m, jc + k); REPAIR: to the fine levels, if the bin
+    // is in the repair set (`w`, `pr`: the plain weight / the reference's own product, rounded once like there)
+    auto rep_set = [&](int col) -> unsigned { return col == 1 ? rep_col1 : (col == nb - 2 ? rep_colz : 0u); };
+    auto add_c = [&](int k, double wcs_k, double w) {
+      if (!REPAIR) { atomicAdd(hc + k * NC, fx_bits(wcs_k * P.hist_dn)); return; }
+      if (((rep_set(jc + k) >> 16) & 1u) && w > kNegligibleW) {
+        const int lv = fine_level(w);
+        atomicAdd(hist_lo + lv * nbins + (unsigned)(jc + k), fx_encode(w, fine_scale(lv)));
+        fine_residual(lv, (unsigned)(jc + k), w, std::false_type{});
+      }
+    };
+    auto add_j = [&](int m, int k, double wr_m, double wcs_k, double w) {
+      if (!REPAIR) { atomicAdd(hj + (m * nb + k) * NC, fx_bits((wr_m * P.hist_dn) * wcs_k)); return; }
+      if ((rep_set(jc + k) >> (jr + m)) & 1u) {
+        const double pr = wr_m * w;
+        if (pr > kNegligibleW) {
+          const int lm = fine_level(pr);
+          atomicAdd(hist_lo + lm * nbins + ((unsigned)nb + hrow + (unsigned)(m * nb + k)), fx_encode(pr, fine_scale(lm)));
+          fine_residual(lm, (unsigned)nb + hrow + (unsigned)(m * nb + k), pr, std::false_type{});
+        }
+      }
+    };
+    // NORMAL mode, rare branches: a LINEAR end-span weight below kLinFlagW flags the bins it lands in (kLinFlagW)
+    auto flag_linear = [&](int k, double w, const double (&wrm)[4]) {
+      const bool last = k == 2 && jc == S - 1;
+      if (w < kLinFlagW && ((k == 1 && jc == 0) || last)) {
+        unsigned bits = 1u << 16;
+#pragma unroll
+        for (int m = 0; m < 4; m++) bits |= (wrm[m] * w > kNegligibleW) ? (1u << (jr + m)) : 0u;
+        atomicOr(lin_flag + (last ? 1 : 0), bits);
+      }
     };
     // Rare: the TARGET sample sits next to a knot (also: clamped saturated, black, integer-position samples) -- its
     // small weights, and their products with the reference weights, go to the fine level of their own exponent --
@@ -1707,13 +1728,16 @@ __device__ __forceinline__ bool eval_cell(const EvalParams &P, const SlotArgs &S
           if (wc[k] < kFineW) {
             if (!REPAIR && wc[k] > kNegligibleW) {
               const int lv = fine_level(fabs(wc[k]));
+              const bool lin = linear_end_small(k, wc[k]);
               lo_add_marginal(lv * nbins + (unsigned)(jc + k), fx_encode(wc[k], fine_scale(lv)));
+              if (lin) fine_residual(lv, (unsigned)(jc + k), wc[k], std::true_type{});
 #pragma unroll
               for (int m = 0; m < 4; m++) {
                 const double pr = wr[m] * wc[k];  // the reference's own product, rounded once like there
                 if (pr > kNegligibleW) {
                   const int lm = fine_level(fabs(pr));
                   atomicAdd(hist_lo + lm * nbins + ((unsigned)nb + hrow + (unsigned)(m * nb + k)), fx_encode(pr, fine_scale(lm)));
+                  if (lin) fine_residual(lm, (unsigned)nb + hrow + (unsigned)(m * nb + k), pr, std::false_type{});
                 }
               }
               flag_linear(k, wc[k], wr);
@@ -1734,6 +1758,7 @@ __device__ __forceinline__ bool eval_cell(const EvalParams &P, const SlotArgs &S
           if (!REPAIR && wc[k] > kNegligibleW) {
             const int lv = fine_level(fabs(wc[k]));
             lo_add_marginal(lv * nbins + (unsigned)(jc + k), fx_encode(wc[k], fine_scale(lv)));
+            if (linear_end_small(k, wc[k])) fine_residual(lv, (unsigned)(jc + k), wc[k], std::true_type{});
             flag_linear(k, wc[k], wr);
           }
         } else {
@@ -1746,6 +1771,7 @@ __device__ __forceinline__ bool eval_cell(const EvalParams &P, const SlotArgs &S
             if (!REPAIR && pr > kNegligibleW) {
               const int lm = fine_level(fabs(pr));
               atomicAdd(hist_lo + lm * nbins + ((unsigned)nb + hrow + (unsigned)(m * nb + k)), fx_encode(pr, fine_scale(lm)));
+              if (small_c && linear_end_small(k, wc[k])) fine_residual(lm, (unsigned)nb + hrow + (unsigned)(m * nb + k), pr, std::false_type{});
             }
           } else {
             add_j(m, k, wr[m], wcs[k], wc[k]);
