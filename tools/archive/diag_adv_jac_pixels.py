@@ -1,9 +1,10 @@
 #!/usr/bin/env python3
+# ARCHIVED: one-off diagnostic of a parity case; kept because profiles/ and HISTORY.md cite its output (as tools/diag_adv_jac_pixels.py). Not part of the test or measurement flow.
 """tools/diag_adv_jac_pixels.py SEED POSE CELL [strict]: an adversarial case's Jacobian-phase per-pixel values (gx, gy, pc, jc,
 dw) of the HIP path (diagnostic kernel) against the oracle built with the defined margin."""
 import importlib, os, sys
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 capi = importlib.import_module("nid-pose-estimation_amd.capi")
 synth = importlib.import_module("nid-pose-estimation_amd.synth")

@@ -1,9 +1,10 @@
 #!/usr/bin/env python3
+# ARCHIVED: one-off diagnostic of a parity case; kept because profiles/ and HISTORY.md cite its output (as tools/diag_case.py). Not part of the test or measurement flow.
 """tools/diag_case.py SEED [SHAPE...]: one random parity case (tests/test_parity_gpu.py::_random_case), per math mode and
 workgroup shape: which cells miss the Jacobian bound, by how much, and how many cells ran the repair pass."""
 import importlib, os, sys
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 capi = importlib.import_module("nid-pose-estimation_amd.capi")
 synth = importlib.import_module("nid-pose-estimation_amd.synth")

@@ -1,4 +1,5 @@
 #!/usr/bin/env python3
+# ARCHIVED: one-off diagnostic of a parity case; kept because profiles/ and HISTORY.md cite its output (as tools/diag_cell.py). Not part of the test or measurement flow.
 """tools/diag_cell.py SEED POSE LIB_A LIB_B: per-cell outputs of two builds of the library on one sweep case, next to the oracle."""
 import importlib, os, sys, subprocess, json
 import numpy as np

@@ -1,10 +1,11 @@
 #!/usr/bin/env python3
+# ARCHIVED: one-off diagnostic of a parity case; kept because profiles/ and HISTORY.md cite its output (as tools/diag_cell_j.py). Not part of the test or measurement flow.
 """tools/diag_cell_j.py SEED POSE_INDEX CELL: recompute one cell's Jacobian in long double from the ORACLE's per-pixel dumps
 (weights, gradients, B-spline derivatives) and compare with what the oracle and the HIP path return -- to tell a
 summation-order / cancellation effect in the reference's own f64 evaluation from an error of the kernel."""
 import importlib, os, sys
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 capi = importlib.import_module("nid-pose-estimation_amd.capi")
 synth = importlib.import_module("nid-pose-estimation_amd.synth")

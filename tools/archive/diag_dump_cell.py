@@ -1,9 +1,10 @@
 #!/usr/bin/env python3
+# ARCHIVED: one-off diagnostic of a parity case; kept because profiles/ and HISTORY.md cite its output (as tools/diag_dump_cell.py). Not part of the test or measurement flow.
 """tools/diag_dump_cell.py SEED POSE OUT.npz: the FAST diagnostic kernel's per-pixel dumps (cost phase and Jacobian phase)
 and per-cell results of one random parity case, saved for offline analysis (tools/diag_fast_terms.py, no GPU)."""
 import importlib, os, sys
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 capi = importlib.import_module("nid-pose-estimation_amd.capi")
 synth = importlib.import_module("nid-pose-estimation_amd.synth")

@@ -1,11 +1,12 @@
 #!/usr/bin/env python3
+# ARCHIVED: one-off diagnostic of a parity case; kept because profiles/ and HISTORY.md cite its output (as tools/diag_fast_terms.py). Not part of the test or measurement flow.
 """tools/diag_fast_terms.py SEED POSE CELL DUMP.npz: which of FAST math's per-sample differences from the reference moves
 one cell's Jacobian -- no GPU.  The cell's Jacobian is recomputed in long double from the ORACLE's per-pixel dumps with
 one family of values at a time replaced by the FAST diagnostic kernel's (tools/diag_dump_cell.py): the histogram
 weights, the Jacobian phase's derivative weights, its image gradient."""
 import importlib, os, sys
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 synth = importlib.import_module("nid-pose-estimation_amd.synth")
 from oracle import oracle_py as O

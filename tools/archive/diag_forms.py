@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
+# ARCHIVED: one-off diagnostic of a parity case; kept because profiles/ and HISTORY.md cite its output (as tools/diag_forms.py). Not part of the test or measurement flow.
 """tools/diag_forms.py NB NT: latency form vs loop form, cell by cell (tests/test_parity_gpu.py::test_latency_form_equals_loop_form)."""
 import importlib, os, sys
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 capi = importlib.import_module("nid-pose-estimation_amd.capi")
 synth = importlib.import_module("nid-pose-estimation_amd.synth")

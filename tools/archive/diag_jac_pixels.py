@@ -1,9 +1,10 @@
 #!/usr/bin/env python3
+# ARCHIVED: one-off diagnostic of a parity case; kept because profiles/ and HISTORY.md cite its output (as tools/diag_jac_pixels.py). Not part of the test or measurement flow.
 """tools/diag_jac_pixels.py SEED POSE CELL: which pixels contribute to the Jacobian on the GPU (FAST, diagnostic kernel,
 Jacobian-phase dump) and in the oracle."""
 import importlib, os, sys
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 capi = importlib.import_module("nid-pose-estimation_amd.capi")
 synth = importlib.import_module("nid-pose-estimation_amd.synth")

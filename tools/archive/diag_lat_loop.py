@@ -1,8 +1,9 @@
+# ARCHIVED: one-off diagnostic of a parity case; kept because profiles/ and HISTORY.md cite its output (as tools/diag_lat_loop.py). Not part of the test or measurement flow.
 """tools/diag_lat_loop.py [NT] [NB]: where the latency form and the loop form of a launch_batch differ (per pose, per cell)."""
 import sys, os
 import numpy as np
-sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
-sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "tests"))
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "..", "tests"))
 import importlib
 capi = importlib.import_module("nid-pose-estimation_amd.capi")
 synth = importlib.import_module("nid-pose-estimation_amd.synth")

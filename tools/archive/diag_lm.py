@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
+# ARCHIVED: one-off diagnostic of a parity case; kept because profiles/ and HISTORY.md cite its output (as tools/diag_lm.py). Not part of the test or measurement flow.
 """tools/diag_lm.py: host-stack LM (legacy operator flow and fused) against the oracle's LM on variants of pair A."""
 import importlib, os, sys
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 hostlib = importlib.import_module("nid-pose-estimation_amd.hostlib")
 synth = importlib.import_module("nid-pose-estimation_amd.synth")

@@ -1,9 +1,10 @@
 #!/usr/bin/env python3
+# ARCHIVED: one-off diagnostic of a parity case; kept because profiles/ and HISTORY.md cite its output (as tools/diag_lm_trace.py). Not part of the test or measurement flow.
 """tools/diag_lm_trace.py [bins]: per-iteration LM trace (trials, chi2, lambda, rho) of the host stack vs the oracle on
 the flash + edge-case pair."""
 import importlib, os, sys
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 hostlib = importlib.import_module("nid-pose-estimation_amd.hostlib")
 synth = importlib.import_module("nid-pose-estimation_amd.synth")

@@ -1,4 +1,5 @@
 #!/usr/bin/env python3
+# ARCHIVED: one-off diagnostic of a parity case; kept because profiles/ and HISTORY.md cite its output (as tools/diag_margin.py). Not part of the test or measurement flow.
 """tools/diag_margin.py SEED [SEED...]: for sweep cases close to (or over) the 1e-9 Jacobian rule, where does the
 difference come from?  Per seed, pose and math mode: the worst cell's |dJ| against the oracle in units of the plain
 allowance (1e-9 of the cell's own scale + f64 roundoff at the frame's scale), the same figure for the ORACLE'S TWIN
@@ -6,7 +7,7 @@ against the oracle (two valid roundings of the reference's own expressions: its 
 _reference_noise), and for FAST against STRICT (what the FAST mode's own arithmetic adds).  GPU needed."""
 import importlib, os, sys
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 capi = importlib.import_module("nid-pose-estimation_amd.capi")
 synth = importlib.import_module("nid-pose-estimation_amd.synth")

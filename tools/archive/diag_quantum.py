@@ -1,4 +1,5 @@
 #!/usr/bin/env python3
+# ARCHIVED: one-off diagnostic of a parity case; kept because profiles/ and HISTORY.md cite its output (as tools/diag_quantum.py). Not part of the test or measurement flow.
 """tools/diag_quantum.py SEED POSE_INDEX CELL [QBITS...]: what the fixed-point quantum of the histogram adds does to one
 cell's Jacobian -- no GPU needed.  The cell's Jacobian is recomputed in long double from the ORACLE's per-pixel dumps
 (i) with exact histograms and (ii) with every coarse addend rounded to a multiple of 2^-q the way k_eval2's hist_add
@@ -6,7 +7,7 @@ does (samples next to a knot -- smaller outer weight below 2^-28, or tiny refere
 weights exactly: the fine levels), for each q given (default 45 52 60)."""
 import importlib, os, sys
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 synth = importlib.import_module("nid-pose-estimation_amd.synth")
 from oracle import oracle_py as O

@@ -1,7 +1,8 @@
+# ARCHIVED: round 2 probe of launch overheads; kept because profiles/ and HISTORY.md cite its output (as tools/launch_cost.py). Not part of the test or measurement flow.
 """Diagnostic: host cost of a launch call and device time of batched launches."""
 import importlib, os, sys, time
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 capi = importlib.import_module("nid-pose-estimation_amd.capi")
 synth = importlib.import_module("nid-pose-estimation_amd.synth")
 pair = synth.make_pair(sys.argv[1] if len(sys.argv) > 1 else "A")

@@ -1,9 +1,10 @@
 #!/usr/bin/env python3
+# ARCHIVED: round 2-3 probe: throughput by workgroup shape; kept because profiles/ and HISTORY.md cite its output (as tools/shape_throughput.py). Not part of the test or measurement flow.
 """tools/shape_throughput.py [A|B]: 256-pose cost + Jacobian launches (one at a time: kernel us) and the pipelined rate per
 workgroup shape of the throughput path (128 = default, 256)."""
 import importlib, os, sys, time
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 capi = importlib.import_module("nid-pose-estimation_amd.capi")
 synth = importlib.import_module("nid-pose-estimation_amd.synth")

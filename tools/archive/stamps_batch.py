@@ -1,9 +1,10 @@
+# ARCHIVED: round 4 probe: per-step stamps of a batch launch; kept because profiles/ and HISTORY.md cite its output (as tools/stamps_batch.py). Not part of the test or measurement flow.
 """Diagnostic: per-phase cycle shares of the evaluation kernel inside a BATCHED launch
 (stamps are taken by the workgroups of pose 0; the other poses provide the contention).
 Usage: python tools/stamps_batch.py [A|B] [bins] [batch]"""
 import importlib, sys, os
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 capi = importlib.import_module("nid-pose-estimation_amd.capi")
 synth = importlib.import_module("nid-pose-estimation_amd.synth")
 cfg = sys.argv[1] if len(sys.argv) > 1 else "A"

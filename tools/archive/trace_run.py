@@ -1,8 +1,9 @@
+# ARCHIVED: round 2 helper for a rocprofv3 trace pass; kept because profiles/ and HISTORY.md cite its output (as tools/trace_run.py). Not part of the test or measurement flow.
 """Workload for a kernel trace: 40 launches of 256 poses (cost + Jacobian, FAST), one at a time on one stream, on the
 plain pair and on the flash pair.  Usage: rocprofv3 --kernel-trace --stats -d DIR -- python3 tools/trace_run.py"""
 import importlib, os, sys
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 capi = importlib.import_module("nid-pose-estimation_amd.capi")
 synth = importlib.import_module("nid-pose-estimation_amd.synth")
 delta = float(np.sqrt(0.95))
