@@ -1,5 +1,5 @@
 #!/bin/bash
-# ARCHIVED: round 2-3 A/B driver over build variants (superseded by tools/ab_kernel.sh); kept because profiles/ and HISTORY.md cite its output (as tools/bench_variants.sh). Not part of the test or measurement flow.
+# ARCHIVED: round 2-3 A/B driver over build variants (superseded by tools/ab_kernel.sh); output recorded in / cited by: profiles/README.md (there as tools/bench_variants.sh). Not part of the test or measurement flow.
 # tools/bench_variants.sh OUTDIR NAME...: bench.py (N=1, no CPU legs) once per experiment build exp/libnid_NAME.so
 # (tools/build_variant.py), one line per variant: sustained it/s, kernel ms for 64 poses alone.
 out=$1; shift

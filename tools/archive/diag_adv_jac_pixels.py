@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-# ARCHIVED: one-off diagnostic of a parity case; kept because profiles/ and HISTORY.md cite its output (as tools/diag_adv_jac_pixels.py). Not part of the test or measurement flow.
+# ARCHIVED: one-off diagnostic of a parity case; output recorded in / cited by: profiles/r05_adversarial.txt, class C (there as tools/diag_adv_jac_pixels.py). Not part of the test or measurement flow.
 """tools/diag_adv_jac_pixels.py SEED POSE CELL [strict]: an adversarial case's Jacobian-phase per-pixel values (gx, gy, pc, jc,
 dw) of the HIP path (diagnostic kernel) against the oracle built with the defined margin."""
 import importlib, os, sys

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-# ARCHIVED: one-off diagnostic of a parity case; kept because profiles/ and HISTORY.md cite its output (as tools/diag_adversarial.py). Not part of the test or measurement flow.
+# ARCHIVED: one-off diagnostic of a parity case; output recorded in / cited by: profiles/r05_adversarial.txt, classes H and C (there as tools/diag_adversarial.py). Not part of the test or measurement flow.
 """tools/diag_adversarial.py SEED...: one constructed case (tests/adversarial_cases.py) in detail -- per math mode, pose and
 cell the entropies and the Jacobian of the HIP path against the oracle (defined margin), the plain oracle and its twin."""
 import importlib, os, sys

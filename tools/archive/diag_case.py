@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-# ARCHIVED: one-off diagnostic of a parity case; kept because profiles/ and HISTORY.md cite its output (as tools/diag_case.py). Not part of the test or measurement flow.
+# ARCHIVED: one-off diagnostic of a parity case; output recorded in / cited by: profiles/r04_parity_sweeps.txt (there as tools/diag_case.py). Not part of the test or measurement flow.
 """tools/diag_case.py SEED [SHAPE...]: one random parity case (tests/test_parity_gpu.py::_random_case), per math mode and
 workgroup shape: which cells miss the Jacobian bound, by how much, and how many cells ran the repair pass."""
 import importlib, os, sys

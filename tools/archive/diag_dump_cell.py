@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-# ARCHIVED: one-off diagnostic of a parity case; kept because profiles/ and HISTORY.md cite its output (as tools/diag_dump_cell.py). Not part of the test or measurement flow.
+# ARCHIVED: one-off diagnostic of a parity case; output recorded in / cited by: profiles/r04_parity_sweeps.txt, HISTORY.md (there as tools/diag_dump_cell.py). Not part of the test or measurement flow.
 """tools/diag_dump_cell.py SEED POSE OUT.npz: the FAST diagnostic kernel's per-pixel dumps (cost phase and Jacobian phase)
 and per-cell results of one random parity case, saved for offline analysis (tools/diag_fast_terms.py, no GPU)."""
 import importlib, os, sys

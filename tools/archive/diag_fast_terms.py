@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-# ARCHIVED: one-off diagnostic of a parity case; kept because profiles/ and HISTORY.md cite its output (as tools/diag_fast_terms.py). Not part of the test or measurement flow.
+# ARCHIVED: one-off diagnostic of a parity case; output recorded in / cited by: profiles/r04_parity_sweeps.txt, HISTORY.md (there as tools/diag_fast_terms.py). Not part of the test or measurement flow.
 """tools/diag_fast_terms.py SEED POSE CELL DUMP.npz: which of FAST math's per-sample differences from the reference moves
 one cell's Jacobian -- no GPU.  The cell's Jacobian is recomputed in long double from the ORACLE's per-pixel dumps with
 one family of values at a time replaced by the FAST diagnostic kernel's (tools/diag_dump_cell.py): the histogram

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-# ARCHIVED: one-off diagnostic of a parity case; kept because profiles/ and HISTORY.md cite its output (as tools/diag_jac_pixels.py). Not part of the test or measurement flow.
+# ARCHIVED: one-off diagnostic of a parity case; output recorded in / cited by: profiles/r04_parity_sweeps.txt (there as tools/diag_jac_pixels.py). Not part of the test or measurement flow.
 """tools/diag_jac_pixels.py SEED POSE CELL: which pixels contribute to the Jacobian on the GPU (FAST, diagnostic kernel,
 Jacobian-phase dump) and in the oracle."""
 import importlib, os, sys

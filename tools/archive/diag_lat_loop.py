@@ -1,4 +1,4 @@
-# ARCHIVED: one-off diagnostic of a parity case; kept because profiles/ and HISTORY.md cite its output (as tools/diag_lat_loop.py). Not part of the test or measurement flow.
+# ARCHIVED: one-off diagnostic of a parity case; output recorded in / cited by: profiles/r05_ablations_A.txt item 5 (there as tools/diag_lat_loop.py). Not part of the test or measurement flow.
 """tools/diag_lat_loop.py [NT] [NB]: where the latency form and the loop form of a launch_batch differ (per pose, per cell)."""
 import sys, os
 import numpy as np

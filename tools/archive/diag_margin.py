@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-# ARCHIVED: one-off diagnostic of a parity case; kept because profiles/ and HISTORY.md cite its output (as tools/diag_margin.py). Not part of the test or measurement flow.
+# ARCHIVED: one-off diagnostic of a parity case; output recorded in / cited by: profiles/r03_parity_sweeps.txt, HISTORY.md, profiles/README.md (there as tools/diag_margin.py). Not part of the test or measurement flow.
 """tools/diag_margin.py SEED [SEED...]: for sweep cases close to (or over) the 1e-9 Jacobian rule, where does the
 difference come from?  Per seed, pose and math mode: the worst cell's |dJ| against the oracle in units of the plain
 allowance (1e-9 of the cell's own scale + f64 roundoff at the frame's scale), the same figure for the ORACLE'S TWIN

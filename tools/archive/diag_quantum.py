@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-# ARCHIVED: one-off diagnostic of a parity case; kept because profiles/ and HISTORY.md cite its output (as tools/diag_quantum.py). Not part of the test or measurement flow.
+# ARCHIVED: one-off diagnostic of a parity case; output recorded in / cited by: profiles/r03_parity_sweeps.txt, HISTORY.md, tests/test_parity_gpu.py (there as tools/diag_quantum.py). Not part of the test or measurement flow.
 """tools/diag_quantum.py SEED POSE_INDEX CELL [QBITS...]: what the fixed-point quantum of the histogram adds does to one
 cell's Jacobian -- no GPU needed.  The cell's Jacobian is recomputed in long double from the ORACLE's per-pixel dumps
 (i) with exact histograms and (ii) with every coarse addend rounded to a multiple of 2^-q the way k_eval2's hist_add

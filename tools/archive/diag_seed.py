@@ -1,4 +1,4 @@
-# ARCHIVED: one-off diagnostic of a parity case; kept because profiles/ and HISTORY.md cite its output (as tools/diag_seed.py). Not part of the test or measurement flow.
+# ARCHIVED: one-off diagnostic of a parity case; output recorded in / cited by: HISTORY.md (there as tools/diag_seed.py). Not part of the test or measurement flow.
 import importlib, os, sys
 import numpy as np
 ROOT = os.getcwd()

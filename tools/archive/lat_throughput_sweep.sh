@@ -1,5 +1,5 @@
 #!/bin/bash
-# ARCHIVED: round 3 sweep of the latency form's throughput (profiles/r03_*); kept because profiles/ and HISTORY.md cite its output (as tools/lat_throughput_sweep.sh). Not part of the test or measurement flow.
+# ARCHIVED: round 3 sweep of the latency form's throughput (profiles/r03_*); output recorded in / cited by: profiles/r02_ablations_A.txt, profiles/README.md (there as tools/lat_throughput_sweep.sh). Not part of the test or measurement flow.
 # tools/lat_throughput_sweep.sh [THREADS...]: cost + Jacobian throughput at 16 poses per launch (the launches whose
 # per-pose records ride in the kernel arguments) per workgroup shape; honours NID_HIP_LIB (tools/build_variant.py).
 mkdir -p gpurun_out/lat_sweep

@@ -1,4 +1,4 @@
-# ARCHIVED: round 2 probe of launch overheads; kept because profiles/ and HISTORY.md cite its output (as tools/launch_cost.py). Not part of the test or measurement flow.
+# ARCHIVED: round 2 probe of launch overheads; output recorded in / cited by: profiles/README.md (there as tools/launch_cost.py). Not part of the test or measurement flow.
 """Diagnostic: host cost of a launch call and device time of batched launches."""
 import importlib, os, sys, time
 import numpy as np

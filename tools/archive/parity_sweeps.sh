@@ -1,5 +1,5 @@
 #!/bin/bash
-# ARCHIVED: chunked driver of the single-process random sweep (rounds 2-3; superseded by tools/parity_sweep_mp.py); kept because HISTORY.md cites it (as tools/parity_sweeps.sh). Not part of the test or measurement flow.
+# ARCHIVED: chunked driver of the single-process random sweep (rounds 2-3; superseded by tools/parity_sweep_mp.py); output recorded in / cited by: HISTORY.md (there as tools/parity_sweeps.sh). Not part of the test or measurement flow.
 # tools/parity_sweeps.sh FIRST CHUNKS [CHUNK]: tools/random_parity_sweep.py over CHUNKS chunks of CHUNK seeds (default 200)
 # at the throughput shape, the same seeds at 512 threads (latency form), then tools/flash_pose_sweep.py; one summary
 # line per chunk (a GPU box kills a silent command after seven minutes).

@@ -1,5 +1,5 @@
 #!/bin/bash
-# ARCHIVED: round 4's sweep / check driver script (its output is under profiles/r04_*); kept because profiles/ and HISTORY.md cite its output (as tools/r04_extra_sweeps.sh). Not part of the test or measurement flow.
+# ARCHIVED: round 4's sweep / check driver script (its output is under profiles/r04_*); output recorded in / cited by: profiles/r04_parity_sweeps.txt (there as tools/r04_extra_sweeps.sh). Not part of the test or measurement flow.
 # tools/r04_extra_sweeps.sh FIRST COUNT [SHAPES]: more fresh cases on the final kernel (appended to profiles/r04_parity_sweeps.txt).
 # (the workers' progress lines go to a file under gpurun_out/ as they come: a run that is silent for 7 minutes is taken for hung)
 out=gpurun_out/r04_sweeps

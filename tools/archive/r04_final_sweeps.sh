@@ -1,5 +1,5 @@
 #!/bin/bash
-# ARCHIVED: round 4's sweep / check driver script (its output is under profiles/r04_*); kept because profiles/ and HISTORY.md cite its output (as tools/r04_final_sweeps.sh). Not part of the test or measurement flow.
+# ARCHIVED: round 4's sweep / check driver script (its output is under profiles/r04_*); output recorded in / cited by: profiles/r04_parity_sweeps.txt, profiles/README.md (there as tools/r04_final_sweeps.sh). Not part of the test or measurement flow.
 # tools/r04_final_sweeps.sh PART: the parity sweeps of profiles/r04_parity_sweeps.txt on the FINAL kernel.
 # PART 1: round 3's ranges (13 000 cases) + this round's first two ranges (14 600); PART 2: 20 600 fresh cases + the flash sweep.
 out=gpurun_out/r04_sweeps

@@ -1,5 +1,5 @@
 #!/bin/bash
-# ARCHIVED: round 4's sweep / check driver script (its output is under profiles/r04_*); kept because profiles/ and HISTORY.md cite its output (as tools/r04_sweeps.sh). Not part of the test or measurement flow.
+# ARCHIVED: round 4's sweep / check driver script (its output is under profiles/r04_*); output recorded in / cited by: profiles/r04_parity_sweeps.txt (there as tools/r04_sweeps.sh). Not part of the test or measurement flow.
 # round 4 parity sweeps on the final kernel: fresh random cases (throughput shape and the 512-thread latency form, both math
 # modes), 256 / 1024 threads on a smaller set, then the flash sweep.  usage: tools/r04_sweeps.sh FIRST COUNT [OUTDIR]
 out=${3:-gpurun_out/r04s}

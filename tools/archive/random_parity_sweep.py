@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-# ARCHIVED: the single-process random sweep of rounds 2-3 (superseded by tools/parity_sweep_mp.py); kept because profiles/ and HISTORY.md cite its output (as tools/random_parity_sweep.py). Not part of the test or measurement flow.
+# ARCHIVED: the single-process random sweep of rounds 2-3 (superseded by tools/parity_sweep_mp.py); output recorded in / cited by: profiles/r02_ablations_A.txt, HISTORY.md, tests/test_parity_gpu.py (there as tools/random_parity_sweep.py). Not part of the test or measurement flow.
 """tools/random_parity_sweep.py FIRST COUNT [shape]: tests/test_parity_gpu.py::test_randomised_pairs over seeds beyond the
 64 the suite runs (a one-off sweep on the GPU box: the exact-decision / fine-level machinery of FAST math has many rare
 corners).  Also evaluates every case in the latency launch shape when `shape` (512 / 1024) is given.  Prints the seeds
