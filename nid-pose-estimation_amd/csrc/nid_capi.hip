@@ -1392,7 +1392,10 @@ SplitPlan plan_split(const nid_ctx *ctx, int n, bool jac) {
   if (ctx->seq_chunk > 0) return {std::min(ctx->seq_chunk, n), ctx->seq_streams != 1};
   if (ctx->external_stream) return {n, false};  // one stream: nothing to run beside
   (void)jac;
-  if (n <= 4) return {n, false};
+  // up to ten poses one launch fills the chip once (10 x 256 cells = one workgroup slot per cell and pose on 256 CUs): a second
+  // launch on the other stream only adds its own latency (profiles/r05_short_sequences.txt: 8 poses 52.6 us against 57.1,
+  // cost only 38.2 against 47.5; 10 poses 57.6 against 59.8)
+  if (n <= 10) return {n, false};
   // as few launches of <= kMaxBatch poses as cover n, at least two, equally filled: 20 -> 10 + 10, 40 -> 14 + 13 + 13
   const int launches = std::max(2, (n + kMaxBatch - 1) / kMaxBatch);
   return {(n + launches - 1) / launches, true};
