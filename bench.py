@@ -469,7 +469,17 @@ def main():
     # instantiation (<= 16 poses: records as kernel arguments) than the timed region (device-resident records); a
     # cold instantiation costs its first launches ~10 us each in instruction-cache misses, idle clocks more.  Same
     # step count on every rank (the launches are collective for N > 1).
-    if args.preheat_seconds > 0:
+    torch.cuda.synchronize(dev)  # (the process's first device-wide synchronisation sets up torch's own streams: not in front of the timed shot)
+    if args.preheat_seconds > 0 and K <= 64:
+        # A SHORT timed region (one short sequence: the driver's --steps 20) is preheated by COUNT, 50 sequences of its own
+        # length (~5 ms; the same count on every rank): enough for the kernel instantiation's code and the launch path to
+        # be warm, and short enough to leave the device at its boost clocks -- measured (tools/first_shot_probe.py,
+        # profiles/r05_short_sequences.txt): the shot behind 20-100 sequences takes 91-92 us, behind 0.25 s of them
+        # 103-131 us (and behind 1-50 ms of idling 125-141 us).
+        n_pre = min(K, Bm * G if multi else B)
+        for _ in range(50):
+            run(n_pre, collect=False)
+    elif args.preheat_seconds > 0:
         n_pre = min(K, Bm * G if multi else B)
         t_pre = time.perf_counter()
         for _ in range(1000):
