@@ -9,6 +9,7 @@ python bench.py --config B > gpurun_out/$tag/bench_B.json 2> gpurun_out/$tag/ben
 python bench.py --steps 20 --warmup 5 > gpurun_out/$tag/bench_A_driver_flags.json 2> gpurun_out/$tag/bench_A_driver_flags.err; echo "bench driver rc=$?"
 bash tools/profile_round.sh $tag > gpurun_out/$tag/profile_round.log 2>&1; echo "profile rc=$?"
 bash tools/pmc_round.sh $tag A > gpurun_out/$tag/pmc_round.log 2>&1; echo "pmc rc=$?"
+bash tools/pmc_round.sh ${tag}B B > gpurun_out/$tag/pmc_round_B.log 2>&1; echo "pmc B rc=$?"
 python tools/latency_sweep.py A 8 > gpurun_out/$tag/launch_cost_A.txt 2> gpurun_out/$tag/launch_cost_A.err; echo "lat A rc=$?"
 python tools/latency_sweep.py B 8 > gpurun_out/$tag/launch_cost_B.txt 2> gpurun_out/$tag/launch_cost_B.err; echo "lat B rc=$?"
 python tools/batch_sweep.py > gpurun_out/$tag/batch_sweep.txt 2> gpurun_out/$tag/batch_sweep.err; echo "batch rc=$?"
@@ -24,4 +25,4 @@ python tools/timed_region_probe.py > gpurun_out/$tag/timed_region_probe.txt 2> g
 python tools/pair_setup.py A 8 > gpurun_out/$tag/pair_setup.txt 2> gpurun_out/$tag/pair_setup.err; echo "pair setup rc=$?"
 python tools/resident_batch_probe.py A > gpurun_out/$tag/short_sequences_A.txt 2> gpurun_out/$tag/short_sequences_A.err; echo "resident batch probe rc=$?"
 ./tools/ubench/valu_wallclock > gpurun_out/$tag/valu_wallclock.txt 2>&1; echo "valu wallclock rc=$?"
-
+python tools/first_shot_probe.py > gpurun_out/$tag/first_shot_probe.txt 2> gpurun_out/$tag/first_shot_probe.err; echo "first shot probe rc=$?"
