@@ -21,8 +21,9 @@
 #include <vector>
 
 #include "nid/nid_c.h"
-#define NID_SETUP_KERNELS 1  // k_tile, k_im1_margins, k_backproject_plain: this translation unit's
 #include "nid_eval_launch.h"
+#include "nid_setup_kernels.hip.h"     // k_tile, k_im1_margins, k_backproject_plain, k_href, k_plain_nid, k_untile_bs: this translation unit's
+#include "nid_resident_kernels.hip.h"  // control words and record layouts of the resident evaluators (their kernels: nid_resident_tu.hip)
 
 using namespace nid;
 

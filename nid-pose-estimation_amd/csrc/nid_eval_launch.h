@@ -11,6 +11,9 @@
 
 namespace nid {
 
+struct ResidentCtl;  // nid_resident_kernels.hip.h
+struct ResBatchCtl;
+
 // which family of k_eval2 instantiations a launch takes (launch_eval2 in nid_capi.hip decides)
 enum EvalFamily {
   kFamLoop = 0,       // bin-specialised (8 / 10) or generic; EXT when P.slots_ext is set (128 / 256 threads)

@@ -1,4 +1,6 @@
-// nid_kernels.hip.h -- hand-written gfx950 kernels of the NID path.
+// nid_kernels.hip.h -- hand-written gfx950 kernels of the NID path: shared types and device helpers, eval_cell (one cell at one
+// pose), the launched kernels k_eval2 / k_repair.  Siblings: nid_setup_kernels.hip.h (once per pair), nid_resident_kernels.hip.h
+// (the kernels that stay on the device between requests).
 //
 // Design (DESIGN.md has the long form):
 //  * one workgroup per cell and candidate pose (a cell is rb x cb pixels, 30x40 = 1200 in both
@@ -640,254 +642,6 @@ __device__ __forceinline__ double fine_scale(int level) {  // 2^(59 + 24 level)
 }
 __device__ __forceinline__ double fine_inv_scale(int level) {
   return __hiloint2double((1023 - 59 - 24 * level) << 20, 0);
-}
-
-// ---------------------------------------------------------------------------
-// Setup: back-projection + tiling.  Calculate3DpointKernel (CudaPoints3d.cu:5-32)
-// == Get3dPointAndIntensity (NID_pose_estimation.cpp:401-432) folded into the
-// cell-major tile writer.  One thread per tile slot.
-#ifdef NID_SETUP_KERNELS  // (plain kernels: defined in ONE translation unit, nid_capi.hip)
-__global__ void k_tile(Geometry g, const double *__restrict__ depth,
-                       const double *__restrict__ points_in, const uint8_t *__restrict__ im0,
-                       const double *__restrict__ Twc /*col-major 16*/, Tiles t,
-                       double *__restrict__ points_out /*3N or null*/) {
-  const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  const long total = (long)g.nloc * g.pstride;
-  if (gid >= total) return;
-  const int cl = (int)(gid / g.pstride);
-  const int s = (int)(gid % g.pstride);
-  double X = NAN, Y = NAN, Z = NAN;
-  int jr = -1;
-  uint8_t i0 = 0;
-  if (s < g.ps) {
-    const int c = g.cell_begin + cl * g.cell_stride;
-    const int ci = c / g.cell_num, cj = c % g.cell_num;
-    const int r = ci * g.rb + s / g.cb;
-    const int col = cj * g.cb + s % g.cb;
-    const long id = (long)r * g.cols + col;
-    i0 = im0[id];
-    bool valid;
-    if (depth) {
-      const double z = depth[id];
-      valid = !(z < 0.01 || z > 100);  // CudaPoints3d.cu:12
-      if (valid) {
-        const double x0 = z * (col - g.cx) / g.fx;
-        const double y0 = z * (r - g.cy) / g.fy;
-        X = Twc[0] * x0 + Twc[4] * y0 + Twc[8] * z + Twc[12];
-        Y = Twc[1] * x0 + Twc[5] * y0 + Twc[9] * z + Twc[13];
-        Z = Twc[2] * x0 + Twc[6] * y0 + Twc[10] * z + Twc[14];
-      }
-      if (points_out) {
-        points_out[3 * id] = X; points_out[3 * id + 1] = Y; points_out[3 * id + 2] = Z;
-      }
-    } else {
-      X = points_in[3 * id]; Y = points_in[3 * id + 1]; Z = points_in[3 * id + 2];
-      valid = !(isnan(X) || isnan(Y) || isnan(Z));  // computeH.cu:145
-      if (!valid) { X = NAN; Y = NAN; Z = NAN; }
-    }
-    if (valid) {
-      double obs = (double)i0;  // types_six_dof_expmap.cpp:553-559
-      if (obs >= 255) obs = 254.999;
-      const double bin_pos_ref = obs * (double)g.S / 255.0;
-      jr = (int)floor(bin_pos_ref);
-    }
-  }
-  t.X[gid] = X; t.Y[gid] = Y; t.Z[gid] = Z;
-  t.JR[gid] = (int8_t)jr;
-  t.I0[gid] = i0;
-}
-
-// Target image for the evaluation kernel: int16 copy of the u8 image with the extrapolated top / left margin
-// (see Win).  dst is (rows + 1) x stride; one thread per destination element of the first `cols + 1` columns.
-__global__ void k_im1_margins(int rows, int cols, int stride, const uint8_t *__restrict__ src, int16_t *__restrict__ dst) {
-  const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (gid >= (long)(rows + 1) * (cols + 1)) return;
-  const int r = (int)(gid / (cols + 1)) - 1, c = (int)(gid % (cols + 1)) - 1;
-  auto at = [&](int rr, int cc) { return (int)src[(size_t)rr * cols + cc]; };
-  auto col_m1 = [&](int rr) { return cols > 1 ? 2 * at(rr, 0) - at(rr, 1) : at(rr, 0); };
-  int v;
-  if (r >= 0 && c >= 0) v = at(r, c);
-  else if (r >= 0) v = col_m1(r);
-  else if (c >= 0) v = rows > 1 ? 2 * at(0, c) - at(1, c) : at(0, c);
-  else v = rows > 1 ? 2 * col_m1(0) - col_m1(1) : col_m1(0);  // corner: never read with a non-zero weight
-  dst[(size_t)(r + 1) * stride + (c + 1)] = (int16_t)v;
-}
-
-// depth pixels that belong to no cell (rows/cols not divisible by cell_num, Q11)
-// still need Calculate3Dpoint's output when the caller asks for points3d.
-__global__ void k_backproject_plain(Geometry g, const double *__restrict__ depth,
-                                    const double *__restrict__ Twc, double *__restrict__ pts) {
-  const long id = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (id >= (long)g.rows * g.cols) return;
-  const int r = (int)(id / g.cols), col = (int)(id % g.cols);
-  const double z = depth[id];
-  double X = NAN, Y = NAN, Z = NAN;
-  if (!(z < 0.01 || z > 100)) {
-    const double x0 = z * (col - g.cx) / g.fx;
-    const double y0 = z * (r - g.cy) / g.fy;
-    X = Twc[0] * x0 + Twc[4] * y0 + Twc[8] * z + Twc[12];
-    Y = Twc[1] * x0 + Twc[5] * y0 + Twc[9] * z + Twc[13];
-    Z = Twc[2] * x0 + Twc[6] * y0 + Twc[10] * z + Twc[14];
-  }
-  pts[3 * id] = X; pts[3 * id + 1] = Y; pts[3 * id + 2] = Z;
-}
-
-// The reference stage's per-pixel outputs in the caller's layout (CudaComputeHref's bs_value / bs_index, image order):
-// one thread per tile slot writes its pixel's four weights (the sign of the first is the evaluation kernel's knot flag:
-// stripped) and its bin index.  Pixels of no cell of this context are not written.
-__global__ void k_untile_bs(Geometry g, Tiles t, double *__restrict__ bsv /*4N or null*/, int *__restrict__ bsi /*N or null*/, int nan_rows) {
-  const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (gid >= (long)g.nloc * g.pstride) return;
-  const int cl = (int)(gid / g.pstride), s = (int)(gid % g.pstride);
-  if (s >= g.ps) return;
-  const int c = g.cell_begin + cl * g.cell_stride;
-  const long id = (long)((c / g.cell_num) * g.rb + s / g.cb) * g.cols + (c % g.cell_num) * g.cb + s % g.cb;
-  if (bsv) {
-    const double4 w = *reinterpret_cast<const double4 *>(t.W + 4 * gid);
-    // nan_rows (nid_set_href_nan_markers): the legacy operators' convention -- a pixel that is invalid or out of frame at
-    // this pose reads NaN, NaN, NaN, NaN (CudaComputeHref.cu:82-87, 126-130); in-frame weights sum to 1, so an all-zero
-    // row is exactly that set
-    const bool none = nan_rows && w.x == 0.0 && w.y == 0.0 && w.z == 0.0 && w.w == 0.0;
-    *reinterpret_cast<double4 *>(bsv + 4 * id) = none ? make_double4(NAN, NAN, NAN, NAN) : make_double4(fabs(w.x), w.y, w.z, w.w);
-  }
-  if (bsi) bsi[id] = (int)t.JR[gid];
-}
-#endif  // NID_SETUP_KERNELS
-
-// ---------------------------------------------------------------------------
-// Setup: reference stage at the initial pose -- computeHref
-// (types_six_dof_expmap.cpp:655-725) / CalculateHrefKernel
-// (CudaComputeHref.cu:33-135) for one cell per workgroup.
-template <int NT>
-__global__ __launch_bounds__(NT) void k_href(Geometry g, Pose pose, Tiles t, int *__restrict__ Nc,
-                                             double *__restrict__ Href, double hist_scale,
-                                             double hist_inv_scale) {
-  __shared__ unsigned long long hist[kMaxBins * kHistCopies];
-  __shared__ double red[2 * (NT / 64)];
-  const int cl = blockIdx.x, tid = threadIdx.x;
-  const int copy = tid & (kHistCopies - 1);
-  for (int i = tid; i < g.nb * kHistCopies; i += NT) hist[i] = 0ull;
-  __syncthreads();
-  const size_t base = (size_t)cl * g.pstride;
-  int count = 0;
-  for (int s = tid; s < g.pstride; s += NT) {
-    const size_t gi = base + s;
-    const int jr = t.JR[gi];
-    double w[4] = {0.0, 0.0, 0.0, 0.0};
-    if (jr >= 0) {
-      double qx, qy, qz;
-      xform_point(pose, t.X[gi], t.Y[gi], t.Z[gi], qx, qy, qz);
-      const double u = g.fx * qx / qz + g.cx;
-      const double v = g.fy * qy / qz + g.cy;
-      if (u >= 0 && u + 3 <= g.cols && v >= 0 && v + 3 <= g.rows) {
-        count++;
-        double obs = (double)t.I0[gi];
-        if (obs >= 255) obs = 254.999;
-        const double bin_pos_ref = obs * (double)g.S / 255.0;
-        double d[4];
-        bspline4<false>(bin_pos_ref, jr, g.S, w, d);
-#pragma unroll
-        for (int k = 0; k < 4; k++) atomicAdd(&hist[(jr + k) * kHistCopies + copy], fx_encode(w[k], hist_scale));
-      }
-    }
-    // the evaluation kernel's "tiny non-zero reference weights" flag rides in the sign of the first weight (hist_add)
-    {
-      const double wmin = fmin(w[0], w[3]);
-      if (wmin < kTinyW && wmin != 0.0) w[0] = -w[0];
-    }
-#pragma unroll
-    for (int k = 0; k < 4; k++) t.W[4 * gi + k] = w[k];  // slot-major: see load_tile_w
-  }
-  double v2[2] = {(double)count, 0.0};
-  block_sum<NT, 2>(v2, red, tid);
-  const int n_c = (int)v2[0];
-  __syncthreads();
-  // entropy of the reference histogram
-  double term = 0.0;
-  if (tid < g.nb) {
-    unsigned long long acc = 0;
-    for (int c = 0; c < kHistCopies; c++) acc += hist[tid * kHistCopies + ((c + tid) & (kHistCopies - 1))];
-    const double p = ((double)(long long)acc * hist_inv_scale) / (double)n_c;
-    if (!(p < kSigma)) term = p * log2(p);
-  }
-  double v1[2] = {term, 0.0};
-  block_sum<NT, 2>(v1, red, tid);
-  if (tid == 0) {
-    Nc[cl] = n_c;
-    Href[cl] = (n_c < 300) ? NAN : (0.0 - v1[0]);  // CudaComputeHref.cu:206-209
-  }
-}
-
-// ---------------------------------------------------------------------------
-// Plain-histogram NID of one cell per workgroup: NID::ComputeHref + NID::ComputeH of the reference's
-// second program (NID_standard_property.cpp:342-485) -- same warp and bilinear sample, HARD binning
-// floor(I * bins / 255), no B-spline, no Jacobian.  Counts are integers (u32 LDS atomics), so the
-// histograms are exact; the entropies are summed by one thread in the reference's bin order.
-// out[cell*6 + {0..5}] = H_ref, H_current, H_joint, nid, MI, n_in.  Cells with fewer than 300 in-frame
-// pixels get NaN for H_current / H_joint / nid / MI (the reference returns early there and then reads an
-// uninitialised nid_: not reproduced).
-template <int NT>
-__global__ __launch_bounds__(NT) void k_plain_nid(Geometry g, Pose pose, Tiles t, const uint8_t *__restrict__ im1,
-                                                  int bins, double *__restrict__ out) {
-  __shared__ unsigned h_ref[kMaxPlainBins], h_cur[kMaxPlainBins], h_joint[kMaxPlainBins * kMaxPlainBins];
-  __shared__ unsigned n_in_s;
-  const int cl = blockIdx.x, tid = threadIdx.x;
-  for (int i = tid; i < bins; i += NT) { h_ref[i] = 0u; h_cur[i] = 0u; }
-  for (int i = tid; i < bins * bins; i += NT) h_joint[i] = 0u;
-  if (tid == 0) n_in_s = 0u;
-  __syncthreads();
-  const size_t base = (size_t)cl * g.pstride;
-  for (int s = tid; s < g.pstride; s += NT) {
-    const size_t gi = base + s;
-    if (t.JR[gi] < 0) continue;  // invalid depth / padding: Get3dPointAndIntensity skips the pixel (:226-227)
-    double qx, qy, qz;
-    xform_point(pose, t.X[gi], t.Y[gi], t.Z[gi], qx, qy, qz);
-    const double u = g.fx * qx / qz + g.cx;  // :357-358
-    const double v = g.fy * qy / qz + g.cy;
-    if (!(u >= 0 && u + 3 <= g.cols && v >= 0 && v + 3 <= g.rows)) continue;  // ob++
-    double i0 = (double)t.I0[gi];
-    if (i0 >= 255) i0 = 254.999;  // :370-373
-    const int br = (int)floor(i0 * bins / 255.0);
-    double ic = bilinear_u8(im1, g.cols, u, v);
-    if (ic >= 255) ic = 254.999;  // :432-435
-    if (ic < 0) ic = 0.0;
-    const int bc = (int)floor(ic * bins / 255.0);
-    atomicAdd(&h_ref[br], 1u);
-    atomicAdd(&h_cur[bc], 1u);
-    atomicAdd(&h_joint[br * bins + bc], 1u);
-    atomicAdd(&n_in_s, 1u);
-  }
-  __syncthreads();
-  if (tid == 0) {
-    const unsigned n_in = n_in_s;
-    const double n = (double)n_in;
-    double Href = 0.0, Hc = 0.0, Hj = 0.0;
-    for (int i = 0; i < bins; i++) {
-      const double p = (double)h_ref[i] / n;
-      if (p < kSigma) continue;
-      Href -= p * log2(p);
-    }
-    double nid = NAN, mi = NAN;
-    if (n_in >= 300u) {
-      for (int i = 0; i < bins; i++) {
-        const double p = (double)h_cur[i] / n;
-        if (p < kSigma) continue;
-        Hc -= p * log2(p);
-      }
-      for (int i = 0; i < bins * bins; i++) {
-        const double p = (double)h_joint[i] / n;
-        if (p < kSigma) continue;
-        Hj -= p * log2(p);
-      }
-      nid = (2 * Hj - Href - Hc) / Hj;  // :469-470
-      mi = Href + Hc - Hj;
-      if (Href == 0.0 && Hc == 0.0 && Hj == 0.0) { mi = 0.0; nid = 0.0; }  // :474-477
-    } else {
-      Hc = NAN; Hj = NAN;
-    }
-    double *o = out + (size_t)cl * 6;
-    o[0] = Href; o[1] = Hc; o[2] = Hj; o[3] = nid; o[4] = mi; o[5] = n;
-  }
 }
 
 // ---------------------------------------------------------------------------
@@ -2825,334 +2579,6 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 2))) void
       __hip_atomic_store(q, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __hip_atomic_store(q + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-  }
-}
-
-// ---------------------------------------------------------------------------
-// The RESIDENT evaluator: the latency form of the evaluation kernel, launched ONCE per frame pair, one workgroup per
-// cell, all of them co-resident; each workgroup waits for a request -- a doorbell word in fine-grained device memory
-// that the CPU writes through the PCIe BAR, behind the request's pose record --, evaluates its cell with eval_cell and
-// writes the cell's record straight to pinned host memory (the DIRECT protocol: the host forms and sums the
-// quadratic forms), then waits again.  A Gauss-Newton / LM loop launches one pose and waits for it: the kernel launch
-// itself -- runtime call, packet, dispatch of 256 workgroups: ~6 us from the enqueue to a first result word on the
-// host, tools/ubench/mailbox_latency.hip -- is then most of what is left of an evaluation; a request to a resident
-// workgroup takes ~2 us there and back.
-// EVERY wave leaves: on the exit word, or after `idle_ticks` of s_memrealtime (100 MHz) without a request (a dead
-// host cannot keep the workgroups spinning); the host retires the kernel itself long before that (nid_capi.hip).
-// The mailbox: ONE 64-byte line -- the request's pose7 (q x y z w, t) in seven words and, in the eighth, its number and
-// flags.  The CPU writes the seven words, a store fence, the eighth word, a store fence (write-combining stores are not
-// ordered among themselves; across the fence they are), so a poll that reads a new eighth word -- the sixteen dwords
-// of the line in one request -- has the request's pose in the same registers: no second trip to memory.  The 3x4
-// matrix is formed on the device with the host's operations (pose_from_pose7 in nid_capi.hip: IEEE, no contraction:
-// the same bits).  Eighth word: (number << 8) | flags; kResExitWord: leave.
-// A pose that exists only as a matrix (the legacy operators hand over a 4x4: nid_evaluate_matrix) takes a second line:
-// M[0..6] | word, M[7..11], 0, 0 | the same word; such a request has arrived when both lines carry its word.
-struct ResidentCtl {
-  unsigned long long w[16];
-};
-constexpr unsigned long long kResExitWord = ~0ull;
-// (measured on A, 256 workgroups: one load at a time + 8 x 64 clocks of sleep answers first; deeper pipelines of loads
-// queue behind each other on the line's memory channel: profiles/r03_launch_cost_A.txt)
-#ifndef NID_RES_POLL_DEPTH
-#define NID_RES_POLL_DEPTH 1
-#endif
-#ifndef NID_RES_POLL_SLEEP
-#define NID_RES_POLL_SLEEP 8
-#endif
-constexpr int kResPollDepth = NID_RES_POLL_DEPTH;
-constexpr unsigned kResJac = 1u, kResRecord = 2u, kResCellout = 4u, kResMatrix = 8u, kResLeave = 0xFFFFFFFFu;
-
-// pose_from_pose7 (nid_capi.hip) on the device: to_homogeneous_matrix (se3quat.h:270-278) = Eigen toRotationMatrix
-__device__ __forceinline__ void pose_from_pose7_dev(const double *p, int mode, Pose &out) {
-#pragma unroll
-  for (int i = 0; i < 7; i++) out.q[i] = p[i];
-  const double x = p[0], y = p[1], z = p[2], w = p[3];
-  const double tx = 2 * x, ty = 2 * y, tz = 2 * z;
-  const double twx = tx * w, twy = ty * w, twz = tz * w;
-  const double txx = tx * x, txy = ty * x, txz = tz * x;
-  const double tyy = ty * y, tyz = tz * y, tzz = tz * z;
-  double *M = out.M;
-  M[0] = 1 - (tyy + tzz); M[1] = txy - twz;       M[2] = txz + twy;        M[3] = p[4];
-  M[4] = txy + twz;       M[5] = 1 - (txx + tzz); M[6] = tyz - twx;        M[7] = p[5];
-  M[8] = txz - twy;       M[9] = tyz + twx;       M[10] = 1 - (txx + tyy); M[11] = p[6];
-  out.mode = mode;
-}
-
-__device__ __forceinline__ unsigned long long ld_sys_u64(const unsigned long long *p) {
-  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-}
-__device__ __forceinline__ unsigned ld_sys_u32(const unsigned *p) {
-  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-}
-
-// (One workgroup per CU: a 512-thread workgroup is two waves per SIMD, so its waves may use 256 registers -- the pose
-// arrives at run time, i.e. it is pinned in scalar registers for the whole evaluation instead of being re-read from
-// the kernel arguments where it is needed, and the scalar registers that no longer fit spill into vector lanes.)
-template <int NT, int NB, int LAT>
-__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT == 512 ? 2 : 4))) void k_resident(EvalParams P, const ResidentCtl *ctl, unsigned long long word0, long long idle_ticks,
-                                                                                                         int xform_mode) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  __shared__ unsigned s_req[2 + 32];  // kResLeave or 0 | (unused) | the request as it sits in the mailbox
-  const Geometry &g = P.g;
-  const int tid = threadIdx.x;
-  const int cl = (int)(blockIdx.x >> 3) * 8 + (int)(blockIdx.x & 7);  // k_eval2's map for one pose
-  if (cl >= g.nloc) return;
-  {  // the B-spline table, once (eval_cell's LDS layout)
-    const int nb = NB > 0 ? NB : g.nb;
-    const int nbins = nb * nb + nb;
-    double *rtab = reinterpret_cast<double *>(smem) + 2 * ((nbins + 1) & ~1);
-    for (int i = tid; i < (nb - 3) * kCoefRow; i += NT) rtab[i] = P.ctab[i];
-  }
-  ResCell rc{P.Nc[cl], P.Href[cl], true};
-  unsigned long long last = word0;
-  long long t_idle = __builtin_amdgcn_s_memrealtime();
-  for (;;) {
-    __syncthreads();  // every wave is back from the previous request: the request words may be rewritten
-    if (tid < 64) {   // wave 0 waits for the request
-      // One poll = the mailbox line's 16 dwords in one request (uncached device memory: ~1 us).  One load at a time
-      // would notice a request between one and two load times after it was written; with kResPollDepth loads in flight
-      // (they return in order: each turn waits for the oldest and issues a new one, then sleeps so that 256
-      // workgroups do not saturate the line's memory channel) it is noticed within about one load time.
-      const unsigned *mail = reinterpret_cast<const unsigned *>(ctl) + (tid & 31);
-      unsigned w[kResPollDepth];
-#pragma unroll
-      for (int k = 0; k < kResPollDepth; k++) w[k] = ld_sys_u32(mail);
-      unsigned got = 0u, leave = 0u;
-      unsigned long long word = last;
-      for (bool done = false; !done;) {
-#pragma unroll
-        for (int k = 0; k < kResPollDepth; k++) {
-          const unsigned v = w[k];
-          w[k] = ld_sys_u32(mail);
-          if (!done) {
-            const unsigned long long t = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)v, 15) << 32) |
-                                         (unsigned)__builtin_amdgcn_readlane((int)v, 14);
-            const unsigned long long t1 = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)v, 31) << 32) |
-                                          (unsigned)__builtin_amdgcn_readlane((int)v, 30);
-            if (t == kResExitWord) { leave = 1u; done = true; }
-            else if (t != last && (!(t & kResMatrix) || t1 == t)) { got = v; word = t; done = true; }
-            else __builtin_amdgcn_s_sleep(NID_RES_POLL_SLEEP);
-          }
-        }
-        if (!done && __builtin_amdgcn_s_memrealtime() - t_idle > idle_ticks) { leave = 1u; done = true; }
-      }
-      if (leave) {
-        if (tid == 0) s_req[0] = kResLeave;
-      } else {
-        last = word;
-        if (tid == 0) s_req[0] = 0u;
-        if (tid < 32) s_req[2 + tid] = got;  // the request, as it sits in the mailbox
-      }
-    }
-    __syncthreads();
-    if ((unsigned)__builtin_amdgcn_readfirstlane((int)s_req[0]) == kResLeave) return;  // every wave of the workgroup, here
-    const unsigned flags = (unsigned)__builtin_amdgcn_readfirstlane((int)s_req[2 + 14]) & 0xFFu;
-    SlotArgs SA = P.slot[0];
-    {
-      double p7[7], m5[5];
-#pragma unroll
-      for (int i = 0; i < 7; i++)
-        p7[i] = __hiloint2double(__builtin_amdgcn_readfirstlane((int)s_req[2 + 2 * i + 1]), __builtin_amdgcn_readfirstlane((int)s_req[2 + 2 * i]));
-#pragma unroll
-      for (int i = 0; i < 5; i++)
-        m5[i] = __hiloint2double(__builtin_amdgcn_readfirstlane((int)s_req[2 + 16 + 2 * i + 1]), __builtin_amdgcn_readfirstlane((int)s_req[2 + 16 + 2 * i]));
-      pose_from_pose7_dev(p7, xform_mode, SA.pose);
-      if (flags & kResMatrix) {  // pose_from_matrix16 (nid_capi.hip): the matrix as it is, computeH.cu:152-154 semantics
-#pragma unroll
-        for (int i = 0; i < 7; i++) { SA.pose.q[i] = i == 3 ? 1.0 : 0.0; SA.pose.M[i] = p7[i]; }
-#pragma unroll
-        for (int i = 0; i < 5; i++) SA.pose.M[7 + i] = m5[i];
-        SA.pose.mode = 1;  // NID_XFORM_MATRIX
-      }
-      // (VALU results, uniform: back to scalar registers, where eval_cell expects a pose to live)
-#pragma unroll
-      for (int i = 0; i < 12; i++) SA.pose.M[i] = wave_uniform(SA.pose.M[i]);
-    }
-    SA.host_quad = (flags & kResRecord) ? 1 : 2;
-    SA.cellout_host = (flags & kResCellout) ? 1 : 0;
-    if (flags & kResJac) eval_cell<NT, true, false, NB, false, false, LAT, false, true>(P, SA, cl, 0, smem, rc);
-    else eval_cell<NT, false, false, NB, false, false, LAT, false, true>(P, SA, cl, 0, smem, rc);
-    rc.fresh = false;
-    t_idle = __builtin_amdgcn_s_memrealtime();
-  }
-}
-
-// ---------------------------------------------------------------------------
-// The resident BATCH evaluator (round 5): the throughput form of the evaluation kernel -- 128-thread workgroups, the loop
-// form, per-pose records in device memory (eval_cell's EXT form), the in-launch reduction -- launched once and kept on
-// the device like k_resident, answering requests of K <= kResBatchMax poses: the candidates of a Gauss-Newton / LM step, a
-// short sequence.  What such a request costs as launches is mostly not evaluation (profiles/r04_short_sequences.txt: 20
-// poses = 92 us in a loop, 132-181 us as one shot behind a device-wide synchronisation -- the first launches after one
-// pay 20-50 us): here it is ONE word written through the PCIe BAR.
-// Grid: `replicas` workgroups per cell (k_eval2's block -> cell map with batch = replicas); the workgroups of a cell
-// share the request's poses through a counter (whoever is free takes the next one).
-// A request: the host fills the poses' SlotArgs records -- exactly as a launch of more than kMaxBatch poses carries them
-// (nid_capi.hip fills both with the same function) -- into PINNED HOST memory, a store fence, and writes the mailbox's
-// word = (request number << 16) | (K << 8) | flags through the BAR.  (A store through the BAR is a PCIe transaction of
-// its own, ~0.2 us each: the records themselves written that way -- 580 words for 20 poses -- cost more than the
-// evaluation; the device fetches them instead.)
-// Uncached memory does not take thousands of readers either (2048 workgroups polling one line, or fetching their records
-// from one place, queue up behind each other on its memory channel), so the request fans out through ordinary device
-// memory, agent-scope stores and loads throughout (no placement assumption):
-//   root   (cell 0, replica 0) polls the mailbox word, copies the K records host -> `grec` (all its threads, eight loads
-//          in flight each), drains, and publishes the word in gword;
-//   leader (replica 0 of every other cell) polls gword; root and leaders forward the word to their cell's record;
-//   the other replicas poll that record.
-// A workgroup copies the record of the pose it is about to evaluate from grec into its OWN entry of a staging array
-// (P.slots_ext, one entry per workgroup), invalidates the scalar cache, and from there on the record is what it is for a
-// launched k_eval2 of a large batch: scalar loads through the constant address space, the quaternion fetched where
-// exact_decisions needs it.  Same eval_cell instantiation up to RES (a table that stays in LDS): the same bits as launches.
-// Bounded like k_resident: exit word (forwarded down the same tree), idle limit by s_memrealtime in every polling loop.
-constexpr int kResBatchMax = 64;
-constexpr int kResBatchRecDwords = (int)(sizeof(SlotArgs) / 4);
-struct ResBatchCtl {
-  unsigned long long w[8];  // one line; the word is w[7]
-};
-__host__ __device__ constexpr unsigned long long resbatch_word(unsigned long long number, int k, unsigned flags) {
-  return (number << 16) | ((unsigned long long)(unsigned)k << 8) | flags;
-}
-// device-side fan-out state, in u64 words: gword in its own 64 bytes | per cell {word, pose counter} | the request's records (grec)
-__host__ __device__ constexpr size_t resbatch_cells_off() { return 8; }
-__host__ __device__ inline size_t resbatch_grec_off(long nloc8) { return 8 + (size_t)nloc8 * 2; }
-__host__ __device__ inline size_t resbatch_fan_words(long nloc8) { return resbatch_grec_off(nloc8) + ((size_t)kResBatchRecDwords * kResBatchMax + 1) / 2; }
-
-template <int NB>
-__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4))) void k_resident_batch(EvalParams P, const ResBatchCtl *ctl, const unsigned *hrec /*pinned host: the records*/,
-                                                                                                unsigned long long *fan, unsigned long long word0, long long idle_ticks, int replicas) {
-  constexpr int NT = 128;
-  static_assert(sizeof(SlotArgs) / 4 <= 64 && sizeof(SlotArgs) % 8 == 0, "a record is copied by one wave, a dword per lane");
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  __shared__ unsigned s_req[4];  // kResLeave or 0 | K | flags | the next pose
-  const Geometry &g = P.g;
-  const int tid = threadIdx.x;
-  const int q = (int)(blockIdx.x >> 3);
-  const int rep = q % replicas;
-  const int cl = (q / replicas) * 8 + (int)(blockIdx.x & 7);  // k_eval2's map with batch = replicas
-  if (cl >= g.nloc) return;
-  {  // the B-spline table, once (eval_cell's LDS layout)
-    const int nb = NB > 0 ? NB : g.nb;
-    const int nbins = nb * nb + nb;
-    double *rtab = reinterpret_cast<double *>(smem) + 2 * ((nbins + 1) & ~1);
-    for (int i = tid; i < (nb - 3) * kCoefRow; i += NT) rtab[i] = P.ctab[i];
-  }
-  ResCell rc{P.Nc[cl], P.Href[cl], true};
-  unsigned long long last = word0;
-  long long t_idle = __builtin_amdgcn_s_memrealtime();
-  const long nloc8 = ((long)g.nloc + 7) / 8 * 8;
-  unsigned long long *mycell = fan + resbatch_cells_off() + (size_t)cl * 2;
-  unsigned *grec = reinterpret_cast<unsigned *>(fan + resbatch_grec_off(nloc8));
-  const bool root = rep == 0 && cl == 0;
-  // the word this workgroup polls, two dwords by two lanes: the mailbox's (root), gword (the other cells' replica 0), the
-  // cell's record (everyone else)
-  const unsigned *src = (root ? reinterpret_cast<const unsigned *>(ctl->w + 7) : reinterpret_cast<const unsigned *>(rep == 0 ? fan : mycell)) + (tid & 1);
-  unsigned *mine = reinterpret_cast<unsigned *>(const_cast<SlotArgs *>(P.slots_ext) + blockIdx.x);  // this workgroup's staging entry
-  for (;;) {
-    __syncthreads();  // every wave is back from the previous request
-    if (tid < 64) {
-      unsigned leave = 0u;
-      for (;;) {
-        const unsigned v = root ? ld_sys_u32(src) : __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const unsigned long long t = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)v, 1) << 32) | (unsigned)__builtin_amdgcn_readlane((int)v, 0);
-        if (t == kResExitWord) { leave = 1u; break; }
-        if (t != last) { last = t; break; }
-        if (__builtin_amdgcn_s_memrealtime() - t_idle > idle_ticks) { leave = 1u; break; }
-        if (root) __builtin_amdgcn_s_sleep(NID_RES_POLL_SLEEP); else __builtin_amdgcn_s_sleep(2);
-      }
-      if (tid == 0) {
-        s_req[0] = leave ? kResLeave : 0u;
-        s_req[1] = (unsigned)(last >> 8) & 0xFFu;
-        s_req[2] = (unsigned)last & 0xFFu;
-      }
-    }
-    __syncthreads();
-    const bool leaving = (unsigned)__builtin_amdgcn_readfirstlane((int)s_req[0]) == kResLeave;
-    const int K = min((int)__builtin_amdgcn_readfirstlane((int)s_req[1]), kResBatchMax);
-    const unsigned flags = (unsigned)__builtin_amdgcn_readfirstlane((int)s_req[2]);
-    if (root && !leaving) {
-      // the K records: pinned host memory -> grec, eight loads in flight per thread (a load over PCIe takes a microsecond or two)
-      const int n = K * kResBatchRecDwords;
-      for (int i0 = tid; i0 < n; i0 += 8 * NT) {
-        unsigned v[8];
-#pragma unroll
-        for (int j = 0; j < 8; j++) v[j] = (i0 + j * NT < n) ? ld_sys_u32(hrec + i0 + j * NT) : 0u;
-#pragma unroll
-        for (int j = 0; j < 8; j++)
-          if (i0 + j * NT < n) __hip_atomic_store(grec + i0 + j * NT, v[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-    }
-    if (rep == 0 && tid == 0) {
-      // publish downwards: the word -- or the exit word -- in gword (root) and in the cell's record
-      const unsigned long long w = leaving ? kResExitWord : last;  // (tid 0 is in wave 0: `last` is the new word)
-      if (root) __hip_atomic_store(fan, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(mycell, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    if (leaving) return;  // every wave of the workgroup, here
-    for (;;) {
-      // The cell's next pose: whoever is free takes it.  The counter word is (request number << 8) | next pose and is
-      // never reset: the first workgroup of a cell to arrive at a request moves it on by compare-and-swap, and a workgroup
-      // that is late (still on its way out of the previous request when the others have begun the next) finds a newer
-      // number and takes nothing -- a counter that the cell's leader reset could hand such a straggler pose 0 again.
-      if (tid == 0) {
-        const unsigned long long myreq = last >> 16;
-        unsigned long long c = __hip_atomic_load(mycell + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        unsigned take = (unsigned)K;
-        for (;;) {
-          unsigned long long want;
-          unsigned cand;
-          if ((c >> 8) == myreq) {
-            cand = (unsigned)(c & 255ull);
-            if (cand >= (unsigned)K) break;
-            want = c + 1;
-          } else if ((c >> 8) < myreq) {
-            cand = 0u;
-            want = (myreq << 8) | 1ull;
-          } else {
-            break;
-          }
-          if (__hip_atomic_compare_exchange_strong(mycell + 1, &c, want, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { take = cand; break; }
-        }
-        s_req[3] = take;
-      }
-      __syncthreads();
-      const int p = (int)__builtin_amdgcn_readfirstlane((int)s_req[3]);
-      if (p >= K) break;
-      // pose p's record: grec -> this workgroup's staging entry
-      if (tid < kResBatchRecDwords) {
-        __hip_atomic_store(mine + tid, __hip_atomic_load(grec + p * kResBatchRecDwords + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
-                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      }
-      __syncthreads();
-      __builtin_amdgcn_s_dcache_inv();
-      // (an opaque copy of the entry's index per pose: the record is read through the CONSTANT address space, whose
-      // loads the optimiser may otherwise take for loop invariant)
-      int pidx = (int)blockIdx.x;
-      asm volatile("" : "+s"(pidx));
-      SlotArgs sa_ext;
-      {
-        typedef const unsigned __attribute__((address_space(4))) *ConstDwords;
-        ConstDwords csrc = (ConstDwords)(reinterpret_cast<uintptr_t>(P.slots_ext + pidx));
-        unsigned *dst = reinterpret_cast<unsigned *>(&sa_ext);
-#pragma unroll
-        for (unsigned i = kPoseQuatDwords; i < sizeof(SlotArgs) / 4; i++) dst[i] = csrc[i];
-      }
-      // The loop-form body WITHOUT the inline repair (kLinFlagW: carrying that code costs the pixel loops their registers);
-      // a cell that wants the repair pass publishes nothing and says so -- workgroup-uniform -- and is done again from
-      // the start by the instantiation that repairs inline: what k_repair does behind a launch, here in place (cold).
-      bool again;
-      if (flags & kResJac) again = eval_cell<NT, true, false, NB, false, true, 0, false, true, false>(P, sa_ext, cl, pidx, smem, rc);
-      else again = eval_cell<NT, false, false, NB, false, true, 0, false, true, false>(P, sa_ext, cl, pidx, smem, rc);
-      if (__builtin_expect(again, 0)) {
-        __syncthreads();
-        if (flags & kResJac) (void)eval_cell<NT, true, false, NB, false, true, 0, false, true, true>(P, sa_ext, cl, pidx, smem, rc);
-        else (void)eval_cell<NT, false, false, NB, false, true, 0, false, true, true>(P, sa_ext, cl, pidx, smem, rc);
-      }
-      rc.fresh = false;
-      __syncthreads();  // (the staging entry and s_req[3] are rewritten for the next pose)
-    }
-    t_idle = __builtin_amdgcn_s_memrealtime();
   }
 }
 

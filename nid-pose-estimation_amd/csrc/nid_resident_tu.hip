@@ -2,6 +2,7 @@
 // four workgroups per CU, the loop form -- contexts of more cells than the device has CUs; k_resident_batch<NB>: the
 // throughput form, several 128-thread workgroups per cell, requests of up to 64 poses): see nid_eval_launch.h
 #include "nid_eval_launch.h"
+#include "nid_resident_kernels.hip.h"
 
 namespace nid {
 
