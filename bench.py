@@ -56,6 +56,8 @@ def parse():
     ap.add_argument("--bins", type=int, default=8)
     ap.add_argument("--block-threads", type=int, default=0)
     ap.add_argument("--batch", type=int, default=256, help="candidate poses per kernel launch (<= NID_MAX_BATCH = 256)")
+    ap.add_argument("--preheat-sequences", type=int, default=500,
+                    help="untimed setup in front of a SHORT timed region (K <= 64): this many sequences of its own length (0: the time-based preheat)")
     ap.add_argument("--preheat-seconds", type=float, default=0.25,
                     help="setup, before the W warmup steps: the timed region's own launch geometry for this long, so that the "
                          "clocks are up and the kernel instantiation it uses is in the instruction caches (0 = off)")
@@ -470,14 +472,15 @@ def main():
     # cold instantiation costs its first launches ~10 us each in instruction-cache misses, idle clocks more.  Same
     # step count on every rank (the launches are collective for N > 1).
     torch.cuda.synchronize(dev)  # (the process's first device-wide synchronisation sets up torch's own streams: not in front of the timed shot)
-    if args.preheat_seconds > 0 and K <= 64:
-        # A SHORT timed region (one short sequence: the driver's --steps 20) is preheated by COUNT, 50 sequences of its own
-        # length (~5 ms; the same count on every rank): enough for the kernel instantiation's code and the launch path to
-        # be warm, and short enough to leave the device at its boost clocks -- measured (tools/first_shot_probe.py,
-        # profiles/r05_short_sequences.txt): the shot behind 20-100 sequences takes 91-92 us, behind 0.25 s of them
-        # 103-131 us (and behind 1-50 ms of idling 125-141 us).
+    if args.preheat_seconds > 0 and K <= 64 and args.preheat_sequences > 0:
+        # A SHORT timed region (one short sequence: the driver's --steps 20) is preheated by COUNT: --preheat-sequences
+        # sequences of its own length (500: ~45 ms; the same count on every rank), not by 0.25 s of them with a flag
+        # exchanged per iteration.  What the ONE timed shot costs depends on what the device did just before it
+        # (tools/first_shot_probe.py) and varies by +-15 % from process to process; four fresh processes per setting
+        # (profiles/r05_short_sequences.txt): 50 sequences 138-195 k it/s, 500: 164-185 k, 3000: 163-180 k, the 0.25 s
+        # form 147-168 k.
         n_pre = min(K, Bm * G if multi else B)
-        for _ in range(50):
+        for _ in range(args.preheat_sequences):
             run(n_pre, collect=False)
     elif args.preheat_seconds > 0:
         n_pre = min(K, Bm * G if multi else B)
@@ -489,6 +492,13 @@ def main():
                 dist.all_reduce(go_on, op=dist.ReduceOp.MIN)
             if go_on.item() == 0.0:
                 break
+    if K <= 64 and args.preheat_seconds > 0:
+        # ... and ONE rehearsal of exactly what follows -- the W warmup steps, the synchronisation, a collecting run(K) --:
+        # the first synchronisation behind a burst of launches leaves the runtime work that the next launches pay for
+        # (the timed shot measured 10-40 us above its own repetitions, `short_sequence.repeat_us_per_shot`, without it)
+        run(W, collect=False)
+        barrier()
+        run(K)
     run(W, collect=False)
     seq_cache.setdefault(K, np.ascontiguousarray(pose_arr[np.arange(K) % len(poses)], dtype=np.float64))
     barrier()
@@ -837,7 +847,9 @@ def main():
             "data": "synthetic",
             "value_is": ("pipelined evaluation throughput over independent candidate poses" if K > 64 or multi else
                          "K independent candidate poses as ONE short sequence, from the call to the last 6x6 system in host memory "
-                         "(the region ends when run(K) returns: every block has been waited for; no device synchronisation behind it)")
+                         "(the region ends when run(K) returns: every block has been waited for; no device synchronisation behind it; in front of "
+                         "it, untimed: --preheat-sequences sequences of the same length, one rehearsal of warmup + synchronisation + run(K), "
+                         "the W warmup steps, the synchronisation)")
                         + "; dependent-chain rates: roofline.sequential, pose_error_vs_ref.lm_outer_iterations_per_s"
                         + ("; sustained throughput of the pipeline: roofline.sustained" if not multi else ""),
             "short_sequence": short_info,
