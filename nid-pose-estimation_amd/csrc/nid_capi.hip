@@ -747,469 +747,8 @@ int timing_events(nid_ctx *ctx, Slot &S) {
   return NID_OK;
 }
 
-// ---- the RESIDENT evaluator (k_resident) ----------------------------------------------------------------------------
-// Host side: the mailbox lives in fine-grained DEVICE memory that the CPU writes through the PCIe BAR (pose record and
-// flags, a store fence, the doorbell word, a store fence); results come back by the DIRECT protocol into res.rec_host
-// (and slot 0's cellout_host for the per-cell calls).  One request in flight at a time.  The kernel is started on its
-// own stream at the first request, retired (exit word + stream synchronisation: microseconds, every workgroup polls the
-// word) by every call that changes what it has cached or frees device memory, and by the next request after
-// kResidentHostIdle without one; a kernel that is gone nevertheless (its own idle limit) is noticed by the unanswered
-// request, which is then re-issued as an ordinary DIRECT launch (resident_fallback).
-// One resident kernel per DEVICE in this process: its workgroups hold most of every CU, a second context's kernel would
-// not be scheduled beside it (its requests would time out into fallbacks while the first one sits there).  The registry
-// names the context that holds a device; another context's nid_set_resident / request is refused (it keeps launching).
-constexpr int kResMaxDevices = 64;
-static std::atomic<nid_ctx *> g_res_owner[kResMaxDevices];  // (contexts of one device may live on different threads)
-static bool res_claim(nid_ctx *ctx) {
-  const int d = ctx->cfg.device;
-  if (d < 0 || d >= kResMaxDevices) return true;
-  nid_ctx *none = nullptr;
-  return g_res_owner[d].compare_exchange_strong(none, ctx) || none == ctx;
-}
-static void res_release(nid_ctx *ctx) {
-  const int d = ctx->cfg.device;
-  nid_ctx *me = ctx;
-  if (d >= 0 && d < kResMaxDevices) g_res_owner[d].compare_exchange_strong(me, nullptr);
-}
-static bool res_held_by_other(const nid_ctx *ctx) {
-  const int d = ctx->cfg.device;
-  if (d < 0 || d >= kResMaxDevices) return false;
-  const nid_ctx *o = g_res_owner[d].load();
-  return o && o != ctx;
-}
-
-int resident_probe(nid_ctx *ctx) {
-  nid_ctx::Resident &R = ctx->res;
-  if (R.probed) return R.probed > 0 ? NID_OK : NID_ERR_UNSUPPORTED;
-  R.probed = -1;
-  // Can the CPU store to device memory?  Asked, not tried: the device's large-BAR attribute (a store to memory the CPU
-  // cannot reach faults, and a fault probe would have to swap the process's SIGSEGV / SIGBUS handlers under the feet
-  // of every other thread).
-  int large_bar = 0;
-  if (hipDeviceGetAttribute(&large_bar, hipDeviceAttributeIsLargeBar, ctx->cfg.device) != hipSuccess || !large_bar) {
-    (void)hipGetLastError();
-    R.why = "the device's memory is not CPU-addressable here (no large BAR): resident requests need a mailbox the host can write";
-    return NID_ERR_UNSUPPORTED;
-  }
-  void *p = nullptr;
-  hipError_t e = hipExtMallocWithFlags(&p, 4096, hipDeviceMallocFinegrained);
-  if (e != hipSuccess) {
-    (void)hipGetLastError();
-    R.why = std::string("hipExtMallocWithFlags(hipDeviceMallocFinegrained): ") + hipGetErrorString(e);
-    return NID_ERR_UNSUPPORTED;
-  }
-  auto fail = [&](const char *what, int rc) {  // every failure path gives back what was created
-    (void)hipGetLastError();
-    (void)hipFree(p);
-    if (R.stream) { (void)hipStreamDestroy(R.stream); R.stream = nullptr; }
-    if (R.rec_host) { (void)hipHostFree(R.rec_host); R.rec_host = nullptr; }
-    R.ctl = nullptr; R.rec_devptr = nullptr;
-    R.why = what;
-    return rc;
-  };
-  e = hipMemset(p, 0, 4096);
-  if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
-  if (e != hipSuccess) return fail("clearing the mailbox failed", NID_ERR_UNSUPPORTED);
-  R.ctl = static_cast<ResidentCtl *>(p);
-  if (hipStreamCreateWithFlags(&R.stream, hipStreamNonBlocking) != hipSuccess) return fail("no stream for the resident kernel", NID_ERR_HIP);
-  const size_t n = (size_t)2 * ctx->g.nloc * kDirectRec;
-  if (hipHostMalloc(reinterpret_cast<void **>(&R.rec_host), n * sizeof(double), hipHostMallocMapped) != hipSuccess) return fail("no pinned memory for the records", NID_ERR_NOMEM);
-  fill_sentinel(R.rec_host, n);
-  if (hipHostGetDevicePointer(reinterpret_cast<void **>(&R.rec_devptr), R.rec_host, 0) != hipSuccess) return fail("hipHostGetDevicePointer failed", NID_ERR_HIP);
-  R.probed = 1;
-  return NID_OK;
-}
-
-inline void store_fence() { __builtin_ia32_sfence(); }
-
-void resident_retire(nid_ctx *ctx) {
-  nid_ctx::Resident &R = ctx->res;
-  if (R.brunning) {  // the batch form: the exit word in its control line, every replica 0 forwards it
-    (void)hipSetDevice(ctx->cfg.device);
-    volatile unsigned long long *w = R.bctl->w;
-    w[7] = kResExitWord;
-    store_fence();
-    (void)hipStreamSynchronize(R.stream);
-    w[7] = resbatch_word(R.bseq, 0, 0);
-    store_fence();
-    R.brunning = false;
-    res_release(ctx);
-  }
-  if (!R.running) return;
-  (void)hipSetDevice(ctx->cfg.device);
-  volatile unsigned long long *w = R.ctl->w;
-  w[7] = kResExitWord;
-  store_fence();
-  (void)hipStreamSynchronize(R.stream);  // every workgroup polls the word: microseconds
-  w[7] = R.seq << 8;                     // (a word no request carries: the next kernel starts from it)
-  store_fence();
-  R.running = false;
-  res_release(ctx);
-}
-
-int resident_launch(nid_ctx *ctx, const EvalParams &P, int nt, size_t lds, unsigned grid) {
-  nid_ctx::Resident &R = ctx->res;
-  // every workgroup must be ON the device for a request to be answered.  A 512-thread workgroup of this kernel is two
-  // waves per SIMD with up to 256 registers each and > 100 KB of LDS: exactly one fits a CU, so the grid must not
-  // exceed the CU count.  (Not hipOccupancyMaxActiveBlocksPerMultiprocessor: the ROCm 7.0 runtime a torch process
-  // carries answers 0 for any kernel with more than 64 KB of dynamic LDS, which the device runs all the same.)
-  // The 256-thread form (k_resident<256, NB, 0>: the loop form, one wave per SIMD and workgroup, at most 128 registers,
-  // ~15-25 KB of LDS) fits FOUR workgroups per CU: contexts of up to 4 x CUs cells (BASELINE configs[1]: 1024 cells on 256
-  // CUs) -- as long as the device is otherwise empty; a workgroup that is not on the device shows as a request that
-  // times out (resident_fallback backs off).
-  int cus = 0;
-  NID_HIP(ctx, hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->cfg.device));
-  const long per_cu = nt == 512 ? 1 : std::min<long>(4, (long)((160 * 1024) / std::max<size_t>(lds, 1)));
-  if ((long)cus * per_cu < (long)grid) {
-    ctx->last_error = "resident evaluator: " + std::to_string(grid) + " workgroups of " + std::to_string(nt) + " threads and " +
-                      std::to_string(lds) + " B of LDS on " + std::to_string(cus) + " CUs";
-    return NID_ERR_UNSUPPORTED;
-  }
-  long long idle_ticks = kResidentIdleTicks;
-  if (const char *e = getenv("NID_RESIDENT_IDLE_US")) idle_ticks = std::max(1L, atol(e)) * 100;  // tests: a kernel that leaves early
-  // the mailbox word the kernel starts from (whatever is there now is not a request)
-  volatile unsigned long long *w = R.ctl->w;
-  w[7] = R.seq << 8;
-  store_fence();
-  launch_resident(P, nt, lds, grid, R.stream, (const ResidentCtl *)R.ctl, R.seq << 8, idle_ticks, ctx->xform);
-  NID_HIP(ctx, hipGetLastError());
-  return NID_OK;
-}
-
-int resident_start(nid_ctx *ctx, int nt) {
-  nid_ctx::Resident &R = ctx->res;
-  int rc = resident_probe(ctx);
-  if (rc) { ctx->last_error = "resident evaluator: mailbox probe failed"; return rc; }
-  EvalParams P{};
-  fill_common_params(ctx, 1.0, &P);  // (the Huber weights of a DIRECT launch are the host's business)
-  P.batch = 1;
-  set_hist_params(P);
-  SlotArgs &A = P.slot[0];
-  Slot &S0 = ctx->slots[0];
-  A.cellout = S0.cellout_host_devptr;
-  A.quad = R.rec_devptr;
-  A.gpart = nullptr; A.ticket = nullptr; A.out_reduced = nullptr; A.host_seq = nullptr;
-  A.launch_seq = 0; A.cellout_host = 0; A.host_quad = 1;
-  // eval_cell's LDS + the cell's tile entries (k_eval2's LAT branch, RES): rounds x threads x (7 doubles + 1 int)
-  if (nt != 512 && nt != 256) { ctx->last_error = "resident evaluator: shape " + std::to_string(nt); return NID_ERR_UNSUPPORTED; }
-  const size_t lds = eval_lds_bytes(P.g, nt, true) + 16 + (size_t)lat_rounds(nt) * nt * (7 * 8 + 4);  // (256 threads: the loop form, no tile entries in LDS)
-  if (lds > 160 * 1024) { ctx->last_error = "resident evaluator: LDS request " + std::to_string(lds); return NID_ERR_UNSUPPORTED; }
-  const unsigned grid = (unsigned)(((P.g.nloc + 7) / 8) * 8);
-  const int nb = P.g.nb;
-  if (!res_claim(ctx)) { ctx->last_error = "resident evaluator: another context's resident kernel holds this device"; return NID_ERR_STATE; }
-  rc = resident_launch(ctx, P, nt, lds, grid);
-  if (rc) { res_release(ctx); return rc; }
-  R.running = true;
-  R.nt = nt;
-  R.starts++;
-  R.last_post = std::chrono::steady_clock::now();
-  return NID_OK;
-}
-
-// may THIS single-pose launch go to the resident kernel?  (FAST math at the 512-thread latency shape -- two waves per
-// SIMD: the resident workgroup may use 256 registers per lane; at 1024 threads it would spill --, its rounds covering a
-// cell, and the shape cost + Jacobian launches of this context use anyway: the Jacobian's last bits depend on it)
-bool resident_usable(const nid_ctx *ctx) {
-  const nid_ctx::Resident &R = ctx->res;
-  if (!R.enabled || R.probed < 0 || R.pending_slot >= 0 || !direct_ok(ctx)) return false;
-  if (R.brunning) return false;  // (the batch form is on the device: single poses go to it too, resident_batch_usable)
-  // another context's resident kernel holds this device: launch (see g_res_owner)
-  if (res_held_by_other(ctx)) return false;
-  if (ctx->math_mode != NID_MATH_FAST || ctx->loop_form) return false;
-  const int nt = ctx->jac_threads;
-  if ((nt != 512 && nt != 256) || nt == R.unfit_nt) return false;
-  if (ctx->cost_threads != 0 && ctx->cost_threads != nt) return false;  // (cost-only results are the same bits in every shape)
-  return nt == 256 ? ctx->g.pstride <= 32 * nt : ctx->g.pstride <= lat_rounds(nt) * nt;  // (256: the loop form's lane masks cover 32 rounds)
-}
-
-// hand one request to the resident kernel (starting it if need be); NID_ERR_UNSUPPORTED: use an ordinary launch
-int resident_post(nid_ctx *ctx, int slot, const Pose &pose, bool jac, bool want_cellout) {
-  nid_ctx::Resident &R = ctx->res;
-  // the mailbox carries a pose7 and the kernel forms the matrix from it -- if the pose's matrix IS that matrix;
-  // a pose that exists only as a matrix (nid_evaluate_matrix) goes as the matrix, in two lines
-  bool as_matrix = false;
-  {
-    Pose chk;
-    pose_from_pose7(pose.q, pose.mode, &chk);
-    if (std::memcmp(chk.M, pose.M, sizeof(chk.M)) != 0) {
-      if (pose.mode != NID_XFORM_MATRIX) return NID_ERR_STATE;
-      as_matrix = true;
-    }
-  }
-  const auto now = std::chrono::steady_clock::now();
-  if (R.running && (R.nt != ctx->jac_threads || now - R.last_post > kResidentHostIdle)) resident_retire(ctx);
-  if (!R.running) {
-    int rc = resident_start(ctx, ctx->jac_threads);
-    if (rc) {
-      if (getenv("NID_RESIDENT_DEBUG")) fprintf(stderr, "[nid resident] start failed: %d %s\n", rc, ctx->last_error.c_str());
-      if (rc == NID_ERR_UNSUPPORTED) { R.unfit_nt = ctx->jac_threads; R.why = ctx->last_error; }  // (this geometry never fits this shape: later nid_set_resident(1) calls say so)
-      return rc;
-    }
-  }
-  R.pose = pose; R.jac = jac; R.want_cellout = want_cellout;
-  // the mailbox line(s): the payload, a store fence, (number << 8 | flags), a store fence (ResidentCtl)
-  volatile unsigned long long *dst = R.ctl->w;
-  unsigned long long words[12];
-  const unsigned flags = (jac ? kResJac : 0u) | (want_cellout ? kResCellout : kResRecord) | (as_matrix ? kResMatrix : 0u);
-  if (as_matrix) {
-    std::memcpy(words, pose.M, sizeof(words));
-    for (int i = 0; i < 7; i++) dst[i] = words[i];
-    for (int i = 0; i < 5; i++) dst[8 + i] = words[7 + i];
-  } else {
-    std::memcpy(words, pose.q, 7 * sizeof(words[0]));
-    for (int i = 0; i < 7; i++) dst[i] = words[i];
-  }
-  store_fence();
-  const unsigned long long word = (++R.seq << 8) | flags;
-  if (as_matrix) dst[15] = word;
-  dst[7] = word;
-  store_fence();  // out of the write-combining buffers now
-  R.last_post = std::chrono::steady_clock::now();
-  R.pending_slot = slot;
-  return NID_OK;
-}
-
-// An ordinary evaluation launch is about to be enqueued.  The resident workgroups hold two waves per SIMD with ~200
-// registers each on every CU they sit on: a launch whose workgroups do not fit beside them would wait until the
-// resident kernel leaves by itself.  So it leaves now -- after the request it may be working on has been collected
-// (its slot keeps the result for nid_wait).
-int wait_host_seq(nid_ctx *ctx, Slot &S);
-int wait_resbatch(nid_ctx *ctx, Slot &S);
-
-int resident_quiesce(nid_ctx *ctx) {
-  nid_ctx::Resident &R = ctx->res;
-  if (R.brunning) {
-    // the batch kernel holds the device: the request it may be working on is collected first (its slots keep their
-    // results for nid_wait), then it leaves
-    if (R.bleft > 0)
-      for (int k = 0; k < R.bn; k++) {
-        Slot &S = ctx->slots[R.bfirst + k];
-        if (!S.resbatch || S.collected) continue;
-        int rc = wait_resbatch(ctx, S);
-        if (rc) return rc;
-        if (S.resbatch) { S.resbatch = false; S.collected = true; }  // (a fallback has made them ordinary launches: nid_wait waits for those)
-      }
-    R.bleft = 0;
-    resident_retire(ctx);
-  }
-  if (!R.running) return NID_OK;
-  if (R.pending_slot >= 0) {
-    Slot &S = ctx->slots[R.pending_slot];
-    int rc = wait_direct(ctx, S);  // (the per-cell calls are blocking: never pending here)
-    if (rc) return rc;
-    S.direct = false;
-    S.collected = true;
-  }
-  resident_retire(ctx);
-  return NID_OK;
-}
-
-// the resident kernel did not answer: take it down and put the request through an ordinary DIRECT launch (into the
-// slot's own record buffer; the per-cell outputs have one buffer either way)
-int resident_fallback(nid_ctx *ctx, Slot &S) {
-  nid_ctx::Resident &R = ctx->res;
-  resident_retire(ctx);  // (if it was still there: no late writes after this)
-  R.fallbacks++;
-  // A request that times out costs 2 ms of spinning plus a launch.  One such event after an idle spell is the kernel's
-  // own idle limit at work; a run of them -- the workgroups are not co-resident: a shared GPU, another process's kernels
-  // -- means the mode does not work here: it is switched off, with the reason on record (nid_last_error,
-  // nid_resident_stats), instead of making every evaluation 100x slower than a launch.
-  R.fallback_run++;
-  if (R.fallback_run >= 3 || (R.fallbacks > 8 && R.fallbacks > R.served)) {
-    R.enabled = false;
-    R.why = "resident evaluator switched off: " + std::to_string(R.fallbacks) + " requests timed out (" + std::to_string(R.served) +
-            " served) -- its workgroups are not staying on the device (a shared GPU?); requests are launched from now on";
-    ctx->last_error = R.why;
-  }
-  fill_sentinel(R.rec_host, (size_t)2 * ctx->g.nloc * kDirectRec);
-  if (R.want_cellout) fill_sentinel(ctx->slots[0].cellout_host, (size_t)ctx->g.nloc * kCellOut);
-  int rc = ensure_quad_host(ctx, S);
-  if (rc) return rc;
-  EvalParams P{};
-  fill_common_params(ctx, 1.0, &P);
-  SlotArgs &A = P.slot[0];
-  fill_slot_args(R.pose, S, nullptr, nullptr, &A);
-  A.quad = S.quad_host_devptr;
-  A.host_quad = R.want_cellout ? 2 : 1;
-  S.quad_dirty = !R.want_cellout;
-  if (R.want_cellout) { A.cellout = ctx->slots[0].cellout_host_devptr; A.cellout_host = 1; }
-  NID_HIP(ctx, hipSetDevice(ctx->cfg.device));
-  S.resident = false;  // from here on the wait is an ordinary DIRECT wait
-  R.pending_slot = -1;
-  return launch_eval(ctx, P, R.jac, ctx->stream);
-}
-
-// ---- the resident BATCH evaluator (k_resident_batch): host side -------------------------------------------------------
-// A request is K <= kResBatchMax poses whose results the host collects slot by slot (nid_wait): the records a launch of
-// more than kMaxBatch poses would copy into a device array are written, through the BAR, behind the mailbox's control
-// line; every pose goes through the in-launch reduction into its slot's pinned block and sequence word, so nid_wait
-// waits for it like for a launched pose.  One request in flight at a time; the kernel is started by the first request
-// (and again when the Huber delta changes: it is a kernel argument), retired like k_resident.  Which requests take this
-// way: resident_batch_usable.  A request the kernel does not answer within kResidentPatience (it had left: its own idle
-// limit) is re-issued as ordinary launches (resident_batch_fallback).
-bool resident_batch_usable(const nid_ctx *ctx, int n, bool jac) {
-  const nid_ctx::Resident &R = ctx->res;
-  if (!R.enabled || !R.benabled || R.probed < 0 || R.bunfit || R.running || R.pending_slot >= 0 || R.bleft > 0) return false;
-  if (n < 1 || n > kResBatchMax || (n < 2 && !R.brunning)) return false;  // (a lone pose does not start it: DIRECT launches are faster)
-  if (ctx->timing || ctx->dbg_enabled || ctx->dbg_stamps || ctx->external_stream) return false;
-  if (res_held_by_other(ctx)) return false;
-  if (ctx->math_mode != NID_MATH_FAST) return false;
-  // cost + Jacobian results carry the workgroup shape in their last bits: the batch kernel is the 128-thread loop form
-  if (jac && ctx->jac_threads != 0 && ctx->jac_threads != 128) return false;
-  return ctx->g.pstride <= 32 * 128;  // (the loop form's lane masks cover 32 rounds)
-}
-
-int resident_batch_start(nid_ctx *ctx, double delta) {
-  nid_ctx::Resident &R = ctx->res;
-  int rc = resident_probe(ctx);
-  if (rc) { ctx->last_error = "resident batch evaluator: mailbox probe failed"; return rc; }
-  EvalParams P{};
-  fill_common_params(ctx, delta, &P);
-  set_hist_params(P);
-  const size_t lds = eval_lds_bytes(P.g, 128, true);
-  int cus = 0;
-  NID_HIP(ctx, hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->cfg.device));
-  // every workgroup must be ON the device: two waves of at most 128 registers each, i.e. eight workgroups per CU, and
-  // their LDS
-  const long per_cu = std::min<long>(8, (long)((160 * 1024) / std::max<size_t>(lds, 1)));
-  const long nloc8 = ((long)P.g.nloc + 7) / 8 * 8;
-  const int replicas = (int)std::min<long>(kResBatchMax, (long)cus * per_cu / nloc8);
-  if (replicas < 1) { R.bunfit = true; ctx->last_error = "resident batch evaluator: more cells than co-resident workgroups"; return NID_ERR_UNSUPPORTED; }
-  const unsigned grid = (unsigned)(nloc8 * replicas);
-  if (!R.bctl) {
-    void *p = nullptr;
-    if (hipExtMallocWithFlags(&p, sizeof(ResBatchCtl), hipDeviceMallocFinegrained) != hipSuccess) { (void)hipGetLastError(); R.bunfit = true; return NID_ERR_UNSUPPORTED; }
-    R.bctl = static_cast<ResBatchCtl *>(p);
-    NID_HIP(ctx, hipMemset(p, 0, sizeof(ResBatchCtl)));
-    NID_HIP(ctx, hipStreamSynchronize(nullptr));
-    int rc2 = dev_alloc(ctx, &R.bfwd, resbatch_fan_words(nloc8));
-    if (rc2) return rc2;
-    if (hipHostMalloc(reinterpret_cast<void **>(&R.brec_host), (size_t)kResBatchMax * sizeof(SlotArgs), hipHostMallocMapped) != hipSuccess) { (void)hipGetLastError(); return NID_ERR_NOMEM; }
-    NID_HIP(ctx, hipHostGetDevicePointer(reinterpret_cast<void **>(&R.brec_devptr), R.brec_host, 0));
-  }
-  if (R.bstage_n < grid) {
-    if (R.bstage) (void)hipFree(R.bstage);
-    R.bstage = nullptr; R.bstage_n = 0;
-    if (hipMalloc(reinterpret_cast<void **>(&R.bstage), (size_t)grid * sizeof(SlotArgs)) != hipSuccess) { (void)hipGetLastError(); return NID_ERR_NOMEM; }
-    R.bstage_n = grid;
-  }
-  P.slots_ext = R.bstage;
-  P.batch = replicas;
-  if (!res_claim(ctx)) { ctx->last_error = "resident evaluator: another context's resident kernel holds this device"; return NID_ERR_STATE; }
-  long long idle_ticks = kResidentIdleTicks;
-  if (const char *e = getenv("NID_RESIDENT_IDLE_US")) idle_ticks = std::max(1L, atol(e)) * 100;
-  // the word the kernel starts from, in the control line and in every cell's forwarding record
-  const unsigned long long word0 = resbatch_word(R.bseq, 0, 0);
-  {
-    std::vector<unsigned long long> f(resbatch_fan_words(nloc8), 0ull);
-    f[0] = word0;                                                        // gword
-    for (long c = 0; c < nloc8; c++) f[resbatch_cells_off() + 2 * c] = word0;  // every cell's {word, pose counter}
-    if (hipMemcpyAsync(R.bfwd, f.data(), f.size() * sizeof(f[0]), hipMemcpyHostToDevice, R.stream) != hipSuccess ||
-        hipStreamSynchronize(R.stream) != hipSuccess) { res_release(ctx); ctx->last_error = hipGetErrorString(hipGetLastError()); return NID_ERR_HIP; }
-  }
-  volatile unsigned long long *w = R.bctl->w;
-  w[7] = word0;
-  store_fence();
-  launch_resident_batch(P, lds, grid, R.stream, R.bctl, reinterpret_cast<const unsigned *>(R.brec_devptr), R.bfwd, word0, idle_ticks, replicas);
-  if (hipGetLastError() != hipSuccess) { res_release(ctx); ctx->last_error = "resident batch evaluator: launch failed"; return NID_ERR_HIP; }
-  R.brunning = true;
-  R.bdelta = delta;
-  R.breplicas = replicas;
-  R.bstarts++;
-  R.last_post = std::chrono::steady_clock::now();
-  return NID_OK;
-}
-
-// NID_ERR_UNSUPPORTED / NID_ERR_STATE: use ordinary launches
-int resident_batch_post(nid_ctx *ctx, int first_slot, int n, const Pose *poses, bool jac, double delta) {
-  nid_ctx::Resident &R = ctx->res;
-  const auto now = std::chrono::steady_clock::now();
-  if (R.brunning && (R.bdelta != delta || now - R.last_post > kResidentHostIdle)) resident_retire(ctx);
-  if (!R.brunning) {
-    int rc = resident_batch_start(ctx, delta);
-    if (rc) {
-      if (getenv("NID_RESIDENT_DEBUG")) fprintf(stderr, "[nid resident] batch start failed: %d %s\n", rc, ctx->last_error.c_str());
-      return rc;
-    }
-  }
-  for (int k = 0; k < n; k++) {
-    Slot &S = ctx->slots[first_slot + k];
-    S.seq++;
-    S.direct = S.resident = S.groups = false;
-    S.external_target = false;
-    SlotArgs &rec = R.brec_host[k];  // (pinned host memory: the kernel's root workgroup fetches the records over PCIe)
-    fill_slot_args(poses[k], S, S.reduced_host_devptr, reinterpret_cast<unsigned long long *>(S.reduced_host_devptr + kReducedLen), &rec);
-    rec.cellout = nullptr;  // (nobody reads the per-cell outputs of such a request)
-    R.bposes[k] = poses[k];
-  }
-  store_fence();
-  __atomic_thread_fence(__ATOMIC_SEQ_CST);  // the records are globally visible before the word leaves
-  volatile unsigned long long *w = R.bctl->w;
-  w[7] = resbatch_word(++R.bseq, n, jac ? kResJac : 0u);  // ONE store through the BAR
-  store_fence();  // out of the write-combining buffers now
-  R.last_post = std::chrono::steady_clock::now();
-  R.bfirst = first_slot; R.bn = n; R.bleft = n; R.bjac = jac;
-  for (int k = 0; k < n; k++) {
-    Slot &S = ctx->slots[first_slot + k];
-    S.resbatch = true;
-    S.collected = false;
-    S.timed = false;
-    S.done_slot = first_slot;
-    S.pending = true;
-  }
-  return NID_OK;
-}
-
-// the batch kernel did not answer: take it down and put what has not arrived through ordinary launches
-int resident_batch_fallback(nid_ctx *ctx) {
-  nid_ctx::Resident &R = ctx->res;
-  resident_retire(ctx);  // (if it was still there: no late writes after this)
-  R.bfallbacks++;
-  R.fallback_run++;
-  if (R.fallback_run >= 3 || (R.bfallbacks > 8 && R.bfallbacks > R.bserved)) {
-    R.enabled = false;
-    R.why = "resident evaluator switched off: " + std::to_string(R.bfallbacks) + " batch requests timed out (" + std::to_string(R.bserved) +
-            " served) -- its workgroups are not staying on the device (a shared GPU?); requests are launched from now on";
-    ctx->last_error = R.why;
-  }
-  NID_HIP(ctx, hipSetDevice(ctx->cfg.device));
-  const int first = R.bfirst, n = R.bn;
-  const bool jac = R.bjac;
-  const double delta = R.bdelta;
-  R.bleft = 0;
-  const size_t n_ticket = 1 + (size_t)((ctx->g.nloc + ctx->group_size - 1) / ctx->group_size);
-  for (int k = 0; k < n; k++) {
-    Slot &S = ctx->slots[first + k];
-    if (!S.resbatch || S.collected) continue;
-    S.resbatch = false;
-    volatile unsigned long long *seqw = reinterpret_cast<volatile unsigned long long *>(S.reduced_host + kReducedLen);
-    if (__atomic_load_n(seqw, __ATOMIC_ACQUIRE) == S.seq) continue;  // this one had arrived
-    // (a pose the kernel left half done: its tickets start from zero again)
-    NID_HIP(ctx, hipMemsetAsync(S.ticket_dev, 0, n_ticket * sizeof(unsigned), ctx->stream));
-    int rc = launch_batch(ctx, first + k, 1, &R.bposes[k], jac ? 1 : 0, delta, nullptr, false, /*relaunch_ok=*/true, /*allow_direct=*/false);
-    if (rc) return rc;
-  }
-  return NID_OK;
-}
-
-// nid_wait for a pose of a batch request: the slot's sequence word, like a launched pose's -- with the resident
-// kernel's patience
-int wait_resbatch(nid_ctx *ctx, Slot &S) {
-  nid_ctx::Resident &R = ctx->res;
-  volatile unsigned long long *seqw = reinterpret_cast<volatile unsigned long long *>(S.reduced_host + kReducedLen);
-  const auto t0 = std::chrono::steady_clock::now();
-  unsigned long spins = 0;
-  while (__atomic_load_n(seqw, __ATOMIC_ACQUIRE) != S.seq) {
-    if ((++spins & 1023ul) == 0 && std::chrono::steady_clock::now() - t0 > kResidentPatience) {
-      int rc = resident_batch_fallback(ctx);
-      if (rc) return rc;
-      return wait_host_seq(ctx, S);  // (an ordinary launch now; S.seq is the relaunch's)
-    }
-  }
-  S.resbatch = false;
-  if (R.bleft > 0 && --R.bleft == 0) { R.bserved++; R.fallback_run = 0; }
-  return NID_OK;
-}
+// ---- the RESIDENT evaluators (k_resident, k_resident_batch): host side -- nid_capi_resident.inc, this translation unit ---
+#include "nid_capi_resident.inc"
 
 int launch_slot(nid_ctx *ctx, int slot, const Pose &pose, int want_jac, double delta,
                 void *reduced_target) {
