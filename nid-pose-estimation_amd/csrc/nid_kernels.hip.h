@@ -1209,6 +1209,21 @@ __device__ __forceinline__ const EvalParams &reread_args() {
   return *(const EvalParams *)(ConstParams)a;
 }
 
+// A READER'S MAP of eval_cell (one function on purpose: its phases share the LDS layout, the per-cell scalars in SGPRs and
+// the register allocation -- out-of-line pieces and second copies were measured, see above; the pieces are lambdas, in this order):
+//   LDS layout, per-cell scalars, level-1 edge exit ....... the head
+//   zero_histograms
+//   hist_add(jr, jc, wr, wc, ...) ......................... ONE sample's 20 addends: the ordinary path at its end (4 marginal
+//       lo_add_marginal, fine_residual, add_c / add_j,        + 16 joint ds_add_u64), in front of it the rare branches -- clamped /
+//       flag_linear                                            near-saturated groups, fine levels, REPAIR routing (kLinFlagW)
+//   phase 1, cost: strict_cost_loop | cost_round<main / second pass> | repair_round, and the loops that drive them
+//       (LAT: rounds unrolled and staged); then the barrier
+//   fold: fold_bin (copies + fine levels + groups -> p, W, p log p), the repair decision (lin_word, repair_wanted),
+//       entropies Hc / Hj in a shape-independent order, residual_and_huber; cost-only launches end here (tail: done,
+//       deferred_to_repair, the DIRECT records or the in-launch reduction finish_and_reduce_w0)
+//   phase 2, Jacobian: the contracted tables (FAST), jac_accumulate_fast | jac_accumulate (STRICT: the dw[4] form),
+//       jac_round<main / second pass> | jac_round_masked (the cost phase's decisions, gomask), the LAT form from registers
+//   block sum of the six accumulators (through LDS for 128 / 256 threads, DPP + LDS beyond), the cell's quadratic form, tail
 template <int NT, bool JAC, bool STRICT, int NB, bool DBG, bool EXT, int LAT, bool BIG, bool RES, bool REPAIR_INLINE = repair_inline_default(LAT, RES, DBG, BIG)>
 __device__ __forceinline__ bool eval_cell(const EvalParams &P, const SlotArgs &SA, const int cl, const int pose_idx, unsigned char *smem,
                                           const ResCell rc = ResCell{0, 0.0, true}) {
