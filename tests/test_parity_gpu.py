@@ -956,6 +956,67 @@ def test_adversarial_cases(capi, oracle, synth, seed):
 
 
 @pytest.mark.gpu
+def test_set_stream_drains_and_refuses_while_pending(capi, synth, pair_S):
+    """nid_set_stream: a switch of the launch stream is refused (NID_ERR_STATE) while a result is uncollected --
+    the repair queue is keyed by stream, two unordered streams must not share one --, and accepted otherwise after the
+    streams in use have been drained; evaluations on a caller's stream, short sequences included (one stream: no split
+    onto the context's second stream), give the bits of the context's own streams, and so does the way back (NULL)."""
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")                      # (a caller's stream, made with the runtime the library itself uses)
+    ctx = capi.from_pair(pair_S, 8)
+    ctx.compute_href(pair_S.pose_init)
+    mine = C.c_void_p(0)
+    assert hip.hipStreamCreate(C.byref(mine)) == 0 and mine.value
+    poses = [synth.perturb_pose7(pair_S.pose_init, [1e-4 * k, 0, 0], [0, 1e-4 * k, 0]) for k in range(20)]
+    base = [ctx.normal_equations(p, DELTA) for p in poses]
+    same = lambda a, b: np.array_equal(_bits(a[0]), _bits(b[0])) and np.array_equal(_bits(a[1]), _bits(b[1])) and a[2:] == b[2:]
+    ctx.launch(0, poses[3], DELTA)                      # uncollected
+    with pytest.raises(capi.NidError):
+        ctx.set_stream(mine.value)
+    assert same(ctx.wait(0), base[3])
+    ctx.set_stream(mine.value)                          # collected: accepted
+    assert all(same(ctx.normal_equations(p, DELTA), b) for p, b in zip(poses[:4], base))
+    ctx.launch_batch(0, poses, DELTA)
+    assert all(same(ctx.wait(k), base[k]) for k in range(20))
+    assert hip.hipStreamSynchronize(mine) == 0
+    ctx.set_stream(None)                                # back to the context's own streams
+    ctx.launch_batch(0, poses, DELTA)
+    assert all(same(ctx.wait(k), base[k]) for k in range(20))
+    ctx.close()
+    assert hip.hipStreamDestroy(mine) == 0
+
+
+@pytest.mark.gpu
+def test_backproject_scratch_and_release(capi, oracle, synth, pair_S):
+    """nid_backproject is context-free and keeps its scratch from call to call (sized max(3N, N + 16) doubles --
+    an image of fewer than 8 pixels used to overrun it --, callers serialised, nid_backproject_release frees it):
+    a tiny image, a larger one, a release in between -- every call the oracle's points, bit for bit."""
+    import ctypes as C
+    lib = capi.load()
+    p = pair_S
+    T = np.ascontiguousarray(synth.matrix_colmajor16(p.T_wc0), dtype=np.float64)
+    dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+
+    def run(depth):
+        depth = np.ascontiguousarray(depth, dtype=np.float64)
+        rows, cols = depth.shape
+        out = np.empty(rows * cols * 3)
+        rc = lib.nid_backproject(dp(depth), dp(T), p.fx, p.fy, p.cx, p.cy, rows, cols, 0, dp(out))
+        assert rc == 0
+        want = oracle.backproject(depth, T, p.fx, p.fy, p.cx, p.cy)
+        assert np.array_equal(_bits(out), _bits(want))
+
+    tiny = np.array([[1.5, 0.0, 2.25]])                 # N = 3 < 8: the stage holds N + 16 doubles
+    run(tiny)
+    run(p.depth_m)
+    assert lib.nid_backproject_release() == 0
+    run(tiny)
+    run(p.depth_m[: p.rows // 2, : p.cols // 2])
+    assert lib.nid_backproject_release() == 0
+    assert lib.nid_backproject_release() == 0           # (nothing held: still fine)
+
+
+@pytest.mark.gpu
 def test_context_lifecycle_and_interleaving(capi, oracle, synth, pair_S, pair_S_edge):
     """Two contexts used alternately, state replaced in place (new target, new reference, recomputed href),
     math mode switched between calls, a context destroyed with launches in flight."""
