@@ -962,8 +962,13 @@ def test_set_stream_drains_and_refuses_while_pending(capi, synth, pair_S):
     streams in use have been drained; evaluations on a caller's stream, short sequences included (one stream: no split
     onto the context's second stream), give the bits of the context's own streams, and so does the way back (NULL)."""
     import ctypes as C
-    hip = C.CDLL("libamdhip64.so")                      # (a caller's stream, made with the runtime the library itself uses)
     ctx = capi.from_pair(pair_S, 8)
+    # a caller's stream, made with the HIP runtime the library itself is linked against (a process that has imported torch
+    # holds torch's bundled copy of libamdhip64 as well: that one does not own the device here)
+    with open("/proc/self/maps") as fh:
+        rts = sorted({ln.split()[-1] for ln in fh if "libamdhip64" in ln and "/torch/" not in ln})
+    assert rts, "the HIP runtime of libnid_hip.so is not mapped"
+    hip = C.CDLL(rts[0])
     ctx.compute_href(pair_S.pose_init)
     mine = C.c_void_p(0)
     assert hip.hipStreamCreate(C.byref(mine)) == 0 and mine.value
