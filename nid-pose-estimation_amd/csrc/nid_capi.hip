@@ -1258,8 +1258,8 @@ int nid_create_strided(const nid_config *cfg, int32_t cell_stride, nid_ctx **out
   if ((rc = dev_alloc(ctx, &ctx->Href_dev, g.nloc))) return fail(rc);
   if ((rc = dev_alloc(ctx, &ctx->repair_count_dev, 1))) return fail(rc);
   if (hipMemset(ctx->repair_count_dev, 0, sizeof(unsigned long long)) != hipSuccess) return fail(NID_ERR_HIP);
-  for (int q = 0; q < 2; q++) {  // one queue per launch stream: [count | exit ticket | pose << 16 | cell ...], see k_repair
-    const size_t n = 2 + (size_t)g.nloc * kMaxBatchExt;
+  for (int q = 0; q < 2; q++) {  // one queue per launch stream: [count | exit ticket | (pose << 16 | cell, repair set x 2) ...], see k_repair
+    const size_t n = 2 + 3 * (size_t)g.nloc * kMaxBatchExt;
     if ((rc = dev_alloc(ctx, &ctx->repair_queue_dev[q], n))) return fail(rc);
     if (hipMemset(ctx->repair_queue_dev[q], 0, n * sizeof(unsigned)) != hipSuccess) return fail(NID_ERR_HIP);
   }

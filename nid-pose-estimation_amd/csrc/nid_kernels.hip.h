@@ -144,7 +144,7 @@ struct EvalParams {
   int *dbg_jc;
   int dbg_jac;  // 0: the dump describes the cost phase (u, v, ic, jc, wc[4]); 1: the Jacobian phase (gx, gy, pc, jc, dw[4])
   unsigned long long *repair_count;  // cells and poses that ran the repair pass (kLinFlagW), or null
-  unsigned *repair_queue;            // [0] entries, [1] k_repair's exit ticket, [2 + i] = pose << 16 | cell: see k_repair
+  unsigned *repair_queue;            // [0] entries, [1] k_repair's exit ticket, [2 + 3 i ..] = pose << 16 | cell, the fold's repair set (two words): see k_repair
   // optional phase stamps (s_memtime) of wave 0 of every workgroup: [nloc][10] (8 phase stamps + s_memrealtime at start/end); diagnostic runs only
   long long *dbg_stamps;
 };
@@ -1224,9 +1224,11 @@ __device__ __forceinline__ const EvalParams &reread_args() {
 //   phase 2, Jacobian: the contracted tables (FAST), jac_accumulate_fast | jac_accumulate (STRICT: the dw[4] form),
 //       jac_round<main / second pass> | jac_round_masked (the cost phase's decisions, gomask), the LAT form from registers
 //   block sum of the six accumulators (through LDS for 128 / 256 threads, DPP + LDS beyond), the cell's quadratic form, tail
-template <int NT, bool JAC, bool STRICT, int NB, bool DBG, bool EXT, int LAT, bool BIG, bool RES, bool REPAIR_INLINE = repair_inline_default(LAT, RES, DBG, BIG)>
+template <int NT, bool JAC, bool STRICT, int NB, bool DBG, bool EXT, int LAT, bool BIG, bool RES, bool REPAIR_INLINE = repair_inline_default(LAT, RES, DBG, BIG),
+          bool PRESET = false>
 __device__ __forceinline__ bool eval_cell(const EvalParams &P, const SlotArgs &SA, const int cl, const int pose_idx, unsigned char *smem,
-                                          const ResCell rc = ResCell{0, 0.0, true}) {
+                                          const ResCell rc = ResCell{0, 0.0, true}, const uint2 preset = uint2{0u, 0u}) {
+  static_assert(!PRESET || (REPAIR_INLINE && LAT == 0 && !RES), "PRESET: k_repair's instantiation");
   static_assert(LAT == 0 || (!STRICT && !EXT), "the latency form exists for FAST math launches of <= kMaxBatch poses (DBG: phase stamps only)");
   const int tid = threadIdx.x;
   constexpr int NC = eval_hist_copies(NT);
@@ -1357,9 +1359,21 @@ __device__ __forceinline__ bool eval_cell(const EvalParams &P, const SlotArgs &S
   // COARSE copies of a bin in the repair set -- to the fine level of its own exponent
   unsigned rep_col1 = 0u, rep_colz = 0u;  // repair_set[0], [1] (wave-uniform; loaded before the repair pass)
   bool repaired = false;                  // this cell ran the repair pass (wave-uniform)
+  // PRESET (k_repair, round 5): the repair set is KNOWN -- the loop-form kernel that queued this cell found it in its fold and
+  // handed it over with the queue entry --, so the cost passes route at once what the repair pass would move: an addend
+  // that NORMAL mode sends to the coarse copies of a bin in the set goes to the bin's fine levels instead (MIXED in
+  // hist_add: the very adds of REPAIR mode, made one traversal earlier; integer sums, so the same bits), the fold finds
+  // those bins' copies empty -- which IS the refold without the copies -- and the third traversal of the pixels is gone.
+  if constexpr (PRESET) {
+    rep_col1 = (preset.x >> 31) ? (preset.x & 0x1FFFFu) : 0u;
+    rep_colz = (preset.y >> 31) ? (preset.y & 0x1FFFFu) : 0u;
+    repaired = true;
+    if (tid == 0 && P.repair_count) atomicAdd(P.repair_count, 1ull);  // (diagnostics: nid_debug_repair_count)
+  }
   auto hist_add = [&](int jr, int jc, const double (&wr_in)[4], const double (&win)[4], auto prescaled, double pcv, int group, auto repair_tag) {
     constexpr bool PRESCALED = decltype(prescaled)::value;
     constexpr bool REPAIR = decltype(repair_tag)::value;
+    constexpr bool MIXED = PRESET && !REPAIR;  // NORMAL mode with the repair set known beforehand (see PRESET)
     if (group != 0) {  // FAST second passes only: 1 = clamped (kClampBins), 2 = near-saturated (kNearSatIc)
       if (REPAIR) return;  // (their sums are exact relative to themselves: coarse copies for weights >= 2^-8 only)
       unsigned long long *hx = (group == 2 ? nsb : clampb) + ((unsigned)copy & (kClampCopies - 1));
@@ -1436,7 +1450,8 @@ __device__ __forceinline__ bool eval_cell(const EvalParams &P, const SlotArgs &S
     // is in the repair set (`w`, `pr`: the plain weight / the reference's own product, rounded once like there)
     auto rep_set = [&](int col) -> unsigned { return col == 1 ? rep_col1 : (col == nb - 2 ? rep_colz : 0u); };
     auto add_c = [&](int k, double wcs_k, double w) {
-      if (!REPAIR) { atomicAdd(hc + k * NC, fx_bits(wcs_k * P.hist_dn)); return; }
+      if constexpr (!REPAIR && !MIXED) { atomicAdd(hc + k * NC, fx_bits(wcs_k * P.hist_dn)); return; }
+      if (MIXED && !((rep_set(jc + k) >> 16) & 1u)) { atomicAdd(hc + k * NC, fx_bits(wcs_k * P.hist_dn)); return; }
       if (((rep_set(jc + k) >> 16) & 1u) && w > kNegligibleW) {
         const int lv = fine_level(w);
         atomicAdd(hist_lo + lv * nbins + (unsigned)(jc + k), fx_encode(w, fine_scale(lv)));
@@ -1444,7 +1459,8 @@ __device__ __forceinline__ bool eval_cell(const EvalParams &P, const SlotArgs &S
       }
     };
     auto add_j = [&](int m, int k, double wr_m, double wcs_k, double w) {
-      if (!REPAIR) { atomicAdd(hj + (m * nb + k) * NC, fx_bits((wr_m * P.hist_dn) * wcs_k)); return; }
+      if constexpr (!REPAIR && !MIXED) { atomicAdd(hj + (m * nb + k) * NC, fx_bits((wr_m * P.hist_dn) * wcs_k)); return; }
+      if (MIXED && !((rep_set(jc + k) >> (jr + m)) & 1u)) { atomicAdd(hj + (m * nb + k) * NC, fx_bits((wr_m * P.hist_dn) * wcs_k)); return; }
       if ((rep_set(jc + k) >> (jr + m)) & 1u) {
         const double pr = wr_m * w;
         if (pr > kNegligibleW) {
@@ -1559,6 +1575,39 @@ __device__ __forceinline__ bool eval_cell(const EvalParams &P, const SlotArgs &S
         for (int m = 0; m < 4; m++) add_j(m, k, wr[m], wcs[k], w);
       }
       return;
+    }
+    if constexpr (MIXED) {
+      if ((rep_col1 | rep_colz) != 0u) {  // an ordinary sample: a column in the repair set takes its addends one by one
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          const double mk = wcs[k] * P.hist_dn;       // (the coarse forms of the ordinary path, below)
+          const unsigned rs = rep_set(jc + k);
+          const double w = wcs[k] * kWcPreInv;        // (the fine forms of REPAIR mode, above)
+          if ((rs >> 16) & 1u) {
+            if (w > kNegligibleW) {
+              const int lv = fine_level(w);
+              atomicAdd(hist_lo + lv * nbins + (unsigned)(jc + k), fx_encode(w, fine_scale(lv)));
+              fine_residual(lv, (unsigned)(jc + k), w, std::false_type{});
+            }
+          } else {
+            atomicAdd(hc + k * NC, fx_bits(mk));
+          }
+#pragma unroll
+          for (int m = 0; m < 4; m++) {
+            if ((rs >> (jr + m)) & 1u) {
+              const double pr = wr[m] * w;
+              if (pr > kNegligibleW) {
+                const int lm = fine_level(pr);
+                atomicAdd(hist_lo + lm * nbins + ((unsigned)nb + hrow + (unsigned)(m * nb + k)), fx_encode(pr, fine_scale(lm)));
+                fine_residual(lm, (unsigned)nb + hrow + (unsigned)(m * nb + k), pr, std::false_type{});
+              }
+            } else {
+              atomicAdd(hj + (m * nb + k) * NC, fx_bits(mk * wr[m]));
+            }
+          }
+        }
+        return;
+      }
     }
     // The marginal addend of column k, wcs[k] * hist_dn = wc * 2^(s - 1074), is a subnormal double whose bit pattern IS
     // the integer I_k = RN(wc * 2^s) (fx_bits).  The joint addends of that column are taken from it: I_k * wr[m], again a
@@ -2001,12 +2050,17 @@ __device__ __forceinline__ bool eval_cell(const EvalParams &P, const SlotArgs &S
         const unsigned i = __hip_atomic_fetch_add(q, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         // (a launch pushes at most one entry per workgroup and k_repair empties the queue behind it: the bound only
         // holds against a queue that was never drained)
-        if (i < (unsigned)P.g.nloc * (unsigned)kMaxBatchExt) q[2 + i] = ((unsigned)pose_idx << 16) | (unsigned)cl;
+        if (i < (unsigned)P.g.nloc * (unsigned)kMaxBatchExt) {  // the entry: which cell and pose, and the repair set the fold found
+          const uint2 rs = *reinterpret_cast<const uint2 *>(repair_set);
+          q[2 + 3 * i] = ((unsigned)pose_idx << 16) | (unsigned)cl;
+          q[3 + 3 * i] = rs.x;
+          q[4 + 3 * i] = rs.y;
+        }
       }
       return true;
     }
   };
-  if constexpr (REPAIR_INLINE)
+  if constexpr (REPAIR_INLINE && !PRESET)
   if (__builtin_expect((lin_col1 | lin_colz | grp_colz) != 0u, 0)) {
     const uint2 rs = *reinterpret_cast<const uint2 *>(repair_set);
     rep_col1 = (unsigned)__builtin_amdgcn_readfirstlane((int)rs.x);
@@ -2572,7 +2626,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 2))) void
   const unsigned count = (unsigned)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
   for (unsigned i = blockIdx.x; i < count; i += gridDim.x) {
     __syncthreads();  // every wave is back from the previous entry (its tail is wave 0's business)
-    const unsigned e = (unsigned)__builtin_amdgcn_readfirstlane((int)q[2 + i]);
+    const unsigned e = (unsigned)__builtin_amdgcn_readfirstlane((int)q[2 + 3 * i]);
+    const uint2 preset = {(unsigned)__builtin_amdgcn_readfirstlane((int)q[3 + 3 * i]), (unsigned)__builtin_amdgcn_readfirstlane((int)q[4 + 3 * i])};
     const int cl = (int)(e & 0xFFFFu), pose_idx = (int)(e >> 16);
     SlotArgs sa_ext;
     if (EXT) {
@@ -2583,7 +2638,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(1, 2))) void
       for (unsigned k = STRICT ? 0u : kPoseQuatDwords; k < sizeof(SlotArgs) / 4; k++) dst[k] = src[k];
     }
     const SlotArgs &SA = EXT ? sa_ext : P.slot[pose_idx];
-    eval_cell<NT, JAC, STRICT, NB, false, EXT, 0, false, false, true>(P, SA, cl, pose_idx, smem);
+    eval_cell<NT, JAC, STRICT, NB, false, EXT, 0, false, false, true, true>(P, SA, cl, pose_idx, smem, ResCell{0, 0.0, true}, preset);
   }
   if (count == 0u && blockIdx.x != 0u) return;  // (nothing queued: one workgroup keeps the ticket's books)
   __syncthreads();
