@@ -21,25 +21,26 @@
 // Differences, all deliberate: no per-call allocation / memset / re-upload.  The
 // frame-pair state is cached per (rows, cols, cell_num, bin_num) and re-uploaded
 // when the CONTENT of a caller buffer has changed.
-// THE CONTRACT: none beyond the reference's, in three strengths (nid_legacy_set_verify_mode):
-//  * NID_LEGACY_VERIFY_BACKGROUND (default): a call checks address, length and 64 samples of each big
-//    buffer (a microsecond in all) and evaluates; a small pool of worker threads (NID_LEGACY_HASH_THREADS,
-//    default 3; 0: none, then this mode is TRUSTED) hashes im0 / points3d / im1 / bs_ref in full beside the
-//    caller, one verification after the other (~0.4 ms each at 640x480).  A buffer rewritten IN PLACE
-//    between two calls is found by the next verification: the following call says so on stderr, counts it
-//    (nid_legacy_stale_detections) and uploads the new content -- at most a few calls have evaluated the
-//    old one, and the caller is told.  The workers read the caller's buffers between calls: a caller that
-//    frees them calls nid_legacy_reset() or nid_legacy_quiesce() first (both end the verification).
-//  * NID_LEGACY_VERIFY_EVERY_CALL: every call hashes all four buffers BEFORE it evaluates and uploads what
-//    differs -- followed on the next call, like with the reference, which uploads everything on every
-//    call (computeH.cu:420-429).  0.36 ms per call at 640x480 (profiles/r05_pair_setup.txt), ten times
-//    the evaluation itself: not the default.
+// THE CONTRACT: none beyond the reference's.  The caller owns every buffer; the operators read them only
+// between their entry and their return (round 6), so a caller may free or rewrite them the moment a call
+// is back -- NID_pose_estimation.cpp:388-395 frees everything right after the last CudaComputeH.  How the
+// operators make sure the device holds what the buffers hold NOW (nid_legacy_set_verify_mode):
+//  * NID_LEGACY_VERIFY_ROTATING (default): a call checks address, length and 64 samples of each big
+//    buffer (a microsecond in all), hands ONE of the 16 slices of im0 / points3d / im1 / bs_ref (1.4 MB in
+//    all at 640x480; slice = call number mod 16) to a small pool of worker threads (NID_LEGACY_HASH_THREADS,
+//    default 3; 0: the caller hashes alone), evaluates on the device meanwhile, and joins the workers before
+//    it returns.  A buffer rewritten IN PLACE is found within 16 calls: that call says so on stderr, counts
+//    it (nid_legacy_stale_detections), uploads the new content and evaluates again before it returns.
+//    nid_legacy_set_verify_slices(k) / NID_LEGACY_VERIFY_SLICES=k: k slices per call (found within 16/k calls).
+//  * NID_LEGACY_VERIFY_EVERY_CALL (= 16 slices per call; NID_LEGACY_VERIFY_EVERY_CALL=1): every call hashes all
+//    four buffers in full and evaluates what they hold now -- the reference's guarantee exactly (it uploads
+//    everything on every call, computeH.cu:420-429), at 0.3-0.4 ms per call at 640x480.
 //  * NID_LEGACY_VERIFY_TRUSTED (nid_legacy_set_trust_buffers(1), NID_LEGACY_TRUST_BUFFERS=1): the cheap
 //    check only; full hashes when it fails, on every 128th call of a pair, and after
 //    nid_legacy_invalidate(parts).  For callers that do not rewrite buffers in place, or say so.
 // bs_counter / Href (1-2 KB) are hashed in full on every call in every mode; a new frame pair (new
 // buffers, or CudaComputeHref) is always noticed at once.  NID_LEGACY_ALWAYS_UPLOAD=1 uploads everything
-// on every call.
+// on every call.  No thread of the library touches a caller buffer outside a call in any mode.
 // Out-of-frame reference weights are NaN in the
 // arrays handed back (as CudaComputeHref.cu:126-130 writes them) but are treated
 // as 0 inside, the CPU edge's convention; the Jacobian in-frame
@@ -86,19 +87,20 @@ void nid_legacy_set_devices(const int32_t *devices, int n, int reduce_rccl);
 // (nid_multi_comm_unique_id on rank 0, handed to every rank).  The communicator is created on first use and kept
 // until the device set changes.
 void nid_legacy_set_rank(int device, int rank, int world, const uint8_t *rccl_id128);
-// drop every cached context (e.g. before the caller frees its buffers)
+// drop every cached context and the device memory behind it (optional: nothing of the caller's is referenced between calls)
 void nid_legacy_reset(void);
 // done with the GPU for now, keep everything for the next frame pair: takes a running resident kernel off the device
 // (the context, its buffers and its communicator stay: the next pair of the same geometry costs no context creation)
 void nid_legacy_quiesce(void);
 // how the operators make sure the device holds what the caller's buffers hold (THE CONTRACT above)
-enum { NID_LEGACY_VERIFY_BACKGROUND = 0, NID_LEGACY_VERIFY_EVERY_CALL = 1, NID_LEGACY_VERIFY_TRUSTED = 2 };
+enum { NID_LEGACY_VERIFY_ROTATING = 0, NID_LEGACY_VERIFY_EVERY_CALL = 1, NID_LEGACY_VERIFY_TRUSTED = 2 };
 void nid_legacy_set_verify_mode(int mode);
+void nid_legacy_set_verify_slices(int per_call);  // ROTATING: slices of 16 checked per call (default 1; < 1: the default)
 void nid_legacy_set_trust_buffers(int on);   // 1: NID_LEGACY_VERIFY_TRUSTED, 0: the default
-// in-place changes the background verification has found and reported so far
+// in-place changes the rotating verification has found and reported so far
 long nid_legacy_stale_detections(void);
 // The caller has changed, IN PLACE, the content of the buffers named by `parts` since its last call (needed with trusted
-// buffers; spares the background mode its detection delay):
+// buffers; spares the rotating mode its detection delay):
 // the next CudaComputeH recomputes their full hashes (and uploads what differs) instead of trusting address + samples.
 enum { NID_LEGACY_REFERENCE = 1 /* im0, points3d */, NID_LEGACY_TARGET = 2 /* im1 */, NID_LEGACY_HREF_STATE = 4 /* bs_ref */ };
 void nid_legacy_invalidate(unsigned parts);

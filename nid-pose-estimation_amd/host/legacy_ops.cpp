@@ -7,28 +7,26 @@
 // What is resident is identified by CONTENT, not by pointer: a caller that frees and re-mallocs its buffers per
 // pair (NID_pose_estimation.cpp:229-251, 385-392) usually gets the same addresses back.
 //   * CudaComputeHref is called once per pair: it always uploads the reference (im0, points3d) afresh;
-//   * CudaComputeH keeps, per caller buffer (im0, points3d, im1, bs_ref, bs_counter, Href), a key: address, length, a
-//     quick fingerprint of 64 samples and a FULL 64-bit hash of the content.
-//     Three modes (nid_legacy_set_verify_mode; round 5):
-//     BACKGROUND (default): a call checks address, length and the quick fingerprint (about a microsecond for all six
-//     buffers) and evaluates; beside it a small pool of worker threads takes the full hashes of the four big buffers --
-//     one verification at a time, started by a call whenever none is running (22 MB at 640x480: ~0.4 ms on three
-//     workers) -- and the first call after a verification that found a buffer changed IN PLACE says so loudly on stderr,
-//     counts it (nid_legacy_stale_detections), and uploads the buffer's current content: a caller that rewrites a buffer
-//     in place without saying so is followed within a verification's time, at most a few calls evaluated on the old
-//     content, and is told.  (Verifying INSIDE every call costs 0.36 ms per call -- ten times the evaluation,
-//     profiles/r05_pair_setup.txt -- which is why it is not the default.)
-//     EVERY_CALL: every call recomputes the full hash of every buffer before it evaluates -- the caller's bytes are read on
-//     every call, like the reference, which re-uploads them on every call (computeH.cu:420-429) -- and uploads what
-//     differs: a change in place is followed on the NEXT call, with nothing asked of the caller.
-//     TRUSTED (nid_legacy_set_trust_buffers(1) or NID_LEGACY_TRUST_BUFFERS=1; round 4's default): the cheap check only;
-//     the full hash is recomputed -- and decides whether the buffer is uploaded -- when the cheap part changed, on every
-//     kRehashEvery-th call of a pair, and after nid_legacy_invalidate().  No thread is started by this mode's calls
-//     once the pair is set up.
-//     In every mode a new frame pair (new buffers, or CudaComputeHref) is noticed at once, and nid_legacy_invalidate(parts)
-//     makes the next call recompute the named parts' full hashes.
-//     The two per-cell arrays (1-2 KB) are fully hashed on every call in both modes; the images' keys carry the hash
-//     of their u8 conversion (what is uploaded) and, in the default mode, of the caller's f64 bytes (what is verified).
+//   * CudaComputeH keeps, per big caller buffer (im0, points3d, im1, bs_ref), a key: address, length, a quick
+//     fingerprint of 64 samples and the 64-bit hashes of its kSlices (16) contiguous slices; per small array
+//     (bs_counter, Href: 1-2 KB) address, length and ONE hash, recomputed on every call.
+//   * EVERY read of a caller buffer happens between the entry and the return of an operator (round 6; round 5's default
+//     let worker threads read them between calls -- a use-after-free for the reference's main(), which frees its
+//     buffers right after the last CudaComputeH, NID_pose_estimation.cpp:388-395).  Two modes
+//     (nid_legacy_set_verify_mode):
+//     ROTATING (default): a call checks address, length and the quick fingerprint of the four big buffers (about a
+//     microsecond), hands slice (call number mod 16) of each of them -- 1/16 of 22 MB at 640x480 -- to the pool's worker
+//     threads, runs the evaluation on the device, and JOINS the workers before it returns.  A slice that no longer hashes
+//     to what its key holds means the buffer was rewritten in place: the call says so on stderr, counts it
+//     (nid_legacy_stale_detections), uploads the buffer's current content and evaluates again before it returns -- an
+//     undeclared change in place is followed within 16 calls (the reference's LM makes 30-60 per pair) and the caller
+//     is told.  nid_legacy_set_verify_slices(16) (NID_LEGACY_VERIFY_EVERY_CALL=1, mode EVERY_CALL) checks every slice on
+//     every call: the reference's guarantee exactly (it re-uploads everything on every call, computeH.cu:420-429).
+//     TRUSTED (nid_legacy_set_trust_buffers(1) or NID_LEGACY_TRUST_BUFFERS=1): the cheap check only; the full hash is
+//     recomputed -- and decides whether the buffer is uploaded -- when the cheap part changed, on every kRehashEvery-th
+//     call of a pair, and after nid_legacy_invalidate().  No thread is woken by this mode's calls once the pair is set up.
+//     In both modes a new frame pair (new buffers, or CudaComputeHref) is noticed at once, and
+//     nid_legacy_invalidate(parts) makes the next call recompute the named parts' hashes in full.
 //     NID_LEGACY_ALWAYS_UPLOAD=1 uploads everything on every call.
 #include "nid/legacy_ops.h"
 
@@ -51,6 +49,8 @@
 
 namespace {
 
+constexpr int kSlices = 16;   // a big buffer's content key: one hash per slice; the default mode checks one slice per call
+
 struct LegacyState {
   nid_multi *m = nullptr;
   int rows = 0, cols = 0, cell = 0, bins = 0;
@@ -58,18 +58,17 @@ struct LegacyState {
   // keys of what is resident on the device(s)
   struct Key {
     const void *addr = nullptr;
-    size_t n = 0;
+    size_t n = 0;             // elements
     uint64_t quick = 0, full = 0;
+    uint64_t slice[kSlices] = {};  // big buffers: the slices' hashes (`full` is their combination)
     bool valid = false;
-    bool full_known = true;  // false: `full` was never taken -- a full check then counts as "changed"
-    uint64_t raw = 0;        // images: the hash of the caller's f64 bytes (`full` is that of the u8 conversion)
-    bool raw_known = false;
+    bool full_known = true;   // false: the hashes were never taken -- a full check then counts as "changed"
   };
   Key k_im0, k_points, k_im1, k_bs_ref, k_counter, k_href;
   bool have_ref = false, have_target = false, have_href = false;
   unsigned long calls = 0;      // CudaComputeH calls on this frame pair (CudaComputeHref starts a new count)
-  unsigned long epoch = 0;      // bumped by every upload: a background verification that straddles one is discarded
   unsigned force_full = 0;      // nid_legacy_invalidate: parts whose full hash the next call recomputes
+  unsigned fresh = 0;           // parts hashed in full or uploaded by the CURRENT call: nothing to verify behind them
 };
 constexpr unsigned long kRehashEvery = 128;
 
@@ -99,7 +98,7 @@ nid_comm *g_comm = nullptr;  // lives across nid_legacy_reset(): one communicato
 long g_uploads = 0;
 
 // NID_LEGACY_TRACE=1: microseconds of every step of the per-pair setup on stderr (tools/pair_setup.py collects them
-// into profiles/r04_pair_setup.txt)
+// into profiles/r06_pair_setup.txt)
 struct StepTrace {
   bool on;
   const char *what;
@@ -117,18 +116,28 @@ struct StepTrace {
   }
 };
 
-int g_verify_mode = -1;  // nid_legacy_set_verify_mode; -1 = the environment (NID_LEGACY_TRUST_BUFFERS=1, NID_LEGACY_VERIFY_EVERY_CALL=1) or the default
+int g_verify_mode = -1;    // nid_legacy_set_verify_mode; -1 = the environment (NID_LEGACY_TRUST_BUFFERS=1, NID_LEGACY_VERIFY_EVERY_CALL=1) or the default
+int g_verify_slices = -1;  // nid_legacy_set_verify_slices; -1 = by mode (ROTATING 1, EVERY_CALL kSlices) or NID_LEGACY_VERIFY_SLICES
 int verify_mode() {
   if (g_verify_mode >= 0) return g_verify_mode;
   static const int env = [] {
     const char *t = getenv("NID_LEGACY_TRUST_BUFFERS"), *e = getenv("NID_LEGACY_VERIFY_EVERY_CALL");
     if (t && t[0] == '1') return (int)NID_LEGACY_VERIFY_TRUSTED;
     if (e && e[0] == '1') return (int)NID_LEGACY_VERIFY_EVERY_CALL;
-    return (int)NID_LEGACY_VERIFY_BACKGROUND;
+    return (int)NID_LEGACY_VERIFY_ROTATING;
   }();
   return env;
 }
 bool trust_buffers() { return verify_mode() == NID_LEGACY_VERIFY_TRUSTED; }
+// slices of every big buffer a CudaComputeH call verifies (0: trusted buffers)
+int slices_per_call() {
+  const int mode = verify_mode();
+  if (mode == NID_LEGACY_VERIFY_TRUSTED) return 0;
+  if (mode == NID_LEGACY_VERIFY_EVERY_CALL) return kSlices;
+  if (g_verify_slices > 0) return std::min(g_verify_slices, kSlices);
+  static const int env = [] { const char *e = getenv("NID_LEGACY_VERIFY_SLICES"); return e ? std::max(1, std::min(kSlices, atoi(e))) : 1; }();
+  return env;
+}
 long g_stale_detections = 0;
 
 bool always_upload() {
@@ -155,20 +164,18 @@ uint64_t fingerprint(const T *a, size_t n) {
 }
 
 // ---- content hashes -------------------------------------------------------------------------------------------
-// A frame pair's big buffers (points3d 7.4 MB, bs_value 9.8 MB at 640x480) are hashed once per pair -- and, in the
-// default mode, on every CudaComputeH call; one core does ~20 GB/s, i.e. 0.4-0.5 ms each.  Buffers of 1 MB and more are
-// therefore hashed in kHashParts contiguous parts by a small pool of worker threads (created at the first use, parked
-// on a condition variable in between), and the key is the combination of the parts' hashes in order.  The pool's size:
-// NID_LEGACY_HASH_THREADS workers beside the caller (default 3; 0: the caller hashes alone, no thread is created).
-constexpr int kHashParts = 4;
-constexpr size_t kHashParallelBytes = 1u << 20;
-
+// A frame pair's big buffers (points3d 7.4 MB, bs_value 9.8 MB at 640x480) are hashed once per pair in full and one
+// slice per call after that; one core does ~20 GB/s.  The slices go to a small pool of worker threads (created at the
+// first use, parked on a condition variable in between) beside the caller.  The pool's size: NID_LEGACY_HASH_THREADS
+// workers (default 3; 0: the caller hashes alone, no thread is created).  A job lives INSIDE one operator call: start()
+// takes the pool, finish() -- always before the operator returns -- gives it back; no worker touches a caller buffer
+// outside start() .. finish().
 class HashPool {
  public:
   static HashPool &get() { static HashPool *p = new HashPool;  return *p; }  // (never destroyed: its parked workers end with the process)
   // start(n, job): job(0..n-1) is handed to the workers -- each takes the next part that nobody has taken -- and the
-  // call returns; finish(): the caller takes what is left and waits for the rest.  One job at a time (start() holds a
-  // lock until finish()); the job must stay valid until finish().
+  // call returns; finish(): the caller takes what is left and waits for the rest.  One job at a time, started and
+  // finished by the same thread; the job must stay valid until finish().
   void start(int nparts, std::function<void(int)> job) {
     call_.lock();
     {
@@ -179,7 +186,7 @@ class HashPool {
       remaining_ = nparts;
       generation_++;
     }
-    if (!workers_.empty() && getpid() == owner_) wake_.notify_all();  // (a fork()ed child has no workers: finish() does all parts)
+    if (has_workers()) wake_.notify_all();  // (a fork()ed child has no workers: finish() does all parts)
   }
   void finish() {
     help();
@@ -191,11 +198,6 @@ class HashPool {
     call_.unlock();
   }
   void run(int nparts, std::function<void(int)> job) { start(nparts, std::move(job)); finish(); }
-  // a started job whose parts the WORKERS have all done (nobody called finish() yet)?  false without workers: finish() does the work then
-  bool done_by_workers() {
-    std::lock_guard<std::mutex> g(m_);
-    return remaining_ == 0;
-  }
   bool has_workers() const { return !workers_.empty() && getpid() == owner_; }
 
  private:
@@ -204,8 +206,10 @@ class HashPool {
     if (const char *e = getenv("NID_LEGACY_HASH_THREADS")) n = std::max(0, std::min(15, atoi(e)));
     for (int w = 0; w < n; w++) workers_.emplace_back([this] { loop(); });
     // fork(): threads do not survive it, locks do -- a child forked while a worker held m_ would wait for it for ever.
-    // The handlers take both locks around the fork, so the child inherits them free (and finds itself without workers
-    // by its pid).
+    // The prepare handler takes call_ (free whenever no operator is inside start() .. finish(): a job never outlives
+    // the call that started it, so a fork() between two calls finds it free; a fork() from another thread waits for
+    // the running call's finish()) and then m_, so the child inherits both free, with no job in flight (and finds
+    // itself without workers by its pid).
     pthread_atfork([] { HashPool &p = get(); p.call_.lock(); p.m_.lock(); },
                    [] { HashPool &p = get(); p.m_.unlock(); p.call_.unlock(); },
                    [] { HashPool &p = get(); p.m_.unlock(); p.call_.unlock(); });
@@ -247,25 +251,18 @@ class HashPool {
 };
 
 // one contiguous run of bytes, 64 bits: eight interleaved multiply-xor lanes over the 8-byte words (eight independent
-// dependency chains keep the multiplier busy: memory-bound, ~0.05 ms/MB on one core).  MARK (unused since the NaN rows of
-// bs_value are written on the device): rows of four doubles, an all-zero row becomes four NaNs first and is hashed as such.
-template <bool MARK>
-uint64_t hash_run(unsigned char *b, size_t bytes, uint64_t salt) {
+// dependency chains keep the multiplier busy: memory-bound, ~0.05 ms/MB on one core)
+uint64_t hash_run(const unsigned char *b, size_t bytes, uint64_t salt) {
   const size_t words = bytes / 8;
   constexpr int L = 8;
   uint64_t h[L] = {0x9E3779B97F4A7C15ull ^ salt, 0xC2B2AE3D27D4EB4Full, 0x165667B19E3779F9ull, 0x27D4EB2F165667C5ull,
                    0x85EBCA77C2B2AE63ull, 0xD6E8FEB86659FD93ull, 0xA0761D6478BD642Full, 0xE7037ED1A0B428DBull};
-  auto mark = [](double *w) {
-    if (w[0] == 0.0 && w[1] == 0.0 && w[2] == 0.0 && w[3] == 0.0) w[0] = w[1] = w[2] = w[3] = NAN;
-  };
   size_t i = 0;
   for (; i + L <= words; i += L) {
-    if (MARK) { mark(reinterpret_cast<double *>(b) + i); mark(reinterpret_cast<double *>(b) + i + 4); }
     uint64_t w[L];
     std::memcpy(w, b + 8 * i, 8 * L);
     for (int k = 0; k < L; k++) { h[k] = (h[k] ^ w[k]) * 0x9FB21C651E98DF25ull; h[k] ^= h[k] >> 29; }
   }
-  if (MARK && i < words) mark(reinterpret_cast<double *>(b) + i);  // (a run of whole rows: at most one row is left)
   for (; i < words; i++) { uint64_t w; std::memcpy(&w, b + 8 * i, 8); h[i % L] = (h[i % L] ^ w) * 0x9FB21C651E98DF25ull; h[i % L] ^= h[i % L] >> 29; }
   for (size_t t = 8 * words; t < bytes; t++) h[0] = (h[0] ^ b[t]) * 0x100000001B3ull;
   uint64_t r = h[0];
@@ -274,187 +271,128 @@ uint64_t hash_run(unsigned char *b, size_t bytes, uint64_t salt) {
   return r;
 }
 
-// the whole content: one run, or kHashParts runs (split at multiples of 64 bytes -- whole bs_value rows) combined in order.
-// PendingHash: the parts are on the pool's workers; get() takes what is left, waits and combines (the caller may have
-// done something else in between: upload_reference hashes the points while they cross PCIe)
-struct PendingHash {
-  uint64_t h[kHashParts] = {};
-  uint64_t direct = 0;
-  bool pooled = false;
-  uint64_t get() {
-    uint64_t r = direct;
-    if (pooled) {
-      HashPool::get().finish();
-      pooled = false;
-      r = h[0];
-      for (int p = 1; p < kHashParts; p++) r = (r ^ h[p]) * 0xFF51AFD7ED558CCDull + p;
-      r ^= r >> 32;
-    }
-    return r ? r : 2;
-  }
-};
-void background_drain();
-template <bool MARK>
-void hash_bytes_begin(unsigned char *b, size_t bytes, PendingHash *ph) {
-  background_drain();
-  if (bytes < kHashParallelBytes) { ph->direct = hash_run<MARK>(b, bytes, bytes); ph->pooled = false; return; }
-  const size_t part = (bytes / kHashParts) & ~(size_t)63;
-  ph->pooled = true;
-  HashPool::get().start(kHashParts, [b, bytes, part, ph](int p) {
-    const size_t lo = part * p, hi = p == kHashParts - 1 ? bytes : part * (p + 1);
-    ph->h[p] = hash_run<MARK>(b + lo, hi - lo, bytes + p);
-  });
+// slice s of a buffer of `bytes` bytes: [lo, hi), split at multiples of 64 bytes (whole bs_value rows); the last slice
+// takes the remainder (a buffer below 1 KB is its last slice alone)
+inline void slice_range(size_t bytes, int s, size_t *lo, size_t *hi) {
+  const size_t part = (bytes / kSlices) & ~(size_t)63;
+  *lo = part * (size_t)s;
+  *hi = s == kSlices - 1 ? bytes : part * (size_t)(s + 1);
 }
-template <bool MARK>
-uint64_t hash_bytes(unsigned char *b, size_t bytes) {
-  PendingHash ph;
-  hash_bytes_begin<MARK>(b, bytes, &ph);
-  return ph.get();
+inline uint64_t combine_slices(const uint64_t *h) {
+  uint64_t r = h[0];
+  for (int p = 1; p < kSlices; p++) r = (r ^ h[p]) * 0xFF51AFD7ED558CCDull + p;
+  r ^= r >> 32;
+  return r ? r : 2;
 }
 
-template <typename T>
-uint64_t full_hash(const T *a, size_t n) {
-  if (!a) return 1;
-  return hash_bytes<false>(reinterpret_cast<unsigned char *>(const_cast<T *>(a)), n * sizeof(T));
-}
-
-// Several buffers in ONE pooled job (the per-call verification of the default mode: four buffers, sixteen parts): each
-// buffer's value is exactly what full_hash gives for it alone (same partition, same combination).
-struct HashReq {
-  const void *data = nullptr;
-  size_t bytes = 0;
-  uint64_t result = 0;
-};
-class ManyHash {
+// Slices [first, first + count) (mod kSlices) of up to four buffers as ONE pooled job: begin() hands the parts to the
+// workers and returns, end() takes what is left, waits, and leaves every requested slice's hash in out[buffer][slice].
+// Both are called inside one operator call.
+class SliceHasher {
  public:
-  // begin(): the parts go to the pool's workers and the call returns; ready(): the workers have done them all;
-  // end(): take what is left, wait, combine -- results in req[].result
-  void begin(const HashReq *reqs, int n) {
+  struct Req { const void *data = nullptr; size_t bytes = 0; };
+  void begin(const Req *reqs, int n, int first, int count) {
     parts_.clear();
-    n_ = n;
-    for (int r = 0; r < n; r++) req[r] = reqs[r];
-    h_.assign((size_t)n * kHashParts, 0);
-    for (int r = 0; r < n; r++) {
-      unsigned char *b = static_cast<unsigned char *>(const_cast<void *>(req[r].data));
-      const size_t bytes = req[r].bytes;
+    for (int r = 0; r < n && r < 4; r++) {
+      const unsigned char *b = static_cast<const unsigned char *>(reqs[r].data);
       if (!b) continue;
-      if (bytes < kHashParallelBytes) { parts_.push_back({r, -1, b, bytes, bytes}); continue; }
-      const size_t part = (bytes / kHashParts) & ~(size_t)63;
-      for (int p = 0; p < kHashParts; p++) {
-        const size_t lo = part * p, hi = p == kHashParts - 1 ? bytes : part * (p + 1);
-        parts_.push_back({r, p, b + lo, hi - lo, bytes + p});
+      for (int c = 0; c < count && c < kSlices; c++) {
+        const int s = (first + c) % kSlices;
+        size_t lo, hi;
+        slice_range(reqs[r].bytes, s, &lo, &hi);
+        parts_.push_back({b + lo, hi - lo, (uint64_t)reqs[r].bytes + (uint64_t)s, &out[r][s]});
       }
     }
+    running_ = true;
     HashPool::get().start((int)parts_.size(), [this](int k) {
       const Part &pt = parts_[(size_t)k];
-      h_[(size_t)pt.req * kHashParts + (pt.idx < 0 ? 0 : pt.idx)] = hash_run<false>(pt.b, pt.bytes, pt.salt);
+      *pt.out = hash_run(pt.b, pt.bytes, pt.salt);
     });
-    running_ = true;
   }
   bool running() const { return running_; }
-  bool ready() { return running_ && HashPool::get().done_by_workers(); }
   void end() {
     if (!running_) return;
     HashPool::get().finish();
     running_ = false;
-    for (int r = 0; r < n_; r++) {
-      if (!req[r].data) { req[r].result = 1; continue; }
-      uint64_t v = h_[(size_t)r * kHashParts];
-      if (req[r].bytes >= kHashParallelBytes) {
-        for (int p = 1; p < kHashParts; p++) v = (v ^ h_[(size_t)r * kHashParts + p]) * 0xFF51AFD7ED558CCDull + p;
-        v ^= v >> 32;
-      }
-      req[r].result = v ? v : 2;
-    }
   }
-  HashReq req[4];
+  uint64_t out[4][kSlices] = {};
 
  private:
-  struct Part { int req, idx; unsigned char *b; size_t bytes; uint64_t salt; };
+  struct Part { const unsigned char *b; size_t bytes; uint64_t salt; uint64_t *out; };
   std::vector<Part> parts_;
-  std::vector<uint64_t> h_;
-  int n_ = 0;
   bool running_ = false;
 };
 
-// The BACKGROUND verification (the default mode): the full hashes of the four big buffers, taken by the pool's workers
-// while the caller carries on; looked at by the next CudaComputeH call that finds them ready.  What they are compared
-// with is what the keys held when the verification STARTED; an upload in between (`epoch`) makes the result moot.
-struct Background {
-  ManyHash mh;
-  const void *addr[4] = {nullptr, nullptr, nullptr, nullptr};
-  size_t n[4] = {0, 0, 0, 0};
-  uint64_t expect[4] = {0, 0, 0, 0};
-  bool have[4] = {false, false, false, false};
-  unsigned long epoch = 0;
-  bool finished = false;  // its results wait to be looked at
-  std::chrono::steady_clock::time_point last_end{};
-} g_bg;
-// between two verifications: what the workers take of the caller's cores and memory bandwidth (back to back they slowed a
-// loop of CudaComputeH calls by 60 %: profiles/r05_pair_setup.txt); a change in place is reported within this + ~0.4 ms
-constexpr std::chrono::microseconds kBackgroundPause(2000);
-
-// every SYNCHRONOUS use of the pool first lets a background verification end (it holds the pool until then)
-void background_drain() {
-  if (g_bg.mh.running()) {
-    g_bg.mh.end();
-    g_bg.finished = true;
-    g_bg.last_end = std::chrono::steady_clock::now();
+// the whole content of one big buffer into its key (all slices, on the pool); begin / end so that the caller can do
+// something else in between (upload_reference hashes the points while they cross PCIe)
+struct FullHash {
+  SliceHasher sh;
+  void begin(const void *data, size_t bytes) { SliceHasher::Req r; r.data = data; r.bytes = bytes; sh.begin(&r, 1, 0, kSlices); }
+  void end(LegacyState::Key *k) {
+    sh.end();
+    std::memcpy(k->slice, sh.out[0], sizeof(k->slice));
+    k->full = combine_slices(k->slice);
+    k->full_known = true;
   }
-}
-
-void hash_many(HashReq *reqs, int n) {
-  background_drain();
-  ManyHash m;
-  m.begin(reqs, n);
-  m.end();
-  for (int r = 0; r < n; r++) reqs[r].result = m.req[r].result;
-}
-
-// Does the caller's buffer still hold what is resident?  Updates the key; `force`: recompute the full hash even if
-// address, length and the quick fingerprint are unchanged (`pre`: that hash, if the caller has taken it already).
+};
 template <typename T>
-bool same_content(LegacyState::Key &k, const T *a, size_t n, bool force, const uint64_t *pre = nullptr) {
+void full_hash_into(LegacyState::Key *k, const T *a, size_t n) {
+  if (!a) { std::memset(k->slice, 0, sizeof(k->slice)); k->full = 1; k->full_known = true; return; }
+  FullHash f;
+  f.begin(a, n * sizeof(T));
+  f.end(k);
+}
+// the small per-cell arrays: one run, on the caller
+template <typename T>
+uint64_t small_hash(const T *a, size_t n) {
+  if (!a) return 1;
+  const uint64_t r = hash_run(reinterpret_cast<const unsigned char *>(a), n * sizeof(T), n * sizeof(T));
+  return r ? r : 2;
+}
+
+// Does the caller's big buffer still hold what is resident?  Updates the key; `force`: recompute the hashes even if
+// address, length and the quick fingerprint are unchanged.  *hashed: the key's hashes were taken by this call.
+template <typename T>
+bool same_content(LegacyState::Key &k, const T *a, size_t n, bool force, bool *hashed) {
   const uint64_t q = fingerprint(a, n);
   const bool cheap_same = k.valid && k.addr == (const void *)a && k.n == n && k.quick == q;
   if (cheap_same && !force) return true;
-  const uint64_t f = pre ? *pre : full_hash(a, n);
-  // a key whose full hash was never taken (trusted mode: CudaComputeHref's bs_value) is completed by its first full
-  // check; in the default mode a key without one counts as "changed"
-  bool same = k.valid && k.n == n && k.full_known && k.full == f;
+  LegacyState::Key now;
+  full_hash_into(&now, a, n);
+  if (hashed) *hashed = true;
+  // a key whose hashes were never taken (trusted mode: CudaComputeHref's bs_value) is completed by its first full
+  // check; in the default mode a key without them counts as "changed"
+  bool same = k.valid && k.n == n && k.full_known && k.full == now.full;
   if (cheap_same && !k.full_known && trust_buffers()) same = true;
-  k.addr = a; k.n = n; k.quick = q; k.full = f; k.valid = true; k.full_known = true;
+  now.addr = a; now.n = n; now.quick = q; now.valid = true;
+  k = now;
   return same;
 }
 template <typename T>
+bool same_small(LegacyState::Key &k, const T *a, size_t n) {
+  const uint64_t f = small_hash(a, n);
+  const bool same = k.valid && k.addr == (const void *)a && k.n == n && k.full == f;
+  k.addr = a; k.n = n; k.quick = 0; k.full = f; k.valid = true; k.full_known = true;
+  return same;
+}
+template <typename T>
+void remember_small(LegacyState::Key &k, const T *a, size_t n) { (void)same_small(k, a, n); }
+template <typename T>
 void remember(LegacyState::Key &k, const T *a, size_t n) {
-  k.addr = a; k.n = n; k.quick = fingerprint(a, n); k.full = full_hash(a, n); k.valid = true; k.full_known = true;
+  full_hash_into(&k, a, n);
+  k.addr = a; k.n = n; k.quick = fingerprint(a, n); k.valid = true;
 }
 
 bool to_u8(const double *im, size_t n, std::vector<uint8_t> *out);
-// An f64 image carrying u8 values (NID_pose_estimation.cpp:245-251).  Its key's `full` hash is that of the CONVERTED image
-// -- the conversion checks every value (an integer in [0, 255] or the call fails), so the u8 image determines the
-// buffer's content, and the conversion is needed for the upload anyway; in the default mode the key also carries the
-// hash of the caller's f64 bytes (`raw`), which is what a per-call verification compares (no conversion while nothing
-// changes; `pre_raw`: that hash, if the caller has taken it already).  `have`: something is resident to compare with.
-// On return *same says whether the resident image can stay; u8 holds the converted image whenever the conversion ran.
+// An f64 image carrying u8 values (NID_pose_estimation.cpp:245-251), keyed like every big buffer on the caller's f64
+// bytes.  `have`: something is resident to compare with.  On return *same says whether the resident image can stay; u8
+// holds the converted image (the conversion checks every value: an integer in [0, 255] or the call fails) when it cannot.
 int check_image(LegacyState::Key &k, const double *im, size_t n, bool force, bool have, std::vector<uint8_t> *u8, bool *same,
-                const uint64_t *pre_raw = nullptr) {
-  const uint64_t q = fingerprint(im, n);
+                bool *hashed) {
   u8->clear();
-  const bool cheap_same = have && k.valid && k.addr == (const void *)im && k.n == n && k.quick == q;
-  if (cheap_same && !force) { *same = true; return NID_OK; }
-  const bool keep_raw = !trust_buffers();
-  uint64_t raw = 0;
-  if (keep_raw) {
-    raw = pre_raw ? *pre_raw : full_hash(im, n);
-    if (cheap_same && k.raw_known && k.raw == raw) { *same = true; return NID_OK; }
-  }
-  if (!to_u8(im, n, u8)) return NID_ERR_UNSUPPORTED;
-  const uint64_t f = full_hash(u8->data(), n);
-  *same = have && k.valid && k.n == n && k.full == f;
-  k.addr = im; k.n = n; k.quick = q; k.full = f; k.valid = true; k.full_known = true;
-  k.raw = raw; k.raw_known = keep_raw;
+  *same = same_content(k, im, n, force || !have, hashed) && have;
+  if (*same) return NID_OK;
+  if (!to_u8(im, n, u8)) { k.valid = false; return NID_ERR_UNSUPPORTED; }
   return NID_OK;
 }
 
@@ -513,36 +451,38 @@ int upload_reference(LegacyState &S, const double *im0, const double *points3d, 
   std::vector<uint8_t> local;
   if (!im || im->empty()) {
     bool dummy;
-    int rc = check_image(S.k_im0, im0, N, true, false, &local, &dummy);
+    int rc = check_image(S.k_im0, im0, N, true, false, &local, &dummy, nullptr);
     if (rc != NID_OK) return rc;
     im = &local;
   }
   // the points' content key is taken WHILE they cross PCIe (7.4 MB at 640x480: 0.2 ms on the pool's threads, hidden)
-  PendingHash ph;
-  if (!points_keyed) hash_bytes_begin<false>(reinterpret_cast<unsigned char *>(const_cast<double *>(points3d)), 3 * N * sizeof(double), &ph);
+  FullHash fh;
+  if (!points_keyed) fh.begin(points3d, 3 * N * sizeof(double));
   int rc = nid_multi_set_reference_points(S.m, points3d, im->data());
   if (!points_keyed) {
-    const uint64_t f = ph.get();  // (on every path: the pool is held until then)
-    if (rc == NID_OK) { S.k_points.addr = points3d; S.k_points.n = 3 * N; S.k_points.quick = fingerprint(points3d, 3 * N); S.k_points.full = f; S.k_points.valid = true; S.k_points.full_known = true; }
+    LegacyState::Key k;
+    fh.end(&k);  // (on every path: the pool is held until then)
+    k.addr = points3d; k.n = 3 * N; k.quick = fingerprint(points3d, 3 * N); k.valid = true;
+    if (rc == NID_OK) S.k_points = k;
   }
   if (rc != NID_OK) return rc;
   S.have_ref = true; S.have_href = false;
-  S.epoch++;
+  S.fresh |= NID_LEGACY_REFERENCE;
   g_uploads++;
   return NID_OK;
 }
 
-int ensure_reference(LegacyState &S, const double *im0, const double *points3d, bool force, const uint64_t *pre_im0 = nullptr,
-                     const uint64_t *pre_points = nullptr) {
+int ensure_reference(LegacyState &S, const double *im0, const double *points3d, bool force) {
   const size_t N = (size_t)S.rows * S.cols;
   std::vector<uint8_t> im;
   bool points_keyed = false;
   if (S.have_ref && !always_upload()) {
-    bool a = false;
-    int rc = check_image(S.k_im0, im0, N, force, true, &im, &a, pre_im0);
+    bool a = false, hashed_a = false, hashed_b = false;
+    int rc = check_image(S.k_im0, im0, N, force, true, &im, &a, &hashed_a);
     if (rc != NID_OK) return rc;
-    const bool b = same_content(S.k_points, points3d, 3 * N, force, pre_points);
+    const bool b = same_content(S.k_points, points3d, 3 * N, force, &hashed_b);
     points_keyed = true;
+    if (hashed_a && hashed_b) S.fresh |= NID_LEGACY_REFERENCE;
     if (a && b) return NID_OK;
   }
   return upload_reference(S, im0, points3d, &im, points_keyed);
@@ -553,8 +493,6 @@ int ensure_reference(LegacyState &S, const double *im0, const double *points3d, 
 void Calculate3Dpoint(double *depth, double *pose_c2w, double *points_3d, double *camera_intrincis, int rows,
                       int cols) {
   StepTrace tr("Calculate3Dpoint");
-  background_drain();       // (points_3d may be the buffer a verification is reading)
-  g_bg.finished = false;
   int rc = nid_backproject(depth, pose_c2w, camera_intrincis[0], camera_intrincis[1], camera_intrincis[2],
                            camera_intrincis[3], rows, cols, g_devices[0], points_3d);
   if (rc != NID_OK) report("Calculate3Dpoint", rc, nullptr);
@@ -565,8 +503,6 @@ void CudaComputeHref(double *im0, double *points3d, double *pose, double *camera
                      int bs_degree, int cell_num, int rows, int cols, double *bs_value, int *bs_index,
                      int *bs_counter, double *Href) {
   StepTrace tr("CudaComputeHref");
-  background_drain();       // (a verification of the previous pair's buffers: over before this pair's are written)
-  g_bg.finished = false;
   nid_multi *m = get_multi(rows, cols, cell_num, bin_num, bs_degree, camera_intrincis);
   if (!m) return;
   tr.step("context (created or reused)");
@@ -596,29 +532,41 @@ void CudaComputeHref(double *im0, double *points3d, double *pose, double *camera
   }
   // the device already holds these weights (CPU-edge convention: 0 instead of NaN)
   S.have_href = true;
-  S.calls = 0;  // (the trusted mode's periodic full check counts the calls of THIS pair)
+  S.calls = 0;  // (the rotation / the trusted mode's periodic full check count the calls of THIS pair)
   if (bs_value && !trust_buffers()) {
-    // default mode: every CudaComputeH call compares the caller's bs_ref with this hash (9.8 MB at 640x480, on the pool).
-    // (The legacy NaN rows, CudaComputeHref.cu:82-87, 126-130, were written on the device: nid_set_href_nan_markers.)
+    // default mode: the CudaComputeH calls compare the caller's bs_ref, slice by slice, with these hashes (9.8 MB at
+    // 640x480, on the pool).  (The legacy NaN rows, CudaComputeHref.cu:82-87, 126-130, were written on the device:
+    // nid_set_href_nan_markers.)
     remember(S.k_bs_ref, bs_value, 4 * N);
   } else if (bs_value) {
     // trusted buffers: address, length and the sampled fingerprint now and NO full hash (0.25 ms even on the pool); the
     // first full check that reaches the key -- the kRehashEvery-th call of the pair, nid_legacy_invalidate -- takes it.
+    S.k_bs_ref = LegacyState::Key();
     S.k_bs_ref.addr = bs_value; S.k_bs_ref.n = 4 * N; S.k_bs_ref.full = 0; S.k_bs_ref.full_known = false;
     S.k_bs_ref.quick = fingerprint(bs_value, 4 * N); S.k_bs_ref.valid = true;
   } else {
     remember(S.k_bs_ref, bs_value, 0);
   }
-  tr.step("content key of bs_value (default: full hash; trusted: fingerprint)");
-  remember(S.k_counter, bs_counter, (size_t)ncell);
-  remember(S.k_href, Href, (size_t)ncell);
+  tr.step("content key of bs_value (default: slice hashes; trusted: fingerprint)");
+  remember_small(S.k_counter, bs_counter, (size_t)ncell);
+  remember_small(S.k_href, Href, (size_t)ncell);
   tr.step("content keys of the per-cell outputs");
 }
 
 namespace {
-nid_multi *ensure_state(double *im0, double *im1, double *points3d, int *bs_counter, double *bs_ref, int *bs_index_ref,
-                        double *camera_intrincis, int bin_num, int bs_degree, int cell_num, int rows, int cols,
-                        double *Href);
+struct CallArgs {
+  double *im0, *im1, *points3d;
+  int *bs_counter;
+  double *bs_ref;
+  int *bs_index_ref;
+  double *camera_intrincis;
+  int bin_num, bs_degree, cell_num, rows, cols;
+  double *Href;
+};
+nid_multi *ensure_state(const CallArgs &a);
+void verify_begin(const CallArgs &a);
+unsigned verify_end(const CallArgs &a);
+nid_multi *follow_change(const CallArgs &a, unsigned stale);
 }
 
 namespace g2o {
@@ -628,13 +576,24 @@ void CudaComputeH(bool calculate_der, double *im0, double *im1, double *points3d
                   int cell_num, int rows, int cols, double *Href, double *pro_target, double *pro_joint,
                   double *Htarget, double *Hjoint, double *der) {
   (void)pro_target; (void)pro_joint;  // accepted, never read or written (computeH.cu:373-502)
-  nid_multi *m = ensure_state(im0, im1, points3d, bs_counter, bs_ref, bs_index_ref, camera_intrincis, bin_num, bs_degree,
-                              cell_num, rows, cols, Href);
+  const CallArgs a = {im0, im1, points3d, bs_counter, bs_ref, bs_index_ref, camera_intrincis, bin_num, bs_degree, cell_num, rows, cols, Href};
+  nid_multi *m = ensure_state(a);
   if (!m) return;
   const int ncell = cell_num * cell_num;
   std::vector<double> ht(ncell), hj(ncell);
+  // this call's slices of the caller's buffers are hashed by the pool's workers WHILE the device evaluates ...
+  verify_begin(a);
   int rc = nid_multi_evaluate_matrix(m, pose, calculate_der ? 1 : 0, ht.data(), hj.data(), nullptr, calculate_der ? der : nullptr);
+  // ... and the workers are joined here, on every path: no read of a caller buffer outlives the call
+  const unsigned stale = verify_end(a);
   if (rc != NID_OK) { report("CudaComputeH", rc, m); return; }
+  if (stale) {
+    // a buffer rewritten in place: what was just evaluated may be its old content -- upload what differs, evaluate again
+    m = follow_change(a, stale);
+    if (!m) return;
+    rc = nid_multi_evaluate_matrix(m, pose, calculate_der ? 1 : 0, ht.data(), hj.data(), nullptr, calculate_der ? der : nullptr);
+    if (rc != NID_OK) { report("CudaComputeH", rc, m); return; }
+  }
   for (int c = 0; c < ncell; c++) {
     // CalculateHKernel: NaN for bs_counter < 300, else `-=` onto the caller's (zeroed) value
     Htarget[c] = std::isnan(ht[c]) ? NAN : Htarget[c] + ht[c];
@@ -647,78 +606,35 @@ void CudaComputeH(bool calculate_der, double *im0, double *im1, double *points3d
 namespace {
 
 // Everything CudaComputeH does before its kernels: the frame-pair state on the device(s), keyed on content.
-nid_multi *ensure_state(double *im0, double *im1, double *points3d, int *bs_counter, double *bs_ref, int *bs_index_ref,
-                        double *camera_intrincis, int bin_num, int bs_degree, int cell_num, int rows, int cols,
-                        double *Href) {
-  nid_multi *m = get_multi(rows, cols, cell_num, bin_num, bs_degree, camera_intrincis);
+nid_multi *ensure_state(const CallArgs &a) {
+  nid_multi *m = get_multi(a.rows, a.cols, a.cell_num, a.bin_num, a.bs_degree, a.camera_intrincis);
   if (!m) return nullptr;
   LegacyState &S = g_state;
-  const size_t N = (size_t)rows * cols;
-  const int ncell = cell_num * cell_num;
+  const size_t N = (size_t)a.rows * a.cols;
+  const int ncell = a.cell_num * a.cell_num;
   const bool first_of_pair = !S.have_target;
   StepTrace tr("CudaComputeH state check");
   tr.on = tr.on && first_of_pair;  // (every later call of a pair takes about a microsecond: not traced)
-  // The full hashes.  Default: on every call, all four big buffers in one pooled job (the caller's bytes are read on every
-  // call, like the reference's uploads).  Trusted buffers: whenever a key's cheap part changed (same_content), on every
-  // kRehashEvery-th call of the pair, after an invalidate.
+  // Full hashes: whenever a key's cheap part changed (same_content), after an invalidate, and with trusted buffers on
+  // every kRehashEvery-th call of the pair.  The default mode's per-call slices: verify_begin / verify_end.
   S.calls++;
-  const int mode = always_upload() ? (int)NID_LEGACY_VERIFY_TRUSTED : verify_mode();
-  const bool verify = mode == NID_LEGACY_VERIFY_EVERY_CALL;
-  const bool periodic = verify || (mode == NID_LEGACY_VERIFY_TRUSTED && S.calls % kRehashEvery == 0);
-  unsigned force = S.force_full;
+  S.fresh = 0;
+  const bool periodic = (trust_buffers() || always_upload()) && S.calls % kRehashEvery == 0;
+  const unsigned force = S.force_full;
   S.force_full = 0;
-  // BACKGROUND: a verification the workers have finished is looked at now.  A buffer whose content no longer hashes to
-  // what its key held when the verification started -- same address, same length, no upload in between -- was rewritten
-  // in place: said loudly, counted, and followed (its part takes the full check below, i.e. it is uploaded).
-  if (mode == NID_LEGACY_VERIFY_BACKGROUND) {
-    if (g_bg.mh.running() && (g_bg.mh.ready() || !HashPool::get().has_workers())) background_drain();
-    if (g_bg.finished) {
-      g_bg.finished = false;
-      if (g_bg.epoch == S.epoch) {
-        const void *now_addr[4] = {im0, points3d, im1, bs_ref};
-        const size_t now_n[4] = {N, 3 * N, N, 4 * N};
-        static const char *what[4] = {"im0", "points3d", "im1", "bs_ref"};
-        static const unsigned part[4] = {NID_LEGACY_REFERENCE, NID_LEGACY_REFERENCE, NID_LEGACY_TARGET, NID_LEGACY_HREF_STATE};
-        for (int k = 0; k < 4; k++)
-          if (g_bg.have[k] && g_bg.addr[k] == now_addr[k] && g_bg.n[k] == now_n[k] && g_bg.mh.req[k].result != g_bg.expect[k] && !(force & part[k])) {
-            std::fprintf(stderr, "[nid legacy] the caller's %s buffer was rewritten IN PLACE between two CudaComputeH calls (found by the background "
-                                 "verification): calls since then may have evaluated its old content; uploading the new content now.  "
-                                 "nid_legacy_invalidate() announces such a change, nid_legacy_set_verify_mode(NID_LEGACY_VERIFY_EVERY_CALL) checks every call.\n", what[k]);
-            force |= part[k];
-            g_stale_detections++;
-          }
-      }
-    }
-  } else {
-    background_drain();
-    g_bg.finished = false;
-  }
-  uint64_t pre[4] = {0, 0, 0, 0};
-  const bool have_pre = verify && S.have_ref && S.have_target && S.have_href;
-  if (have_pre) {
-    HashReq req[4];
-    req[0].data = im0; req[0].bytes = N * sizeof(double);
-    req[1].data = points3d; req[1].bytes = 3 * N * sizeof(double);
-    req[2].data = im1; req[2].bytes = N * sizeof(double);
-    req[3].data = bs_ref; req[3].bytes = 4 * N * sizeof(double);
-    hash_many(req, 4);
-    for (int k = 0; k < 4; k++) pre[k] = req[k].result;
-    tr.on = tr.on || (StepTrace("").on && S.calls == 2);  // (traced once per pair: the second call is the first that only verifies)
-    tr.step("per-call verification: full hashes of im0, points3d, im1, bs_ref");
-  }
-  int rc = ensure_reference(S, im0, points3d, periodic || (force & NID_LEGACY_REFERENCE), have_pre ? &pre[0] : nullptr, have_pre ? &pre[1] : nullptr);
+  int rc = ensure_reference(S, a.im0, a.points3d, periodic || (force & NID_LEGACY_REFERENCE));
   if (rc != NID_OK) { report("CudaComputeH(reference upload)", rc, m); return nullptr; }
   {
     std::vector<uint8_t> im;
-    bool same = false;
+    bool same = false, hashed = false;
     const bool have = S.have_target && !always_upload();
-    rc = check_image(S.k_im1, im1, N, periodic || (force & NID_LEGACY_TARGET), have, &im, &same, have_pre ? &pre[2] : nullptr);
+    rc = check_image(S.k_im1, a.im1, N, periodic || (force & NID_LEGACY_TARGET), have, &im, &same, &hashed);
     if (rc != NID_OK) { report("CudaComputeH(im1 is not u8-valued)", rc, m); return nullptr; }
+    if (hashed) S.fresh |= NID_LEGACY_TARGET;
     if (!same) {
       rc = nid_multi_set_target_u8(m, im.data());
-      if (rc != NID_OK) { report("CudaComputeH(target upload)", rc, m); return nullptr; }
+      if (rc != NID_OK) { report("CudaComputeH(target upload)", rc, m); S.k_im1.valid = false; return nullptr; }
       S.have_target = true;
-      S.epoch++;
       g_uploads++;
     }
   }
@@ -728,44 +644,89 @@ nid_multi *ensure_state(double *im0, double *im1, double *points3d, int *bs_coun
   // that brings one replaces them: Href is part of the key.  The per-cell arrays are small: full hashes every call.
   const bool fh = periodic || (force & NID_LEGACY_HREF_STATE);
   bool same = S.have_href && !always_upload();
+  bool keyed = false;  // bs_ref's slice hashes were taken by this call
   if (same) {
-    const bool a = same_content(S.k_bs_ref, bs_ref, 4 * N, fh, have_pre ? &pre[3] : nullptr), b = same_content(S.k_counter, bs_counter, (size_t)ncell, true);
-    const bool c = !Href || same_content(S.k_href, Href, (size_t)ncell, true);
-    same = a && b && c;
+    const bool x = same_content(S.k_bs_ref, a.bs_ref, 4 * N, fh, &keyed), y = same_small(S.k_counter, a.bs_counter, (size_t)ncell);
+    const bool z = !a.Href || same_small(S.k_href, a.Href, (size_t)ncell);
+    if (keyed) S.fresh |= NID_LEGACY_HREF_STATE;
+    same = x && y && z;
   }
   if (!same) {
     std::vector<double> href(ncell, 0.0);
-    if (Href) for (int c = 0; c < ncell; c++) href[c] = Href[c];
-    rc = nid_multi_set_href_state(m, bs_counter, href.data(), bs_ref, bs_index_ref);
+    if (a.Href) for (int c = 0; c < ncell; c++) href[c] = a.Href[c];
+    rc = nid_multi_set_href_state(m, a.bs_counter, href.data(), a.bs_ref, a.bs_index_ref);
     if (rc != NID_OK) { report("CudaComputeH(href state upload)", rc, m); return nullptr; }
-    remember(S.k_bs_ref, bs_ref, 4 * N); remember(S.k_counter, bs_counter, (size_t)ncell);
-    if (Href) remember(S.k_href, Href, (size_t)ncell); else S.k_href = LegacyState::Key();
+    if (!keyed) remember(S.k_bs_ref, a.bs_ref, 4 * N);
+    remember_small(S.k_counter, a.bs_counter, (size_t)ncell);
+    if (a.Href) remember_small(S.k_href, a.Href, (size_t)ncell); else S.k_href = LegacyState::Key();
     S.have_href = true;
-    S.epoch++;
+    S.fresh |= NID_LEGACY_HREF_STATE;
     g_uploads++;
   }
   tr.step("href state keys checked");
-  // BACKGROUND: start the next verification (one at a time, with a pause between two) against what the keys hold NOW
-  // (not by a pair's first call: everything was hashed or uploaded by this very call, and a caller that continues on the
-  // nid_multi_* interface -- nid_legacy_prepare: g2o_min's fused flows -- never comes back to look at the result)
-  if (mode == NID_LEGACY_VERIFY_BACKGROUND && !first_of_pair && !g_bg.mh.running() && !g_bg.finished && HashPool::get().has_workers() &&
-      std::chrono::steady_clock::now() - g_bg.last_end > kBackgroundPause) {
-    HashReq req[4];
-    const void *addr[4] = {im0, points3d, im1, bs_ref};
-    const size_t cnt[4] = {N, 3 * N, N, 4 * N};
-    const LegacyState::Key *key[4] = {&S.k_im0, &S.k_points, &S.k_im1, &S.k_bs_ref};
-    for (int k = 0; k < 4; k++) {
-      const bool image = k == 0 || k == 2;
-      g_bg.have[k] = key[k]->valid && key[k]->addr == addr[k] && key[k]->n == cnt[k] && (image ? key[k]->raw_known : key[k]->full_known);
-      g_bg.addr[k] = addr[k]; g_bg.n[k] = cnt[k];
-      g_bg.expect[k] = image ? key[k]->raw : key[k]->full;
-      req[k].data = g_bg.have[k] ? addr[k] : nullptr;
-      req[k].bytes = cnt[k] * sizeof(double);
-    }
-    g_bg.epoch = S.epoch;
-    g_bg.mh.begin(req, 4);
-  }
   return m;
+}
+
+// The default mode's verification of ONE call: slices [calls * k, calls * k + k) mod kSlices of im0, points3d, im1 and
+// bs_ref -- those whose keys this very call has not just taken -- go to the pool's workers (verify_begin, right before the
+// evaluation is launched); verify_end joins them and returns the parts (NID_LEGACY_*) whose slice no longer hashes to the
+// key's value.  Both inside the operator: the caller's buffers are not read once it has returned.
+SliceHasher g_verify;
+struct VerifyPlan { const LegacyState::Key *key[4]; const void *addr[4]; size_t n[4]; bool on[4]; int first, count; } g_plan;
+
+void verify_begin(const CallArgs &a) {
+  LegacyState &S = g_state;
+  const int k = always_upload() ? 0 : slices_per_call();
+  if (k <= 0) return;
+  const size_t N = (size_t)a.rows * a.cols;
+  static const unsigned part[4] = {NID_LEGACY_REFERENCE, NID_LEGACY_REFERENCE, NID_LEGACY_TARGET, NID_LEGACY_HREF_STATE};
+  const LegacyState::Key *key[4] = {&S.k_im0, &S.k_points, &S.k_im1, &S.k_bs_ref};
+  const void *addr[4] = {a.im0, a.points3d, a.im1, a.bs_ref};
+  const size_t cnt[4] = {N, 3 * N, N, 4 * N};
+  SliceHasher::Req req[4];
+  bool any = false;
+  for (int b = 0; b < 4; b++) {
+    g_plan.key[b] = key[b]; g_plan.addr[b] = addr[b]; g_plan.n[b] = cnt[b];
+    g_plan.on[b] = !(S.fresh & part[b]) && key[b]->valid && key[b]->full_known && key[b]->addr == addr[b] && key[b]->n == cnt[b] && addr[b];
+    req[b].data = g_plan.on[b] ? addr[b] : nullptr;
+    req[b].bytes = cnt[b] * sizeof(double);
+    any = any || g_plan.on[b];
+  }
+  if (!any) return;
+  g_plan.count = k;
+  g_plan.first = (int)((S.calls * (unsigned long)k) % kSlices);
+  g_verify.begin(req, 4, g_plan.first, g_plan.count);
+}
+
+unsigned verify_end(const CallArgs &a) {
+  (void)a;
+  if (!g_verify.running()) return 0;
+  g_verify.end();
+  static const unsigned part[4] = {NID_LEGACY_REFERENCE, NID_LEGACY_REFERENCE, NID_LEGACY_TARGET, NID_LEGACY_HREF_STATE};
+  static const char *what[4] = {"im0", "points3d", "im1", "bs_ref"};
+  unsigned stale = 0;
+  for (int b = 0; b < 4; b++) {
+    if (!g_plan.on[b]) continue;
+    for (int c = 0; c < g_plan.count; c++) {
+      const int s = (g_plan.first + c) % kSlices;
+      if (g_verify.out[b][s] == g_plan.key[b]->slice[s]) continue;
+      stale |= part[b];
+      if (g_plan.count < kSlices) {  // (every slice on every call: nothing stale was ever evaluated -- followed silently, like the reference)
+        std::fprintf(stderr, "[nid legacy] the caller's %s buffer was rewritten IN PLACE between two CudaComputeH calls (slice %d of %d no "
+                             "longer matches what is on the device): earlier calls may have evaluated its old content; uploading the new "
+                             "content and evaluating again.  nid_legacy_invalidate() announces such a change, "
+                             "nid_legacy_set_verify_mode(NID_LEGACY_VERIFY_EVERY_CALL) checks every slice on every call.\n", what[b], s, kSlices);
+        g_stale_detections++;
+      }
+      break;
+    }
+  }
+  return stale;
+}
+
+nid_multi *follow_change(const CallArgs &a, unsigned stale) {
+  g_state.force_full |= stale;
+  return ensure_state(a);
 }
 
 }  // namespace
@@ -825,31 +786,32 @@ void nid_legacy_set_rank(int device, int rank, int world, const uint8_t *rccl_id
 void nid_legacy_invalidate(unsigned parts) { g_state.force_full |= parts; }
 
 void nid_legacy_set_verify_mode(int mode) {
-  background_drain();
-  g_bg.finished = false;
-  g_verify_mode = (mode == NID_LEGACY_VERIFY_EVERY_CALL || mode == NID_LEGACY_VERIFY_TRUSTED) ? mode : (int)NID_LEGACY_VERIFY_BACKGROUND;
+  g_verify_mode = (mode == NID_LEGACY_VERIFY_EVERY_CALL || mode == NID_LEGACY_VERIFY_TRUSTED) ? mode : (int)NID_LEGACY_VERIFY_ROTATING;
 }
-void nid_legacy_set_trust_buffers(int on) { nid_legacy_set_verify_mode(on ? NID_LEGACY_VERIFY_TRUSTED : NID_LEGACY_VERIFY_BACKGROUND); }
+void nid_legacy_set_verify_slices(int per_call) { g_verify_slices = per_call < 1 ? -1 : std::min(per_call, kSlices); }
+void nid_legacy_set_trust_buffers(int on) { nid_legacy_set_verify_mode(on ? NID_LEGACY_VERIFY_TRUSTED : NID_LEGACY_VERIFY_ROTATING); }
 long nid_legacy_stale_detections(void) { return g_stale_detections; }
 
 void nid_legacy_reset(void) {
-  background_drain();  // (it reads the caller's buffers: "before the caller frees its buffers")
-  g_bg.finished = false;
   if (g_state.m) nid_multi_destroy(g_state.m);
   g_state = LegacyState();
   (void)nid_backproject_release();  // Calculate3Dpoint's scratch
 }
 
 void nid_legacy_quiesce(void) {
-  background_drain();  // (no worker reads the caller's buffers once this returns)
   if (g_state.m) (void)nid_multi_resident_pause(g_state.m);
 }
 
 nid_multi *nid_legacy_prepare(double *im0, double *im1, double *points3d, int *bs_counter, double *bs_ref,
                               int *bs_index_ref, double *camera_intrincis, int bin_num, int bs_degree, int cell_num,
                               int rows, int cols, double *Href) {
-  return ensure_state(im0, im1, points3d, bs_counter, bs_ref, bs_index_ref, camera_intrincis, bin_num, bs_degree, cell_num,
-                      rows, cols, Href);
+  const CallArgs a = {im0, im1, points3d, bs_counter, bs_ref, bs_index_ref, camera_intrincis, bin_num, bs_degree, cell_num, rows, cols, Href};
+  nid_multi *m = ensure_state(a);
+  if (!m) return nullptr;
+  // (no evaluation to overlap with: this call's slices are hashed on the spot)
+  verify_begin(a);
+  const unsigned stale = verify_end(a);
+  return stale ? follow_change(a, stale) : m;
 }
 
 nid_multi *nid_legacy_multi(void) { return g_state.m; }

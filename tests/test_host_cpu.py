@@ -73,7 +73,7 @@ def test_host_library_exports(hostlib):
     nm = subprocess.run(["nm", "-D", "--defined-only", hostlib.LIB_PATH], capture_output=True, text=True).stdout
     for sym in ("nid_host_run_lm", "nid_host_run_pyramid_lm", "nid_pyr_down_u8", "nid_pyr_down_depth_u16",
                 "nid_host_standard_property", "nid_png_info", "nid_png_read_gray_u8", "nid_png_read_u16", "nid_legacy_reset", "nid_legacy_context", "nid_legacy_upload_count",
-                "nid_legacy_set_jacobian_bound", "nid_legacy_set_trust_buffers", "nid_legacy_set_verify_mode", "nid_legacy_stale_detections", "nid_legacy_invalidate", "nid_legacy_set_devices", "nid_legacy_set_rank", "nid_legacy_multi",
+                "nid_legacy_set_jacobian_bound", "nid_legacy_set_trust_buffers", "nid_legacy_set_verify_mode", "nid_legacy_set_verify_slices", "nid_legacy_stale_detections", "nid_legacy_invalidate", "nid_legacy_set_devices", "nid_legacy_set_rank", "nid_legacy_multi",
                 "nid_host_set_devices", "nid_host_set_rank"):
         assert re.search(rf" T {sym}\b", nm), sym
     # the three legacy operators keep their C++ linkage (mangled), as in the reference
@@ -83,6 +83,75 @@ def test_host_library_exports(hostlib):
     # and the host library must not contain or link the oracle
     ldd = subprocess.run(["ldd", hostlib.LIB_PATH], capture_output=True, text=True).stdout
     assert "oracle" not in ldd and "libnid_hip.so" in ldd
+
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _build_with_stub(tmp_path, caller, name):
+    """host/legacy_ops.cpp + a caller + tests/cpp/nid_hip_stub.cpp (the entry points of libnid_hip.so the operators
+    call, without a GPU) as ONE AddressSanitizer build."""
+    exe = tmp_path / name
+    subprocess.check_call(["g++", "-fsanitize=address", "-fno-omit-frame-pointer", "-O1", "-g", "-std=c++17", "-pthread",
+                           "-I", os.path.join(ROOT, "include", "nid", "compat"), "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cpp", caller),
+                           os.path.join(ROOT, "nid-pose-estimation_amd", "host", "legacy_ops.cpp"),
+                           os.path.join(ROOT, "tests", "cpp", "nid_hip_stub.cpp"), "-o", str(exe)])
+    return exe
+
+
+@pytest.mark.parametrize("threads", ["3", "0"])
+def test_legacy_operators_read_caller_buffers_only_inside_a_call_asan(tmp_path, threads):
+    """VERDICT r05 item 1 / ADVICE r05 (high), without a GPU: the reference's call pattern (tests/cpp/legacy_lm_caller.cpp:
+    CudaComputeHref, 48 CudaComputeH calls with host work in between, one undeclared in-place change, then the frees of
+    NID_pose_estimation.cpp:388-395 at once) on host/legacy_ops.cpp under AddressSanitizer, the HIP library stubbed.  A
+    worker thread that reads a caller buffer after its call has returned is a heap-use-after-free here (round 5's
+    default mode fails this test with exactly that report).  Default verification mode; with and without pool threads."""
+    exe = _build_with_stub(tmp_path, "legacy_lm_caller.cpp", "legacy_lm_caller_asan")
+    rows, cols, cell, nb, ncalls, change_at, pause_every = 480, 640, 16, 8, 48, 21, 8
+    N, ncell = rows * cols, cell * cell
+    rng = np.random.default_rng(3)
+    change_px = (rows // cell // 2) * cols + cols // cell // 2          # inside cell 0, off the 64 sampled indices
+    assert change_px not in {int(k * (N - 1) // 63) for k in range(64)}
+    im1 = rng.integers(0, 256, N).astype(np.float64)
+    with open(tmp_path / "in.bin", "wb") as f:
+        np.array([rows, cols, cell, nb, ncalls, change_at, change_px, pause_every], dtype=np.int32).tofile(f)
+        np.array([481.2, -480.0, 319.5, 239.5, 1 / 5000.0]).tofile(f)
+        np.eye(4).reshape(-1).tofile(f)
+        np.eye(4).reshape(-1).tofile(f)
+        poses = np.tile(np.eye(4).reshape(-1), (ncalls, 1))
+        poses[:, 12] = np.arange(ncalls) * 1e-3
+        poses.tofile(f)
+        (2.0 + rng.random(N)).tofile(f)
+        rng.integers(0, 256, N).astype(np.float64).tofile(f)
+        im1.tofile(f)
+    env = dict(os.environ, NID_LEGACY_HASH_THREADS=threads, ASAN_OPTIONS="detect_leaks=0:abort_on_error=0", MALLOC_PERTURB_="165")
+    for drop in ("NID_LEGACY_TRUST_BUFFERS", "NID_LEGACY_VERIFY_EVERY_CALL", "NID_LEGACY_VERIFY_SLICES", "NID_LEGACY_ALWAYS_UPLOAD", "LD_PRELOAD"):
+        env.pop(drop, None)
+    r = subprocess.run([str(exe), str(tmp_path)], capture_output=True, text=True, timeout=300, env=env)
+    assert "AddressSanitizer" not in r.stderr and r.returncode == 0, r.stderr[-4000:]
+    assert r.stderr.count("rewritten IN PLACE") == 1, r.stderr[-2000:]
+    rec = np.fromfile(tmp_path / "out.bin", dtype=np.float64, offset=4 * ncell).reshape(ncalls, 8, ncell)
+    # the stub's "evaluation" returns per-cell sums of the RESIDENT target: which content each call evaluated
+    rb, cb = rows // cell, cols // cell
+    old0 = -im1.reshape(rows, cols)[:rb, :cb].sum()
+    new0 = old0 - (255.0 - 2 * im1[change_px])
+    ht0 = rec[:, 0, 0]
+    followed = int(np.argmax(ht0 == new0))
+    assert np.all(ht0[:change_at] == old0) and change_at <= followed < change_at + 16, (followed, ht0)
+    assert np.all(ht0[followed:] == new0) and np.all(ht0[:followed] == old0)
+    assert np.all(rec[:, 0, 1:] == rec[0, 0, 1:])                       # no other cell's target changed
+
+
+def test_fork_between_legacy_calls_asan(tmp_path):
+    """fork() after a CudaComputeH.  The hash pool's job lives inside one call, its fork handlers
+    find the locks free; the child (no worker threads) hashes alone and still follows an in-place change.  The caller
+    (tests/cpp/legacy_fork_caller.cpp) ends itself with SIGALRM if anybody hangs."""
+    exe = _build_with_stub(tmp_path, "legacy_fork_caller.cpp", "legacy_fork_caller_asan")
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0")
+    env.pop("LD_PRELOAD", None)
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120, env=env)
+    assert r.returncode == 0 and "fork ok" in r.stdout and "AddressSanitizer" not in r.stderr, (r.returncode, r.stderr[-3000:])
 
 
 def test_pyramid_downsampling_matches_oracle(hostlib, oracle):

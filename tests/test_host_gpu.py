@@ -127,6 +127,115 @@ def test_compiled_cpp_caller_of_the_legacy_operators(hostlib, oracle, synth, pai
     assert np.all(np.abs(der[act] - J_o[act]) <= 1e-9 * np.maximum(scale, 1e-6 * scale.max()))
 
 
+def _write_lm_caller_input(path, pair, nb, poses16, change_at, change_px, pause_every, pose0_16, T16):
+    with open(path, "wb") as f:
+        np.array([pair.rows, pair.cols, pair.cell, nb, len(poses16), change_at, change_px, pause_every], dtype=np.int32).tofile(f)
+        for a in (pair.intr, T16, pose0_16, np.concatenate(poses16), pair.depth_m, pair.im0.astype(np.float64), pair.im1.astype(np.float64)):
+            np.ascontiguousarray(a, dtype=np.float64).tofile(f)
+
+
+def test_reference_call_pattern_then_free_at_once(hostlib, oracle, synth, pair_A, tmp_path):
+    """VERDICT r05 item 1.  tests/cpp/legacy_lm_caller.cpp replays the reference's whole use of the operators at 640x480
+    -- Calculate3Dpoint, CudaComputeHref, 48 CudaComputeH calls in the LM's pattern (der / cost / cost / verbose cost,
+    changing poses, 3 ms of host work before every eighth), ONE undeclared in-place change of an im1 pixel that avoids
+    the sampled indices, then the frees of NID_pose_estimation.cpp:388-395 at once (7.4 and 9.8 MB blocks: free() unmaps
+    them) -- and calls nothing else: no nid_legacy_*.  In the DEFAULT mode, compiled at -O2, MALLOC_PERTURB_ set, 50
+    processes: every one exits 0 with the same bytes; the change is followed within 16 calls and reported once; before
+    it and after it the records equal what the operators give on freshly uploaded buffers, bit for bit."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pkg = os.path.join(root, "nid-pose-estimation_amd")
+    exe = tmp_path / "legacy_lm_caller"
+    subprocess.check_call(["g++", "-O2", "-std=c++14", "-pthread", "-I", os.path.join(root, "include", "nid", "compat"),
+                           "-I", os.path.join(root, "include"), os.path.join(root, "tests", "cpp", "legacy_lm_caller.cpp"),
+                           "-o", str(exe), "-L", pkg, "-lnid_host", "-lnid_hip", f"-Wl,-rpath,{pkg}"])
+    pair, nb, ncalls, change_at, pause_every = pair_A, 8, 48, 21, 8
+    N, ncell = pair.rows * pair.cols, pair.cell ** 2
+    change_px = (pair.rows // pair.cell // 2) * pair.cols + pair.cols // pair.cell // 2      # inside cell 0
+    assert change_px not in {int(k * (N - 1) // 63) for k in range(64)}
+    M_init = oracle.se3_to_matrix16(pair.pose_init)
+    poses7, poses16 = [], []
+    for k in range(ncalls):   # an LM-like walk: from the initial pose towards the true one, a new pose per call
+        w = k / (ncalls - 1.0)
+        p7 = np.array(pair.pose_init if k % 3 else pair.pose_true, dtype=np.float64).copy()
+        p7[4:7] = (1 - w) * pair.pose_init[4:7] + w * pair.pose_true[4:7]
+        poses7.append(p7)
+        poses16.append(oracle.se3_to_matrix16(p7))
+    T16 = synth.matrix_colmajor16(pair.T_wc0)
+    _write_lm_caller_input(tmp_path / "in.bin", pair, nb, poses16, change_at, change_px, pause_every, M_init, T16)
+    env = dict(os.environ, MALLOC_PERTURB_="165")
+    for drop in ("NID_LEGACY_TRUST_BUFFERS", "NID_LEGACY_VERIFY_EVERY_CALL", "NID_LEGACY_VERIFY_SLICES", "NID_LEGACY_ALWAYS_UPLOAD"):
+        env.pop(drop, None)
+    first = None
+    for run in range(50):
+        r = subprocess.run([str(exe), str(tmp_path)], capture_output=True, text=True, timeout=300, env=env)
+        assert r.returncode == 0, (run, r.returncode, r.stderr[-2000:])
+        assert r.stderr.count("rewritten IN PLACE") == 1, (run, r.stderr[-2000:])
+        out = open(tmp_path / "out.bin", "rb").read()
+        if first is None:
+            first = out
+        assert out == first, f"run {run}: another result than run 0"
+    cnt = np.frombuffer(first, dtype=np.int32, count=ncell)
+    rec = np.frombuffer(first, dtype=np.float64, offset=4 * ncell).reshape(ncalls, 8, ncell)
+
+    # what the operators give for each pose on freshly handed-over buffers, unchanged and changed target
+    lib = hostlib.load()
+    lib.nid_legacy_reset()
+    lib.nid_legacy_set_verify_mode.argtypes = [hostlib.C.c_int]
+    lib.nid_legacy_set_verify_mode(1)   # every slice on every call
+    dp = lambda a: a.ctypes.data_as(hostlib.c_dp)
+    ip = lambda a: a.ctypes.data_as(hostlib.c_ip)
+    try:
+        depth = np.ascontiguousarray(pair.depth_m.reshape(-1)); intr = pair.intr.copy(); pts = np.zeros(3 * N)
+        im0 = pair.im0.reshape(-1).astype(np.float64); im1 = pair.im1.reshape(-1).astype(np.float64)
+        bsv = np.zeros(4 * N); bsi = np.zeros(N, dtype=np.int32); cnt2 = np.zeros(ncell, dtype=np.int32); href = np.zeros(ncell)
+        lib.nid_legacy_call_Calculate3Dpoint(dp(depth), dp(T16), dp(pts), dp(intr), pair.rows, pair.cols)
+        lib.nid_legacy_call_CudaComputeHref(dp(im0), dp(pts), dp(M_init), dp(intr), nb, 3, pair.cell, pair.rows, pair.cols,
+                                            dp(bsv), ip(bsi), ip(cnt2), dp(href))
+        assert np.array_equal(cnt, cnt2)
+        act = cnt >= 300
+
+        def evaluate(k):
+            Ht = np.zeros(ncell); Hj = np.zeros(ncell); der = np.zeros(6 * ncell)
+            lib.nid_legacy_call_CudaComputeH(1, dp(im0), dp(im1), dp(pts), ip(cnt2), dp(bsv), ip(bsi), dp(poses16[k]), dp(intr),
+                                             nb, 3, pair.cell, pair.rows, pair.cols, dp(href), dp(Ht), dp(Hj), dp(der))
+            return Ht, Hj, der.reshape(ncell, 6)
+
+        before = [evaluate(k) for k in range(ncalls)]
+        im1[change_px] = 255.0 - im1[change_px]
+        after = [evaluate(k) for k in range(ncalls)]
+    finally:
+        lib.nid_legacy_set_verify_mode(0)
+        lib.nid_legacy_reset()
+    followed_at = None
+    for k in range(ncalls):
+        Ht_b, Hj_b, der_b = before[k]
+        Ht_a, Hj_a, der_a = after[k]
+        assert not np.array_equal(_bits(Ht_a[:1]), _bits(Ht_b[:1])), "the changed pixel must matter to cell 0"
+        is_after = np.array_equal(_bits(rec[k, 0][act]), _bits(Ht_a[act]))
+        is_before = np.array_equal(_bits(rec[k, 0][act]), _bits(Ht_b[act]))
+        assert is_after or is_before, f"call {k}: neither the old nor the new target"
+        if followed_at is None and is_after:
+            followed_at = k
+        want = (Ht_a, Hj_a, der_a) if is_after else (Ht_b, Hj_b, der_b)
+        assert k >= change_at or is_before
+        assert followed_at is None or is_after, f"call {k}: back on the old content"
+        assert np.array_equal(_bits(rec[k, 1][act]), _bits(want[1][act]))
+        if k % 4 == 0:
+            assert np.array_equal(_bits(rec[k].reshape(-1)[2 * ncell:].reshape(ncell, 6)[act]), _bits(want[2][act]))
+    assert followed_at is not None and change_at <= followed_at < change_at + 16, followed_at
+    # ... and the oracle on the last call with a Jacobian (the changed target)
+    k = ncalls - 4
+    o = oracle.from_pair(pair, nb, jac_bound="cpu", xform="matrix")
+    o.compute_href(pair.pose_init)
+    im1_changed = pair.im1.copy().reshape(-1); im1_changed[change_px] = 255 - im1_changed[change_px]
+    o.set_target(im1_changed.reshape(pair.rows, pair.cols))
+    Hc_o, Hj_o, _, J_o = o.evaluate(poses7[k], True)
+    np.testing.assert_allclose(rec[k, 0][act], Hc_o[act], rtol=0, atol=1e-11)
+    np.testing.assert_allclose(rec[k, 1][act], Hj_o[act], rtol=0, atol=1e-11)
+    scale = np.abs(J_o[act]).max(axis=1, keepdims=True)
+    assert np.all(np.abs(rec[k].reshape(-1)[2 * ncell:].reshape(ncell, 6)[act] - J_o[act]) <= 1e-9 * np.maximum(scale, 1e-6 * scale.max()))
+
+
 def _compare_traces(recs, recs_o, pose, pose_o, synth):
     assert len(recs) == len(recs_o)
     for r, ro in zip(recs, recs_o):

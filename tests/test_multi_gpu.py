@@ -299,7 +299,7 @@ def test_legacy_operators_follow_buffer_contents(hostlib, oracle, synth, pair_S,
     lib.nid_legacy_set_trust_buffers.argtypes = [hostlib.C.c_int]
     lib.nid_legacy_set_verify_mode.argtypes = [hostlib.C.c_int]
     lib.nid_legacy_stale_detections.restype = hostlib.C.c_long
-    VERIFY_BACKGROUND, VERIFY_EVERY_CALL = 0, 1
+    VERIFY_ROTATING, VERIFY_EVERY_CALL = 0, 1
     lib.nid_legacy_set_verify_mode(VERIFY_EVERY_CALL)   # (the strongest of the three modes first; the default is further down)
     samples = {int(k * (N - 1) // 63) for k in range(64)}
     cellpx = (pair.rows // pair.cell // 2) * pair.cols + pair.cols // pair.cell // 2      # inside cell 0
@@ -341,31 +341,44 @@ def test_legacy_operators_follow_buffer_contents(hostlib, oracle, synth, pair_S,
     u1 = lib.nid_legacy_upload_count()
     assert np.array_equal(evaluate(), base) and lib.nid_legacy_upload_count() == u1
 
-    # The DEFAULT, NID_LEGACY_VERIFY_BACKGROUND: the calls check the cheap keys only, the pool's workers hash the buffers in
-    # full beside them; an undeclared change in place is found by the verification that follows it, and the next call after
-    # that says so (stderr, nid_legacy_stale_detections), uploads the new content and evaluates it.
-    import time
-    lib.nid_legacy_set_verify_mode(VERIFY_BACKGROUND)
-    assert np.array_equal(evaluate(), base)
-    time.sleep(0.02)
+    # The DEFAULT, NID_LEGACY_VERIFY_ROTATING (round 6): every call checks the cheap keys and ONE of the 16 slices of each big
+    # buffer -- hashed by the pool's workers while the device evaluates, joined before the call returns -- so an undeclared
+    # change in place is found within 16 calls, by a call that says so (stderr, nid_legacy_stale_detections), uploads the
+    # new content and evaluates it before it returns.  Nothing of the caller's is read between calls.
+    lib.nid_legacy_set_verify_mode(VERIFY_ROTATING)
     assert np.array_equal(evaluate(), base)
     d0, u0 = lib.nid_legacy_stale_detections(), lib.nid_legacy_upload_count()
     im1[cellpx] = 255.0 - im1[cellpx]                              # undeclared
-    got = None
-    for k in range(20):                                            # (a few calls may still see the old content)
-        got = evaluate()
+    got, calls = None, 0
+    for k in range(16):                                            # (up to 15 calls may still see the old content)
+        got = evaluate(); calls += 1
         if not np.array_equal(got, base):
             break
-        time.sleep(0.005)
-    assert got[0, 0] != base[0, 0] and np.array_equal(got[1:], base[1:]), "the change was never followed"
+    assert got[0, 0] != base[0, 0] and np.array_equal(got[1:], base[1:]), "the change was not followed within 16 calls"
     assert lib.nid_legacy_stale_detections() == d0 + 1 and lib.nid_legacy_upload_count() == u0 + 1
+    assert np.array_equal(evaluate(), got)                         # ... and stays followed
     im1[cellpx] = 255.0 - im1[cellpx]
     lib.nid_legacy_invalidate(2)                                   # declared: at once, and not counted as a detection
     assert np.array_equal(evaluate(), base) and lib.nid_legacy_stale_detections() == d0 + 1
-    for k in range(10):                                            # nothing changes: nothing is reported or uploaded
+    for k in range(40):                                            # nothing changes: nothing is reported or uploaded
         assert np.array_equal(evaluate(), base)
-        time.sleep(0.002)
     assert lib.nid_legacy_stale_detections() == d0 + 1 and lib.nid_legacy_upload_count() == u0 + 2
+    # a change in the LAST slice of the largest buffer (bs_ref's final row: not a sampled index either), 4 slices per call
+    lib.nid_legacy_set_verify_slices.argtypes = [hostlib.C.c_int]
+    lib.nid_legacy_set_verify_slices(4)
+    lastpx = N - 2
+    keep = bsv[4 * lastpx:4 * lastpx + 4].copy()
+    assert all(4 * lastpx + q not in {int(k * (4 * N - 1) // 63) for k in range(64)} for q in range(4))
+    bsv[4 * lastpx:4 * lastpx + 4] = np.where(np.isnan(keep), 0.0, keep + 0.25)
+    for k in range(4):
+        got = evaluate()
+        if lib.nid_legacy_stale_detections() == d0 + 2:
+            break
+    assert lib.nid_legacy_stale_detections() == d0 + 2, "a change in the last slice was not found within 16 / 4 calls"
+    bsv[4 * lastpx:4 * lastpx + 4] = keep
+    lib.nid_legacy_invalidate(4)
+    assert np.array_equal(evaluate(), base)
+    lib.nid_legacy_set_verify_slices(0)
 
     # TRUSTED buffers (opt-in, round 4's default): address + length + 64 samples per call; a change in place is declared
     # with nid_legacy_invalidate and followed at once, or undeclared and followed within 128 calls of the pair.
@@ -397,7 +410,7 @@ def test_legacy_operators_follow_buffer_contents(hostlib, oracle, synth, pair_S,
     assert np.isnan(evaluate()[0, 0])
     cnt[:] = cnt_keep
     assert np.array_equal(evaluate(), base)
-    lib.nid_legacy_set_verify_mode(VERIFY_BACKGROUND)
+    lib.nid_legacy_set_verify_mode(VERIFY_ROTATING)
     lib.nid_legacy_reset()
 
 

@@ -1,9 +1,10 @@
 #!/usr/bin/env python3
 """tools/pair_setup.py [A|B] [bins]: where a frame pair's time goes on the host stack (nid_host_run_lm = the reference
 driver's sequence: Calculate3Dpoint, CudaComputeHref, graph, optimize(10)): the steps' microseconds as the libraries
-stamp them under NID_LEGACY_TRACE=1, third of three runs (library and clocks warm) -- in the three verification modes of
-the legacy operators (include/nid/legacy_ops.h): the default (background verification), every call (the "per-call
-verification" line is what that costs per call, traced on a pair's second call), trusted buffers (round 4's behaviour)."""
+stamp them under NID_LEGACY_TRACE=1, third of three runs (library and clocks warm) -- in the verification modes of
+the legacy operators (include/nid/legacy_ops.h): the default (rotating: one slice of 16 per call, inside the call), the same
+without pool threads, every slice on every call, trusted buffers.  The per-call cost of a mode is its optimize() of the
+reference flow (fused = 0: one CudaComputeH per evaluation) against the trusted mode's."""
 import importlib, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 cfg = sys.argv[1] if len(sys.argv) > 1 else "A"
@@ -20,8 +21,9 @@ if os.environ.get("NID_PAIR_SETUP_CHILD"):
         hostlib.run_lm(pair, bins, pair.pose_init, 10, fused=fused)
         print(f"[run] wall {1e3 * (time.perf_counter() - t0):.3f} ms, optimize() {1e3 * hostlib.last_optimize_seconds():.3f} ms", file=sys.stderr, flush=True)
     sys.exit(0)
-for mode, extra in (("DEFAULT, NID_LEGACY_VERIFY_BACKGROUND: cheap keys per call, full hashes by the pool's workers beside the caller", {}),
-                    ("NID_LEGACY_VERIFY_EVERY_CALL: every CudaComputeH call verifies the caller's buffers by full hash before it evaluates", {"NID_LEGACY_VERIFY_EVERY_CALL": "1"}),
+for mode, extra in (("DEFAULT, NID_LEGACY_VERIFY_ROTATING: cheap keys + ONE of 16 slices of each big buffer per call, hashed by the pool's workers WHILE the device evaluates, joined before the call returns", {}),
+                    ("NID_LEGACY_VERIFY_ROTATING without pool threads (NID_LEGACY_HASH_THREADS=0: the caller hashes its slice behind the evaluation)", {"NID_LEGACY_HASH_THREADS": "0"}),
+                    ("NID_LEGACY_VERIFY_EVERY_CALL: all 16 slices on every CudaComputeH call", {"NID_LEGACY_VERIFY_EVERY_CALL": "1"}),
                     ("NID_LEGACY_VERIFY_TRUSTED (nid_legacy_set_trust_buffers(1) / NID_LEGACY_TRUST_BUFFERS=1: round 4's behaviour)", {"NID_LEGACY_TRUST_BUFFERS": "1"})):
     p = subprocess.run([sys.executable, os.path.abspath(__file__), cfg, str(bins)], capture_output=True, text=True,
                        env=dict(os.environ, NID_PAIR_SETUP_CHILD="1", NID_LEGACY_TRACE="1", **extra))
