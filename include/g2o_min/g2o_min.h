@@ -23,6 +23,8 @@
 #include <iosfwd>
 #include <vector>
 
+struct nid_multi;
+
 namespace g2o {
 
 // ---- tiny fixed-size algebra (column-major where Eigen's .data() matters) ----
@@ -306,6 +308,9 @@ class SparseOptimizer {
   int *bs_index_ref_ = nullptr;
   double *Href_ = nullptr;
   std::vector<double> robustchi2_his_;
+  // (not in the reference) the frame pair is already on the device(s), set up through the C-ABI
+  // (nid_legacy_set_pair_u16): the fused flows evaluate on these shards and never touch the array fields above
+  nid_multi *native_pair_ = nullptr;
 
  private:
   friend class OptimizationAlgorithmLevenberg;

@@ -93,6 +93,7 @@ void nid_legacy_reset(void);
 // (the context, its buffers and its communicator stay: the next pair of the same geometry costs no context creation)
 void nid_legacy_quiesce(void);
 // how the operators make sure the device holds what the caller's buffers hold (THE CONTRACT above)
+#define NID_LEGACY_SLICES 32 /* slices per big buffer; ROTATING checks one of them per call */
 enum { NID_LEGACY_VERIFY_ROTATING = 0, NID_LEGACY_VERIFY_EVERY_CALL = 1, NID_LEGACY_VERIFY_TRUSTED = 2 };
 void nid_legacy_set_verify_mode(int mode);
 void nid_legacy_set_verify_slices(int per_call);  // ROTATING: slices of 16 checked per call (default 1; < 1: the default)
@@ -114,6 +115,14 @@ nid_multi *nid_legacy_multi(void);
 nid_multi *nid_legacy_prepare(double *im0, double *im1, double *points3d, int *bs_counter, double *bs_ref,
                               int *bs_index_ref, double *camera_intrincis, int bin_num, int bs_degree, int cell_num,
                               int rows, int cols, double *Href);
+// A whole frame pair in the formats the reference's driver reads (u16 depth, u8 images; NID_pose_estimation.cpp:84-113) on
+// the operators' context -- nid_multi_set_pair_u16 (nid_multi.h): back-projection, tiling and the reference stage at
+// pose0 on the device, bs_counter / Href (per cell, NaN = inactive; plain values, not subtracted onto anything) back --
+// for hosts that continue on the nid_multi_* interface and read none of the operators' per-pixel arrays.
+// camera_intrincis = {fx, fy, cx, cy, depth_factor}.  NULL on error (reported on stderr).
+nid_multi *nid_legacy_set_pair_u16(const uint16_t *depth_u16, const uint8_t *im0, const uint8_t *im1, const double *T_wc0_colmajor16,
+                                   const double *pose0_colmajor16, const double *camera_intrincis, int bin_num, int bs_degree,
+                                   int cell_num, int rows, int cols, int32_t *bs_counter, double *Href);
 // number of host->device uploads of frame-pair data done so far (tests: must not grow per call)
 long nid_legacy_upload_count(void);
 }

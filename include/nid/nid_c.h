@@ -197,6 +197,16 @@ int nid_set_reference_depth(nid_ctx *ctx, const double *depth_m, const uint8_t *
 /* same, from an existing AoS point cloud (NaN xyz = invalid), as handed to
  * CudaComputeHref / CudaComputeH */
 int nid_set_reference_points(nid_ctx *ctx, const double *points3d, const uint8_t *im0);
+/* One frame pair in the formats the reference's driver reads from disk (NID_pose_estimation.cpp:84-113: u8 grey
+ * images, u16 depth whose metres are value * depth_factor, :73,106), handed over in ONE call: what Calculate3Dpoint
+ * (CudaPoints3d.cu:35-73), the reference upload, the target upload and CudaComputeHref (CudaComputeHref.cu:139-222) do
+ * together, with 1.2 MB across PCIe at 640x480, one stream, one synchronisation, and only bs_counter / Href (may be
+ * NULL) coming back.  The reference stage runs at pose0 -- given as pose7 OR as a column-major 4x4 (exactly one of the two
+ * non-NULL; the matrix form is what the legacy operators take).  Same device state, bit for bit, as
+ * nid_set_reference_depth(depth_u16 * depth_factor) + nid_set_target_u8 + nid_compute_href[_matrix]. */
+int nid_set_pair_u16(nid_ctx *ctx, const uint16_t *depth_u16, double depth_factor, const uint8_t *im0, const uint8_t *im1,
+                     const double *T_wc0_colmajor16, const double *pose0_7, const double *pose0_colmajor16,
+                     int32_t *bs_counter, double *Href);
 /* context-free Calculate3Dpoint (CudaPoints3d.cuh:6): depth f64 metres -> AoS world points, NaN = invalid */
 int nid_backproject(const double *depth_m, const double *T_wc0_colmajor16, double fx, double fy, double cx,
                     double cy, int32_t rows, int32_t cols, int32_t device, double *points3d);

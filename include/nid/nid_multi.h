@@ -114,6 +114,11 @@ int nid_multi_resident_pause(nid_multi *m); /* nid_resident_pause on every shard
 int nid_multi_set_reference_depth(nid_multi *m, const double *depth_m, const uint8_t *im0, const double *T_wc0_colmajor16);
 int nid_multi_set_reference_points(nid_multi *m, const double *points3d, const uint8_t *im0);
 int nid_multi_set_target_u8(nid_multi *m, const uint8_t *im1);
+/* nid_set_pair_u16 (nid_c.h) on every shard -- all of them enqueued before the first is waited for --, bs_counter /
+ * Href for every cell of the image as with nid_multi_compute_href */
+int nid_multi_set_pair_u16(nid_multi *m, const uint16_t *depth_u16, double depth_factor, const uint8_t *im0, const uint8_t *im1,
+                           const double *T_wc0_colmajor16, const double *pose0_7, const double *pose0_colmajor16,
+                           int32_t *bs_counter, double *Href);
 /* bs_counter / Href: every cell of the image (summed across processes when a communicator is live);
  * bs_value / bs_index: the pixels of the cells this PROCESS owns */
 int nid_multi_compute_href(nid_multi *m, const double *pose7, int32_t *bs_counter, double *Href, double *bs_value,

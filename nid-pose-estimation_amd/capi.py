@@ -40,7 +40,7 @@ class NidConfig(C.Structure):
 SYMBOLS = [
     "nid_abi_version", "nid_status_string", "nid_last_error", "nid_device_count", "nid_create", "nid_create_strided",
     "nid_destroy", "nid_set_options", "nid_set_math_mode", "nid_set_href_nan_markers", "nid_set_stream", "nid_set_block_threads", "nid_set_launch_shape",
-    "nid_set_reference_depth", "nid_set_reference_points", "nid_backproject", "nid_backproject_release", "nid_get_points3d", "nid_set_target_u8",
+    "nid_set_reference_depth", "nid_set_pair_u16", "nid_set_reference_points", "nid_backproject", "nid_backproject_release", "nid_get_points3d", "nid_set_target_u8",
     "nid_set_target_f64", "nid_set_reference_image_f64", "nid_compute_href",
     "nid_compute_href_matrix", "nid_set_href_state", "nid_plain_nid", "nid_evaluate", "nid_evaluate_matrix",
     "nid_normal_equations", "nid_launch", "nid_launch_batch", "nid_launch_chain", "nid_launch_batch_to", "nid_run_sequence", "nid_run_chain", "nid_set_loop_form", "nid_set_direct_results", "nid_set_resident", "nid_resident_pause", "nid_resident_stats", "nid_resident_batch_stats", "nid_wait", "nid_slot_buffers", "nid_debug_read_device", "nid_launch_to",
@@ -80,6 +80,7 @@ def load():
     lib.nid_set_block_threads.argtypes = [vp, C.c_int]
     lib.nid_set_launch_shape.argtypes = [vp, C.c_int, C.c_int]
     lib.nid_set_reference_depth.argtypes = [vp, c_dp, c_u8p, c_dp]
+    lib.nid_set_pair_u16.argtypes = [vp, C.POINTER(C.c_uint16), C.c_double, c_u8p, c_u8p, c_dp, c_dp, c_dp, c_ip, c_dp]
     lib.nid_set_reference_points.argtypes = [vp, c_dp, c_u8p]
     lib.nid_get_points3d.argtypes = [vp, c_dp]
     lib.nid_backproject.argtypes = [c_dp, c_dp] + [C.c_double] * 4 + [C.c_int32] * 3 + [c_dp]
@@ -207,6 +208,19 @@ class Context:
         self._check(self.lib.nid_set_reference_depth(self.h, _dp(d), im.ctypes.data_as(c_u8p), _dp(T)),
                     "nid_set_reference_depth")
 
+    def set_pair_u16(self, depth_u16, depth_factor, im0, im1, T_wc0_colmajor16, pose0, matrix=False):
+        """nid_set_pair_u16: the whole pair in the driver's formats + the reference stage at pose0 (pose7, or a
+        column-major 4x4 with matrix=True); returns (bs_counter, Href)."""
+        d = np.ascontiguousarray(depth_u16, dtype=np.uint16).reshape(-1)
+        a, b, T, p = _u8(im0).reshape(-1), _u8(im1).reshape(-1), _d(T_wc0_colmajor16), _d(pose0)
+        assert d.size == self.rows * self.cols and a.size == d.size and b.size == d.size and T.size == 16 and p.size == (16 if matrix else 7)
+        cnt = np.zeros(self.ncell, dtype=np.int32)
+        href = np.full(self.ncell, np.nan)
+        self._check(self.lib.nid_set_pair_u16(self.h, d.ctypes.data_as(C.POINTER(C.c_uint16)), float(depth_factor), a.ctypes.data_as(c_u8p),
+                                              b.ctypes.data_as(c_u8p), _dp(T), None if matrix else _dp(p), _dp(p) if matrix else None,
+                                              _ip(cnt), _dp(href)), "nid_set_pair_u16")
+        return cnt, href
+
     def set_reference_points(self, points3d, im0):
         p, im = _d(points3d).reshape(-1), _u8(im0).reshape(-1)
         assert p.size == 3 * self.rows * self.cols and im.size == self.rows * self.cols
@@ -232,6 +246,12 @@ class Context:
         self._check(self.lib.nid_compute_href(self.h, _dp(_d(pose7)), _ip(cnt), _dp(href), _dp(bsv), _ip(bsi)),
                     "nid_compute_href")
         return (cnt, href, bsv, bsi) if dump else (cnt, href)
+
+    def compute_href_matrix(self, pose16):
+        cnt = np.zeros(self.ncell, dtype=np.int32)
+        href = np.full(self.ncell, np.nan)
+        self._check(self.lib.nid_compute_href_matrix(self.h, _dp(_d(pose16)), _ip(cnt), _dp(href), None, None), "nid_compute_href_matrix")
+        return cnt, href
 
     # ---- per iteration --------------------------------------------------------
     def plain_nid(self, pose7, bins=8):
@@ -484,7 +504,7 @@ MULTI_SYMBOLS = [
     "nid_multi_comm_init_local", "nid_multi_comm_ranks", "nid_multi_time_exchange", "nid_multi_set_exchange_hook", "nid_multi_set_reduce_mode",
     "nid_multi_set_options",
     "nid_multi_set_math_mode", "nid_multi_set_href_nan_markers", "nid_multi_set_block_threads", "nid_multi_set_launch_shape", "nid_multi_set_resident", "nid_multi_set_reference_depth",
-    "nid_multi_set_reference_points", "nid_multi_set_target_u8", "nid_multi_compute_href",
+    "nid_multi_set_reference_points", "nid_multi_set_target_u8", "nid_multi_set_pair_u16", "nid_multi_compute_href",
     "nid_multi_compute_href_matrix", "nid_multi_set_href_state", "nid_multi_evaluate", "nid_multi_evaluate_matrix",
     "nid_multi_normal_equations", "nid_multi_launch_batch", "nid_multi_launch_chain", "nid_multi_wait", "nid_multi_run_sequence",
     "nid_multi_contract_bytes",
@@ -520,6 +540,7 @@ def _load_multi():
     lib.nid_multi_set_block_threads.argtypes = [vp, C.c_int]
     lib.nid_multi_set_reference_depth.argtypes = [vp, c_dp, c_u8p, c_dp]
     lib.nid_multi_set_target_u8.argtypes = [vp, c_u8p]
+    lib.nid_multi_set_pair_u16.argtypes = [vp, C.POINTER(C.c_uint16), C.c_double, c_u8p, c_u8p, c_dp, c_dp, c_dp, c_ip, c_dp]
     lib.nid_multi_compute_href.argtypes = [vp, c_dp, c_ip, c_dp, c_dp, c_ip]
     lib.nid_multi_set_href_state.argtypes = [vp, c_ip, c_dp, c_dp, c_ip]
     lib.nid_multi_evaluate.argtypes = [vp, c_dp, C.c_int, c_dp, c_dp, c_dp, c_dp]
@@ -653,6 +674,16 @@ class Multi:
     def set_target(self, im1):
         im = _u8(im1).reshape(-1)
         self._check(self.lib.nid_multi_set_target_u8(self.h, im.ctypes.data_as(c_u8p)), "nid_multi_set_target_u8")
+
+    def set_pair_u16(self, depth_u16, depth_factor, im0, im1, T_wc0_colmajor16, pose0, matrix=False):
+        d = np.ascontiguousarray(depth_u16, dtype=np.uint16).reshape(-1)
+        a, b, T, p = _u8(im0).reshape(-1), _u8(im1).reshape(-1), _d(T_wc0_colmajor16), _d(pose0)
+        cnt = np.zeros(self.ncell, dtype=np.int32)
+        href = np.full(self.ncell, np.nan)
+        self._check(self.lib.nid_multi_set_pair_u16(self.h, d.ctypes.data_as(C.POINTER(C.c_uint16)), float(depth_factor), a.ctypes.data_as(c_u8p),
+                                                    b.ctypes.data_as(c_u8p), _dp(T), None if matrix else _dp(p), _dp(p) if matrix else None,
+                                                    _ip(cnt), _dp(href)), "nid_multi_set_pair_u16")
+        return cnt, href
 
     def compute_href(self, pose7, dump=False):
         cnt = np.zeros(self.ncell, dtype=np.int32)

@@ -61,6 +61,14 @@ __global__ void k_tile(Geometry g, const double *__restrict__ depth,
   t.I0[gid] = i0;
 }
 
+// The driver's depth map as it comes off the disk: u16 at 1/5000 m (NID_pose_estimation.cpp:73,106:
+// depth.convertTo(depth, CV_64F, depth_factor) -- one IEEE multiplication per pixel, no contraction) -> the f64 metres
+// k_tile / k_backproject_plain read.  nid_set_pair_u16: 0.6 MB cross PCIe instead of 2.5 MB.
+__global__ void k_depth_u16(long n, const uint16_t *__restrict__ src, double factor, double *__restrict__ dst) {
+  const long id = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (id < n) dst[id] = (double)src[id] * factor;
+}
+
 // Target image for the evaluation kernel: int16 copy of the u8 image with the extrapolated top / left margin
 // (see Win).  dst is (rows + 1) x stride; one thread per destination element of the first `cols + 1` columns.
 __global__ void k_im1_margins(int rows, int cols, int stride, const uint8_t *__restrict__ src, int16_t *__restrict__ dst) {

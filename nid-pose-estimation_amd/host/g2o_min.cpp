@@ -341,8 +341,10 @@ OptimizationAlgorithmLevenberg::SolverResult OptimizationAlgorithmLevenberg::sol
   // the shards the legacy operators run on (one context on one GPU, or the cells of the pair spread over several:
   // include/nid/nid_multi.h): H, b and chi2 arrive already summed over the whole image
   const auto t_start = std::chrono::steady_clock::now();
-  nid_multi *ctx = nid_legacy_multi();
-  if (!ctx || iteration == 0) {  // first use: the legacy operator's own upload of the frame-pair state
+  nid_multi *ctx = opt->native_pair_ ? opt->native_pair_ : nid_legacy_multi();
+  if (opt->native_pair_) {
+    if (iteration == 0) _haveNext = false;
+  } else if (!ctx || iteration == 0) {  // first use: the legacy operator's own upload of the frame-pair state
     ctx = nid_legacy_prepare(opt->im0_, opt->im1_, opt->points3d_, opt->bs_counter_, opt->bs_value_ref_,
                              opt->bs_index_ref_, opt->camera_intrincis_, opt->bin_num_, opt->bs_degree_, opt->cell_num_,
                              opt->rows_, opt->cols_, opt->Href_);

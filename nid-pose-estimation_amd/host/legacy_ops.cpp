@@ -30,6 +30,7 @@
 //     NID_LEGACY_ALWAYS_UPLOAD=1 uploads everything on every call.
 #include "nid/legacy_ops.h"
 
+#include <atomic>
 #include <chrono>
 #include <algorithm>
 #include <cmath>
@@ -49,7 +50,7 @@
 
 namespace {
 
-constexpr int kSlices = 16;   // a big buffer's content key: one hash per slice; the default mode checks one slice per call
+constexpr int kSlices = NID_LEGACY_SLICES;   // a big buffer's content key: one hash per slice; the default mode checks one slice per call
 
 struct LegacyState {
   nid_multi *m = nullptr;
@@ -178,15 +179,17 @@ class HashPool {
   // finished by the same thread; the job must stay valid until finish().
   void start(int nparts, std::function<void(int)> job) {
     call_.lock();
+    bool parked;
     {
       std::lock_guard<std::mutex> g(m_);
       job_ = std::move(job);
       next_ = 0;
       nparts_ = nparts;
       remaining_ = nparts;
-      generation_++;
+      generation_.fetch_add(1, std::memory_order_release);
+      parked = parked_ > 0;
     }
-    if (has_workers()) wake_.notify_all();  // (a fork()ed child has no workers: finish() does all parts)
+    if (parked && has_workers()) wake_.notify_all();  // (a fork()ed child has no workers: finish() does all parts)
   }
   void finish() {
     help();
@@ -204,6 +207,7 @@ class HashPool {
   HashPool() : owner_(getpid()) {
     int n = 3;
     if (const char *e = getenv("NID_LEGACY_HASH_THREADS")) n = std::max(0, std::min(15, atoi(e)));
+    if (const char *e = getenv("NID_LEGACY_HASH_SPIN_US")) spin_us_ = std::max(0, std::min(100000, atoi(e)));
     for (int w = 0; w < n; w++) workers_.emplace_back([this] { loop(); });
     // fork(): threads do not survive it, locks do -- a child forked while a worker held m_ would wait for it for ever.
     // The prepare handler takes call_ (free whenever no operator is inside start() .. finish(): a job never outlives
@@ -230,14 +234,27 @@ class HashPool {
       if (last) done_.notify_all();
     }
   }
+  // A worker that has just served a job keeps POLLING for the next one for spin_us_ microseconds before it parks on the
+  // condition variable: the operators are called back to back by the LM (one call per 30-60 us), and a parked thread
+  // takes 10-20 us to come back -- as long as the whole evaluation it is supposed to hide behind
+  // (profiles/r06_pair_setup.txt).  NID_LEGACY_HASH_SPIN_US (default 150; 0: park at once).
   void loop() {
     unsigned long seen = 0;
     for (;;) {
-      {
-        std::unique_lock<std::mutex> g(m_);
-        wake_.wait(g, [&] { return generation_ != seen; });
-        seen = generation_;
+      const auto t0 = std::chrono::steady_clock::now();
+      bool got = false;
+      while (spin_us_ > 0) {
+        if (generation_.load(std::memory_order_acquire) != seen) { got = true; break; }
+        __builtin_ia32_pause();
+        if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(spin_us_)) break;
       }
+      if (!got) {
+        std::unique_lock<std::mutex> g(m_);
+        parked_++;
+        wake_.wait(g, [&] { return generation_.load(std::memory_order_acquire) != seen; });
+        parked_--;
+      }
+      seen = generation_.load(std::memory_order_acquire);
       help();
     }
   }
@@ -245,8 +262,9 @@ class HashPool {
   std::condition_variable wake_, done_;
   std::function<void(int)> job_;
   std::vector<std::thread> workers_;
-  unsigned long generation_ = 0;
-  int next_ = 0, nparts_ = 0, remaining_ = 0;
+  std::atomic<unsigned long> generation_{0};
+  int next_ = 0, nparts_ = 0, remaining_ = 0, parked_ = 0;
+  int spin_us_ = 150;
   const pid_t owner_;
 };
 
@@ -812,6 +830,24 @@ nid_multi *nid_legacy_prepare(double *im0, double *im1, double *points3d, int *b
   verify_begin(a);
   const unsigned stale = verify_end(a);
   return stale ? follow_change(a, stale) : m;
+}
+
+// The frame pair in the driver's own formats on the context the operators use (same cache, same devices / ranks /
+// communicator), through nid_multi_set_pair_u16: for hosts that need none of the operators' per-pixel arrays (the fused LM
+// flows of g2o_min).  The caller-buffer keys are dropped: a legacy call that follows re-uploads whatever it is handed.
+nid_multi *nid_legacy_set_pair_u16(const uint16_t *depth_u16, const uint8_t *im0, const uint8_t *im1, const double *T_wc0_colmajor16,
+                                   const double *pose0_colmajor16, const double *camera_intrincis, int bin_num, int bs_degree,
+                                   int cell_num, int rows, int cols, int32_t *bs_counter, double *Href) {
+  nid_multi *m = get_multi(rows, cols, cell_num, bin_num, bs_degree, camera_intrincis);
+  if (!m) return nullptr;
+  LegacyState &S = g_state;
+  S.k_im0 = S.k_points = S.k_im1 = S.k_bs_ref = S.k_counter = S.k_href = LegacyState::Key();
+  S.have_ref = S.have_target = S.have_href = false;
+  S.calls = 0;
+  int rc = nid_multi_set_pair_u16(m, depth_u16, camera_intrincis[4], im0, im1, T_wc0_colmajor16, nullptr, pose0_colmajor16, bs_counter, Href);
+  if (rc != NID_OK) { report("nid_legacy_set_pair_u16", rc, m); return nullptr; }
+  g_uploads++;
+  return m;
 }
 
 nid_multi *nid_legacy_multi(void) { return g_state.m; }

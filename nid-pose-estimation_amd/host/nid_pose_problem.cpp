@@ -43,13 +43,19 @@ int nid_host_run_lm(const nid_pose_problem *pb, double *pose7_inout, nid_host_lm
   std::vector<double> intrinscis = {pb->fx, pb->fy, pb->cx, pb->cy, pb->depth_factor};
   static thread_local std::vector<double> bs_value, points_3d_all, im0_data, im1_data, depth;
   static thread_local std::vector<int> bin_index;
-  bs_value.resize(4 * N); points_3d_all.resize(3 * N); im0_data.resize(N); im1_data.resize(N); depth.resize(N); bin_index.resize(N);
+  // The fused flows read none of the operators' per-pixel arrays: the pair goes to the device in the driver's own formats
+  // (round 6; NID_HOST_LEGACY_SETUP=1 or pb->legacy_setup: the reference main()'s route, as before)
+  static const bool env_legacy_setup = getenv("NID_HOST_LEGACY_SETUP") != nullptr;
+  const bool native = pb->fused != 0 && !pb->legacy_setup && !env_legacy_setup;
   std::vector<double> Href(cell * cell, 0.0);
   std::vector<int> bs_counter(cell * cell);
-  for (size_t i = 0; i < N; i++) { im0_data[i] = (double)pb->im0[i]; im1_data[i] = (double)pb->im1[i]; }
-  for (size_t i = 0; i < N; i++) depth[i] = (double)pb->depth_u16[i] * pb->depth_factor;  // convertTo(CV_64F, 1/5000), :106
   std::vector<double> T_wc0(pb->T_wc0_colmajor, pb->T_wc0_colmajor + 16);
-  stamp("caller's buffers (u8 / u16 -> f64, allocations)");
+  if (!native) {
+    bs_value.resize(4 * N); points_3d_all.resize(3 * N); im0_data.resize(N); im1_data.resize(N); depth.resize(N); bin_index.resize(N);
+    for (size_t i = 0; i < N; i++) { im0_data[i] = (double)pb->im0[i]; im1_data[i] = (double)pb->im1[i]; }
+    for (size_t i = 0; i < N; i++) depth[i] = (double)pb->depth_u16[i] * pb->depth_factor;  // convertTo(CV_64F, 1/5000), :106
+    stamp("caller's buffers (u8 / u16 -> f64, allocations)");
+  }
 
   g2o::SparseOptimizer optimizer;
   g2o::BlockSolver_6_X::LinearSolverType *linearSolver = new g2o::LinearSolverDense();
@@ -72,14 +78,21 @@ int nid_host_run_lm(const nid_pose_problem *pb, double *pose7_inout, nid_host_lm
 
   // :253, :257
   stamp("optimizer, solver, vertex");
-  Calculate3Dpoint(depth.data(), T_wc0.data(), points_3d_all.data(), intrinscis.data(), rows, cols);
-  stamp("Calculate3Dpoint");
   g2o::Matrix4d M0 = vSE3->estimate().to_homogeneous_matrix();
-  CudaComputeHref(im0_data.data(), points_3d_all.data(), M0.data(), intrinscis.data(), bin_num, bs_degree, cell,
-                  rows, cols, bs_value.data(), bin_index.data(), bs_counter.data(), Href.data());
-
-  stamp("CudaComputeHref");
-  if (!nid_legacy_multi()) {  // the operators print and carry on like the reference's (computeH.cu:454-473); a run must not
+  nid_multi *native_pair = nullptr;
+  if (native) {
+    // what :253 and :257 compute, on the device: 1.2 MB up at 640x480, the per-cell counts and Href back
+    native_pair = nid_legacy_set_pair_u16(pb->depth_u16, pb->im0, pb->im1, T_wc0.data(), M0.data(), intrinscis.data(), bin_num,
+                                          bs_degree, cell, rows, cols, bs_counter.data(), Href.data());
+    stamp("nid_legacy_set_pair_u16 (uploads, back-projection, tiles, margins, reference stage)");
+  } else {
+    Calculate3Dpoint(depth.data(), T_wc0.data(), points_3d_all.data(), intrinscis.data(), rows, cols);
+    stamp("Calculate3Dpoint");
+    CudaComputeHref(im0_data.data(), points_3d_all.data(), M0.data(), intrinscis.data(), bin_num, bs_degree, cell,
+                    rows, cols, bs_value.data(), bin_index.data(), bs_counter.data(), Href.data());
+    stamp("CudaComputeHref");
+  }
+  if (native ? !native_pair : !nid_legacy_multi()) {  // the operators print and carry on like the reference's (computeH.cu:454-473); a run must not
     if (log_buf && log_cap > 0) std::snprintf(log_buf, (size_t)log_cap, "the NID operators could not set up their device state (see stderr)");
     nid_legacy_reset();
     return -3;
@@ -90,6 +103,7 @@ int nid_host_run_lm(const nid_pose_problem *pb, double *pose7_inout, nid_host_lm
   optimizer.bin_num_ = bin_num; optimizer.bs_degree_ = bs_degree; optimizer.cell_num_ = cell;
   optimizer.bs_counter_ = bs_counter.data(); optimizer.bs_value_ref_ = bs_value.data();
   optimizer.bs_index_ref_ = bin_index.data(); optimizer.Href_ = Href.data();
+  optimizer.native_pair_ = native_pair;
 
   const double deltaNID = pb->huber_delta > 0 ? pb->huber_delta : std::sqrt(0.95);  // :279
   for (int i = 0; i < cell; i++)

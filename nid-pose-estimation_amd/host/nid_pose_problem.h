@@ -19,7 +19,10 @@ typedef struct {
                                    single-pose evaluations, one per outer iteration in the steady state (the flow the
                                    resident evaluator -- nid_legacy_set_resident -- is made for) */
   int32_t strict_math;      /* 1 = NID_MATH_STRICT, 0 = NID_MATH_FAST */
-  int32_t pad_;
+  int32_t legacy_setup;     /* fused != 0 only.  0 (default): the pair is set up through the C-ABI in the driver's own formats
+                               (nid_legacy_set_pair_u16: u16 depth + u8 images up, counts and Href back -- nothing else crosses
+                               PCIe); 1: through Calculate3Dpoint / CudaComputeHref like the reference's main() (what fused == 0
+                               always does: the per-edge flow calls CudaComputeH with the operators' arrays).  Same pose bits. */
   double fx, fy, cx, cy, depth_factor, huber_delta;
   const uint8_t *im0, *im1;        /* rows*cols */
   const uint16_t *depth_u16;       /* rows*cols, metres = value * depth_factor */

@@ -19,7 +19,7 @@ c_ip = C.POINTER(C.c_int)
 class PoseProblem(C.Structure):
     _fields_ = [("rows", C.c_int32), ("cols", C.c_int32), ("cell_num", C.c_int32), ("bin_num", C.c_int32),
                 ("iterations", C.c_int32), ("jac_bound_cuda", C.c_int32), ("fused", C.c_int32),
-                ("strict_math", C.c_int32), ("pad_", C.c_int32),
+                ("strict_math", C.c_int32), ("legacy_setup", C.c_int32),
                 ("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double), ("cy", C.c_double),
                 ("depth_factor", C.c_double), ("huber_delta", C.c_double),
                 ("im0", C.POINTER(C.c_uint8)), ("im1", C.POINTER(C.c_uint8)),
@@ -114,8 +114,9 @@ def huber(e2, delta):
 
 
 def run_lm(pair, bin_num, pose7, iterations=10, jac_bound_cuda=False, fused=False, huber_delta=None, synth=None,
-           strict=False):
-    """The reference driver's optimisation (NID_pose_estimation.cpp:163-366) on the C++ host stack."""
+           strict=False, legacy_setup=False):
+    """The reference driver's optimisation (NID_pose_estimation.cpp:163-366) on the C++ host stack.  legacy_setup: the
+    fused flows set the pair up through Calculate3Dpoint / CudaComputeHref (round 5's route) instead of natively."""
     import importlib
     synth = synth or importlib.import_module("nid-pose-estimation_amd.synth")
     im0 = np.ascontiguousarray(pair.im0, dtype=np.uint8)
@@ -123,7 +124,7 @@ def run_lm(pair, bin_num, pose7, iterations=10, jac_bound_cuda=False, fused=Fals
     dep = np.ascontiguousarray(pair.depth_u16, dtype=np.uint16)
     T = _d(synth.matrix_colmajor16(pair.T_wc0))
     pb = PoseProblem(pair.rows, pair.cols, pair.cell, bin_num, iterations, 1 if jac_bound_cuda else 0,
-                     int(fused), 1 if strict else 0, 0, pair.fx, pair.fy, pair.cx, pair.cy, 1.0 / 5000,
+                     int(fused), 1 if strict else 0, 1 if legacy_setup else 0, pair.fx, pair.fy, pair.cx, pair.cy, 1.0 / 5000,
                      float(huber_delta) if huber_delta else 0.0,
                      im0.ctypes.data_as(C.POINTER(C.c_uint8)), im1.ctypes.data_as(C.POINTER(C.c_uint8)),
                      dep.ctypes.data_as(C.POINTER(C.c_uint16)), _dp(T))
@@ -138,13 +139,13 @@ def run_lm(pair, bin_num, pose7, iterations=10, jac_bound_cuda=False, fused=Fals
     return p, recs, log.value.decode(errors="replace")
 
 
-def _problem(pair, bin_num, iterations, jac_bound_cuda, fused, huber_delta, strict, synth):
+def _problem(pair, bin_num, iterations, jac_bound_cuda, fused, huber_delta, strict, synth, legacy_setup=False):
     im0 = np.ascontiguousarray(pair.im0, dtype=np.uint8)
     im1 = np.ascontiguousarray(pair.im1, dtype=np.uint8)
     dep = np.ascontiguousarray(pair.depth_u16, dtype=np.uint16)
     T = _d(synth.matrix_colmajor16(pair.T_wc0))
     pb = PoseProblem(pair.rows, pair.cols, pair.cell, bin_num, iterations, 1 if jac_bound_cuda else 0,
-                     int(fused), 1 if strict else 0, 0, pair.fx, pair.fy, pair.cx, pair.cy, 1.0 / 5000,
+                     int(fused), 1 if strict else 0, 1 if legacy_setup else 0, pair.fx, pair.fy, pair.cx, pair.cy, 1.0 / 5000,
                      float(huber_delta) if huber_delta else 0.0,
                      im0.ctypes.data_as(C.POINTER(C.c_uint8)), im1.ctypes.data_as(C.POINTER(C.c_uint8)),
                      dep.ctypes.data_as(C.POINTER(C.c_uint16)), _dp(T))
@@ -152,12 +153,12 @@ def _problem(pair, bin_num, iterations, jac_bound_cuda, fused, huber_delta, stri
 
 
 def run_pyramid_lm(pair, bin_num, pose7, levels=3, iterations=10, jac_bound_cuda=False, fused=False,
-                   huber_delta=None, synth=None, strict=False):
+                   huber_delta=None, synth=None, strict=False, legacy_setup=False):
     """Coarse-to-fine schedule (own definition, host/nid_pyramid.cpp): `iterations` LM iterations per level,
     coarsest level first.  Returns (pose7, [records per level, coarsest first], log)."""
     import importlib
     synth = synth or importlib.import_module("nid-pose-estimation_amd.synth")
-    pb, keep = _problem(pair, bin_num, iterations, jac_bound_cuda, fused, huber_delta, strict, synth)
+    pb, keep = _problem(pair, bin_num, iterations, jac_bound_cuda, fused, huber_delta, strict, synth, legacy_setup)
     lib = load()
     lib.nid_host_run_pyramid_lm.restype = C.c_int
     lib.nid_host_run_pyramid_lm.argtypes = [C.POINTER(PoseProblem), C.c_int, c_dp, C.POINTER(LmRecord), C.c_int,

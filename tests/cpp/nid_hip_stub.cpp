@@ -81,6 +81,13 @@ int nid_multi_set_reference_points(nid_multi *m, const double *points3d, const u
   m->im0.assign(im0, im0 + npix(m));
   return NID_OK;
 }
+int nid_multi_set_pair_u16(nid_multi *m, const uint16_t *, double, const uint8_t *im0, const uint8_t *im1, const double *, const double *,
+                           const double *, int32_t *bs_counter, double *Href) {
+  m->im0.assign(im0, im0 + npix(m));
+  m->im1.assign(im1, im1 + npix(m));
+  for (int c = 0; c < ncell(m); c++) { if (bs_counter) bs_counter[c] = 1000; if (Href) Href[c] = 1.0 + c; }
+  return NID_OK;
+}
 int nid_multi_set_target_u8(nid_multi *m, const uint8_t *im1) { m->im1.assign(im1, im1 + npix(m)); return NID_OK; }
 int nid_multi_compute_href_matrix(nid_multi *m, const double *, int32_t *bs_counter, double *Href, double *bs_value, int32_t *bs_index) {
   const size_t N = npix(m);

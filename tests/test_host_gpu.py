@@ -136,21 +136,22 @@ def _write_lm_caller_input(path, pair, nb, poses16, change_at, change_px, pause_
 
 def test_reference_call_pattern_then_free_at_once(hostlib, oracle, synth, pair_A, tmp_path):
     """VERDICT r05 item 1.  tests/cpp/legacy_lm_caller.cpp replays the reference's whole use of the operators at 640x480
-    -- Calculate3Dpoint, CudaComputeHref, 48 CudaComputeH calls in the LM's pattern (der / cost / cost / verbose cost,
+    -- Calculate3Dpoint, CudaComputeHref, 64 CudaComputeH calls in the LM's pattern (der / cost / cost / verbose cost,
     changing poses, 3 ms of host work before every eighth), ONE undeclared in-place change of an im1 pixel that avoids
     the sampled indices, then the frees of NID_pose_estimation.cpp:388-395 at once (7.4 and 9.8 MB blocks: free() unmaps
     them) -- and calls nothing else: no nid_legacy_*.  In the DEFAULT mode, compiled at -O2, MALLOC_PERTURB_ set, 50
-    processes: every one exits 0 with the same bytes; the change is followed within 16 calls and reported once; before
+    processes: every one exits 0 with the same bytes; the change is followed within NID_LEGACY_SLICES calls and reported once; before
     it and after it the records equal what the operators give on freshly uploaded buffers, bit for bit."""
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     pkg = os.path.join(root, "nid-pose-estimation_amd")
+    SLICES = int(re.search(r"#define NID_LEGACY_SLICES (\d+)", open(os.path.join(root, "include", "nid", "legacy_ops.h")).read()).group(1))
     exe = tmp_path / "legacy_lm_caller"
     subprocess.check_call(["g++", "-O2", "-std=c++14", "-pthread", "-I", os.path.join(root, "include", "nid", "compat"),
                            "-I", os.path.join(root, "include"), os.path.join(root, "tests", "cpp", "legacy_lm_caller.cpp"),
                            "-o", str(exe), "-L", pkg, "-lnid_host", "-lnid_hip", f"-Wl,-rpath,{pkg}"])
-    pair, nb, ncalls, change_at, pause_every = pair_A, 8, 48, 21, 8
+    pair, nb, ncalls, change_at, pause_every = pair_A, 8, 64, 13, 8
     N, ncell = pair.rows * pair.cols, pair.cell ** 2
-    change_px = (pair.rows // pair.cell // 2) * pair.cols + pair.cols // pair.cell // 2      # inside cell 0
+    change_px = (pair.rows // 2 + 7) * pair.cols + pair.cols // 2 + 9      # mid-image: sampled under every pose of the walk
     assert change_px not in {int(k * (N - 1) // 63) for k in range(64)}
     M_init = oracle.se3_to_matrix16(pair.pose_init)
     poses7, poses16 = [], []
@@ -210,7 +211,7 @@ def test_reference_call_pattern_then_free_at_once(hostlib, oracle, synth, pair_A
     for k in range(ncalls):
         Ht_b, Hj_b, der_b = before[k]
         Ht_a, Hj_a, der_a = after[k]
-        assert not np.array_equal(_bits(Ht_a[:1]), _bits(Ht_b[:1])), "the changed pixel must matter to cell 0"
+        assert not np.array_equal(_bits(Ht_a[act]), _bits(Ht_b[act])), "the changed pixel must matter to some cell"
         is_after = np.array_equal(_bits(rec[k, 0][act]), _bits(Ht_a[act]))
         is_before = np.array_equal(_bits(rec[k, 0][act]), _bits(Ht_b[act]))
         assert is_after or is_before, f"call {k}: neither the old nor the new target"
@@ -222,7 +223,7 @@ def test_reference_call_pattern_then_free_at_once(hostlib, oracle, synth, pair_A
         assert np.array_equal(_bits(rec[k, 1][act]), _bits(want[1][act]))
         if k % 4 == 0:
             assert np.array_equal(_bits(rec[k].reshape(-1)[2 * ncell:].reshape(ncell, 6)[act]), _bits(want[2][act]))
-    assert followed_at is not None and change_at <= followed_at < change_at + 16, followed_at
+    assert followed_at is not None and change_at <= followed_at < change_at + SLICES, followed_at
     # ... and the oracle on the last call with a Jacobian (the changed target)
     k = ncalls - 4
     o = oracle.from_pair(pair, nb, jac_bound="cpu", xform="matrix")
@@ -374,6 +375,32 @@ def test_lm_fused_path_equals_per_edge_path(hostlib, synth, pair_A):
         assert [r["chi2"] for r in recs_i] == [r["chi2"] for r in recs_b] and np.array_equal(pose_i, pose_b)
     finally:
         hostlib.set_resident(False)
+
+
+@pytest.mark.parametrize("strict", [False, True])
+def test_native_pair_setup_equals_the_legacy_operators_route(hostlib, synth, pair_A, pair_S_edge, strict):
+    """VERDICT r05 item 3: the fused flows hand the frame pair over in the driver's own formats (u16 depth, u8 images;
+    nid_legacy_set_pair_u16 -> nid_multi_set_pair_u16: back-projection, tiles, margins and the reference stage on the
+    device, counts and Href back).  Same chi2 sequence and the same pose, BIT FOR BIT, as round 5's route through
+    Calculate3Dpoint / CudaComputeHref (points and weights taken back to the host and uploaded again) -- plain pair, the
+    edge-case pair (depth holes, saturated / black patches, an inactive cell), the pyramid, FAST and STRICT."""
+    for pair, nb in ((pair_A, 8), (pair_S_edge, 10)):
+        for fused in (1, 2, 4):
+            pose_n, recs_n, _ = hostlib.run_lm(pair, nb, pair.pose_init, 10, fused=fused, strict=strict)
+            pose_l, recs_l, _ = hostlib.run_lm(pair, nb, pair.pose_init, 10, fused=fused, strict=strict, legacy_setup=True)
+            assert [r["lm_trials"] for r in recs_n] == [r["lm_trials"] for r in recs_l]
+            assert [r["chi2"] for r in recs_n] == [r["chi2"] for r in recs_l], (fused, nb)
+            assert np.array_equal(_bits(pose_n), _bits(pose_l))
+    # a legacy-route pair right behind a native one (and back): the operators' content keys were dropped, nothing stale
+    pose_a, _, _ = hostlib.run_lm(pair_A, 8, pair_A.pose_init, 4, fused=0, strict=strict)
+    pose_b, _, _ = hostlib.run_lm(pair_A, 8, pair_A.pose_init, 4, fused=2, strict=strict)
+    pose_c, _, _ = hostlib.run_lm(pair_A, 8, pair_A.pose_init, 4, fused=0, strict=strict)
+    assert np.array_equal(_bits(pose_a), _bits(pose_c))
+    np.testing.assert_allclose(synth.pose7_minimal(pose_a), synth.pose7_minimal(pose_b), rtol=0, atol=1e-8)
+    pose_p, per_p, _ = hostlib.run_pyramid_lm(pair_A, 8, pair_A.pose_init, levels=3, iterations=10, fused=2, strict=strict)
+    pose_q, per_q, _ = hostlib.run_pyramid_lm(pair_A, 8, pair_A.pose_init, levels=3, iterations=10, fused=2, strict=strict, legacy_setup=True)
+    assert [[r["chi2"] for r in lv] for lv in per_p] == [[r["chi2"] for r in lv] for lv in per_q]
+    assert np.array_equal(_bits(pose_p), _bits(pose_q))
 
 
 def test_pyramid_lm_pose_parity(hostlib, oracle, synth, pair_A):

@@ -341,20 +341,21 @@ def test_legacy_operators_follow_buffer_contents(hostlib, oracle, synth, pair_S,
     u1 = lib.nid_legacy_upload_count()
     assert np.array_equal(evaluate(), base) and lib.nid_legacy_upload_count() == u1
 
-    # The DEFAULT, NID_LEGACY_VERIFY_ROTATING (round 6): every call checks the cheap keys and ONE of the 16 slices of each big
+    # The DEFAULT, NID_LEGACY_VERIFY_ROTATING (round 6): every call checks the cheap keys and ONE of the 32 slices of each big
     # buffer -- hashed by the pool's workers while the device evaluates, joined before the call returns -- so an undeclared
-    # change in place is found within 16 calls, by a call that says so (stderr, nid_legacy_stale_detections), uploads the
+    # change in place is found within 32 calls, by a call that says so (stderr, nid_legacy_stale_detections), uploads the
     # new content and evaluates it before it returns.  Nothing of the caller's is read between calls.
     lib.nid_legacy_set_verify_mode(VERIFY_ROTATING)
     assert np.array_equal(evaluate(), base)
     d0, u0 = lib.nid_legacy_stale_detections(), lib.nid_legacy_upload_count()
     im1[cellpx] = 255.0 - im1[cellpx]                              # undeclared
     got, calls = None, 0
-    for k in range(16):                                            # (up to 15 calls may still see the old content)
+    SLICES = 32                                                    # NID_LEGACY_SLICES (include/nid/legacy_ops.h)
+    for k in range(SLICES):                                        # (up to SLICES - 1 calls may still see the old content)
         got = evaluate(); calls += 1
         if not np.array_equal(got, base):
             break
-    assert got[0, 0] != base[0, 0] and np.array_equal(got[1:], base[1:]), "the change was not followed within 16 calls"
+    assert got[0, 0] != base[0, 0] and np.array_equal(got[1:], base[1:]), "the change was not followed within NID_LEGACY_SLICES calls"
     assert lib.nid_legacy_stale_detections() == d0 + 1 and lib.nid_legacy_upload_count() == u0 + 1
     assert np.array_equal(evaluate(), got)                         # ... and stays followed
     im1[cellpx] = 255.0 - im1[cellpx]
@@ -370,11 +371,11 @@ def test_legacy_operators_follow_buffer_contents(hostlib, oracle, synth, pair_S,
     keep = bsv[4 * lastpx:4 * lastpx + 4].copy()
     assert all(4 * lastpx + q not in {int(k * (4 * N - 1) // 63) for k in range(64)} for q in range(4))
     bsv[4 * lastpx:4 * lastpx + 4] = np.where(np.isnan(keep), 0.0, keep + 0.25)
-    for k in range(4):
+    for k in range(SLICES // 4):
         got = evaluate()
         if lib.nid_legacy_stale_detections() == d0 + 2:
             break
-    assert lib.nid_legacy_stale_detections() == d0 + 2, "a change in the last slice was not found within 16 / 4 calls"
+    assert lib.nid_legacy_stale_detections() == d0 + 2, "a change in the last slice was not found within SLICES / 4 calls"
     bsv[4 * lastpx:4 * lastpx + 4] = keep
     lib.nid_legacy_invalidate(4)
     assert np.array_equal(evaluate(), base)

@@ -355,6 +355,42 @@ def test_reference_from_points_equals_reference_from_depth(capi, oracle, pair_S_
         assert np.array_equal(_bits(x[act]), _bits(y[act]))
 
 
+@pytest.mark.parametrize("matrix", [False, True])
+def test_pair_u16_equals_the_three_step_setup(capi, oracle, synth, pair_S_edge, pair_A, matrix):
+    """nid_set_pair_u16 (round 6): u16 depth + u8 images in one call -- the same device state, bit for bit, as
+    nid_set_reference_depth(depth * 1/5000) + nid_set_target_u8 + nid_compute_href[_matrix]: counts, Href, the
+    back-projected points, every per-cell output of an evaluation; and against the oracle like any other set-up.
+    Also on shards (nid_multi_set_pair_u16, two shards on one device) and after an earlier pair on the same context."""
+    for pair, nb in ((pair_S_edge, 10), (pair_A, 8)):
+        T = synth.matrix_colmajor16(pair.T_wc0)
+        xf = capi.XFORM_MATRIX if matrix else capi.XFORM_QUAT
+        a = capi.from_pair(pair, nb, xform=xf)
+        pose0 = oracle.se3_to_matrix16(pair.pose_init) if matrix else pair.pose_init
+        ca, ha = a.compute_href_matrix(pose0) if matrix else a.compute_href(pair.pose_init)
+        b = capi.Context(pair.rows, pair.cols, pair.cell, nb, pair.fx, pair.fy, pair.cx, pair.cy, xform=xf)
+        other = np.roll(pair.im1, 5, axis=0)
+        b.set_pair_u16(pair.depth_u16, 1.0 / 5000, other, pair.im0, T, pose0, matrix=matrix)   # an earlier, different pair
+        cb, hb = b.set_pair_u16(pair.depth_u16, 1.0 / 5000, pair.im0, pair.im1, T, pose0, matrix=matrix)
+        assert np.array_equal(ca, cb)
+        act = ca >= 300
+        assert np.array_equal(_bits(ha[act]), _bits(hb[act])) and np.isnan(hb[~act]).all()
+        pa, pb = a.get_points3d(), b.get_points3d()
+        assert np.array_equal(np.isnan(pa), np.isnan(pb)) and np.array_equal(_bits(pa[~np.isnan(pa)]), _bits(pb[~np.isnan(pb)]))
+        for pose in (pair.pose_init, pair.pose_true):
+            for x, y in zip(a.evaluate(pose, True), b.evaluate(pose, True)):
+                assert np.array_equal(_bits(x[act]), _bits(y[act]))
+        o = oracle.from_pair(pair, nb, xform="matrix" if matrix else "quat")
+        co, ho = o.compute_href(pair.pose_init)
+        assert np.array_equal(cb, co)
+        np.testing.assert_allclose(hb[act], ho[act], rtol=0, atol=1e-11)
+        m = capi.Multi(pair.rows, pair.cols, pair.cell, nb, pair.fx, pair.fy, pair.cx, pair.cy, devices=[0, 0], xform=xf)
+        cm, hm = m.set_pair_u16(pair.depth_u16, 1.0 / 5000, pair.im0, pair.im1, T, pose0, matrix=matrix)
+        assert np.array_equal(cm, ca) and np.array_equal(_bits(hm[act]), _bits(ha[act]))
+        m.close()
+    with pytest.raises(capi.NidError):   # missing buffers / not exactly one pose form
+        b._check(b.lib.nid_set_pair_u16(b.h, None, 0.0, None, None, None, None, None, None, None), "nid_set_pair_u16")
+
+
 def test_bitwise_reproducible_and_kernel_variant_independent(capi, synth, pair_A):
     """Histograms are accumulated in 64-bit fixed point and every reduction has a fixed order, so a
     launch is bitwise reproducible; the generic-bin-count diagnostic build (taken when the pixel
