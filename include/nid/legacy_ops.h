@@ -26,15 +26,17 @@
 // is back -- NID_pose_estimation.cpp:388-395 frees everything right after the last CudaComputeH.  How the
 // operators make sure the device holds what the buffers hold NOW (nid_legacy_set_verify_mode):
 //  * NID_LEGACY_VERIFY_ROTATING (default): a call checks address, length and 64 samples of each big
-//    buffer (a microsecond in all), hands ONE of the 16 slices of im0 / points3d / im1 / bs_ref (1.4 MB in
-//    all at 640x480; slice = call number mod 16) to a small pool of worker threads (NID_LEGACY_HASH_THREADS,
-//    default 3; 0: the caller hashes alone), evaluates on the device meanwhile, and joins the workers before
-//    it returns.  A buffer rewritten IN PLACE is found within 16 calls: that call says so on stderr, counts
-//    it (nid_legacy_stale_detections), uploads the new content and evaluates again before it returns.
-//    nid_legacy_set_verify_slices(k) / NID_LEGACY_VERIFY_SLICES=k: k slices per call (found within 16/k calls).
-//  * NID_LEGACY_VERIFY_EVERY_CALL (= 16 slices per call; NID_LEGACY_VERIFY_EVERY_CALL=1): every call hashes all
-//    four buffers in full and evaluates what they hold now -- the reference's guarantee exactly (it uploads
-//    everything on every call, computeH.cu:420-429), at 0.3-0.4 ms per call at 640x480.
+//    buffer (a microsecond in all) and hands a few of the 128 slices of im0 / points3d / im1 / bs_ref -- 1/32
+//    of every buffer on average, 0.7 MB at 640x480; 6 slices with the Jacobian, 3 without: what hides behind
+//    the call's own evaluation -- to a small pool of worker threads (NID_LEGACY_HASH_THREADS, default 3; 0:
+//    the caller hashes alone), evaluates on the device meanwhile, and JOINS the workers before it returns.
+//    A buffer rewritten IN PLACE is found within 43 calls (35 in the LM's pattern; the reference's LM makes
+//    40-60 per pair): that call says so on stderr, counts it (nid_legacy_stale_detections), uploads the new
+//    content and evaluates again before it returns.  +3-5 us per call (profiles/r06_legacy_call_cost.txt).
+//    nid_legacy_set_verify_slices(k) / NID_LEGACY_VERIFY_SLICES=k: k slices per call instead of 4.
+//  * NID_LEGACY_VERIFY_EVERY_CALL (= all 128 slices on every call; NID_LEGACY_VERIFY_EVERY_CALL=1): every call
+//    hashes all four buffers in full and evaluates what they hold now -- the reference's guarantee exactly
+//    (it uploads everything on every call, computeH.cu:420-429), at 0.4 ms per call at 640x480.
 //  * NID_LEGACY_VERIFY_TRUSTED (nid_legacy_set_trust_buffers(1), NID_LEGACY_TRUST_BUFFERS=1): the cheap
 //    check only; full hashes when it fails, on every 128th call of a pair, and after
 //    nid_legacy_invalidate(parts).  For callers that do not rewrite buffers in place, or say so.
@@ -93,10 +95,11 @@ void nid_legacy_reset(void);
 // (the context, its buffers and its communicator stay: the next pair of the same geometry costs no context creation)
 void nid_legacy_quiesce(void);
 // how the operators make sure the device holds what the caller's buffers hold (THE CONTRACT above)
-#define NID_LEGACY_SLICES 32 /* slices per big buffer; ROTATING checks one of them per call */
+#define NID_LEGACY_SLICES 128        /* slices per big buffer (a content key holds one hash per slice) */
+#define NID_LEGACY_SLICES_PER_CALL 4 /* ROTATING checks this many of them per call: 1/32 of every buffer */
 enum { NID_LEGACY_VERIFY_ROTATING = 0, NID_LEGACY_VERIFY_EVERY_CALL = 1, NID_LEGACY_VERIFY_TRUSTED = 2 };
 void nid_legacy_set_verify_mode(int mode);
-void nid_legacy_set_verify_slices(int per_call);  // ROTATING: slices of 16 checked per call (default 1; < 1: the default)
+void nid_legacy_set_verify_slices(int per_call);  // ROTATING: slices (of NID_LEGACY_SLICES) per call; < 1: NID_LEGACY_SLICES_PER_CALL
 void nid_legacy_set_trust_buffers(int on);   // 1: NID_LEGACY_VERIFY_TRUSTED, 0: the default
 // in-place changes the rotating verification has found and reported so far
 long nid_legacy_stale_detections(void);

@@ -8,20 +8,20 @@
 // pair (NID_pose_estimation.cpp:229-251, 385-392) usually gets the same addresses back.
 //   * CudaComputeHref is called once per pair: it always uploads the reference (im0, points3d) afresh;
 //   * CudaComputeH keeps, per big caller buffer (im0, points3d, im1, bs_ref), a key: address, length, a quick
-//     fingerprint of 64 samples and the 64-bit hashes of its kSlices (16) contiguous slices; per small array
+//     fingerprint of 64 samples and the 64-bit hashes of its kSlices (128) contiguous slices; per small array
 //     (bs_counter, Href: 1-2 KB) address, length and ONE hash, recomputed on every call.
 //   * EVERY read of a caller buffer happens between the entry and the return of an operator (round 6; round 5's default
 //     let worker threads read them between calls -- a use-after-free for the reference's main(), which frees its
 //     buffers right after the last CudaComputeH, NID_pose_estimation.cpp:388-395).  Two modes
 //     (nid_legacy_set_verify_mode):
 //     ROTATING (default): a call checks address, length and the quick fingerprint of the four big buffers (about a
-//     microsecond), hands slice (call number mod 16) of each of them -- 1/16 of 22 MB at 640x480 -- to the pool's worker
+//     microsecond), hands a few of their 128 slices -- 1/32 of every buffer per call on average -- to the pool's worker
 //     threads, runs the evaluation on the device, and JOINS the workers before it returns.  A slice that no longer hashes
 //     to what its key holds means the buffer was rewritten in place: the call says so on stderr, counts it
 //     (nid_legacy_stale_detections), uploads the buffer's current content and evaluates again before it returns -- an
-//     undeclared change in place is followed within 16 calls (the reference's LM makes 30-60 per pair) and the caller
-//     is told.  nid_legacy_set_verify_slices(16) (NID_LEGACY_VERIFY_EVERY_CALL=1, mode EVERY_CALL) checks every slice on
-//     every call: the reference's guarantee exactly (it re-uploads everything on every call, computeH.cu:420-429).
+//     undeclared change in place is followed within 43 calls (the reference's LM makes 40-60 per pair) and the caller
+//     is told.  NID_LEGACY_VERIFY_EVERY_CALL=1 (mode EVERY_CALL) checks every slice on every call: the reference's
+//     guarantee exactly (it re-uploads everything on every call, computeH.cu:420-429).
 //     TRUSTED (nid_legacy_set_trust_buffers(1) or NID_LEGACY_TRUST_BUFFERS=1): the cheap check only; the full hash is
 //     recomputed -- and decides whether the buffer is uploaded -- when the cheap part changed, on every kRehashEvery-th
 //     call of a pair, and after nid_legacy_invalidate().  No thread is woken by this mode's calls once the pair is set up.
@@ -39,6 +39,7 @@
 #include <cstring>
 #include <condition_variable>
 #include <functional>
+#include <memory>
 #include <mutex>
 #include <pthread.h>
 #include <thread>
@@ -68,6 +69,7 @@ struct LegacyState {
   Key k_im0, k_points, k_im1, k_bs_ref, k_counter, k_href;
   bool have_ref = false, have_target = false, have_href = false;
   unsigned long calls = 0;      // CudaComputeH calls on this frame pair (CudaComputeHref starts a new count)
+  unsigned long rot = 0;        // the rotating verification's cursor: the next slice to check
   unsigned force_full = 0;      // nid_legacy_invalidate: parts whose full hash the next call recomputes
   unsigned fresh = 0;           // parts hashed in full or uploaded by the CURRENT call: nothing to verify behind them
 };
@@ -136,7 +138,7 @@ int slices_per_call() {
   if (mode == NID_LEGACY_VERIFY_TRUSTED) return 0;
   if (mode == NID_LEGACY_VERIFY_EVERY_CALL) return kSlices;
   if (g_verify_slices > 0) return std::min(g_verify_slices, kSlices);
-  static const int env = [] { const char *e = getenv("NID_LEGACY_VERIFY_SLICES"); return e ? std::max(1, std::min(kSlices, atoi(e))) : 1; }();
+  static const int env = [] { const char *e = getenv("NID_LEGACY_VERIFY_SLICES"); return e ? std::max(1, std::min(kSlices, atoi(e))) : NID_LEGACY_SLICES_PER_CALL; }();
   return env;
 }
 long g_stale_detections = 0;
@@ -177,33 +179,39 @@ class HashPool {
   // start(n, job): job(0..n-1) is handed to the workers -- each takes the next part that nobody has taken -- and the
   // call returns; finish(): the caller takes what is left and waits for the rest.  One job at a time, started and
   // finished by the same thread; the job must stay valid until finish().
-  void start(int nparts, std::function<void(int)> job) {
+  // Parts are claimed with one atomic increment on the JOB's own counter (a worker that comes late holds the old job
+  // object and finds nothing left in it: it can never touch the next job's parts); the mutex is for parking only.
+  void start(int nparts, std::function<void(int)> fn) {
     call_.lock();
-    bool parked;
-    {
+    auto j = std::make_shared<Job>();
+    j->fn = std::move(fn);
+    j->nparts = nparts;
+    j->remaining.store(nparts, std::memory_order_relaxed);
+    mine_ = j;
+    std::atomic_store(&current_, j);
+    generation_.fetch_add(1);  // (sequentially consistent with parked_: either this thread sees a parking worker, or the worker sees the new generation)
+    if (parked_.load() > 0 && has_workers()) {  // (a fork()ed child has no workers: finish() does all parts)
       std::lock_guard<std::mutex> g(m_);
-      job_ = std::move(job);
-      next_ = 0;
-      nparts_ = nparts;
-      remaining_ = nparts;
-      generation_.fetch_add(1, std::memory_order_release);
-      parked = parked_ > 0;
+      wake_.notify_all();
     }
-    if (parked && has_workers()) wake_.notify_all();  // (a fork()ed child has no workers: finish() does all parts)
   }
   void finish() {
-    help();
-    {
-      std::unique_lock<std::mutex> g(m_);
-      done_.wait(g, [&] { return remaining_ == 0; });
-      job_ = nullptr;
-    }
+    Job &j = *mine_;
+    help(j);
+    while (j.remaining.load(std::memory_order_acquire) > 0) __builtin_ia32_pause();  // (parts in other threads' hands: microseconds)
+    std::atomic_store(&current_, std::shared_ptr<Job>());
+    mine_.reset();
     call_.unlock();
   }
   void run(int nparts, std::function<void(int)> job) { start(nparts, std::move(job)); finish(); }
   bool has_workers() const { return !workers_.empty() && getpid() == owner_; }
 
  private:
+  struct Job {
+    std::function<void(int)> fn;
+    int nparts = 0;
+    std::atomic<int> next{0}, remaining{0};
+  };
   HashPool() : owner_(getpid()) {
     int n = 3;
     if (const char *e = getenv("NID_LEGACY_HASH_THREADS")) n = std::max(0, std::min(15, atoi(e)));
@@ -218,52 +226,44 @@ class HashPool {
                    [] { HashPool &p = get(); p.m_.unlock(); p.call_.unlock(); },
                    [] { HashPool &p = get(); p.m_.unlock(); p.call_.unlock(); });
   }
-  void help() {  // take parts until none is left
+  static void help(Job &j) {  // take parts until none is left
     for (;;) {
-      std::function<void(int)> *job;
-      int part;
-      {
-        std::lock_guard<std::mutex> g(m_);
-        if (next_ >= nparts_ || !job_) return;
-        part = next_++;
-        job = &job_;
-      }
-      (*job)(part);
-      bool last;
-      { std::lock_guard<std::mutex> g(m_); last = --remaining_ == 0; }
-      if (last) done_.notify_all();
+      const int part = j.next.fetch_add(1, std::memory_order_acq_rel);
+      if (part >= j.nparts) return;
+      j.fn(part);
+      j.remaining.fetch_sub(1, std::memory_order_release);
     }
   }
   // A worker that has just served a job keeps POLLING for the next one for spin_us_ microseconds before it parks on the
   // condition variable: the operators are called back to back by the LM (one call per 30-60 us), and a parked thread
   // takes 10-20 us to come back -- as long as the whole evaluation it is supposed to hide behind
-  // (profiles/r06_pair_setup.txt).  NID_LEGACY_HASH_SPIN_US (default 150; 0: park at once).
+  // (profiles/r06_legacy_call_cost.txt).  NID_LEGACY_HASH_SPIN_US (default 150; 0: park at once).
   void loop() {
     unsigned long seen = 0;
     for (;;) {
       const auto t0 = std::chrono::steady_clock::now();
       bool got = false;
-      while (spin_us_ > 0) {
+      for (unsigned spins = 0; spin_us_ > 0; spins++) {
         if (generation_.load(std::memory_order_acquire) != seen) { got = true; break; }
         __builtin_ia32_pause();
-        if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(spin_us_)) break;
+        if ((spins & 63) == 63 && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(spin_us_)) break;
       }
       if (!got) {
         std::unique_lock<std::mutex> g(m_);
-        parked_++;
-        wake_.wait(g, [&] { return generation_.load(std::memory_order_acquire) != seen; });
-        parked_--;
+        parked_.fetch_add(1);
+        wake_.wait(g, [&] { return generation_.load() != seen; });
+        parked_.fetch_sub(1);
       }
       seen = generation_.load(std::memory_order_acquire);
-      help();
+      if (std::shared_ptr<Job> j = std::atomic_load(&current_)) help(*j);
     }
   }
   std::mutex call_, m_;
-  std::condition_variable wake_, done_;
-  std::function<void(int)> job_;
+  std::condition_variable wake_;
+  std::shared_ptr<Job> current_, mine_;
   std::vector<std::thread> workers_;
   std::atomic<unsigned long> generation_{0};
-  int next_ = 0, nparts_ = 0, remaining_ = 0, parked_ = 0;
+  std::atomic<int> parked_{0};
   int spin_us_ = 150;
   const pid_t owner_;
 };
@@ -582,7 +582,7 @@ struct CallArgs {
   double *Href;
 };
 nid_multi *ensure_state(const CallArgs &a);
-void verify_begin(const CallArgs &a);
+void verify_begin(const CallArgs &a, bool long_call);
 unsigned verify_end(const CallArgs &a);
 nid_multi *follow_change(const CallArgs &a, unsigned stale);
 }
@@ -600,7 +600,7 @@ void CudaComputeH(bool calculate_der, double *im0, double *im1, double *points3d
   const int ncell = cell_num * cell_num;
   std::vector<double> ht(ncell), hj(ncell);
   // this call's slices of the caller's buffers are hashed by the pool's workers WHILE the device evaluates ...
-  verify_begin(a);
+  verify_begin(a, calculate_der);
   int rc = nid_multi_evaluate_matrix(m, pose, calculate_der ? 1 : 0, ht.data(), hj.data(), nullptr, calculate_der ? der : nullptr);
   // ... and the workers are joined here, on every path: no read of a caller buffer outlives the call
   const unsigned stale = verify_end(a);
@@ -692,10 +692,14 @@ nid_multi *ensure_state(const CallArgs &a) {
 SliceHasher g_verify;
 struct VerifyPlan { const LegacyState::Key *key[4]; const void *addr[4]; size_t n[4]; bool on[4]; int first, count; } g_plan;
 
-void verify_begin(const CallArgs &a) {
+void verify_begin(const CallArgs &a, bool long_call) {
   LegacyState &S = g_state;
-  const int k = always_upload() ? 0 : slices_per_call();
+  int k = always_upload() ? 0 : slices_per_call();
   if (k <= 0) return;
+  // a call hashes what hides behind its own evaluation: an evaluation with the Jacobian phase takes twice a cost-only one
+  // (20 against 10 us of device time at 640x480; the pool reads ~45 MB/ms), so it takes 1.5 k slices and a cost-only call
+  // 0.75 k -- the LM's pattern of one in four covers 15/16 k per call on average (profiles/r06_legacy_call_cost.txt)
+  if (k < kSlices && k >= 4) k = long_call ? k + k / 2 : k - k / 4;
   const size_t N = (size_t)a.rows * a.cols;
   static const unsigned part[4] = {NID_LEGACY_REFERENCE, NID_LEGACY_REFERENCE, NID_LEGACY_TARGET, NID_LEGACY_HREF_STATE};
   const LegacyState::Key *key[4] = {&S.k_im0, &S.k_points, &S.k_im1, &S.k_bs_ref};
@@ -712,7 +716,8 @@ void verify_begin(const CallArgs &a) {
   }
   if (!any) return;
   g_plan.count = k;
-  g_plan.first = (int)((S.calls * (unsigned long)k) % kSlices);
+  g_plan.first = (int)(S.rot % kSlices);
+  S.rot += (unsigned long)k;
   g_verify.begin(req, 4, g_plan.first, g_plan.count);
 }
 
@@ -827,7 +832,7 @@ nid_multi *nid_legacy_prepare(double *im0, double *im1, double *points3d, int *b
   nid_multi *m = ensure_state(a);
   if (!m) return nullptr;
   // (no evaluation to overlap with: this call's slices are hashed on the spot)
-  verify_begin(a);
+  verify_begin(a, false);
   const unsigned stale = verify_end(a);
   return stale ? follow_change(a, stale) : m;
 }

@@ -37,7 +37,7 @@ int main() {
     for (int k = 0; k < 20; k++) if (call(k) != want) _exit(12);
     im1[N / 2 + 17] = 255.0 - im1[N / 2 + 17];   // an in-place change is still followed in the child (hashing alone)
     bool seen = false;
-    for (int k = 0; k < NID_LEGACY_SLICES + 1; k++) seen = seen || call(k) != want;
+    for (int k = 0; k < NID_LEGACY_SLICES / NID_LEGACY_SLICES_PER_CALL + 1; k++) seen = seen || call(k) != want;
     _exit(seen ? 0 : 13);
   }
   for (int k = 0; k < 20; k++) if (call(k) != want) return 14;

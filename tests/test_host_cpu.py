@@ -108,7 +108,9 @@ def test_legacy_operators_read_caller_buffers_only_inside_a_call_asan(tmp_path, 
     worker thread that reads a caller buffer after its call has returned is a heap-use-after-free here (round 5's
     default mode fails this test with exactly that report).  Default verification mode; with and without pool threads."""
     exe = _build_with_stub(tmp_path, "legacy_lm_caller.cpp", "legacy_lm_caller_asan")
-    SLICES = int(re.search(r"#define NID_LEGACY_SLICES (\d+)", open(os.path.join(ROOT, "include", "nid", "legacy_ops.h")).read()).group(1))
+    hdr = open(os.path.join(ROOT, "include", "nid", "legacy_ops.h")).read()
+    per_call = int(re.search(r"#define NID_LEGACY_SLICES_PER_CALL (\d+)", hdr).group(1))
+    SLICES = -(-int(re.search(r"#define NID_LEGACY_SLICES (\d+)", hdr).group(1)) // (per_call - per_call // 4))   # calls until every slice was checked (cost-only calls check 3/4 of per_call)
     rows, cols, cell, nb, ncalls, change_at, pause_every = 480, 640, 16, 8, 64, 13, 8
     N, ncell = rows * cols, cell * cell
     rng = np.random.default_rng(3)

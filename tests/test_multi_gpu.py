@@ -341,16 +341,16 @@ def test_legacy_operators_follow_buffer_contents(hostlib, oracle, synth, pair_S,
     u1 = lib.nid_legacy_upload_count()
     assert np.array_equal(evaluate(), base) and lib.nid_legacy_upload_count() == u1
 
-    # The DEFAULT, NID_LEGACY_VERIFY_ROTATING (round 6): every call checks the cheap keys and ONE of the 32 slices of each big
+    # The DEFAULT, NID_LEGACY_VERIFY_ROTATING (round 6): every call checks the cheap keys and a few of the 128 slices of each big
     # buffer -- hashed by the pool's workers while the device evaluates, joined before the call returns -- so an undeclared
-    # change in place is found within 32 calls, by a call that says so (stderr, nid_legacy_stale_detections), uploads the
+    # change in place is found within 43 calls (35 in the LM's pattern), by a call that says so (stderr, nid_legacy_stale_detections), uploads the
     # new content and evaluates it before it returns.  Nothing of the caller's is read between calls.
     lib.nid_legacy_set_verify_mode(VERIFY_ROTATING)
     assert np.array_equal(evaluate(), base)
     d0, u0 = lib.nid_legacy_stale_detections(), lib.nid_legacy_upload_count()
     im1[cellpx] = 255.0 - im1[cellpx]                              # undeclared
     got, calls = None, 0
-    SLICES = 32                                                    # NID_LEGACY_SLICES (include/nid/legacy_ops.h)
+    SLICES = 43                                                    # ceil(NID_LEGACY_SLICES / (3/4 NID_LEGACY_SLICES_PER_CALL)): cost-only calls (include/nid/legacy_ops.h)
     for k in range(SLICES):                                        # (up to SLICES - 1 calls may still see the old content)
         got = evaluate(); calls += 1
         if not np.array_equal(got, base):
@@ -366,16 +366,16 @@ def test_legacy_operators_follow_buffer_contents(hostlib, oracle, synth, pair_S,
     assert lib.nid_legacy_stale_detections() == d0 + 1 and lib.nid_legacy_upload_count() == u0 + 2
     # a change in the LAST slice of the largest buffer (bs_ref's final row: not a sampled index either), 4 slices per call
     lib.nid_legacy_set_verify_slices.argtypes = [hostlib.C.c_int]
-    lib.nid_legacy_set_verify_slices(4)
+    lib.nid_legacy_set_verify_slices(16)                           # four times the default
     lastpx = N - 2
     keep = bsv[4 * lastpx:4 * lastpx + 4].copy()
     assert all(4 * lastpx + q not in {int(k * (4 * N - 1) // 63) for k in range(64)} for q in range(4))
     bsv[4 * lastpx:4 * lastpx + 4] = np.where(np.isnan(keep), 0.0, keep + 0.25)
-    for k in range(SLICES // 4):
+    for k in range(11):                                            # 128 slices, 12 per cost-only call
         got = evaluate()
         if lib.nid_legacy_stale_detections() == d0 + 2:
             break
-    assert lib.nid_legacy_stale_detections() == d0 + 2, "a change in the last slice was not found within SLICES / 4 calls"
+    assert lib.nid_legacy_stale_detections() == d0 + 2, "a change in the last slice was not found within 11 calls"
     bsv[4 * lastpx:4 * lastpx + 4] = keep
     lib.nid_legacy_invalidate(4)
     assert np.array_equal(evaluate(), base)
