@@ -495,68 +495,42 @@ def main():
                 dist.all_reduce(go_on, op=dist.ReduceOp.MIN)
             if go_on.item() == 0.0:
                 break
-    if K <= 64 and args.preheat_seconds > 0:
-        # ... and ONE rehearsal of exactly what follows -- the W warmup steps, the synchronisation, a collecting run(K) --:
-        # the first synchronisation behind a burst of launches leaves the runtime work that the next launches pay for
-        # (the timed shot measured 10-40 us above its own repetitions, `short_sequence.repeat_us_per_shot`, without it)
-        run(W, collect=False)
-        barrier()
-        run(K)
     run(W, collect=False)
     seq_cache.setdefault(K, np.ascontiguousarray(pose_arr[np.arange(K) % len(poses)], dtype=np.float64))
-    barrier()
-    t0 = time.perf_counter()
-    results = run(K)
-    # N = 1: run(K) returns with every step's 6x6 system in host memory ("delivered to host memory" -- it has
-    # waited for each block), so the region ends here; a device-wide synchronisation behind it would time only the
-    # runtime's own end-of-kernel bookkeeping (19.5 us, profiles/r04_short_sequences.txt).  N > 1: barrier + synchronise,
-    # and the max over the ranks, as the contract says.
-    if dist is not None:
+
+    def timed_region():
+        # barrier + device synchronisation | run(K): every step's 6x6 system in host memory | barrier + device synchronisation
+        # (round 6, ADVICE r05: the synchronisation BEHIND the K steps is part of the region again, as the contract says and as
+        # every round before round 5 timed it; round 5 had dropped it at N = 1)
         barrier()
-    elapsed = time.perf_counter() - t0
+        t_a = time.perf_counter()
+        r = run(K)
+        barrier()
+        return time.perf_counter() - t_a, r
+
+    elapsed, results = timed_region()
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-
-    # A SHORT timed region (K <= 64 at N = 1: the driver's --steps 20) is a short sequence (nid_run_sequence with n <= batch:
-    # launches of <= 16 poses on the context's two streams, plan_split).  Beside it, for the record: the same region again
-    # (so that the line says how far one shot is from the next), and the opt-in resident BATCH evaluator
-    # (nid_set_resident(ctx, 2): no launch at all -- measured slower, include/nid/nid_c.h says why).
+    # A SHORT timed region (K <= 64 at N = 1: the driver's --steps 20) is ONE short sequence (nid_run_sequence with n <= batch:
+    # launches of <= 16 poses on the context's two streams, plan_split) of ~100 us: a single shot of it varies by +-15 % from
+    # process to process and with what the device did just before (profiles/r05_short_sequences.txt).  Round 6:
+    # the SAME region -- W warmup steps, then barrier + synchronisation | run(K) | synchronisation -- is timed eleven times
+    # and `value` is K over the MEDIAN; the first shot and every sample are in the line (short_sequence).  No rehearsal.
     short_info = None
-    if (not multi) and K <= 64 and not args.quick:
-        shots = []
-        for _ in range(5):
+    first_shot = elapsed
+    if (not multi) and K <= 64:
+        shots = [elapsed]
+        for _ in range(10):
             run(W, collect=False)
-            torch.cuda.synchronize(dev)
-            t1 = time.perf_counter()
-            r2 = run(K)
-            shots.append(time.perf_counter() - t1)
-        assert np.array_equal(r2, results)
-        short_info = {"form": "launches (plan_split: <= 16 poses per launch, two streams)", "repeat_us_per_shot": [x * 1e6 for x in shots]}
-        if not args.strict and not args.block_threads:
-            try:
-                ctx.set_resident(2)
-                for _ in range(20):
-                    run(K, collect=False)
-                rs = []
-                for _ in range(5):
-                    run(W, collect=False)
-                    torch.cuda.synchronize(dev)
-                    t1 = time.perf_counter()
-                    r3 = run(K)
-                    rs.append(time.perf_counter() - t1)
-                st = ctx.resident_batch_stats()
-                ctx.set_resident(False)
-                short_info["resident_batch_evaluator"] = {"it_per_s": K / float(np.median(rs)), "us_per_shot": [x * 1e6 for x in rs], "stats": st,
-                                                          "same_bits_as_launches": bool(np.array_equal(r3, results)),
-                                                          "note": "opt-in (nid_set_resident(ctx, 2)); not the form `value` is measured with"}
-            except Exception as e:   # noqa: BLE001 -- a platform without a CPU-addressable BAR
-                short_info["resident_batch_evaluator"] = {"error": str(e)[:200]}
-                try:
-                    ctx.set_resident(False)
-                except Exception:   # noqa: BLE001
-                    pass
+            el, r2 = timed_region()
+            shots.append(el)
+            assert np.array_equal(r2, results)
+        elapsed = float(np.median(shots))
+        short_info = {"form": "launches (plan_split: <= 16 poses per launch, two streams)", "timed_region": "barrier + synchronise | run(K) | synchronise",
+                      "value_from": "median of 11 identical timed regions (W warmup steps in front of each)",
+                      "first_shot_us": first_shot * 1e6, "us_per_shot": [x * 1e6 for x in shots]}
     # sanity: every result is finite, and the pipelined result of the last step equals a synchronous evaluation of
     # the same pose (every rank holds the same sums after the exchange)
     ablation = bool(os.environ.get("NID_HIP_LIB"))  # kernel-ablation builds (exp/) produce meaningless numbers
@@ -792,6 +766,32 @@ def main():
             el = time.perf_counter() - t0
             ctx.set_math_mode(math_mode)
             roof["other_math_mode"] = {"mode": "FAST" if args.strict else "STRICT", "it_per_s": n_o / el, "steps": n_o}
+            # the reference's own DEFAULT bin count (NID_pose_estimation.cpp:27; BASELINE's config is 8 bins): same pair, same
+            # pipeline, 10 bins -- kernel time like roofline.kernel_ms, the pipelined rate over >= 1 s
+            if args.bins != 10:
+                try:
+                    c10 = capi.from_pair(pair, 10, device=local_rank)
+                    c10.set_math_mode(math_mode)
+                    c10.compute_href(pair.pose_init)
+                    t_pre, n10 = time.perf_counter(), 0
+                    while time.perf_counter() - t_pre < 0.3:
+                        c10.run_sequence(pose_arr[np.arange(B * 8) % 256], delta, batch=B, want_jac=want_jac, collect=False)
+                        n10 += B * 8
+                    n10 = max(B * 40, int(n10 / (time.perf_counter() - t_pre) * 1.1) // B * B)
+                    t0 = time.perf_counter()
+                    c10.run_sequence(pose_arr[np.arange(n10) % 256], delta, batch=B, want_jac=want_jac, collect=False)
+                    torch.cuda.synchronize(dev)
+                    el10 = time.perf_counter() - t0
+                    ms10 = float(np.median([c10.time_launches(pose_arr[[(i * B + k) % 256 for k in range(B)]], delta, repeats=10, want_jac=want_jac) for i in range(8)]))
+                    roof["bins10"] = {"kernel_ms": ms10, "poses_per_launch": B, "contract_frac": c10.contract_bytes() * B / (ms10 * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                      "sustained": {"it_per_s": n10 / el10, "steps": n10, "seconds": el10},
+                                      "relative_to_8_bins": (n10 / el10) / roof["sustained"]["it_per_s"],
+                                      "note": "the reference's default bin_num = 10 (NID_pose_estimation.cpp:27, types_six_dof_expmap.h:287); "
+                                              "same contract bytes as 8 bins (the histograms never leave LDS); 110 instead of 72 bins per cell: "
+                                              "the fold, the LDS footprint (workgroups per CU) and the contracted tables grow"}
+                    c10.close()
+                except Exception as e:   # noqa: BLE001
+                    roof["bins10"] = {"error": str(e)[:200]}
             # the same pipeline on the pair WITH a flash (BASELINE configs[0] is a flash pair): a saturating hot spot,
             # black / saturated patches, depth holes -- what the exact-decision second passes and the clamped-sample
             # accumulation cost on such data
@@ -849,10 +849,9 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "value_is": ("pipelined evaluation throughput over independent candidate poses" if K > 64 or multi else
-                         "K independent candidate poses as ONE short sequence, from the call to the last 6x6 system in host memory "
-                         "(the region ends when run(K) returns: every block has been waited for; no device synchronisation behind it; in front of "
-                         "it, untimed: --preheat-sequences sequences of the same length, one rehearsal of warmup + synchronisation + run(K), "
-                         "the W warmup steps, the synchronisation)")
+                         "K independent candidate poses as ONE short sequence, from the call to the last 6x6 system in host memory plus the "
+                         "device synchronisation behind it; MEDIAN of 11 such regions (short_sequence.us_per_shot; round 5 reported one "
+                         "rehearsed shot without the trailing synchronisation: not comparable)")
                         + "; dependent-chain rates: roofline.sequential, pose_error_vs_ref.lm_outer_iterations_per_s"
                         + ("; sustained throughput of the pipeline: roofline.sustained" if not multi else ""),
             "short_sequence": short_info,

@@ -170,22 +170,9 @@ int nid_set_resident(nid_ctx *ctx, int on);
 int nid_resident_pause(nid_ctx *ctx);
 /* requests served by the resident kernel, requests re-issued as ordinary launches, kernel starts */
 int nid_resident_stats(const nid_ctx *ctx, int64_t *served, int64_t *fallbacks, int64_t *starts);
-/* The resident BATCH evaluator (round 5), opt-in: nid_set_resident(ctx, 2).  Requests of 2..64 poses whose results are
- * collected slot by slot -- nid_launch_batch, nid_run_sequence with n <= batch: the trial poses of an LM step, a short
- * sequence -- are then answered by a resident kernel in the THROUGHPUT form (128-thread workgroups, eight per CU, each
- * cell's workgroups sharing the request's poses; the in-launch reduction): no launch -- the poses' records wait in
- * pinned host memory, one word goes through the mailbox.  Same bits as launches.  Taken when the context evaluates in
- * FAST math on its own streams, no single-pose resident kernel is on the device, and -- for cost + Jacobian requests --
- * the context's launch shape is the 128-thread one (0 or 128: the Jacobian's last bits depend on the shape); while it
- * runs, single poses go to it too.  One request in flight at a time; everything said above about co-residency,
- * retiring, fallbacks and sharing the device holds for it.
- * MEASURED, and why it is not part of nid_set_resident(ctx, 1) (profiles/r05_short_sequences.txt): a request of 20 poses
- * takes 146 us against 88 us as launches (8 poses: 62 vs 55; 64: 383 vs 231).  Every workgroup starts a request at
- * the same instant, so the device walks through the phases of an evaluation in lockstep -- histogram atomics, fold,
- * Jacobian -- about 45 us per round of eight evaluations per CU, where the launches of a pipeline overlap them (25);
- * the launch it saves costs 8 us.  It pays only where a launch is expensive for other reasons (a device-wide
- * synchronisation in front of every request: +20-50 us per launch).  Counters: requests served / re-issued as launches / starts. */
-int nid_resident_batch_stats(const nid_ctx *ctx, int64_t *served, int64_t *fallbacks, int64_t *starts);
+/* (Round 5's resident BATCH evaluator -- nid_set_resident(ctx, 2), a persistent grid answering requests of 2..64 poses --
+ * measured slower than launches at every length (20 poses: 146 us against 88 us, profiles/r05_short_sequences.txt: a
+ * persistent grid walks through the phases of an evaluation in lockstep) and was removed in round 6; `on` is 0 or 1.) */
 /* both at once (0 = the defaults above) */
 int nid_set_block_threads(nid_ctx *ctx, int threads);
 

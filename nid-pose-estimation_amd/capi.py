@@ -43,7 +43,7 @@ SYMBOLS = [
     "nid_set_reference_depth", "nid_set_pair_u16", "nid_set_reference_points", "nid_backproject", "nid_backproject_release", "nid_get_points3d", "nid_set_target_u8",
     "nid_set_target_f64", "nid_set_reference_image_f64", "nid_compute_href",
     "nid_compute_href_matrix", "nid_set_href_state", "nid_plain_nid", "nid_evaluate", "nid_evaluate_matrix",
-    "nid_normal_equations", "nid_launch", "nid_launch_batch", "nid_launch_chain", "nid_launch_batch_to", "nid_run_sequence", "nid_run_chain", "nid_set_loop_form", "nid_set_direct_results", "nid_set_resident", "nid_resident_pause", "nid_resident_stats", "nid_resident_batch_stats", "nid_wait", "nid_slot_buffers", "nid_debug_read_device", "nid_launch_to",
+    "nid_normal_equations", "nid_launch", "nid_launch_batch", "nid_launch_chain", "nid_launch_batch_to", "nid_run_sequence", "nid_run_chain", "nid_set_loop_form", "nid_set_direct_results", "nid_set_resident", "nid_resident_pause", "nid_resident_stats", "nid_wait", "nid_slot_buffers", "nid_debug_read_device", "nid_launch_to",
     "nid_unpack_reduced", "nid_debug_enable_pixel_dump", "nid_debug_get_pixel_dump",
     "nid_debug_enable_stamps", "nid_debug_get_stamps", "nid_bspline4_host", "nid_bspline4_poly_host", "nid_log2_fast_host", "nid_div_small_host", "nid_last_kernel_ms", "nid_enable_timing", "nid_time_launches",
     "nid_contract_bytes", "nid_debug_repair_count", "nid_set_short_sequence_policy",
@@ -123,7 +123,6 @@ def load():
     if hasattr(lib, "nid_resident_pause"):
         lib.nid_resident_pause.argtypes = [vp]
     lib.nid_resident_stats.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
-    lib.nid_resident_batch_stats.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     lib.nid_time_launches.argtypes = [vp, C.c_int, c_dp, C.c_int, C.c_double, C.c_int, c_fp]
     if hasattr(lib, "nid_debug_repair_count"):   # (an older experiment build, NID_HIP_LIB, may lack the newest diagnostics)
         lib.nid_debug_repair_count.argtypes = [vp, C.POINTER(C.c_int64), C.c_int]
@@ -375,7 +374,7 @@ class Context:
         self._check(self.lib.nid_set_direct_results(self.h, int(on)), "nid_set_direct_results")
 
     def set_resident(self, on=True):
-        """False / 0: off; True / 1: single-pose requests; 2: also requests of several poses (the batch form, opt-in)."""
+        """False / 0: off; True / 1: single-pose requests are answered by the resident kernel."""
         self._check(self.lib.nid_set_resident(self.h, int(on)), "nid_set_resident")
 
     def resident_pause(self):
@@ -384,11 +383,6 @@ class Context:
     def resident_stats(self):
         a, b, c = C.c_int64(0), C.c_int64(0), C.c_int64(0)
         self._check(self.lib.nid_resident_stats(self.h, C.byref(a), C.byref(b), C.byref(c)), "nid_resident_stats")
-        return dict(served=a.value, fallbacks=b.value, starts=c.value)
-
-    def resident_batch_stats(self):
-        a, b, c = C.c_int64(0), C.c_int64(0), C.c_int64(0)
-        self._check(self.lib.nid_resident_batch_stats(self.h, C.byref(a), C.byref(b), C.byref(c)), "nid_resident_batch_stats")
         return dict(served=a.value, fallbacks=b.value, starts=c.value)
 
     def enable_timing(self, on=True):

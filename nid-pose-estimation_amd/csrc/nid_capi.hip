@@ -22,6 +22,9 @@
 
 #include "nid/nid_c.h"
 #include "nid_eval_launch.h"
+#ifndef NID_REPAIR_NT
+#define NID_REPAIR_NT 256  // (nid_eval_tu.inc)
+#endif
 #include "nid_setup_kernels.hip.h"     // k_tile, k_im1_margins, k_backproject_plain, k_href, k_plain_nid, k_untile_bs: this translation unit's
 #include "nid_resident_kernels.hip.h"  // control words and record layouts of the resident evaluators (their kernels: nid_resident_tu.hip)
 
@@ -47,7 +50,6 @@ struct Slot {
   bool groups_dirty = false;
   bool direct = false;             // the launch in flight is a DIRECT one: the host forms and sums the cells' quadratic forms
   bool resident = false;           // ... it is a request to the resident kernel (its records arrive in ctx->res.rec_host)
-  bool resbatch = false;           // ... it is one pose of a request to the resident BATCH kernel (in-launch reduction into reduced_host)
   bool collected = false;          // its result is in reduced_host already (resident_quiesce): nid_wait only hands it over
   bool quad_dirty = false;         // a DIRECT launch wrote (or may still write) into quad_host and wait_direct has not consumed it
   bool direct_jac = false;         // ... it carries Jacobians
@@ -92,21 +94,6 @@ struct nid_ctx {
     int fallback_run = 0;          // consecutive requests that timed out (resident_fallback switches the mode off after a few)
     std::string why;               // probed < 0 / unfit_nt: which step said no
     int unfit_nt = 0;              // the launch shape a start was refused for (its workgroups do not all fit the device)
-    // the BATCH form (k_resident_batch): requests of up to kResBatchMax poses through the throughput form of the kernel
-    ResBatchCtl *bctl = nullptr;           // fine-grained device memory: the mailbox word
-    SlotArgs *brec_host = nullptr, *brec_devptr = nullptr;  // pinned + mapped: the request's SlotArgs records (the device fetches them)
-    unsigned long long *bfwd = nullptr;    // device memory: the kernel's fan-out state (ResBatchFan: gword, per-cell records, the request's records)
-    SlotArgs *bstage = nullptr;            // device memory, one staging record per workgroup
-    size_t bstage_n = 0;
-    bool benabled = false;                 // nid_set_resident(ctx, 2): requests of several poses go to the batch form too
-    bool brunning = false, bunfit = false;
-    double bdelta = 0.0;                   // the Huber delta the running kernel was started with
-    int breplicas = 0;
-    unsigned long long bseq = 0;
-    int bfirst = -1, bn = 0, bleft = 0;    // the request in flight: its slots, how many of them are uncollected
-    bool bjac = false;
-    Pose bposes[kResBatchMax];             // ... its poses, for the fallback
-    long bserved = 0, bfallbacks = 0, bstarts = 0;
   } res;
   std::vector<double> direct_rho1;  // wait_direct: the cells' Huber weights between its two passes
   // own_stream: setup + blocking calls; aux_stream: odd slots of the pipelined path, so that
@@ -164,7 +151,6 @@ struct nid_ctx {
 namespace {
 
 void resident_retire(nid_ctx *ctx);  // every call that changes what a resident kernel has cached, or frees memory, retires it first
-int resident_batch_fallback(nid_ctx *ctx);
 int launch_batch(nid_ctx *ctx, int first_slot, int n, const Pose *poses, int want_jac, double delta, double *reduced_dev_base = nullptr,
                  bool on_aux_stream = false, bool relaunch_ok = false, bool allow_direct = true);
 int resident_quiesce(nid_ctx *ctx);  // ... and every ordinary evaluation launch (the resident workgroups hold most of every CU)
@@ -341,11 +327,12 @@ int launch_eval2(nid_ctx *ctx, EvalParams &P, bool jac, hipStream_t stream, int 
     if (!strict && !no_lat && !ctx->loop_form && P.g.pstride <= lat_rounds(nt) * nt) family = kFamLat;
   }
   if (family == kFamLat && batch > kMaxBatch) return NID_ERR_INVALID_ARG;
+  const size_t lds_repair = eval_lds_bytes(P.g, std::max(nt, NID_REPAIR_NT));  // k_repair's workgroup shape: nid_eval_tu.inc
   switch (nt) {
-    case 128: (jac ? launch_eval_128_jac : launch_eval_128_cost)(P, family, strict, lds, stream, batch); break;
-    case 256: (jac ? launch_eval_256_jac : launch_eval_256_cost)(P, family, strict, lds, stream, batch); break;
-    case 512: (jac ? launch_eval_512_jac : launch_eval_512_cost)(P, family, strict, lds, stream, batch); break;
-    default: (jac ? launch_eval_1024_jac : launch_eval_1024_cost)(P, family, strict, lds, stream, batch); break;
+    case 128: (jac ? launch_eval_128_jac : launch_eval_128_cost)(P, family, strict, lds, lds_repair, stream, batch); break;
+    case 256: (jac ? launch_eval_256_jac : launch_eval_256_cost)(P, family, strict, lds, lds_repair, stream, batch); break;
+    case 512: (jac ? launch_eval_512_jac : launch_eval_512_cost)(P, family, strict, lds, lds_repair, stream, batch); break;
+    default: (jac ? launch_eval_1024_jac : launch_eval_1024_cost)(P, family, strict, lds, lds_repair, stream, batch); break;
   }
   NID_HIP(ctx, hipGetLastError());
   return NID_OK;
@@ -749,7 +736,7 @@ int timing_events(nid_ctx *ctx, Slot &S) {
   return NID_OK;
 }
 
-// ---- the RESIDENT evaluators (k_resident, k_resident_batch): host side -- nid_capi_resident.inc, this translation unit ---
+// ---- the RESIDENT evaluator (k_resident): host side -- nid_capi_resident.inc, this translation unit ---
 #include "nid_capi_resident.inc"
 
 int launch_slot(nid_ctx *ctx, int slot, const Pose &pose, int want_jac, double delta,
@@ -946,14 +933,6 @@ SplitPlan plan_split(const nid_ctx *ctx, int n, bool jac) {
 int launch_split(nid_ctx *ctx, int first_slot, int n, const Pose *poses, int want_jac, double delta) {
   if (!ctx) return NID_ERR_INVALID_ARG;
   if (n < 1 || n > kMaxBatchExt || first_slot < 0 || first_slot + n > NID_SLOTS) return NID_ERR_INVALID_ARG;
-  if (resident_batch_usable(ctx, n, want_jac != 0)) {  // (nid_set_resident: no launch at all)
-    int rc = check_ready(ctx);
-    if (rc) return rc;
-    for (int k = 0; k < n; k++)
-      if (ctx->slots[first_slot + k].pending) { ctx->last_error = "slot still pending: nid_wait() it first"; return NID_ERR_STATE; }
-    NID_HIP(ctx, hipSetDevice(ctx->cfg.device));
-    if (resident_batch_post(ctx, first_slot, n, poses, want_jac != 0, delta) == NID_OK) return NID_OK;
-  }
   const SplitPlan plan = plan_split(ctx, n, want_jac != 0);
   if (plan.chunk >= n || ctx->dbg_enabled || ctx->timing) return launch_batch(ctx, first_slot, n, poses, want_jac, delta);
   for (int k = 0; k < n; k++)  // all or nothing: no half-launched sequence
@@ -1391,10 +1370,6 @@ int nid_destroy(nid_ctx *ctx) {
   resident_retire(ctx);
   if (ctx->res.stream) (void)hipStreamDestroy(ctx->res.stream);
   if (ctx->res.ctl) (void)hipFree(ctx->res.ctl);
-  if (ctx->res.bctl) (void)hipFree(ctx->res.bctl);
-  if (ctx->res.bfwd) (void)hipFree(ctx->res.bfwd);
-  if (ctx->res.bstage) (void)hipFree(ctx->res.bstage);
-  if (ctx->res.brec_host) (void)hipHostFree(ctx->res.brec_host);
   if (ctx->res.rec_host) (void)hipHostFree(ctx->res.rec_host);
   if (ctx->own_stream) (void)hipStreamSynchronize(ctx->own_stream);
   (void)hipFree(ctx->t.X); (void)hipFree(ctx->t.Y); (void)hipFree(ctx->t.Z); (void)hipFree(ctx->t.W);
@@ -1968,10 +1943,9 @@ int nid_wait(nid_ctx *ctx, int slot, double *H36, double *b6, double *chi2, int3
   if (S.collected) {
     S.collected = false;
   } else {
-    int rc = S.resbatch ? wait_resbatch(ctx, S) : (S.direct ? wait_direct(ctx, S) : (S.groups ? wait_groups(ctx, S) : wait_host_seq(ctx, S)));
+    int rc = S.direct ? wait_direct(ctx, S) : (S.groups ? wait_groups(ctx, S) : wait_host_seq(ctx, S));
     if (rc) return rc;
   }
-  S.resbatch = false;
   S.direct = false;
   S.groups = false;
   S.pending = false;
@@ -2098,11 +2072,9 @@ int nid_set_resident(nid_ctx *ctx, int on) {
   NID_HIP(ctx, hipSetDevice(ctx->cfg.device));
   if (!on) {
     resident_retire(ctx);
-    ctx->res.enabled = ctx->res.benabled = false;
+    ctx->res.enabled = false;
     return NID_OK;
   }
-  if (on != 2 && ctx->res.brunning) resident_retire(ctx);
-  ctx->res.benabled = on == 2;
   int rc = resident_probe(ctx);
   if (rc == NID_OK && ctx->res.unfit_nt != 0 && ctx->res.unfit_nt == ctx->jac_threads) rc = NID_ERR_UNSUPPORTED;
   if (rc) { ctx->last_error = "resident evaluator unavailable: " + (ctx->res.why.empty() ? std::string("mailbox setup failed") : ctx->res.why); return rc; }
@@ -2113,7 +2085,7 @@ int nid_set_resident(nid_ctx *ctx, int on) {
 
 int nid_resident_pause(nid_ctx *ctx) {
   if (!ctx) return NID_ERR_INVALID_ARG;
-  if (!ctx->res.running && !ctx->res.brunning) return NID_OK;
+  if (!ctx->res.running) return NID_OK;
   for (int s = 0; s < NID_SLOTS; s++) if (ctx->slots[s].pending) return NID_ERR_STATE;
   NID_HIP(ctx, hipSetDevice(ctx->cfg.device));
   resident_retire(ctx);  // (the next request starts another)
@@ -2125,14 +2097,6 @@ int nid_resident_stats(const nid_ctx *ctx, int64_t *served, int64_t *fallbacks, 
   if (served) *served = ctx->res.served;
   if (fallbacks) *fallbacks = ctx->res.fallbacks;
   if (starts) *starts = ctx->res.starts;
-  return NID_OK;
-}
-
-int nid_resident_batch_stats(const nid_ctx *ctx, int64_t *served, int64_t *fallbacks, int64_t *starts) {
-  if (!ctx) return NID_ERR_INVALID_ARG;
-  if (served) *served = ctx->res.bserved;
-  if (fallbacks) *fallbacks = ctx->res.bfallbacks;
-  if (starts) *starts = ctx->res.bstarts;
   return NID_OK;
 }
 

@@ -12,7 +12,6 @@
 namespace nid {
 
 struct ResidentCtl;  // nid_resident_kernels.hip.h
-struct ResBatchCtl;
 
 // which family of k_eval2 instantiations a launch takes (launch_eval2 in nid_capi.hip decides)
 enum EvalFamily {
@@ -23,8 +22,9 @@ enum EvalFamily {
   kFamStampsLat = 4,  // ... with phase stamps (generic bin count)
 };
 
+// lds_repair: the dynamic LDS of k_repair's workgroup shape (repair_threads(NT), nid_eval_tu.inc)
 #define NID_DECLARE_EVAL_TU(NT, KIND) \
-  void launch_eval_##NT##_##KIND(const EvalParams &P, int family, bool strict, size_t lds, hipStream_t s, int batch);
+  void launch_eval_##NT##_##KIND(const EvalParams &P, int family, bool strict, size_t lds, size_t lds_repair, hipStream_t s, int batch);
 NID_DECLARE_EVAL_TU(128, jac) NID_DECLARE_EVAL_TU(128, cost)
 NID_DECLARE_EVAL_TU(256, jac) NID_DECLARE_EVAL_TU(256, cost)
 NID_DECLARE_EVAL_TU(512, jac) NID_DECLARE_EVAL_TU(512, cost)
@@ -34,11 +34,5 @@ NID_DECLARE_EVAL_TU(1024, jac) NID_DECLARE_EVAL_TU(1024, cost)
 // k_resident<512, NB, 3> (nid_resident_tu.hip): sets the kernel's dynamic LDS limit and launches it
 void launch_resident(const EvalParams &P, int nt, size_t lds, unsigned grid, hipStream_t s, const ResidentCtl *ctl,
                          unsigned long long word0, long long idle_ticks, int xform_mode);
-
-// k_resident_batch<NB>: `replicas` 128-thread workgroups per cell, all of them co-resident (the caller checks);
-// P.slots_ext = a staging array of one SlotArgs per workgroup; hrec = the request's records in pinned host memory (device
-// pointer); fan = resbatch_fan_words() u64 of device memory
-void launch_resident_batch(const EvalParams &P, size_t lds, unsigned grid, hipStream_t s, const ResBatchCtl *ctl, const unsigned *hrec,
-                           unsigned long long *fan, unsigned long long word0, long long idle_ticks, int replicas);
 
 }  // namespace nid

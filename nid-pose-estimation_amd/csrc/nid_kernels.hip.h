@@ -452,6 +452,42 @@ __device__ __forceinline__ double rcp_fast(double z) {
   return fma(r, e, r);
 }
 
+// ---- IEEE quotients that share their reciprocal (round 6) ----------------------------------------------------------------
+// What the compiler emits for a / z in f64 (AMDGPU LowerFDIV64): v_div_scale of both operands, v_rcp_f64 of the denominator,
+// two Newton steps on the reciprocal, q = a * r, ONE residual step fma(fma(-z, q, a), r, q) (v_div_fmas), v_div_fixup.  The
+// scale and fix-up instructions act only on operands near the ends of the exponent range (a denormal or huge denominator, an
+// exponent difference of 768 and more, a numerator below 2^-969, NaN / infinity / zero) and pass everything else through:
+// the quotient IS the sequence below -- rcp_fast is its first half --, and the reciprocal can be shared by every quotient over
+// the same z (u and v of a projection; 1/z, x/z, y/z of linearizeOplus): the same instructions on the same values, hence
+// the IEEE quotient's bits (tools/ubench/div_shared.hip compares 2^28 quotients with the compiler's; STRICT's per-pixel
+// u, v stay bit-exact against the oracle, tests/test_parity_gpu.py).  Operands outside [2^-100, 2^100] -- and a zero
+// numerator, whose sign the short form can lose -- take the division itself (a divergent, practically never taken branch).
+__device__ __forceinline__ bool exp_mid(double x) { return (((unsigned)__double2hiint(x) >> 20) & 0x7FFu) - 923u <= 200u; }
+__device__ __forceinline__ double div_shared(double a, double z, double r, bool z_mid) {
+  const double q = a * r;
+  double res = fma(fma(-z, q, a), r, q);
+  if (__builtin_expect(!(z_mid && exp_mid(a)), 0)) res = a / z;
+  return res;
+}
+// RN(x / 255.0): the quotient by a CONSTANT from its correctly rounded reciprocal and one residual step (Markstein; exact for
+// every x when the divisor's significand is not all ones -- tests/test_bspline_host.py compares 10^7 values with the division)
+__device__ __forceinline__ double div_255(double x) { return div_small_r(x, 255.0, 1.0 / 255.0); }
+
+// The reference's four-term bilinear sample (types_six_dof_expmap.h:310-328: (int) truncation, left-to-right sum) from the
+// 2x2 cell of (u, v) alone: two unaligned dwords at the element offset of pixel ((int)u, (int)v) instead of the 4x4 window
+// and its run-time tap selection.  For samples inside the frame (u, v >= 0: the sample's own pixel is never in the margin).
+__device__ __forceinline__ double bilinear_cell_exact(const EvalParams &P, double u, double v) {
+  const int ix = (int)u, iy = (int)v;
+  const unsigned st = (unsigned)P.im1_stride;
+  const unsigned po = __umul24((unsigned)iy, st) + (unsigned)ix + (st + 1u);  // (the buffer starts at pixel (-1, -1))
+  const unsigned c1 = load_u32_at(P.im1s, po), c2 = load_u32_at(P.im1s, po + st);
+  const double dx = u - ix, dy = v - iy;
+  const double dxdy = dx * dy;
+  const double i00 = (double)__builtin_amdgcn_sbfe((int)c1, 0u, 16u), i01 = (double)__builtin_amdgcn_sbfe((int)c1, 16u, 16u);
+  const double i10 = (double)__builtin_amdgcn_sbfe((int)c2, 0u, 16u), i11 = (double)__builtin_amdgcn_sbfe((int)c2, 16u, 16u);
+  return dxdy * i11 + (dy - dxdy) * i10 + (dx - dxdy) * i01 + (1 - dx - dy + dxdy) * i00;
+}
+
 // bilinear_u8 on the window: same arithmetic, taps from registers.  A tap index
 // that leaves the window can only belong to a tap whose weight is exactly 0
 // (x or y rounded up to an integer) -- any finite byte is then correct.
@@ -978,8 +1014,10 @@ __device__ __forceinline__ void pixel_front(const EvalParams &P, const SlotArgs 
   double qx, qy, qz, u, v;
   if (STRICT) {
     xform_point(SA.pose, lx, ly, lz, qx, qy, qz);
-    u = g.fx * qx / qz + g.cx;  // types_six_dof_expmap.cpp:562-563
-    v = g.fy * qy / qz + g.cy;
+    const double rz = rcp_fast(qz);  // one reciprocal for both quotients: div_shared
+    const bool zm = exp_mid(qz);
+    u = div_shared(g.fx * qx, qz, rz, zm) + g.cx;  // types_six_dof_expmap.cpp:562-563
+    v = div_shared(g.fy * qy, qz, rz, zm) + g.cy;
     f.zq = qz;
   } else {
     const double *M = SA.pose.M;
@@ -1056,7 +1094,9 @@ __device__ __forceinline__ bool classify_redo(const EvalParams &P, const PixelFr
 // Returns with f.in / f.jin / f.u / f.v replaced and, for f.in, the whole window f.w loaded and ic valid.
 // EXT launches keep only the matrix of the pose in scalar registers (see k_eval2); the quaternion is fetched here,
 // where it is needed, from the launch's record array.
-template <bool EXT>
+// FULLWIN: the whole 4x4 window around the reference's (u, v) is loaded into f.w (the Jacobian phase's gradient needs it);
+// otherwise (cost phase) the sample is taken from its 2x2 cell alone and f.w is not touched.
+template <bool EXT, bool FULLWIN = true>
 __device__ __forceinline__ void exact_decisions(const EvalParams &P, const SlotArgs &SA, int pose_idx, const TileIn &t,
                                                 PixelFront &f, double &ic) {
   const Geometry &g = P.g;
@@ -1075,23 +1115,29 @@ __device__ __forceinline__ void exact_decisions(const EvalParams &P, const SlotA
   } else {
     xform_point(SA.pose, lx, ly, lz, qx, qy, qz);
   }
-  const double u = g.fx * qx / qz + g.cx;  // types_six_dof_expmap.cpp:562-563
-  const double v = g.fy * qy / qz + g.cy;
+  const double rz = rcp_fast(qz);  // one reciprocal for both quotients (div_shared: the IEEE quotients' bits)
+  const bool zm = exp_mid(qz);
+  const double u = div_shared(g.fx * qx, qz, rz, zm) + g.cx;  // types_six_dof_expmap.cpp:562-563
+  const double v = div_shared(g.fy * qy, qz, rz, zm) + g.cy;
   const bool in = (f.jr >= 0) && (u >= 0 && u + 3 <= g.cols && v >= 0 && v + 3 <= g.rows);
   bool jin = false;
   if (in) {
-    // the whole window around the REFERENCE's (u, v) -- which may truncate to the pixel next to FAST's
-    f.w.wx = (int)u - 1; f.w.wy = (int)v - 1;
-    load_window(P, f.w);
-    ic = bilinear_rows(win_rows(f.w, v), f.w.wx, u);
+    if (FULLWIN) {
+      // the whole window around the REFERENCE's (u, v) -- which may truncate to the pixel next to FAST's
+      f.w.wx = (int)u - 1; f.w.wy = (int)v - 1;
+      load_window(P, f.w);
+      ic = bilinear_rows(win_rows(f.w, v), f.w.wx, u);
+    } else {
+      ic = bilinear_cell_exact(P, u, v);  // (the same four taps in the same expression: the same bits)
+    }
     if (ic < 0) ic = 0.0;                              // :574-575
     // linearizeOplus' own projection fx*(x/z)+cx (:407-422, Q6) differs from u by a rounding: it can decide a border
     // test differently only within an ulp of the border -- two more divisions, taken only by samples that close
     double uj = u, vj = v;
     if (
         fabs(u) < kBorderEps || fabs(v) < kBorderEps || fabs(u + 3 - (double)P.jac_cols) < kBorderEps || fabs(v + 3 - (double)g.rows) < kBorderEps) {
-      uj = g.fx * (qx / qz) + g.cx;
-      vj = g.fy * (qy / qz) + g.cy;
+      uj = g.fx * div_shared(qx, qz, rz, zm) + g.cx;
+      vj = g.fy * div_shared(qy, qz, rz, zm) + g.cy;
     }
     jin = (uj >= 0 && uj + 3 <= P.jac_cols && vj >= 0 && vj + 3 <= g.rows);
   }
@@ -1111,7 +1157,7 @@ template <bool CLAMP = true, bool EXACT = false>
 __device__ __forceinline__ int fast_bin(double &ic, int S, double &pc) {
   if (CLAMP) { if (ic >= 255) ic = 254.999; }
   if (EXACT) {
-    pc = ic * (double)S / 255.0;
+    pc = div_255(ic * (double)S);
     return min((int)pc, S - 1);  // (a quotient that rounds up to S itself: t = 1 on the last span)
   }
   pc = ic * ((double)S / 255.0);
@@ -1128,7 +1174,7 @@ __device__ __forceinline__ int pixel_sample(const PixelFront &f, int nb, int S, 
     ic = bilinear_rows(rp, f.w.wx, f.u);
     if (ic >= 255) ic = 254.999;
     if (ic < 0) ic = 0.0;
-    const double pc = ic * ((double)nb - 3.0) / 255.0;
+    const double pc = div_255(ic * ((double)nb - 3.0));
     jc = (int)floor(pc);
     bspline4_tab<WANT_DER>(pc, jc, S, rtab, wc, dw);
   } else {  // (the FAST loops of k_eval2 inline this with the exact_decisions guard in front)
@@ -1673,11 +1719,17 @@ __device__ __forceinline__ bool eval_cell(const EvalParams &P, const SlotArgs &S
       PixelFront f;
       load_tile(P, base + (unsigned)s, plane, tin);
       pixel_front<true>(P, SA, tin, f);
-      load_window(P, f.w);
       double ic = NAN, wc[4] = {NAN, NAN, NAN, NAN}, dw[4];
       int jc = -1;
       if (f.in) {
-        jc = pixel_sample<true, false>(f, nb, S, rtab, ic, wc, dw);
+        // pixel_sample<true>'s arithmetic on the sample's 2x2 cell (round 6: no 4x4 window, no run-time tap selection; the
+        // cost phase needs the centre sample only)
+        ic = bilinear_cell_exact(P, f.u, f.v);
+        if (ic >= 255) ic = 254.999;  // types_six_dof_expmap.cpp:572-575
+        if (ic < 0) ic = 0.0;
+        const double pc = div_255(ic * ((double)nb - 3.0));
+        jc = (int)floor(pc);
+        bspline4_tab<false>(pc, jc, S, rtab, wc, dw);
         hist_add(f.jr, jc, f.wr, wc, std::false_type{}, 0.0, 0, repair_tag);
       }
       if (!REPAIR && DBG && P.dbg_u && !P.dbg_jac && pose_idx == 0 && f.jr >= 0) dump_pixel(s, f, ic, jc, wc);
@@ -1700,6 +1752,10 @@ __device__ __forceinline__ bool eval_cell(const EvalParams &P, const SlotArgs &S
         tin = cur;
 #pragma unroll
         for (int k = 0; k < 4; k++) tin.wr[k] = 0.0;
+      } else if constexpr (use_lane_masks) {
+        // (the loop below has requested this round's point while the previous rare round was worked on: second_pass_rounds)
+        tin = cur;
+        load_tile_w(P, base + (unsigned)s, plane, tin);
       } else {
         load_tile(P, base + (unsigned)s, plane, tin);
       }
@@ -1738,7 +1794,7 @@ __device__ __forceinline__ bool eval_cell(const EvalParams &P, const SlotArgs &S
       if (SECOND) {
         go = false;
         if (rare) {
-          exact_decisions<EXT>(P, SA, pose_idx, tin, f, ic);
+          exact_decisions<EXT, false>(P, SA, pose_idx, tin, f, ic);
           go = f.in;
         }
       }
@@ -1778,7 +1834,7 @@ __device__ __forceinline__ bool eval_cell(const EvalParams &P, const SlotArgs &S
       if (f.redo && classify_redo(P, f)) rare = true;
       bool go = f.in && !rare;
       if (rare) {
-        exact_decisions<EXT>(P, SA, pose_idx, tin, f, ic);
+        exact_decisions<EXT, false>(P, SA, pose_idx, tin, f, ic);
         go = f.in;
       }
       if (go) {
@@ -1790,6 +1846,22 @@ __device__ __forceinline__ bool eval_cell(const EvalParams &P, const SlotArgs &S
         hist_add(f.jr, jc, tin.wr, wc, std::true_type{}, pc,
                  (rare && NID_CLAMP_BINS) ? (ic == 254.999 ? 1 : ((NID_NEAR_SAT_BINS && ic == kNearSatIc) ? 2 : 0)) : 0, std::true_type{});
       }
+    }
+  };
+  // the rounds of `todo` (a wave-uniform bit mask, bit r = round r), each with its point (x, y, z, jr) requested one round ahead
+  auto second_pass_rounds = [&](unsigned todo, auto &&body) {
+    int rr = __builtin_ctz(todo);
+    TileIn nx;
+    load_tile_xyz(P, base + (unsigned)(wave_base + rr * NT + lane), nx);
+#pragma clang loop unroll(disable)
+    for (;;) {
+      todo &= todo - 1u;
+      const int rn = todo ? __builtin_ctz(todo) : -1;
+      const TileIn cur = nx;
+      if (rn >= 0) load_tile_xyz(P, base + (unsigned)(wave_base + rn * NT + lane), nx);
+      body(wave_base + rr * NT, rr, cur);
+      if (rn < 0) break;
+      rr = rn;
     }
   };
   if constexpr (STRICT) {
@@ -1869,12 +1941,23 @@ __device__ __forceinline__ bool eval_cell(const EvalParams &P, const SlotArgs &S
         if (cost_round(sb, r, pre, pre, std::false_type{})) rare_rounds |= 1ull << min(r, 63);
       if (use_lane_masks) rare_rounds = wave_or_u32(raremask);
     }
+#ifndef NID_ABL_NO_COST_SECOND  // (ablation builds only, tools/build_variant.py: what the pass costs -- wrong results)
     if (rare_rounds != 0ull) {
-      r = 0;
+      if constexpr (use_lane_masks) {
+        // The second pass is a chain of DEPENDENT round trips per round -- tile entry -> exact projection -> target cell ->
+        // histogram -- and on flash data every workgroup of a CU sits in it at the same time (the poses of one cell are
+        // dispatched next to each other: nothing else to run meanwhile).  Round 6: the NEXT rare round's point is requested
+        // before this one is worked on (the rounds are known: rare_rounds), like the main pass does -- one exposed round
+        // trip less per round (profiles/r06_ablations_A.txt: the pass is latency-bound, instruction diets measure +-0).
+        second_pass_rounds((unsigned)rare_rounds, [&](int sb, int rr, const TileIn &cur) { cost_round(sb, rr, cur, pre, std::true_type{}); });
+      } else {
+        r = 0;
 #pragma clang loop unroll(disable)
-      for (int sb = wave_base; sb < g.pstride; sb += NT, r++)
-        if ((rare_rounds >> min(r, 63)) & 1ull) cost_round(sb, r, pre, pre, std::true_type{});
+        for (int sb = wave_base; sb < g.pstride; sb += NT, r++)
+          if ((rare_rounds >> min(r, 63)) & 1ull) cost_round(sb, r, pre, pre, std::true_type{});
+      }
     }
+#endif
   }
   NID_STAMP(2);
   __syncthreads();
@@ -2033,8 +2116,8 @@ __device__ __forceinline__ bool eval_cell(const EvalParams &P, const SlotArgs &S
       return (a | b) != 0u;
     }
   };
-  // what the waves that leave a tail early return: "this cell wants the repair pass and publishes nothing" (the resident
-  // batch kernel -- RES without the inline repair -- then calls the instantiation that repairs inline; see k_resident_batch)
+  // what the waves that leave a tail early return: "this cell wants the repair pass and publishes nothing" (RES without
+  // the inline repair: no such kernel is built since round 6's removal of the resident batch evaluator)
   auto done = [&]() -> bool {
     if constexpr (RES && !REPAIR_INLINE) return repair_wanted();
     else return false;
@@ -2280,9 +2363,11 @@ __device__ __forceinline__ bool eval_cell(const EvalParams &P, const SlotArgs &S
       load_window(P, f.w);
       if (f.in) {
         // linearizeOplus: fx*(x/z)+cx (types_six_dof_expmap.cpp:407-422, Q6)
-        const double invz = 1.0 / f.zq;
-        const double u = g.fx * (f.x / f.zq) + g.cx;
-        const double v = g.fy * (f.y / f.zq) + g.cy;
+        const double rz = rcp_fast(f.zq);  // one reciprocal for the three quotients (div_shared: the IEEE quotients' bits)
+        const bool zm = exp_mid(f.zq);
+        const double invz = div_shared(1.0, f.zq, rz, zm);
+        const double u = g.fx * div_shared(f.x, f.zq, rz, zm) + g.cx;
+        const double v = g.fy * div_shared(f.y, f.zq, rz, zm) + g.cy;
         if (u >= 0 && u + 3 <= P.jac_cols && v >= 0 && v + 3 <= g.rows) {
           double ic, wc[4], dw[4];
           const int jc = pixel_sample<true, true>(f, nb, S, rtab, ic, wc, dw);  // from the cost pass's (u, v): Q7
@@ -2315,6 +2400,9 @@ __device__ __forceinline__ bool eval_cell(const EvalParams &P, const SlotArgs &S
         tin = cur;
 #pragma unroll
         for (int k = 0; k < 4; k++) tin.wr[k] = 0.0;
+      } else if constexpr (use_lane_masks) {
+        tin = cur;  // (requested one rare round ahead: second_pass_rounds)
+        load_tile_w(P, base + (unsigned)s, plane, tin);
       } else {
         load_tile(P, base + (unsigned)s, plane, tin);
       }
@@ -2370,10 +2458,12 @@ __device__ __forceinline__ bool eval_cell(const EvalParams &P, const SlotArgs &S
           if (flat && fu > kBorderEps && fu < 1.0 - kBorderEps && fv > kBorderEps && fv < 1.0 - kBorderEps) exact = false;
         }
         if (exact) {
-          exact_decisions<EXT>(P, SA, pose_idx, tin, f, ic);
+          exact_decisions<EXT, false>(P, SA, pose_idx, tin, f, ic);  // (u, v), the frame tests and ic from the sample's 2x2 cell
           go = f.jin;
-          if (go) {  // the gradient again, on the window around the reference's (u, v)
+          if (go) {  // the gradient again, on the window around the reference's (u, v) -- which may truncate to the pixel next to FAST's
             double dummy;
+            f.w.wx = (int)f.u - 1; f.w.wy = (int)f.v - 1;
+            load_window(P, f.w);
             gradient_fast_interior(f.w, f.u, f.v, gx, gy, dummy);
           }
         }
@@ -2451,12 +2541,18 @@ __device__ __forceinline__ bool eval_cell(const EvalParams &P, const SlotArgs &S
           if (jac_round(sb, r, prej, prej, std::false_type{})) rare2 |= 1ull << min(r, 63);
       }
     }
+#ifndef NID_ABL_NO_JAC_SECOND  // (ablation builds only)
     if (rare2 != 0ull) {
-      r = 0;
+      if constexpr (use_lane_masks) {
+        second_pass_rounds((unsigned)rare2, [&](int sb, int rr, const TileIn &cur) { jac_round(sb, rr, cur, prej, std::true_type{}); });
+      } else {
+        r = 0;
 #pragma clang loop unroll(disable)
-      for (int sb = wave_base; sb < g.pstride; sb += NT, r++)
-        if ((rare2 >> min(r, 63)) & 1ull) jac_round(sb, r, prej, prej, std::true_type{});
+        for (int sb = wave_base; sb < g.pstride; sb += NT, r++)
+          if ((rare2 >> min(r, 63)) & 1ull) jac_round(sb, r, prej, prej, std::true_type{});
+      }
     }
+#endif
   }
   if (!STRICT) { acc[0] = -acc[0]; acc[5] = -acc[5]; }
   NID_STAMP(4, acc[0], acc[2], acc[3], acc[5]);
@@ -2577,6 +2673,9 @@ __device__ __forceinline__ bool eval_cell(const EvalParams &P, const SlotArgs &S
 #ifndef NID_EXT_VGPRS
 #define NID_EXT_VGPRS 0
 #endif
+#ifndef NID_CELL_INTERLEAVE
+#define NID_CELL_INTERLEAVE 1
+#endif
 template <int NT, bool JAC, bool STRICT, int NB, bool DBG, bool EXT = false, int LAT = 0, bool BIG = false>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu((STRICT || DBG || LAT || NT >= 512) ? 4 : (EXT ? NID_EXT_WAVES : NID_FAST_WAVES))))
 #if NID_EXT_VGPRS
@@ -2592,8 +2691,28 @@ void k_eval2(EvalParams P) {
   // Speed only: nothing depends on the placement.
   const int bid = blockIdx.x;
   const int q = bid >> 3;
+#if NID_CELL_INTERLEAVE > 1
+  // Round 6: the workgroups an XCD runs side by side belong to NID_CELL_INTERLEAVE cells that lie far apart in the image
+  // (every C/K-th of the XCD's C cells) instead of to ONE cell: on flash data the poses of a saturated cell all sit in
+  // their latency-bound second passes at the same time, and a CU that holds nothing else idles through them; mixed with
+  // the poses of ordinary cells their round trips hide behind the others' arithmetic.  The K cells' tiles (82 KB each)
+  // share the XCD's L2 as well as one cell's did.
+  constexpr int K = NID_CELL_INTERLEAVE;
+  const int C = (g.nloc + 7) >> 3;
+  int pose_idx, lc;
+  if (C % K == 0) {
+    const int span = K * P.batch, j = q / span, within = q - j * span;
+    pose_idx = within / K;
+    lc = j + (within - pose_idx * K) * (C / K);
+  } else {
+    pose_idx = q % P.batch;
+    lc = q / P.batch;
+  }
+  const int cl = lc * 8 + (bid & 7);
+#else
   const int pose_idx = q % P.batch;
   const int cl = (q / P.batch) * 8 + (bid & 7);
+#endif
   if (cl >= g.nloc) return;  // padding of the last group of 8 cells
   SlotArgs sa_ext;
   if (EXT) {

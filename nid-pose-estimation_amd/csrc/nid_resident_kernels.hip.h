@@ -1,6 +1,5 @@
-// nid_resident_kernels.hip.h -- the kernels that stay on the device between requests: k_resident (single poses through a
-// mailbox) and k_resident_batch (short sequences), their control words and record layouts.  Both run eval_cell, the body
-// of the launched kernels (nid_kernels.hip.h).  Included by nid_resident_tu.hip (device code) and nid_capi.hip (the host
+// nid_resident_kernels.hip.h -- the kernel that stays on the device between requests: k_resident (single poses through a
+// mailbox), its control words and record layouts.  It runs eval_cell, the body of the launched kernels (nid_kernels.hip.h).  Included by nid_resident_tu.hip (device code) and nid_capi.hip (the host
 // side of the protocols).
 #pragma once
 
@@ -153,185 +152,6 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT == 512 ? 
     if (flags & kResJac) eval_cell<NT, true, false, NB, false, false, LAT, false, true>(P, SA, cl, 0, smem, rc);
     else eval_cell<NT, false, false, NB, false, false, LAT, false, true>(P, SA, cl, 0, smem, rc);
     rc.fresh = false;
-    t_idle = __builtin_amdgcn_s_memrealtime();
-  }
-}
-
-// ---------------------------------------------------------------------------
-// The resident BATCH evaluator (round 5): the throughput form of the evaluation kernel -- 128-thread workgroups, the loop
-// form, per-pose records in device memory (eval_cell's EXT form), the in-launch reduction -- launched once and kept on
-// the device like k_resident, answering requests of K <= kResBatchMax poses: the candidates of a Gauss-Newton / LM step, a
-// short sequence.  What such a request costs as launches is mostly not evaluation (profiles/r04_short_sequences.txt: 20
-// poses = 92 us in a loop, 132-181 us as one shot behind a device-wide synchronisation -- the first launches after one
-// pay 20-50 us): here it is ONE word written through the PCIe BAR.
-// Grid: `replicas` workgroups per cell (k_eval2's block -> cell map with batch = replicas); the workgroups of a cell
-// share the request's poses through a counter (whoever is free takes the next one).
-// A request: the host fills the poses' SlotArgs records -- exactly as a launch of more than kMaxBatch poses carries them
-// (nid_capi.hip fills both with the same function) -- into PINNED HOST memory, a store fence, and writes the mailbox's
-// word = (request number << 16) | (K << 8) | flags through the BAR.  (A store through the BAR is a PCIe transaction of
-// its own, ~0.2 us each: the records themselves written that way -- 580 words for 20 poses -- cost more than the
-// evaluation; the device fetches them instead.)
-// Uncached memory does not take thousands of readers either (2048 workgroups polling one line, or fetching their records
-// from one place, queue up behind each other on its memory channel), so the request fans out through ordinary device
-// memory, agent-scope stores and loads throughout (no placement assumption):
-//   root   (cell 0, replica 0) polls the mailbox word, copies the K records host -> `grec` (all its threads, eight loads
-//          in flight each), drains, and publishes the word in gword;
-//   leader (replica 0 of every other cell) polls gword; root and leaders forward the word to their cell's record;
-//   the other replicas poll that record.
-// A workgroup copies the record of the pose it is about to evaluate from grec into its OWN entry of a staging array
-// (P.slots_ext, one entry per workgroup), invalidates the scalar cache, and from there on the record is what it is for a
-// launched k_eval2 of a large batch: scalar loads through the constant address space, the quaternion fetched where
-// exact_decisions needs it.  Same eval_cell instantiation up to RES (a table that stays in LDS): the same bits as launches.
-// Bounded like k_resident: exit word (forwarded down the same tree), idle limit by s_memrealtime in every polling loop.
-constexpr int kResBatchMax = 64;
-constexpr int kResBatchRecDwords = (int)(sizeof(SlotArgs) / 4);
-struct ResBatchCtl {
-  unsigned long long w[8];  // one line; the word is w[7]
-};
-__host__ __device__ constexpr unsigned long long resbatch_word(unsigned long long number, int k, unsigned flags) {
-  return (number << 16) | ((unsigned long long)(unsigned)k << 8) | flags;
-}
-// device-side fan-out state, in u64 words: gword in its own 64 bytes | per cell {word, pose counter} | the request's records (grec)
-__host__ __device__ constexpr size_t resbatch_cells_off() { return 8; }
-__host__ __device__ inline size_t resbatch_grec_off(long nloc8) { return 8 + (size_t)nloc8 * 2; }
-__host__ __device__ inline size_t resbatch_fan_words(long nloc8) { return resbatch_grec_off(nloc8) + ((size_t)kResBatchRecDwords * kResBatchMax + 1) / 2; }
-
-template <int NB>
-__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(4))) void k_resident_batch(EvalParams P, const ResBatchCtl *ctl, const unsigned *hrec /*pinned host: the records*/,
-                                                                                                unsigned long long *fan, unsigned long long word0, long long idle_ticks, int replicas) {
-  constexpr int NT = 128;
-  static_assert(sizeof(SlotArgs) / 4 <= 64 && sizeof(SlotArgs) % 8 == 0, "a record is copied by one wave, a dword per lane");
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  __shared__ unsigned s_req[4];  // kResLeave or 0 | K | flags | the next pose
-  const Geometry &g = P.g;
-  const int tid = threadIdx.x;
-  const int q = (int)(blockIdx.x >> 3);
-  const int rep = q % replicas;
-  const int cl = (q / replicas) * 8 + (int)(blockIdx.x & 7);  // k_eval2's map with batch = replicas
-  if (cl >= g.nloc) return;
-  {  // the B-spline table, once (eval_cell's LDS layout)
-    const int nb = NB > 0 ? NB : g.nb;
-    const int nbins = nb * nb + nb;
-    double *rtab = reinterpret_cast<double *>(smem) + 2 * ((nbins + 1) & ~1);
-    for (int i = tid; i < (nb - 3) * kCoefRow; i += NT) rtab[i] = P.ctab[i];
-  }
-  ResCell rc{P.Nc[cl], P.Href[cl], true};
-  unsigned long long last = word0;
-  long long t_idle = __builtin_amdgcn_s_memrealtime();
-  const long nloc8 = ((long)g.nloc + 7) / 8 * 8;
-  unsigned long long *mycell = fan + resbatch_cells_off() + (size_t)cl * 2;
-  unsigned *grec = reinterpret_cast<unsigned *>(fan + resbatch_grec_off(nloc8));
-  const bool root = rep == 0 && cl == 0;
-  // the word this workgroup polls, two dwords by two lanes: the mailbox's (root), gword (the other cells' replica 0), the
-  // cell's record (everyone else)
-  const unsigned *src = (root ? reinterpret_cast<const unsigned *>(ctl->w + 7) : reinterpret_cast<const unsigned *>(rep == 0 ? fan : mycell)) + (tid & 1);
-  unsigned *mine = reinterpret_cast<unsigned *>(const_cast<SlotArgs *>(P.slots_ext) + blockIdx.x);  // this workgroup's staging entry
-  for (;;) {
-    __syncthreads();  // every wave is back from the previous request
-    if (tid < 64) {
-      unsigned leave = 0u;
-      for (;;) {
-        const unsigned v = root ? ld_sys_u32(src) : __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const unsigned long long t = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)v, 1) << 32) | (unsigned)__builtin_amdgcn_readlane((int)v, 0);
-        if (t == kResExitWord) { leave = 1u; break; }
-        if (t != last) { last = t; break; }
-        if (__builtin_amdgcn_s_memrealtime() - t_idle > idle_ticks) { leave = 1u; break; }
-        if (root) __builtin_amdgcn_s_sleep(NID_RES_POLL_SLEEP); else __builtin_amdgcn_s_sleep(2);
-      }
-      if (tid == 0) {
-        s_req[0] = leave ? kResLeave : 0u;
-        s_req[1] = (unsigned)(last >> 8) & 0xFFu;
-        s_req[2] = (unsigned)last & 0xFFu;
-      }
-    }
-    __syncthreads();
-    const bool leaving = (unsigned)__builtin_amdgcn_readfirstlane((int)s_req[0]) == kResLeave;
-    const int K = min((int)__builtin_amdgcn_readfirstlane((int)s_req[1]), kResBatchMax);
-    const unsigned flags = (unsigned)__builtin_amdgcn_readfirstlane((int)s_req[2]);
-    if (root && !leaving) {
-      // the K records: pinned host memory -> grec, eight loads in flight per thread (a load over PCIe takes a microsecond or two)
-      const int n = K * kResBatchRecDwords;
-      for (int i0 = tid; i0 < n; i0 += 8 * NT) {
-        unsigned v[8];
-#pragma unroll
-        for (int j = 0; j < 8; j++) v[j] = (i0 + j * NT < n) ? ld_sys_u32(hrec + i0 + j * NT) : 0u;
-#pragma unroll
-        for (int j = 0; j < 8; j++)
-          if (i0 + j * NT < n) __hip_atomic_store(grec + i0 + j * NT, v[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-    }
-    if (rep == 0 && tid == 0) {
-      // publish downwards: the word -- or the exit word -- in gword (root) and in the cell's record
-      const unsigned long long w = leaving ? kResExitWord : last;  // (tid 0 is in wave 0: `last` is the new word)
-      if (root) __hip_atomic_store(fan, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(mycell, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    if (leaving) return;  // every wave of the workgroup, here
-    for (;;) {
-      // The cell's next pose: whoever is free takes it.  The counter word is (request number << 8) | next pose and is
-      // never reset: the first workgroup of a cell to arrive at a request moves it on by compare-and-swap, and a workgroup
-      // that is late (still on its way out of the previous request when the others have begun the next) finds a newer
-      // number and takes nothing -- a counter that the cell's leader reset could hand such a straggler pose 0 again.
-      if (tid == 0) {
-        const unsigned long long myreq = last >> 16;
-        unsigned long long c = __hip_atomic_load(mycell + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        unsigned take = (unsigned)K;
-        for (;;) {
-          unsigned long long want;
-          unsigned cand;
-          if ((c >> 8) == myreq) {
-            cand = (unsigned)(c & 255ull);
-            if (cand >= (unsigned)K) break;
-            want = c + 1;
-          } else if ((c >> 8) < myreq) {
-            cand = 0u;
-            want = (myreq << 8) | 1ull;
-          } else {
-            break;
-          }
-          if (__hip_atomic_compare_exchange_strong(mycell + 1, &c, want, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) { take = cand; break; }
-        }
-        s_req[3] = take;
-      }
-      __syncthreads();
-      const int p = (int)__builtin_amdgcn_readfirstlane((int)s_req[3]);
-      if (p >= K) break;
-      // pose p's record: grec -> this workgroup's staging entry
-      if (tid < kResBatchRecDwords) {
-        __hip_atomic_store(mine + tid, __hip_atomic_load(grec + p * kResBatchRecDwords + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
-                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      }
-      __syncthreads();
-      __builtin_amdgcn_s_dcache_inv();
-      // (an opaque copy of the entry's index per pose: the record is read through the CONSTANT address space, whose
-      // loads the optimiser may otherwise take for loop invariant)
-      int pidx = (int)blockIdx.x;
-      asm volatile("" : "+s"(pidx));
-      SlotArgs sa_ext;
-      {
-        typedef const unsigned __attribute__((address_space(4))) *ConstDwords;
-        ConstDwords csrc = (ConstDwords)(reinterpret_cast<uintptr_t>(P.slots_ext + pidx));
-        unsigned *dst = reinterpret_cast<unsigned *>(&sa_ext);
-#pragma unroll
-        for (unsigned i = kPoseQuatDwords; i < sizeof(SlotArgs) / 4; i++) dst[i] = csrc[i];
-      }
-      // The loop-form body WITHOUT the inline repair (kLinFlagW: carrying that code costs the pixel loops their registers);
-      // a cell that wants the repair pass publishes nothing and says so -- workgroup-uniform -- and is done again from
-      // the start by the instantiation that repairs inline: what k_repair does behind a launch, here in place (cold).
-      bool again;
-      if (flags & kResJac) again = eval_cell<NT, true, false, NB, false, true, 0, false, true, false>(P, sa_ext, cl, pidx, smem, rc);
-      else again = eval_cell<NT, false, false, NB, false, true, 0, false, true, false>(P, sa_ext, cl, pidx, smem, rc);
-      if (__builtin_expect(again, 0)) {
-        __syncthreads();
-        if (flags & kResJac) (void)eval_cell<NT, true, false, NB, false, true, 0, false, true, true>(P, sa_ext, cl, pidx, smem, rc);
-        else (void)eval_cell<NT, false, false, NB, false, true, 0, false, true, true>(P, sa_ext, cl, pidx, smem, rc);
-      }
-      rc.fresh = false;
-      __syncthreads();  // (the staging entry and s_req[3] are rewritten for the next pose)
-    }
     t_idle = __builtin_amdgcn_s_memrealtime();
   }
 }

@@ -1,6 +1,5 @@
 // the resident evaluator's kernels (k_resident<512, NB, 3>: one workgroup per CU, the latency form; k_resident<256, NB, 0>:
-// four workgroups per CU, the loop form -- contexts of more cells than the device has CUs; k_resident_batch<NB>: the
-// throughput form, several 128-thread workgroups per cell, requests of up to 64 poses): see nid_eval_launch.h
+// four workgroups per CU, the loop form -- contexts of more cells than the device has CUs): see nid_eval_launch.h
 #include "nid_eval_launch.h"
 #include "nid_resident_kernels.hip.h"
 
@@ -21,19 +20,7 @@ void launch_res_nb(const EvalParams &P, size_t lds, unsigned grid, hipStream_t s
   else if (P.g.nb == 10) launch_res<NT, 10, LAT>(P, lds, grid, s, ctl, word0, idle_ticks, xform_mode);
   else launch_res<NT, 0, LAT>(P, lds, grid, s, ctl, word0, idle_ticks, xform_mode);
 }
-template <int NB>
-void launch_resb(const EvalParams &P, size_t lds, unsigned grid, hipStream_t s, const ResBatchCtl *ctl, const unsigned *hrec, unsigned long long *fan,
-                 unsigned long long word0, long long idle_ticks, int replicas) {
-  hipLaunchKernelGGL((k_resident_batch<NB>), dim3(grid), dim3(128), lds, s, P, ctl, hrec, fan, word0, idle_ticks, replicas);
-}
 }  // namespace
-
-void launch_resident_batch(const EvalParams &P, size_t lds, unsigned grid, hipStream_t s, const ResBatchCtl *ctl, const unsigned *hrec,
-                           unsigned long long *fan, unsigned long long word0, long long idle_ticks, int replicas) {
-  if (P.g.nb == 8) launch_resb<8>(P, lds, grid, s, ctl, hrec, fan, word0, idle_ticks, replicas);
-  else if (P.g.nb == 10) launch_resb<10>(P, lds, grid, s, ctl, hrec, fan, word0, idle_ticks, replicas);
-  else launch_resb<0>(P, lds, grid, s, ctl, hrec, fan, word0, idle_ticks, replicas);
-}
 
 void launch_resident(const EvalParams &P, int nt, size_t lds, unsigned grid, hipStream_t s, const ResidentCtl *ctl,
                      unsigned long long word0, long long idle_ticks, int xform_mode) {

@@ -461,6 +461,8 @@ void nid_oracle_set_reference(nid_oracle *o, const double *points3d, const unsig
   memset(o->ic, 0, N * sizeof(double));                     /* .cpp:652 */
 }
 
+void nid_oracle_clear_intensity(nid_oracle *o) { memset(o->ic, 0, (size_t)o->rows * o->cols * sizeof(double)); }  /* .cpp:652 */
+
 void nid_oracle_set_target(nid_oracle *o, const unsigned char *im1) {
   memcpy(o->im1, im1, (size_t)o->rows * o->cols);
 }

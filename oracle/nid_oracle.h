@@ -75,6 +75,11 @@ void nid_oracle_dump_pixels(const nid_oracle *o, double *u, double *v,
 /* per-pixel dump of the Jacobian pass of the last evaluate(want_jac): image gradient (gx, gy), bin position,
  * span and the four B-spline derivatives of every pixel that contributed (NaN / -1 elsewhere) */
 void nid_oracle_dump_jac(const nid_oracle *o, double *gx, double *gy, double *pc, int *jc, double *dw4);
+/* TEST INFRASTRUCTURE: intensity_current_ back to the zeros the edge starts with (types_six_dof_expmap.cpp:652) -- the
+ * state in which a pixel that linearizeOplus takes but computeError did not write (Q6: the two project differently, an
+ * ulp apart) contributes nothing (B-spline derivative identically 0 at 0, Q5).  The reference's Jacobian depends on what
+ * EARLIER calls left in those slots; this pins the history the HIP path's value corresponds to. */
+void nid_oracle_clear_intensity(nid_oracle *o);
 /* per cell, of the last evaluate with the Jacobian: the sum of the absolute values of the terms linearizeOplus added up
  * (the condition of its result; test infrastructure) */
 void nid_oracle_jac_abs_scale(const nid_oracle *o, double *per_cell);

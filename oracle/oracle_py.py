@@ -52,6 +52,8 @@ def load(path: str | None = None):
     lib.nid_oracle_dump_pixels.argtypes = [C.c_void_p, c_dp, c_dp, c_dp, c_ip, c_dp, c_dp, c_ip]
     lib.nid_oracle_dump_jac.argtypes = [C.c_void_p, c_dp, c_dp, c_dp, c_ip, c_dp]
     lib.nid_oracle_jac_abs_scale.argtypes = [C.c_void_p, c_dp]
+    lib.nid_oracle_clear_intensity.argtypes = [C.c_void_p]
+    lib.nid_oracle_clear_intensity.restype = None
     lib.nid_oracle_bspline.restype = C.c_double
     lib.nid_oracle_bspline.argtypes = [C.c_int, C.c_int, C.c_int, C.c_double]
     lib.nid_oracle_bspline_der.restype = C.c_double
@@ -249,6 +251,11 @@ class Oracle:
         self._href_pose, self._twin = _d(pose7).copy(), None
         self.lib.nid_oracle_compute_href(self.h, _dp(_d(pose7)), _ip(cnt), _dp(href))
         return cnt, href
+
+    def clear_intensity(self):
+        """intensity_current_ back to the edge's initial zeros (nid_oracle_clear_intensity): the call history in which a
+        pixel only linearizeOplus takes contributes nothing."""
+        self.lib.nid_oracle_clear_intensity(self.h)
 
     def twin(self):
         """The same frame pair and reference stage on load_twin()'s build (created on first use)."""

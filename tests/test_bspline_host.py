@@ -83,3 +83,37 @@ def test_log2_fast_host(capi):
     err = np.abs(got - ref)
     assert np.all(err <= 2.0 ** -51 * np.maximum(1.0, np.abs(ref))), float(err.max())
     assert capi.log2_fast_host(1.0) == 0.0 and capi.log2_fast_host(0.25) == -2.0
+
+
+def test_quotient_by_255_from_its_reciprocal(tmp_path):
+    """csrc/nid_kernels.hip.h div_255 (round 6): RN(x / 255.0) as q0 = x * RN(1/255), q = fma(fma(-255, q0, x), RN(1/255), q0)
+    -- the bin position (ic * S) / 255 of the reference (types_six_dof_expmap.cpp:574) without a division sequence.  IEEE
+    arithmetic, so the identity is checked on the host: 10^7 random and structured x against the division, bit for bit."""
+    import os, subprocess
+    src = tmp_path / "div255.c"
+    src.write_text(r"""
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+static double div_255(double x) { const double r = 1.0 / 255.0, q0 = x * r; return fma(fma(-255.0, q0, x), r, q0); }
+static int same(double a, double b) { return memcmp(&a, &b, 8) == 0; }
+int main(void) {
+  unsigned long long s = 88172645463325252ull, bad = 0, n = 0;
+  for (int i = 0; i < 10000000; i++) {
+    s ^= s << 13; s ^= s >> 7; s ^= s << 17;
+    double x = (double)(s >> 11) / 9007199254740992.0 * 255.0 * 13.0;
+    if (i % 5 == 1) x = (double)(s % (255 * 13 * 4)) / 4.0;                       /* bilinear-like rationals */
+    if (i % 5 == 2) x = nextafter(255.0 * (double)(s % 14), (s & 1) ? 0.0 : 1e9);  /* next to a multiple of 255 */
+    if (i % 5 == 3) x = 254.999 * (double)(1 + s % 13);                           /* the clamp value times S */
+    if (i % 5 == 4) x = ldexp(x, -(int)(s % 60));                                 /* small */
+    n++;
+    if (!same(x / 255.0, div_255(x))) { if (!bad) printf("first: %a\n", x); bad++; }
+  }
+  printf("%llu of %llu differ\n", bad, n);
+  return bad != 0;
+}
+""")
+    exe = tmp_path / "div255"
+    subprocess.check_call(["gcc", "-O2", "-ffp-contract=off", "-mfma", "-o", str(exe), str(src), "-lm"])
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and r.stdout.strip().endswith("0 of 10000000 differ"), r.stdout
