@@ -1102,6 +1102,14 @@ __device__ __forceinline__ void exact_decisions(const EvalParams &P, const SlotA
   const Geometry &g = P.g;
   const double lx = t.x, ly = t.y, lz = t.z;  // the second pass has the tile entry already
   double qx, qy, qz;
+#ifdef NID_ABL_EXACT_MATRIX  // (ablation builds only: the FAST matrix transform in place of the configured one -- other bits)
+  if (true) {
+    const double *M = SA.pose.M;
+    qx = fma(M[0], lx, fma(M[1], ly, fma(M[2], lz, M[3])));
+    qy = fma(M[4], lx, fma(M[5], ly, fma(M[6], lz, M[7])));
+    qz = fma(M[8], lx, fma(M[9], ly, fma(M[10], lz, M[11])));
+  } else
+#endif
   if (EXT && SA.pose.mode == 0) {
     Pose pq;
     // scalar loads through the constant address space, like the rest of the record (k_eval2)
@@ -1376,6 +1384,22 @@ __device__ __forceinline__ bool eval_cell(const EvalParams &P, const SlotArgs &S
   // (RES: the previous request's tail has cleared the histograms -- except in the throughput shapes, whose Jacobian block
   // sum goes through the histogram area AFTER the fold (NID_XPOSE_SUM) while the other waves are already gone)
   constexpr bool kResRezero = RES && NT <= 256 && NID_XPOSE_SUM;
+  // Latency form (launched): the cell's tile entries are REQUESTED before the histograms are zeroed and the B-spline table is
+  // copied, and warped -- target windows requested -- before the barrier behind those: neither needs LDS, and a launch of
+  // one pose per CU has nothing else to hide the two dependent round trips behind (round 6: the phase stamps of the
+  // single-pose kernel, profiles/r06_latency_A.txt).  The same operations on the same values: the same bits.
+  constexpr bool kLatEarly = LAT > 0 && !RES;
+  constexpr int kLatN = LAT > 0 ? LAT : 1;
+  TileIn lat_tin[kLatN];
+  PixelFront lat_fr[kLatN];
+  WinC lat_wc[kLatN];
+  WinJ lat_wj[kLatN];
+  (void)lat_tin; (void)lat_fr; (void)lat_wc; (void)lat_wj;
+  if constexpr (kLatEarly) {
+#pragma unroll
+    for (int q = 0; q < LAT; q++)
+      if (wave_base + q * NT < g.pstride) load_tile(P, base + (unsigned)(wave_base + q * NT + lane), plane, lat_tin[q]);
+  }
   if (!RES || rc.fresh || kResRezero) zero_histograms(0);
   if (RES) {
     // (the resident kernel has loaded the table once)
@@ -1387,6 +1411,15 @@ __device__ __forceinline__ bool eval_cell(const EvalParams &P, const SlotArgs &S
   } else {
     // (the host's table carries kWcPre on its value coefficients, see hist_add / fx_bits)
     for (int i = tid; i < S * kCoefRow; i += NT) rtab[i] = P.ctab[i];
+  }
+  if constexpr (kLatEarly) {
+#pragma unroll
+    for (int q = 0; q < LAT; q++)
+      if (wave_base + q * NT < g.pstride) {
+        pixel_front<false>(P, SA, lat_tin[q], lat_fr[q]);
+        if (JAC) load_win_jac_e(P, lat_fr[q].e0, lat_wj[q]);
+        else load_win_centre_e(P, lat_fr[q].e0, lat_wc[q]);
+      }
   }
   if (!RES || rc.fresh || kResRezero) __syncthreads();  // (a later resident request: the waves have met at the kernel's own barriers since)
   NID_STAMP(1);
@@ -1422,6 +1455,10 @@ __device__ __forceinline__ bool eval_cell(const EvalParams &P, const SlotArgs &S
     constexpr bool MIXED = PRESET && !REPAIR;  // NORMAL mode with the repair set known beforehand (see PRESET)
     if (group != 0) {  // FAST second passes only: 1 = clamped (kClampBins), 2 = near-saturated (kNearSatIc)
       if (REPAIR) return;  // (their sums are exact relative to themselves: coarse copies for weights >= 2^-8 only)
+#ifdef NID_ABL_NO_GROUP_ADDS  // (ablation builds only: the groups' classification without their LDS atomics -- wrong results)
+      clamp_flag[group - 1] = 1u;
+      return;
+#endif
       unsigned long long *hx = (group == 2 ? nsb : clampb) + ((unsigned)copy & (kClampCopies - 1));
       unsigned long long *hlo = group == 2 ? ns_lo : clamp_lo;
       {
@@ -1793,6 +1830,9 @@ __device__ __forceinline__ bool eval_cell(const EvalParams &P, const SlotArgs &S
       }
       if (SECOND) {
         go = false;
+#ifdef NID_ABL_COST2_NO_EXACT  // (ablation builds only: the second pass's loop, loads and mask tests alone)
+        rare = false;
+#endif
         if (rare) {
           exact_decisions<EXT, false>(P, SA, pose_idx, tin, f, ic);
           go = f.in;
@@ -1805,6 +1845,9 @@ __device__ __forceinline__ bool eval_cell(const EvalParams &P, const SlotArgs &S
         jc = fast_bin<SECOND || kMainPassClamps, SECOND>(ic, S, pc);
         bspline4_poly<false, JAC && !SECOND, !SECOND>(pc, jc, rtab, wc, dw);
         // (second pass: `ic` is the reference's own sample, evaluated exactly and clamped like there)
+#ifdef NID_ABL_COST2_NO_HIST  // (ablation builds only: the second pass without its histogram updates -- wrong results)
+        if (!SECOND)
+#endif
         hist_add(f.jr, jc, SECOND ? f.wr : tin.wr, wc, std::true_type{}, pc,
                  (SECOND && NID_CLAMP_BINS) ? (ic == 254.999 ? 1 : ((NID_NEAR_SAT_BINS && ic == kNearSatIc) ? 2 : 0)) : 0, std::false_type{});
       } else {
@@ -1870,15 +1913,16 @@ __device__ __forceinline__ bool eval_cell(const EvalParams &P, const SlotArgs &S
     int r = 0;
     if constexpr (LAT > 0) {
       // staged main pass (see the template comment); the host launches this form only if LAT rounds cover the cell
-      TileIn tin[LAT];
-      PixelFront fr[LAT];
-      WinC wcn[LAT];
-      WinJ wjn[LAT];
+      TileIn (&tin)[kLatN] = lat_tin;
+      PixelFront (&fr)[kLatN] = lat_fr;
+      WinC (&wcn)[kLatN] = lat_wc;
+      WinJ (&wjn)[kLatN] = lat_wj;
       // RES: the cell's tile entries stay in LDS from the kernel's first request on (every thread re-reads what it
       // wrote itself: [round][field][thread] doubles, then the bin indices) -- an LDS read instead of an L2 round trip
       // at the head of every request
       double *tcache = reinterpret_cast<double *>((reinterpret_cast<uintptr_t>(lds_tail) + 15) & ~(uintptr_t)15);
       int *jcache = reinterpret_cast<int *>(tcache + LAT * 7 * NT);
+      if constexpr (!kLatEarly) {
 #pragma unroll
       for (int q = 0; q < LAT; q++)
         if (wave_base + q * NT < g.pstride) {
@@ -1906,6 +1950,7 @@ __device__ __forceinline__ bool eval_cell(const EvalParams &P, const SlotArgs &S
           if (JAC) load_win_jac_e(P, fr[q].e0, wjn[q]);
           else load_win_centre_e(P, fr[q].e0, wcn[q]);
         }
+      }  // (!kLatEarly)
 #pragma unroll
       for (int q = 0; q < LAT; q++) {
         lat[q].go = false;
@@ -2673,9 +2718,6 @@ __device__ __forceinline__ bool eval_cell(const EvalParams &P, const SlotArgs &S
 #ifndef NID_EXT_VGPRS
 #define NID_EXT_VGPRS 0
 #endif
-#ifndef NID_CELL_INTERLEAVE
-#define NID_CELL_INTERLEAVE 1
-#endif
 template <int NT, bool JAC, bool STRICT, int NB, bool DBG, bool EXT = false, int LAT = 0, bool BIG = false>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu((STRICT || DBG || LAT || NT >= 512) ? 4 : (EXT ? NID_EXT_WAVES : NID_FAST_WAVES))))
 #if NID_EXT_VGPRS
@@ -2691,28 +2733,11 @@ void k_eval2(EvalParams P) {
   // Speed only: nothing depends on the placement.
   const int bid = blockIdx.x;
   const int q = bid >> 3;
-#if NID_CELL_INTERLEAVE > 1
-  // Round 6: the workgroups an XCD runs side by side belong to NID_CELL_INTERLEAVE cells that lie far apart in the image
-  // (every C/K-th of the XCD's C cells) instead of to ONE cell: on flash data the poses of a saturated cell all sit in
-  // their latency-bound second passes at the same time, and a CU that holds nothing else idles through them; mixed with
-  // the poses of ordinary cells their round trips hide behind the others' arithmetic.  The K cells' tiles (82 KB each)
-  // share the XCD's L2 as well as one cell's did.
-  constexpr int K = NID_CELL_INTERLEAVE;
-  const int C = (g.nloc + 7) >> 3;
-  int pose_idx, lc;
-  if (C % K == 0) {
-    const int span = K * P.batch, j = q / span, within = q - j * span;
-    pose_idx = within / K;
-    lc = j + (within - pose_idx * K) * (C / K);
-  } else {
-    pose_idx = q % P.batch;
-    lc = q / P.batch;
-  }
-  const int cl = lc * 8 + (bid & 7);
-#else
+  // (Round 6 tried the opposite -- the workgroups an XCD runs side by side spread over 2 / 4 / 8 cells far apart in the image,
+  // so that a saturated cell's latency-bound second passes overlap other cells' arithmetic: plain pair 790 -> 840-850 us per
+  // 256 poses, flash pair 1047 -> 1280-1470 us, profiles/r06_ablations_A.txt.  The poses of ONE cell side by side it stays.)
   const int pose_idx = q % P.batch;
   const int cl = (q / P.batch) * 8 + (bid & 7);
-#endif
   if (cl >= g.nloc) return;  // padding of the last group of 8 cells
   SlotArgs sa_ext;
   if (EXT) {
