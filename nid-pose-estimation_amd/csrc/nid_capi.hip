@@ -260,14 +260,16 @@ void set_hist_params(EvalParams &P) {
   P.hist_inv_scale = std::ldexp(1.0, -hs);
 }
 
-size_t eval_lds_bytes(const Geometry &g, int nt, bool resident = false) {
+// nb_spec: the bin count the kernel is specialised for (its template's NB; 0 = a generic kernel): eval_hist_copies
+size_t eval_lds_bytes(const Geometry &g, int nt, bool resident = false, int nb_spec = -1) {
+  if (nb_spec < 0) nb_spec = (g.nb == 8 || g.nb == 10) ? g.nb : 0;
   const int nbins = g.nb * g.nb + g.nb;
   // copies + fine levels (the Jacobian block sum of the throughput shapes reuses the area: at least kXposeDoubles); tab + term
   // clamped samples: coarse copies, fine levels, folded sums, flags; near-saturated samples: folded sums, and their bins
   // unless the weight tables lend them their area (near_sat_aliased)
   const size_t clamp_bytes = (size_t)kClampBins(g.nb) * (kClampCopies + kFineLevels + 1) * 8 + (size_t)kFlagWords * 4 + (size_t)(g.nb + 1) * 8 +
                              ((near_sat_aliased(g.nb) && !resident) ? 0 : (size_t)kNearSatBinBytes(g.nb) + 8);
-  const size_t hist_bytes = std::max((size_t)nbins * (eval_hist_copies(nt) + kFineLevels) * 8 + clamp_bytes, (size_t)kXposeDoubles(nt) * 8);
+  const size_t hist_bytes = std::max((size_t)nbins * (eval_hist_copies(nt, nb_spec) + kFineLevels) * 8 + clamp_bytes, (size_t)kXposeDoubles(nt) * 8);
   return hist_bytes + 2 * (size_t)((nbins + 1) & ~1) * 8 + (size_t)g.S * kCoefRow * 8 + (size_t)kFlagDoubles * 8 + (size_t)kRedDoubles(nt) * 8;
 }
 
@@ -306,11 +308,7 @@ int launch_eval2(nid_ctx *ctx, EvalParams &P, bool jac, hipStream_t stream, int 
   const bool stamps_lat = dbg && !ctx->dbg_enabled && !ctx->loop_form && ctx->math_mode != NID_MATH_STRICT && nt >= 512 &&
                           P.g.pstride <= lat_rounds(nt) * nt && batch <= kMaxBatch;
   if (dbg && nt > 256 && !stamps_lat) nt = 256;
-  size_t lds = eval_lds_bytes(P.g, nt);
   set_hist_params(P);
-  if (lds > 160 * 1024) return NID_ERR_UNSUPPORTED;
-  static const char *pad_env = getenv("NID_OCCUPANCY_LDS_PAD");  // occupancy experiments (DESIGN.md 7): pad the LDS request
-  if (pad_env) lds = std::min<size_t>(160 * 1024, lds + (size_t)atoi(pad_env));
   const bool strict = ctx->math_mode == NID_MATH_STRICT;
   // The kernels live in one translation unit per workgroup shape and kind (nid_eval_launch.h).  Families: the latency
   // form (512 / 1024 threads, FAST math, <= kMaxBatch poses, LAT rounds cover the cell) with or without phase stamps;
@@ -327,7 +325,14 @@ int launch_eval2(nid_ctx *ctx, EvalParams &P, bool jac, hipStream_t stream, int 
     if (!strict && !no_lat && !ctx->loop_form && P.g.pstride <= lat_rounds(nt) * nt) family = kFamLat;
   }
   if (family == kFamLat && batch > kMaxBatch) return NID_ERR_INVALID_ARG;
-  const size_t lds_repair = eval_lds_bytes(P.g, std::max(nt, NID_REPAIR_NT));  // k_repair's workgroup shape: nid_eval_tu.inc
+  // (the bin-specialised kernels -- the loop and latency families at 8 / 10 bins -- may keep fewer histogram copies than the
+  // generic ones the other families run: eval_hist_copies)
+  const int nb_spec = (family == kFamLoop || family == kFamLat) && (P.g.nb == 8 || P.g.nb == 10) ? P.g.nb : 0;
+  size_t lds = eval_lds_bytes(P.g, nt, false, nb_spec);
+  if (lds > 160 * 1024) return NID_ERR_UNSUPPORTED;
+  static const char *pad_env = getenv("NID_OCCUPANCY_LDS_PAD");  // occupancy experiments (DESIGN.md 7): pad the LDS request
+  if (pad_env) lds = std::min<size_t>(160 * 1024, lds + (size_t)atoi(pad_env));
+  const size_t lds_repair = eval_lds_bytes(P.g, std::max(nt, NID_REPAIR_NT), false, nb_spec);  // k_repair's workgroup shape: nid_eval_tu.inc
   switch (nt) {
     case 128: (jac ? launch_eval_128_jac : launch_eval_128_cost)(P, family, strict, lds, lds_repair, stream, batch); break;
     case 256: (jac ? launch_eval_256_jac : launch_eval_256_cost)(P, family, strict, lds, lds_repair, stream, batch); break;

@@ -54,7 +54,12 @@ namespace nid {
 // consecutive lanes (MI355X_MICROARCH.md, LDS table): 16 copies give every lane of a group its own
 // address and its own pair of banks, so more copies buy nothing and cost zeroing + fold time.
 constexpr int kHistCopies = 16;
-constexpr int eval_hist_copies(int nt) { return nt >= 128 ? kHistCopies : 8; }  // k_eval2, by workgroup shape
+// k_eval2's copies, by workgroup shape and -- round 6 -- by the bin count the kernel is specialised for: NID_HIST_COPIES_NB10
+// copies in the 10-bin instantiations (`nb_spec` = the template's NB; 0 = the generic kernels: always kHistCopies)
+#ifndef NID_HIST_COPIES_NB10
+#define NID_HIST_COPIES_NB10 16
+#endif
+constexpr int eval_hist_copies(int nt, int nb_spec = 0) { return nt >= 128 ? (nb_spec == 10 ? NID_HIST_COPIES_NB10 : kHistCopies) : 8; }
 constexpr int kMaxBins = 16;
 constexpr int kMaxPlainBins = 32;  // plain-histogram mode (k_plain_nid)
 constexpr int kCellOut = 10;      // Hc, Hj, err, J[6], Nc
@@ -1285,7 +1290,7 @@ __device__ __forceinline__ bool eval_cell(const EvalParams &P, const SlotArgs &S
   static_assert(!PRESET || (REPAIR_INLINE && LAT == 0 && !RES), "PRESET: k_repair's instantiation");
   static_assert(LAT == 0 || (!STRICT && !EXT), "the latency form exists for FAST math launches of <= kMaxBatch poses (DBG: phase stamps only)");
   const int tid = threadIdx.x;
-  constexpr int NC = eval_hist_copies(NT);
+  constexpr int NC = eval_hist_copies(NT, NB);
   const Geometry &g = P.g;
   const int nb = NB > 0 ? NB : g.nb;
   const int nbins = nb * nb + nb;

@@ -420,13 +420,38 @@ void report(const char *where, int rc, nid_multi *m) {
                m ? nid_multi_last_error(m) : "");
 }
 
+// Contexts of OTHER geometries than the current one, most recently used last (round 6): a coarse-to-fine schedule walks
+// through three or four geometries per frame pair (host/nid_pyramid.cpp), and creating a context is ~6 ms of allocations
+// (18 of the pyramid's 33 ms per pair went there).  At most kParkedMax of them are kept; a parked context holds no
+// resident kernel and its caller-buffer keys are dropped.
+constexpr size_t kParkedMax = 4;
+std::vector<LegacyState> g_parked;
+
+void apply_options(nid_multi *m, int cell);
+
 nid_multi *get_multi(int rows, int cols, int cell, int bins, int deg, const double *intr) {
   LegacyState &S = g_state;
-  const bool same = S.m && S.rows == rows && S.cols == cols && S.cell == cell && S.bins == bins &&
-                    S.intr[0] == intr[0] && S.intr[1] == intr[1] && S.intr[2] == intr[2] && S.intr[3] == intr[3];
-  if (same) return S.m;
-  if (S.m) nid_multi_destroy(S.m);
+  auto matches = [&](const LegacyState &T) {
+    return T.m && T.rows == rows && T.cols == cols && T.cell == cell && T.bins == bins &&
+           T.intr[0] == intr[0] && T.intr[1] == intr[1] && T.intr[2] == intr[2] && T.intr[3] == intr[3];
+  };
+  if (matches(S)) return S.m;
+  if (S.m) {  // park the current context
+    (void)nid_multi_resident_pause(S.m);
+    LegacyState keep;
+    keep.m = S.m; keep.rows = S.rows; keep.cols = S.cols; keep.cell = S.cell; keep.bins = S.bins;
+    std::memcpy(keep.intr, S.intr, sizeof(keep.intr));
+    g_parked.push_back(keep);
+    if (g_parked.size() > kParkedMax) { nid_multi_destroy(g_parked.front().m); g_parked.erase(g_parked.begin()); }
+  }
   S = LegacyState();
+  for (size_t k = 0; k < g_parked.size(); k++)
+    if (matches(g_parked[k])) {
+      S = g_parked[k];  // (no keys, nothing "resident": the next call hands its pair over afresh)
+      g_parked.erase(g_parked.begin() + (long)k);
+      apply_options(S.m, cell);
+      return S.m;
+    }
   nid_config cfg;
   std::memset(&cfg, 0, sizeof(cfg));
   cfg.rows = rows; cfg.cols = cols; cfg.cell_num = cell; cfg.bin_num = bins; cfg.bs_degree = deg;
@@ -445,6 +470,13 @@ nid_multi *get_multi(int rows, int cols, int cell, int bins, int deg, const doub
     rc = nid_multi_attach_comm(m, g_comm);
     if (rc != NID_OK) { report("nid_multi_attach_comm", rc, m); nid_multi_destroy(m); return nullptr; }
   }
+  apply_options(m, cell);
+  S.m = m; S.rows = rows; S.cols = cols; S.cell = cell; S.bins = bins;
+  std::memcpy(S.intr, intr, sizeof(S.intr));
+  return m;
+}
+
+void apply_options(nid_multi *m, int cell) {
   // the operator signatures carry a 4x4 matrix: computeH.cu:152-154 semantics for the transform
   nid_multi_set_options(m, g_jac_bound, NID_XFORM_MATRIX);
   nid_multi_set_math_mode(m, g_math_mode);
@@ -452,10 +484,7 @@ nid_multi *get_multi(int rows, int cols, int cell, int bins, int deg, const doub
   // the operators are blocking, one pose (or one LM rejection chain) at a time: latency matters, not the
   // pipelined throughput the 128-thread default is tuned for (nid_set_launch_shape, tools/latency_sweep.py)
   nid_multi_set_launch_shape(m, jac_threads_for(cell * cell, g_world > 1 ? g_world : (int)g_devices.size()), g_cost_threads);
-  if (resident_wanted()) (void)nid_multi_set_resident(m, 1);  // (unsupported platform: the launched form)
-  S.m = m; S.rows = rows; S.cols = cols; S.cell = cell; S.bins = bins;
-  std::memcpy(S.intr, intr, sizeof(S.intr));
-  return m;
+  (void)nid_multi_set_resident(m, resident_wanted() ? 1 : 0);  // (unsupported platform: the launched form)
 }
 
 bool to_u8(const double *im, size_t n, std::vector<uint8_t> *out) {
@@ -817,6 +846,8 @@ long nid_legacy_stale_detections(void) { return g_stale_detections; }
 
 void nid_legacy_reset(void) {
   if (g_state.m) nid_multi_destroy(g_state.m);
+  for (LegacyState &T : g_parked) nid_multi_destroy(T.m);
+  g_parked.clear();
   g_state = LegacyState();
   (void)nid_backproject_release();  // Calculate3Dpoint's scratch
 }

@@ -23,6 +23,13 @@ NID_DIRECT_TRACE=1 python tools/direct_trace.py > gpurun_out/$tag/direct_trace.t
 python tools/short_seq_sweep.py A 8 > gpurun_out/$tag/short_seq_A.txt 2> gpurun_out/$tag/short_seq_A.err; echo "short seq rc=$?"
 python tools/timed_region_probe.py > gpurun_out/$tag/timed_region_probe.txt 2> gpurun_out/$tag/timed_region_probe.err; echo "probe rc=$?"
 python tools/pair_setup.py A 8 > gpurun_out/$tag/pair_setup.txt 2> gpurun_out/$tag/pair_setup.err; echo "pair setup rc=$?"
-python tools/resident_batch_probe.py A > gpurun_out/$tag/short_sequences_A.txt 2> gpurun_out/$tag/short_sequences_A.err; echo "resident batch probe rc=$?"
+python tools/legacy_call_cost.py A 8 > gpurun_out/$tag/legacy_call_cost.txt 2> gpurun_out/$tag/legacy_call_cost.err; echo "legacy call cost rc=$?"
+./tools/ubench/div_shared > gpurun_out/$tag/div_shared.txt 2>&1; echo "div_shared rc=$?"
+[ -f exp/libnid_hip_r6base.so ] && ROUNDS=2 python tools/flash_ab.py exp/libnid_hip_r6base.so default > gpurun_out/$tag/flash_ab.txt 2>&1; echo "flash ab rc=$?"
+# the reference's default bin count: kernel stats (one launch in flight) and the SQ counter passes at 10 bins
+( R=$(pwd); cd /tmp && export TMPDIR=/tmp && NID_ONE_STREAM=1 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${tag}_A10/trace -- python3 $R/bench.py --bins 10 --steps 4000 --warmup 200 --no-cpu-baseline --no-flash > $R/gpurun_out/${tag}_A10_bench_onestream.json 2>/dev/null ); echo "bins10 trace rc=$?"
+bash tools/pmc_round.sh ${tag}A10 A 256 10 > gpurun_out/$tag/pmc_round_A10.log 2>&1; echo "pmc A10 rc=$?"
+# a flash launch split into k_eval2 and the k_repair behind it
+( R=$(pwd); cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${tag}_flash/trace -- python3 $R/tools/flash_profile.py flash FAST > $R/gpurun_out/$tag/flash_profile.txt 2>&1 ); echo "flash profile rc=$?"
 ./tools/ubench/valu_wallclock > gpurun_out/$tag/valu_wallclock.txt 2>&1; echo "valu wallclock rc=$?"
 python tools/first_shot_probe.py > gpurun_out/$tag/first_shot_probe.txt 2> gpurun_out/$tag/first_shot_probe.err; echo "first shot probe rc=$?"
