@@ -528,9 +528,20 @@ def main():
             shots.append(el)
             assert np.array_equal(r2, results)
         elapsed = float(np.median(shots))
+        # for continuity with BENCH_r05 (whose region ended when run(K) returned, no synchronisation behind it): the same
+        # five times in that definition -- reported, not `value`
+        r05_shots = []
+        for _ in range(5):
+            run(W, collect=False)
+            barrier()
+            t_a = time.perf_counter()
+            run(K)
+            r05_shots.append(time.perf_counter() - t_a)
         short_info = {"form": "launches (plan_split: <= 16 poses per launch, two streams)", "timed_region": "barrier + synchronise | run(K) | synchronise",
                       "value_from": "median of 11 identical timed regions (W warmup steps in front of each)",
-                      "first_shot_us": first_shot * 1e6, "us_per_shot": [x * 1e6 for x in shots]}
+                      "first_shot_us": first_shot * 1e6, "us_per_shot": [x * 1e6 for x in shots],
+                      "without_trailing_synchronisation_us_per_shot": [x * 1e6 for x in r05_shots],
+                      "it_per_s_without_trailing_synchronisation": K / float(np.median(r05_shots))}
     # sanity: every result is finite, and the pipelined result of the last step equals a synchronous evaluation of
     # the same pose (every rank holds the same sums after the exchange)
     ablation = bool(os.environ.get("NID_HIP_LIB"))  # kernel-ablation builds (exp/) produce meaningless numbers

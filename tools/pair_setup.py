@@ -21,12 +21,12 @@ if os.environ.get("NID_PAIR_SETUP_CHILD"):
         hostlib.run_lm(pair, bins, pair.pose_init, 10, fused=fused)
         print(f"[run] wall {1e3 * (time.perf_counter() - t0):.3f} ms, optimize() {1e3 * hostlib.last_optimize_seconds():.3f} ms", file=sys.stderr, flush=True)
     sys.exit(0)
-for mode, extra in (("DEFAULT, NID_LEGACY_VERIFY_ROTATING: cheap keys + ONE of 32 slices of each big buffer per call, hashed by the pool's workers (polling for 150 us behind a job) WHILE the device evaluates, joined before the call returns; fused flows: NATIVE pair setup (nid_legacy_set_pair_u16)", {}),
+for mode, extra in (("DEFAULT, NID_LEGACY_VERIFY_ROTATING: cheap keys + 3 (cost-only) / 6 (with the Jacobian) of the 128 slices of each big buffer per call, hashed by the pool's workers (polling for 150 us behind a job) WHILE the device evaluates, joined before the call returns; fused flows: NATIVE pair setup (nid_legacy_set_pair_u16)", {}),
                     ("fused flows through the legacy operators' setup (NID_HOST_LEGACY_SETUP=1: round 5's route)", {"NID_HOST_LEGACY_SETUP": "1"}),
-                    ("ROTATING, 2 of 32 slices per call (NID_LEGACY_VERIFY_SLICES=2: a change is found within 16 calls)", {"NID_LEGACY_VERIFY_SLICES": "2", "NID_HOST_LEGACY_SETUP": "1"}),
+                    ("ROTATING, 2 of 128 slices per call (NID_LEGACY_VERIFY_SLICES=2: a change is found within 64 calls)", {"NID_LEGACY_VERIFY_SLICES": "2", "NID_HOST_LEGACY_SETUP": "1"}),
                     ("ROTATING, workers park at once (NID_LEGACY_HASH_SPIN_US=0)", {"NID_LEGACY_HASH_SPIN_US": "0", "NID_HOST_LEGACY_SETUP": "1"}),
                     ("ROTATING without pool threads (NID_LEGACY_HASH_THREADS=0: the caller hashes its slice behind the evaluation)", {"NID_LEGACY_HASH_THREADS": "0", "NID_HOST_LEGACY_SETUP": "1"}),
-                    ("NID_LEGACY_VERIFY_EVERY_CALL: all 32 slices on every CudaComputeH call", {"NID_LEGACY_VERIFY_EVERY_CALL": "1", "NID_HOST_LEGACY_SETUP": "1"}),
+                    ("NID_LEGACY_VERIFY_EVERY_CALL: all 128 slices on every CudaComputeH call", {"NID_LEGACY_VERIFY_EVERY_CALL": "1", "NID_HOST_LEGACY_SETUP": "1"}),
                     ("NID_LEGACY_VERIFY_TRUSTED (nid_legacy_set_trust_buffers(1) / NID_LEGACY_TRUST_BUFFERS=1: round 4's behaviour)", {"NID_LEGACY_TRUST_BUFFERS": "1", "NID_HOST_LEGACY_SETUP": "1"})):
     p = subprocess.run([sys.executable, os.path.abspath(__file__), cfg, str(bins)], capture_output=True, text=True,
                        env=dict(os.environ, NID_PAIR_SETUP_CHILD="1", NID_LEGACY_TRACE="1", **extra))
