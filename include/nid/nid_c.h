@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define NID_ABI_VERSION 2 /* 2: NID_SLOTS 128 -> 1024, NID_MAX_BATCH 64 -> 256, launch shapes, launch chains, strided cell sets, nid_multi.h */
+#define NID_ABI_VERSION 3 /* 2: NID_SLOTS 128 -> 1024, NID_MAX_BATCH 64 -> 256, launch shapes, launch chains, strided cell sets, nid_multi.h; 3: nid_set_pair_u16 / nid_multi_set_pair_u16 added, nid_resident_batch_stats and nid_set_resident(ctx, 2) removed */
 
 typedef enum {
   NID_OK = 0,
