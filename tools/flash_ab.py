@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """tools/flash_ab.py LIB [LIB ...]: same-box A/B of library builds (tools/build_variant.py): for every library, in
 round-robin order and ROUNDS times, the kernel time of a 256-pose cost+Jacobian launch (FAST) on the plain and on the
-flash pair and the pipelined rate -- each library in its own process (NID_HIP_LIB)."""
+flash pair and the pipelined rate -- each library in its own process (NID_HIP_LIB).  NID_AB_BINS: bin count (8);
+NID_AB_THREADS=J,C: launch shape of the cost+Jacobian and cost-only launches."""
 import json, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 WORKER = r'''
@@ -14,6 +15,8 @@ delta = float(np.sqrt(0.95)); out = {}
 for name, kw in (("plain", {}), ("flash", dict(flash=True, edge_cases=True))):
     pair = synth.make_pair("A", **kw)
     ctx = capi.from_pair(pair, int(os.environ.get("NID_AB_BINS", "8")))
+    if os.environ.get("NID_AB_THREADS"):  # workgroup shape of cost+Jacobian / cost-only launches (nid_set_launch_shape)
+        ctx.set_launch_shape(*[int(v) for v in os.environ["NID_AB_THREADS"].split(",")])
     ctx.compute_href(pair.pose_init)
     poses = np.stack([synth.perturb_pose7(pair.pose_init, [1e-4 * k, 0, 0], [0, 1e-4 * k, 0]) for k in range(256)])
     seq = poses[np.arange(256 * 120) %% 256]
