@@ -163,3 +163,24 @@ A('''__device__ __forceinline__ bool eval_cell(const EvalParams &P, const SlotAr
 }  // namespace nid''')
 open('/tmp/nid_eval_cell.hip.h', 'w').write('\n'.join(out) + '\n')
 print("ok", sum(s.count('\n') + 1 for s in out))
+
+# ---- second attempt (later in round 6): the two arrays that kept the whole object in memory.  fold_bin's select chains on the members
+# cw[4] / nw[4] reach SROA as one load at a selected offset into the object; as locals of fold() they are separate small allocas again
+# (profiles/r06_ablations_A.txt item 10: no scratch any more, +-2..5 VGPRs per kernel, +3.4 % on the headline kernel: reverted again).
+p = '/tmp/nid_eval_cell.hip.h'
+s = open(p).read()
+members = """  double cw[4] = {0.0, 0.0, 0.0, 0.0};  // the clamped samples' four target weights, as the sample path computes them
+  double nw[4] = {0.0, 0.0, 0.0, 0.0};  // ... and the near-saturated samples'
+  int jc_cl = 0, jc_ns = 0;
+"""
+assert members in s
+s = s.replace(members, '')
+s = s.replace('unsigned long long fold_bin(int b, CoarseTag coarse_tag, double &mass_out) {',
+              'unsigned long long fold_bin(int b, CoarseTag coarse_tag, double &mass_out, const double (&cw)[4], const double (&nw)[4], int jc_cl, int jc_ns) {')
+s = s.replace('fold_bin(b, std::true_type{}, mass)', 'fold_bin(b, std::true_type{}, mass, cw, nw, jc_cl, jc_ns)')
+s = s.replace('fold_bin(b, std::false_type{}, mass)', 'fold_bin(b, std::false_type{}, mass, cw, nw, jc_cl, jc_ns)')
+s = s.replace("""    any_clamped = any_sat && flagw.x != 0u; any_ns = any_sat && flagw.y != 0u;
+    if (any_sat) {""", """    any_clamped = any_sat && flagw.x != 0u; any_ns = any_sat && flagw.y != 0u;
+""" + members.replace('\n  ', '\n    ').replace('  double cw', '    double cw', 1) + """    if (any_sat) {""")
+open(p, 'w').write(s)
+
