@@ -1283,6 +1283,9 @@ __device__ __forceinline__ const EvalParams &reread_args() {
 //   phase 2, Jacobian: the contracted tables (FAST), jac_accumulate_fast | jac_accumulate (STRICT: the dw[4] form),
 //       jac_round<main / second pass> | jac_round_masked (the cost phase's decisions, gomask), the LAT form from registers
 //   block sum of the six accumulators (through LDS for 128 / 256 threads, DPP + LDS beyond), the cell's quadratic form, tail
+#ifdef NID_CENSUS
+static __device__ unsigned long long g_census[64];
+#endif
 template <int NT, bool JAC, bool STRICT, int NB, bool DBG, bool EXT, int LAT, bool BIG, bool RES, bool REPAIR_INLINE = repair_inline_default(LAT, RES, DBG, BIG),
           bool PRESET = false>
 __device__ __forceinline__ bool eval_cell(const EvalParams &P, const SlotArgs &SA, const int cl, const int pose_idx, unsigned char *smem,
@@ -1994,6 +1997,21 @@ __device__ __forceinline__ bool eval_cell(const EvalParams &P, const SlotArgs &S
 #ifndef NID_ABL_NO_COST_SECOND  // (ablation builds only, tools/build_variant.py: what the pass costs -- wrong results)
     if (rare_rounds != 0ull) {
       if constexpr (use_lane_masks) {
+#ifdef NID_CENSUS  // (census builds only, tools/rare_census.py: how full the second pass's rounds are)
+        {
+          int c = __builtin_popcount(raremask);
+          for (int o = 32; o; o >>= 1) c += __shfl_xor(c, o);
+          const int R = __builtin_popcount((unsigned)rare_rounds);
+          if (lane == 0) {
+            atomicAdd(&g_census[0], 1ull);                                   // waves with a second pass
+            atomicAdd(&g_census[1], (unsigned long long)R);                  // rounds they run now
+            atomicAdd(&g_census[2], (unsigned long long)((c + 63) / 64));    // rounds of the same samples packed per wave
+            atomicAdd(&g_census[3], (unsigned long long)c);                  // rare samples
+            atomicAdd(&g_census[8 + min(R, 31)], 1ull);                      // histogram of R
+            atomicAdd(&g_census[40 + min((c + 63) / 64, 15)], 1ull);         // histogram of the packed count
+          }
+        }
+#endif
         // The second pass is a chain of DEPENDENT round trips per round -- tile entry -> exact projection -> target cell ->
         // histogram -- and on flash data every workgroup of a CU sits in it at the same time (the poses of one cell are
         // dispatched next to each other: nothing else to run meanwhile).  Round 6: the NEXT rare round's point is requested
