@@ -1179,6 +1179,42 @@ def test_flash_pair_cells(capi, oracle, synth, nb, math):
         np.testing.assert_allclose(b, b_o, rtol=0, atol=1e-9 * np.abs(b_o).max())
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("math", MODES)
+@pytest.mark.parametrize("nb", [8, 10])
+def test_flash_pair_along_the_references_own_lm_trajectory(capi, oracle, synth, nb, math):
+    """the LM traces on the flash pair can only be compared loosely (the reference's cost is noisy at
+    1e-8 on saturated data and its own optimisation does not reproduce itself: tests/test_host_gpu.py::
+    test_lm_pose_parity_flash_pair).  The tight statement is the teacher-forced one: at EVERY pose the reference's own ten
+    LM iterations accept on this pair (the oracle's trace), every cell and the Huber-weighted 6x6 system agree at the
+    bounds of any other data -- so whatever parts the two optimisations is the noise of the cost function, not the path."""
+    pair = synth.make_pair("A", flash=True, edge_cases=True)
+    ctx = capi.from_pair(pair, nb, math=_mode(capi, math))
+    o = oracle.from_pair(pair, nb)
+    cnt, _ = ctx.compute_href(pair.pose_init)
+    cnt_o, _ = o.compute_href(pair.pose_init)
+    assert np.array_equal(cnt, cnt_o)
+    o_lm = oracle.from_pair(pair, nb, jac_bound="cpu", xform="matrix")  # (the driver's own set-up: test_lm_pose_parity_flash_pair)
+    o_lm.compute_href(pair.pose_init)
+    _, recs = o_lm.lm(pair.pose_init, 10)
+    poses = [pair.pose_init] + [r["pose7"] for r in recs]
+    assert len(poses) >= 6
+    seen = 0
+    for k, pose in enumerate(poses):
+        if k and np.array_equal(pose, poses[k - 1]):
+            continue  # (an iteration whose trials were all rejected keeps the pose)
+        ref = o.evaluate(pose, True)
+        _compare_cells(ctx.evaluate(pose, True), ref, cnt_o, noise=None)
+        H, b, chi2, na = ctx.normal_equations(pose, DELTA)
+        H_o, b_o, chi2_o, na_o = oracle.normal_equations(ref[2], ref[3], DELTA)
+        assert na == na_o
+        np.testing.assert_allclose(chi2, chi2_o, rtol=1e-12)
+        np.testing.assert_allclose(H, H_o, rtol=0, atol=1e-9 * np.abs(H_o).max())
+        np.testing.assert_allclose(b, b_o, rtol=0, atol=1e-9 * np.abs(b_o).max())
+        seen += 1
+    assert seen >= 5
+
+
 def _identity_pose(synth, pair):
     R = pair.T_wc0[:3, :3].T
     return synth.pose7_from_Rt(R, -R @ pair.T_wc0[:3, 3])
