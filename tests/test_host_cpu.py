@@ -88,11 +88,11 @@ def test_host_library_exports(hostlib):
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _build_with_stub(tmp_path, caller, name):
+def _build_with_stub(tmp_path, caller, name, sanitizer="address"):
     """host/legacy_ops.cpp + a caller + tests/cpp/nid_hip_stub.cpp (the entry points of libnid_hip.so the operators
-    call, without a GPU) as ONE AddressSanitizer build."""
+    call, without a GPU) as ONE sanitizer build (AddressSanitizer unless told otherwise)."""
     exe = tmp_path / name
-    subprocess.check_call(["g++", "-fsanitize=address", "-fno-omit-frame-pointer", "-O1", "-g", "-std=c++17", "-pthread",
+    subprocess.check_call(["g++", "-fsanitize=" + sanitizer, "-fno-omit-frame-pointer", "-O1", "-g", "-std=c++17", "-pthread",
                            "-I", os.path.join(ROOT, "include", "nid", "compat"), "-I", os.path.join(ROOT, "include"),
                            os.path.join(ROOT, "tests", "cpp", caller),
                            os.path.join(ROOT, "nid-pose-estimation_amd", "host", "legacy_ops.cpp"),
@@ -100,17 +100,9 @@ def _build_with_stub(tmp_path, caller, name):
     return exe
 
 
-@pytest.mark.parametrize("threads", ["3", "0"])
-def test_legacy_operators_read_caller_buffers_only_inside_a_call_asan(tmp_path, threads):
-    """VERDICT r05 item 1 / ADVICE r05 (high), without a GPU: the reference's call pattern (tests/cpp/legacy_lm_caller.cpp:
-    CudaComputeHref, 64 CudaComputeH calls with host work in between, one undeclared in-place change, then the frees of
-    NID_pose_estimation.cpp:388-395 at once) on host/legacy_ops.cpp under AddressSanitizer, the HIP library stubbed.  A
-    worker thread that reads a caller buffer after its call has returned is a heap-use-after-free here (round 5's
-    default mode fails this test with exactly that report).  Default verification mode; with and without pool threads."""
-    exe = _build_with_stub(tmp_path, "legacy_lm_caller.cpp", "legacy_lm_caller_asan")
-    hdr = open(os.path.join(ROOT, "include", "nid", "legacy_ops.h")).read()
-    per_call = int(re.search(r"#define NID_LEGACY_SLICES_PER_CALL (\d+)", hdr).group(1))
-    SLICES = -(-int(re.search(r"#define NID_LEGACY_SLICES (\d+)", hdr).group(1)) // (per_call - per_call // 4))   # calls until every slice was checked (cost-only calls check 3/4 of per_call)
+def _write_lm_caller_input(tmp_path):
+    """in.bin of tests/cpp/legacy_lm_caller.cpp: 640x480, 16x16 cells, 64 CudaComputeH calls, one undeclared in-place
+    change of the target (a pixel of cell 0 off the fingerprint's 64 sampled indices) in front of call 13"""
     rows, cols, cell, nb, ncalls, change_at, pause_every = 480, 640, 16, 8, 64, 13, 8
     N, ncell = rows * cols, cell * cell
     rng = np.random.default_rng(3)
@@ -128,6 +120,22 @@ def test_legacy_operators_read_caller_buffers_only_inside_a_call_asan(tmp_path, 
         (2.0 + rng.random(N)).tofile(f)
         rng.integers(0, 256, N).astype(np.float64).tofile(f)
         im1.tofile(f)
+    return rows, cols, cell, nb, ncalls, change_at, change_px, im1
+
+
+@pytest.mark.parametrize("threads", ["3", "0"])
+def test_legacy_operators_read_caller_buffers_only_inside_a_call_asan(tmp_path, threads):
+    """VERDICT r05 item 1 / ADVICE r05 (high), without a GPU: the reference's call pattern (tests/cpp/legacy_lm_caller.cpp:
+    CudaComputeHref, 64 CudaComputeH calls with host work in between, one undeclared in-place change, then the frees of
+    NID_pose_estimation.cpp:388-395 at once) on host/legacy_ops.cpp under AddressSanitizer, the HIP library stubbed.  A
+    worker thread that reads a caller buffer after its call has returned is a heap-use-after-free here (round 5's
+    default mode fails this test with exactly that report).  Default verification mode; with and without pool threads."""
+    exe = _build_with_stub(tmp_path, "legacy_lm_caller.cpp", "legacy_lm_caller_asan")
+    hdr = open(os.path.join(ROOT, "include", "nid", "legacy_ops.h")).read()
+    per_call = int(re.search(r"#define NID_LEGACY_SLICES_PER_CALL (\d+)", hdr).group(1))
+    SLICES = -(-int(re.search(r"#define NID_LEGACY_SLICES (\d+)", hdr).group(1)) // (per_call - per_call // 4))   # calls until every slice was checked (cost-only calls check 3/4 of per_call)
+    rows, cols, cell, nb, ncalls, change_at, change_px, im1 = _write_lm_caller_input(tmp_path)
+    ncell = cell * cell
     env = dict(os.environ, NID_LEGACY_HASH_THREADS=threads, ASAN_OPTIONS="detect_leaks=0:abort_on_error=0", MALLOC_PERTURB_="165")
     for drop in ("NID_LEGACY_TRUST_BUFFERS", "NID_LEGACY_VERIFY_EVERY_CALL", "NID_LEGACY_VERIFY_SLICES", "NID_LEGACY_ALWAYS_UPLOAD", "LD_PRELOAD"):
         env.pop(drop, None)
@@ -144,6 +152,22 @@ def test_legacy_operators_read_caller_buffers_only_inside_a_call_asan(tmp_path, 
     assert np.all(ht0[:change_at] == old0) and change_at <= followed < change_at + SLICES, (followed, ht0)
     assert np.all(ht0[followed:] == new0) and np.all(ht0[:followed] == old0)
     assert np.all(rec[:, 0, 1:] == rec[0, 0, 1:])                       # no other cell's target changed
+
+
+def test_legacy_operators_hash_pool_under_thread_sanitizer(tmp_path):
+    """The same compiled caller under ThreadSanitizer (three pool workers): the pool claims parts on the job's own
+    counter, wakes parked workers through a generation word and joins them inside the call -- no report of a data race
+    between a worker and the caller (the results written by the workers are read behind finish()'s acquire)."""
+    exe = _build_with_stub(tmp_path, "legacy_lm_caller.cpp", "legacy_lm_caller_tsan", sanitizer="thread")
+    _write_lm_caller_input(tmp_path)
+    env = dict(os.environ, NID_LEGACY_HASH_THREADS="3", TSAN_OPTIONS="halt_on_error=0")
+    for drop in ("NID_LEGACY_TRUST_BUFFERS", "NID_LEGACY_VERIFY_EVERY_CALL", "NID_LEGACY_VERIFY_SLICES", "NID_LEGACY_ALWAYS_UPLOAD", "LD_PRELOAD"):
+        env.pop(drop, None)
+    r = subprocess.run([str(exe), str(tmp_path)], capture_output=True, text=True, timeout=600, env=env)
+    if "unexpected memory mapping" in r.stderr:
+        pytest.skip("ThreadSanitizer cannot map its shadow memory in this environment")
+    assert "ThreadSanitizer" not in r.stderr and r.returncode == 0, r.stderr[-4000:]
+    assert r.stderr.count("rewritten IN PLACE") == 1, r.stderr[-2000:]
 
 
 def test_fork_between_legacy_calls_asan(tmp_path):
