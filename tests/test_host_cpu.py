@@ -325,6 +325,35 @@ def test_png_reader_and_grey_conversion(hostlib, tmp_path):
     assert lib.nid_png_info(os.fsencode(str(bad)), None, None, None, None) == -2
 
 
+def test_png_reader_survives_mutated_files(tmp_path):
+    """host/nid_png.cpp reads files a driver is pointed at: 4 000 mutants of five valid PNGs (tests/cpp/png_fuzz.cpp: bit flips,
+    truncations, rewritten header fields and chunk lengths, inserted runs -- chunk CRCs re-made for most, so the parser behind
+    the CRC check sees them) under AddressSanitizer + UndefinedBehaviorSanitizer: refused or decoded, never a report."""
+    rng = np.random.default_rng(5)
+    rgb = rng.integers(0, 256, (13, 17, 3), dtype=np.uint8)
+    rgba = np.concatenate([rgb, rng.integers(0, 256, (13, 17, 1), dtype=np.uint8)], axis=2)
+    pal = rng.integers(0, 256, (16, 3), dtype=np.uint8)
+    seeds = {"rgb": _png_bytes(rgb, 8, 2, [0, 1, 2, 3, 4], split=2), "rgba": _png_bytes(rgba, 8, 6, [4, 3]),
+             "d16": _png_bytes(rng.integers(0, 65536, (9, 11)).astype(np.uint16), 16, 0, [2, 4, 1, 3]),
+             "pal": _png_bytes(rng.integers(0, 16, (7, 5), dtype=np.uint8), 8, 3, [0, 1], palette=pal),
+             "g8": _png_bytes(rng.integers(0, 256, (9, 11), dtype=np.uint8), 8, 0, [1, 4])}
+    paths = []
+    for name, data in seeds.items():
+        (tmp_path / f"{name}.png").write_bytes(data)
+        paths.append(str(tmp_path / f"{name}.png"))
+    exe = tmp_path / "png_fuzz"
+    subprocess.check_call(["g++", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-O1", "-g", "-std=c++17",
+                           "-I", os.path.join(ROOT, "nid-pose-estimation_amd", "host"), "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cpp", "png_fuzz.cpp"),
+                           os.path.join(ROOT, "nid-pose-estimation_amd", "host", "nid_png.cpp"), "-lz", "-o", str(exe)])
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0")
+    env.pop("LD_PRELOAD", None)
+    r = subprocess.run([str(exe), "4000", str(tmp_path)] + paths, capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and "Sanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-4000:]
+    m = re.search(r"4000 mutants: (\d+) decoded, (\d+) refused", r.stdout)
+    assert m and int(m.group(1)) > 20 and int(m.group(2)) > 2000, r.stdout
+
+
 def test_driver_refuses_cpu_mode(tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     exe = os.path.join(root, "nid-pose-estimation_amd", "nid_pose_estimation")
