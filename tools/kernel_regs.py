@@ -21,8 +21,13 @@ with tempfile.TemporaryDirectory() as d:
     os.makedirs(outdir, exist_ok=True)
     def build(u):
         out = os.path.join(outdir, os.path.basename(u)[:-4] + ".s")
+        unit = []  # the product's own per-unit flags (csrc/UNIT_FLAGS)
+        for line in (open(csrc + "/UNIT_FLAGS") if os.path.exists(csrc + "/UNIT_FLAGS") and not os.environ.get("NID_NO_UNIT_FLAGS") else []):
+            line = line.split("#", 1)[0].strip()
+            if line and line.split(":", 1)[0].strip() in os.path.basename(u):
+                unit += line.split(":", 1)[1].split()
         subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "--cuda-device-only", "-S",
-                               *args, "-I", root + "/include", "-I", csrc, "-o", out, u], stderr=subprocess.DEVNULL)
+                               *unit, *args, "-I", root + "/include", "-I", csrc, "-o", out, u], stderr=subprocess.DEVNULL)
         return out
     with ThreadPoolExecutor(8) as pool:
         outs = list(pool.map(build, units))
