@@ -3,7 +3,7 @@
 import json, sys
 d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
 r = d["roofline"]
-print("value", round(d["value"]), "it/s; sustained", round(r.get("sustained", {}).get("it_per_s", 0)), "kernel_ms", r["kernel_ms"], "frac", round(r["frac"], 4),
+print("value", round(d["value"]), "it/s; sustained", round(r.get("sustained", {}).get("it_per_s", 0)), "kernel_ms", r["kernel_ms"], "frac", round(r["frac"], 4), "valu busy", round(r.get("valu_pipe", {}).get("busy_frac", float("nan")), 4),
       "issue frac", round(r.get("issue_bound", {}).get("frac", 0), 3))
 if "sequential" in r:
     s = r["sequential"]
