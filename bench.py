@@ -857,7 +857,7 @@ def main():
             "preheat_seconds": args.preheat_seconds,   # setup before the warmup steps: clocks + instruction caches (see --help)
             "ms_per_step": elapsed / K * 1e3,
             "higher_is_better": True,
-            "scaling": "strong" if world > 1 else None,
+            "scaling": "strong",   # one frame pair's cells over the ranks: the total work is fixed at every N (N = 1 is the curve's base)
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",

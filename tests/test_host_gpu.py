@@ -520,7 +520,7 @@ def test_bench_multi_rank_code_path_on_one_gpu(tmp_path):
                          capture_output=True, text=True, env=env, timeout=600)
     assert one.returncode == 0, one.stderr[-2000:]
     r1 = json.loads(one.stdout.strip().splitlines()[-1])
-    assert r1["scaling"] is None and r1["n_gpus"] == 1
+    assert r1["scaling"] == "strong" and r1["n_gpus"] == 1
     sh = subprocess.run([sys.executable, bench, "--steps", "300", "--warmup", "70", "--no-cpu-baseline", "--shards", "3"],
                         capture_output=True, text=True, env=env, timeout=600)
     assert sh.returncode == 0, sh.stderr[-2000:]
