@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define NID_ABI_VERSION 3 /* 2: NID_SLOTS 128 -> 1024, NID_MAX_BATCH 64 -> 256, launch shapes, launch chains, strided cell sets, nid_multi.h; 3: nid_set_pair_u16 / nid_multi_set_pair_u16 added, nid_resident_batch_stats and nid_set_resident(ctx, 2) removed */
+#define NID_ABI_VERSION 4 /* 2: NID_SLOTS 128 -> 1024, NID_MAX_BATCH 64 -> 256, launch shapes, launch chains, strided cell sets, nid_multi.h; 3: nid_set_pair_u16 / nid_multi_set_pair_u16 added, nid_resident_batch_stats and nid_set_resident(ctx, 2) removed; 4: nid_time_kernel added, nid_last_kernel_ms's eval_ms ends in front of the repair kernel */
 
 typedef enum {
   NID_OK = 0,
@@ -340,6 +340,12 @@ int nid_enable_timing(nid_ctx *ctx, int enable);
  * stream, from one pair of HIP events around the whole group (what a kernel trace reports per launch) */
 int nid_time_launches(nid_ctx *ctx, int n, const double *poses7, int want_jac, double delta, int repeats,
                       float *ms_per_launch);
+/* average duration (ms) of the evaluation kernel ALONE over `repeats` n-pose launches issued one at a time: one HIP event
+ * right in front of the kernel (behind the in-stream copy of the per-pose records) and one right behind it (in front of the
+ * repair kernel that follows every loop-form launch) -- the figure a kernel trace reports for that kernel; nid_time_launches
+ * brackets whole launches back to back (copy + kernel + repair kernel + dispatch gaps: about 3 % more at 256 poses).
+ * nid_enable_timing / nid_last_kernel_ms report the same interval per launch.  (ABI 4) */
+int nid_time_kernel(nid_ctx *ctx, int n, const double *poses7, int want_jac, double delta, int repeats, float *ms_kernel);
 /* algorithmic (contract) bytes of one evaluation over this context's cells:
  * 68 B per pixel + 64 B per cell */
 int64_t nid_contract_bytes(const nid_ctx *ctx);

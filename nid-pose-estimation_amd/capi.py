@@ -45,7 +45,7 @@ SYMBOLS = [
     "nid_compute_href_matrix", "nid_set_href_state", "nid_plain_nid", "nid_evaluate", "nid_evaluate_matrix",
     "nid_normal_equations", "nid_launch", "nid_launch_batch", "nid_launch_chain", "nid_launch_batch_to", "nid_run_sequence", "nid_run_chain", "nid_set_loop_form", "nid_set_direct_results", "nid_set_resident", "nid_resident_pause", "nid_resident_stats", "nid_wait", "nid_slot_buffers", "nid_debug_read_device", "nid_launch_to",
     "nid_unpack_reduced", "nid_debug_enable_pixel_dump", "nid_debug_get_pixel_dump",
-    "nid_debug_enable_stamps", "nid_debug_get_stamps", "nid_bspline4_host", "nid_bspline4_poly_host", "nid_log2_fast_host", "nid_div_small_host", "nid_last_kernel_ms", "nid_enable_timing", "nid_time_launches",
+    "nid_debug_enable_stamps", "nid_debug_get_stamps", "nid_bspline4_host", "nid_bspline4_poly_host", "nid_log2_fast_host", "nid_div_small_host", "nid_last_kernel_ms", "nid_enable_timing", "nid_time_launches", "nid_time_kernel",
     "nid_contract_bytes", "nid_debug_repair_count", "nid_set_short_sequence_policy",
 ]
 
@@ -124,6 +124,8 @@ def load():
         lib.nid_resident_pause.argtypes = [vp]
     lib.nid_resident_stats.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     lib.nid_time_launches.argtypes = [vp, C.c_int, c_dp, C.c_int, C.c_double, C.c_int, c_fp]
+    if hasattr(lib, "nid_time_kernel"):   # (an older experiment build, NID_HIP_LIB, may lack it)
+        lib.nid_time_kernel.argtypes = [vp, C.c_int, c_dp, C.c_int, C.c_double, C.c_int, c_fp]
     if hasattr(lib, "nid_debug_repair_count"):   # (an older experiment build, NID_HIP_LIB, may lack the newest diagnostics)
         lib.nid_debug_repair_count.argtypes = [vp, C.POINTER(C.c_int64), C.c_int]
     if hasattr(lib, "nid_set_short_sequence_policy"):
@@ -399,6 +401,14 @@ class Context:
         ms = C.c_float(0)
         self._check(self.lib.nid_time_launches(self.h, ps.shape[0], _dp(ps), int(want_jac), float(delta), int(repeats),
                                                C.byref(ms)), "nid_time_launches")
+        return float(ms.value)
+
+    def time_kernel(self, poses7, delta, repeats=10, want_jac=True):
+        """ms of the evaluation kernel ALONE per launch of these poses (events right around k_eval2, one launch at a time)."""
+        ps = np.ascontiguousarray(np.asarray(poses7, dtype=np.float64).reshape(-1, 7))
+        ms = C.c_float(0)
+        self._check(self.lib.nid_time_kernel(self.h, ps.shape[0], _dp(ps), int(want_jac), float(delta), int(repeats),
+                                             C.byref(ms)), "nid_time_kernel")
         return float(ms.value)
 
     def contract_bytes(self):

@@ -294,7 +294,7 @@ int pick_threads(const nid_ctx *ctx, bool jac, int batch) {
   return nt;
 }
 
-int launch_eval2(nid_ctx *ctx, EvalParams &P, bool jac, hipStream_t stream, int batch) {
+int launch_eval2(nid_ctx *ctx, EvalParams &P, bool jac, hipStream_t stream, int batch, hipEvent_t eval_end = nullptr) {
   { int rc = resident_quiesce(ctx); if (rc) return rc; }
   P.batch = batch;
   // Workgroup shape of the throughput path: 128 threads.  Measured on MI355X (16 poses per launch, two launches in
@@ -334,17 +334,17 @@ int launch_eval2(nid_ctx *ctx, EvalParams &P, bool jac, hipStream_t stream, int 
   if (pad_env) lds = std::min<size_t>(160 * 1024, lds + (size_t)atoi(pad_env));
   const size_t lds_repair = eval_lds_bytes(P.g, std::max(nt, NID_REPAIR_NT), false, nb_spec);  // k_repair's workgroup shape: nid_eval_tu.inc
   switch (nt) {
-    case 128: (jac ? launch_eval_128_jac : launch_eval_128_cost)(P, family, strict, lds, lds_repair, stream, batch); break;
-    case 256: (jac ? launch_eval_256_jac : launch_eval_256_cost)(P, family, strict, lds, lds_repair, stream, batch); break;
-    case 512: (jac ? launch_eval_512_jac : launch_eval_512_cost)(P, family, strict, lds, lds_repair, stream, batch); break;
-    default: (jac ? launch_eval_1024_jac : launch_eval_1024_cost)(P, family, strict, lds, lds_repair, stream, batch); break;
+    case 128: (jac ? launch_eval_128_jac : launch_eval_128_cost)(P, family, strict, lds, lds_repair, stream, batch, eval_end); break;
+    case 256: (jac ? launch_eval_256_jac : launch_eval_256_cost)(P, family, strict, lds, lds_repair, stream, batch, eval_end); break;
+    case 512: (jac ? launch_eval_512_jac : launch_eval_512_cost)(P, family, strict, lds, lds_repair, stream, batch, eval_end); break;
+    default: (jac ? launch_eval_1024_jac : launch_eval_1024_cost)(P, family, strict, lds, lds_repair, stream, batch, eval_end); break;
   }
   NID_HIP(ctx, hipGetLastError());
   return NID_OK;
 }
 
-int launch_eval(nid_ctx *ctx, EvalParams &P, bool jac, hipStream_t stream, int batch = 1) {
-  return launch_eval2(ctx, P, jac, stream, batch);
+int launch_eval(nid_ctx *ctx, EvalParams &P, bool jac, hipStream_t stream, int batch = 1, hipEvent_t eval_end = nullptr) {
+  return launch_eval2(ctx, P, jac, stream, batch, eval_end);
 }
 
 void fill_common_params(nid_ctx *ctx, double delta, EvalParams *P) {
@@ -805,9 +805,8 @@ int launch_slot(nid_ctx *ctx, int slot, const Pose &pose, int want_jac, double d
   S.timed = ctx->timing;
   if (S.timed) { rc = timing_events(ctx, S); if (rc) return rc; }
   if (S.timed) NID_HIP(ctx, hipEventRecord(S.e0, st));
-  rc = launch_eval(ctx, P, want_jac != 0, st);
+  rc = launch_eval(ctx, P, want_jac != 0, st, 1, S.timed ? S.e1 : nullptr);  // (timed: e1 right behind k_eval2, in front of k_repair)
   if (rc) return rc;
-  if (S.timed) NID_HIP(ctx, hipEventRecord(S.e1, st));
   if (S.external_target) NID_HIP(ctx, hipEventRecord(S.done, st));
   S.done_slot = slot;
   S.pending = true;
@@ -890,13 +889,12 @@ int launch_batch(nid_ctx *ctx, int first_slot, int n, const Pose *poses, int wan
   S0.timed = ctx->timing;
   if (S0.timed) { rc = timing_events(ctx, S0); if (rc) return rc; }
   if (S0.timed) NID_HIP(ctx, hipEventRecord(S0.e0, st));
-  rc = launch_eval(ctx, P, want_jac != 0, st, n);
+  rc = launch_eval(ctx, P, want_jac != 0, st, n, S0.timed ? S0.e1 : nullptr);  // (timed: e1 right behind k_eval2, in front of k_repair)
   if (rc) return rc;
   if (ring >= 0) {
     NID_HIP(ctx, hipEventRecord(ctx->ext_done[ring], st));
     ctx->ext_busy[ring] = true;
   }
-  if (S0.timed) NID_HIP(ctx, hipEventRecord(S0.e1, st));
   // caller-owned result buffer: the launch is over when its ONE event is (recorded on the batch's first slot; the
   // other slots point at it -- an event record per pose cost ~4 us each, 1 ms of host time per 256-pose launch)
   if (S0.external_target) NID_HIP(ctx, hipEventRecord(S0.done, st));
@@ -2166,6 +2164,42 @@ int nid_time_launches(nid_ctx *ctx, int n, const double *poses7, int want_jac, d
   float ms = 0.f;
   NID_HIP(ctx, hipEventElapsedTime(&ms, S0.e0, S0.e1));
   *ms_per_launch = ms / (float)repeats;
+  return NID_OK;
+}
+
+
+int nid_time_kernel(nid_ctx *ctx, int n, const double *poses7, int want_jac, double delta, int repeats, float *ms_kernel) {
+  // The evaluation kernel ALONE: every repeat is one n-pose launch with an event right in front of k_eval2 (behind the in-stream
+  // copy of the per-pose records) and one right behind it (in front of k_repair), awaited before the next -- what a kernel trace
+  // reports for that kernel (nid_time_launches brackets whole launches back to back: copy + k_eval2 + k_repair + dispatch gaps).
+  if (!ctx || !poses7 || !ms_kernel || n < 1 || n > kMaxBatchExt || repeats < 1) return NID_ERR_INVALID_ARG;
+  NID_HIP(ctx, hipSetDevice(ctx->cfg.device));
+  for (int s = 0; s < NID_SLOTS; s++) if (ctx->slots[s].pending) return NID_ERR_STATE;
+  Pose p[kMaxBatchExt];
+  for (int k = 0; k < n; k++) pose_from_pose7(poses7 + 7 * k, ctx->xform, &p[k]);
+  struct TimingOn { nid_ctx *c; bool was; ~TimingOn() { c->timing = was; } } timing_on{ctx, ctx->timing};
+  ctx->timing = true;
+  double *target = nullptr;
+  if (n > kMaxBatch) {
+    int rc = ensure_seq_ring(ctx, n);
+    if (rc) return rc;
+    target = ctx->seq_dev[0];
+  }
+  double sum = 0.0;
+  for (int r = 0; r < repeats; r++) {
+    int rc = launch_batch(ctx, 0, n, p, want_jac, delta, target, false, /*relaunch_ok=*/false, /*allow_direct=*/false);
+    if (rc) return rc;
+    for (int k = 0; k < n; k++) {
+      rc = nid_wait(ctx, k, nullptr, nullptr, nullptr, nullptr);
+      if (rc) return rc;
+    }
+    Slot &S0 = ctx->slots[0];
+    NID_HIP(ctx, hipEventSynchronize(S0.e1));
+    float ms = 0.f;
+    NID_HIP(ctx, hipEventElapsedTime(&ms, S0.e0, S0.e1));
+    sum += ms;
+  }
+  *ms_kernel = (float)(sum / repeats);
   return NID_OK;
 }
 

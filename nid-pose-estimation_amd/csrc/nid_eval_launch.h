@@ -23,8 +23,9 @@ enum EvalFamily {
 };
 
 // lds_repair: the dynamic LDS of k_repair's workgroup shape (repair_threads(NT), nid_eval_tu.inc)
+// eval_end: null, or an event recorded right behind k_eval2 -- in front of k_repair -- (timed launches: nid_time_kernel)
 #define NID_DECLARE_EVAL_TU(NT, KIND) \
-  void launch_eval_##NT##_##KIND(const EvalParams &P, int family, bool strict, size_t lds, size_t lds_repair, hipStream_t s, int batch);
+  void launch_eval_##NT##_##KIND(const EvalParams &P, int family, bool strict, size_t lds, size_t lds_repair, hipStream_t s, int batch, hipEvent_t eval_end);
 NID_DECLARE_EVAL_TU(128, jac) NID_DECLARE_EVAL_TU(128, cost)
 NID_DECLARE_EVAL_TU(256, jac) NID_DECLARE_EVAL_TU(256, cost)
 NID_DECLARE_EVAL_TU(512, jac) NID_DECLARE_EVAL_TU(512, cost)

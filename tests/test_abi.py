@@ -31,7 +31,7 @@ def test_header_symbols_are_exported(capi):
 
 def test_abi_version_and_strings(capi):
     lib = capi.load()
-    assert lib.nid_abi_version() == 3
+    assert lib.nid_abi_version() == 4
     assert lib.nid_status_string(0) == b"ok"
     assert b"invalid" in lib.nid_status_string(-1)
 

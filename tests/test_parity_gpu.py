@@ -1438,9 +1438,31 @@ def test_direct_results_equal_in_launch_reduction(capi, synth, pair_S_edge, cfg,
             # timed launches are re-issued into the same buffers before the host looks: never DIRECT, and they leave
             # nothing behind for the next DIRECT launch of the slot to mistake for its own records
             ctx.time_launches(np.stack(poses[:1]), DELTA, repeats=3, want_jac=want_jac)
+            ctx.time_kernel(np.stack(poses[:1]), DELTA, repeats=2, want_jac=want_jac)
             for p, r in zip(poses[::-1], ref[::-1]):
                 got = ctx.normal_equations(p, DELTA, want_jac=want_jac)
                 assert _same_bits(got[0], r[0]) and _same_bits(got[2], r[2]) and got[3] == r[3]
+    ctx.close()
+
+
+@pytest.mark.gpu
+def test_kernel_timing_brackets_the_evaluation_kernel(capi, synth):
+    """nid_time_kernel (ABI 4): events right around k_eval2 -- behind the copy of the per-pose records, in front of k_repair.
+    It can only be shorter than a whole launch timed back to back (nid_time_launches), by no more than the copy, the
+    repair kernel's empty pass and the dispatch gaps; it leaves the context usable and the results untouched."""
+    pair = synth.make_pair("A")
+    ctx = capi.from_pair(pair, 8)
+    ctx.compute_href(pair.pose_init)
+    poses = np.stack([synth.perturb_pose7(pair.pose_init, [1e-4 * k, 0, 0], [0, 1e-4 * k, 0]) for k in range(64)])
+    ref = ctx.normal_equations(poses[3], DELTA)
+    for n in (1, 16, 64):
+        ctx.time_launches(poses[:n], DELTA, repeats=5)   # warm
+        launch = float(np.median([ctx.time_launches(poses[:n], DELTA, repeats=5) for _ in range(5)]))
+        kernel = float(np.median([ctx.time_kernel(poses[:n], DELTA, repeats=5) for _ in range(5)]))
+        assert 0.0 < kernel <= launch * 1.05, (n, kernel, launch)
+        assert launch - kernel < 0.08, (n, kernel, launch)     # ms: copy + empty repair pass + gaps, not a second kernel
+    got = ctx.normal_equations(poses[3], DELTA)
+    assert _same_bits(got[0], ref[0]) and _same_bits(got[1], ref[1]) and _same_bits(got[2], ref[2])
     ctx.close()
 
 
