@@ -333,11 +333,13 @@ int nid_plain_nid(nid_ctx *ctx, const double *pose7, int bins, double *Href, dou
 double nid_log2_fast_host(double x);
 /* host twin of the kernels' division-by-small-constant helper */
 double nid_div_small_host(double x, double d);
-/* timing of the last launch on its stream, ms (hipEvent) */
+/* timing of a slot's last launch, ms (hipEvent; launches issued while nid_enable_timing is on): eval_ms = the evaluation kernel,
+ * events right in front of and right behind it (ABI 4: in front of the repair kernel that follows a loop-form launch) */
 int nid_last_kernel_ms(nid_ctx *ctx, int slot, float *eval_ms, float *reduce_ms);
 int nid_enable_timing(nid_ctx *ctx, int enable);
 /* average duration (ms) of `repeats` identical n-pose launches issued back to back on the context's
- * stream, from one pair of HIP events around the whole group (what a kernel trace reports per launch) */
+ * stream, from one pair of HIP events around the whole group: what a launch costs with nothing beside it -- the in-stream copy
+ * of the per-pose records, the evaluation kernel, the repair kernel behind it, the dispatch gaps */
 int nid_time_launches(nid_ctx *ctx, int n, const double *poses7, int want_jac, double delta, int repeats,
                       float *ms_per_launch);
 /* average duration (ms) of the evaluation kernel ALONE over `repeats` n-pose launches issued one at a time: one HIP event
