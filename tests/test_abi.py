@@ -120,3 +120,18 @@ def test_multi_cell_ranges_and_argument_checks(capi):
     assert lib.nid_multi_create_rank(C.byref(cfg), 0, 3, 2, C.byref(h)) == -1   # rank >= world
     if lib.nid_device_count() == 0:
         assert lib.nid_multi_create(C.byref(cfg), dv.ctypes.data_as(capi.c_ip), 2, C.byref(h)) == -2   # no CPU fallback
+
+
+def test_unit_flags_reach_only_the_throughput_unit():
+    """csrc/UNIT_FLAGS (round 6): the machine scheduler's max-ilp strategy goes to the 128-thread cost + Jacobian unit and to no
+    other -- the latency units measure slower with it (profiles/r06_sched_strategy_ab.txt).  build() and the variant / register
+    tools read the same file."""
+    import importlib
+    import os
+    entry = importlib.import_module("__graft_entry__")
+    csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "nid-pose-estimation_amd", "csrc")
+    units = sorted(f for f in os.listdir(csrc) if f.endswith(".hip"))
+    assert "nid_eval_nt128_jac.hip" in units and len(units) >= 10
+    flagged = {u: entry._unit_flags(u) for u in units}
+    assert flagged["nid_eval_nt128_jac.hip"] == ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]
+    assert all(not f for u, f in flagged.items() if u != "nid_eval_nt128_jac.hip"), flagged
