@@ -1353,7 +1353,7 @@ __device__ __forceinline__ bool eval_cell(const EvalParams &P, const SlotArgs &S
     return false;
   }
   NID_STAMP(0);
-  const int copy = tid & (NC - 1);
+  const int copy = (NC & (NC - 1)) == 0 ? (tid & (NC - 1)) : (tid % NC);  // (a copy count that is no power of two: experiments, NID_HIST_COPIES_NB10)
   const unsigned base = (unsigned)cl * (unsigned)g.pstride;
   const unsigned plane = (unsigned)g.nloc * (unsigned)g.pstride;
   // pstride is a multiple of 64, so a wave is either entirely inside the tile or entirely past
@@ -2094,7 +2094,7 @@ __device__ __forceinline__ bool eval_cell(const EvalParams &P, const SlotArgs &S
       unsigned acc_hi = 0;
 #pragma unroll
       for (int c = 0; c < NC / 2; c++) {
-        const uint4 q = hv[(c + b) & (NC / 2 - 1)];
+        const uint4 q = hv[((NC / 2) & (NC / 2 - 1)) == 0 ? ((c + b) & (NC / 2 - 1)) : ((c + b) % (NC / 2))];
         acc_lo += q.x;
         acc_lo += q.z;
         acc_hi += q.y + q.w;
