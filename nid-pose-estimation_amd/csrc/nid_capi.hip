@@ -1852,7 +1852,8 @@ int nid_run_sequence(nid_ctx *ctx, const double *poses7, int n, int batch, int w
   // (copy stream + event).  (The blocking calls let the kernel write each pose's block straight to host memory --
   // lowest latency; for a stream of launches that is 256 system-scope fences and PCIe writes per launch from
   // inside the kernel: this form measured 254 k -> 270-280 k evaluations/s on 640x480.)
-  if (!ctx || !poses7 || n < 0 || batch < 1 || batch > kMaxBatchExt || NID_SLOTS % batch) return NID_ERR_INVALID_ARG;
+  // (any batch <= NID_MAX_BATCH: ring entry r owns the slots r * batch .. r * batch + batch - 1, and depth * batch <= NID_SLOTS below)
+  if (!ctx || !poses7 || n < 0 || batch < 1 || batch > kMaxBatchExt) return NID_ERR_INVALID_ARG;
   NID_HIP(ctx, hipSetDevice(ctx->cfg.device));
   for (int s = 0; s < NID_SLOTS; s++) if (ctx->slots[s].pending) return NID_ERR_STATE;
   if (n <= batch) {
